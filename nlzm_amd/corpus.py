@@ -1,0 +1,188 @@
+"""Seeded synthetic corpora: stand-ins for enwik8/enwik9/calgary.tar.
+
+None of the real corpora exist on the build or GPU boxes (no network), so every
+benchmark and test input comes from here.  The generators are deterministic for a
+given (kind, size, seed) on any machine (numpy PCG64 streams only).
+
+``syn_text``   Zipf(s=1.1) draws over a 50,000-word vocabulary of seeded 2-12 letter
+               lowercase words; separators {" " 80 %, ", " 8 %, ". " 8 %, "\\n" 4 %};
+               then spans of 300-200,000 bytes (log-uniform) are overwritten by copies
+               of earlier spans (about 8 % of the bytes: long-range / RK256 regime) and
+               runs of 70-5,000 identical bytes are written over about 1 % of them
+               (nice-length skip, BT4 early-return path).  SURVEY.md's per-word
+               probabilities (0.002 / 0.0005) would make the file >90 % copies, so the
+               rates are scaled to those coverages instead.
+``random``     uniform random bytes (expansion path).
+``runs``       long byte runs and short periodic patterns.
+``mixed``      text, binary records, runs and duplicated blocks interleaved (the
+               calgary.tar stand-in).
+
+If ``$NLZM_CORPUS_DIR`` holds the real file (enwik8, enwik9, calgary.tar) ``load()``
+returns that instead.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+SEED = 0x4E4C5A4D
+
+SIZES = {
+    "calgary": 3_152_896,
+    "enwik8": 100_000_000,
+    "enwik9": 1_000_000_000,
+}
+
+
+def _vocab(rng: np.random.Generator, nwords: int = 50_000):
+    lens = rng.integers(2, 13, size=nwords)
+    # letter frequencies roughly English-like so hashes of 2/3/4-grams are skewed
+    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+    w = 1.0 / np.arange(1, 27) ** 0.8
+    w /= w.sum()
+    flat = letters[rng.choice(26, size=int(lens.sum()), p=w)]
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    return flat, starts.astype(np.int64), lens.astype(np.int64)
+
+
+_SEPS = [b" ", b", ", b". ", b"\n"]
+_SEP_P = np.array([0.80, 0.08, 0.08, 0.04])
+
+
+def _text_block(rng, vocab, cdf, nbytes: int) -> np.ndarray:
+    """About nbytes of words+separators (>= nbytes, caller trims)."""
+    flat, starts, lens = vocab
+    ntok = int(nbytes / 6.5) + 64
+    tok = np.searchsorted(cdf, rng.random(ntok), side="right").astype(np.int32)
+    sep = rng.choice(4, size=ntok, p=_SEP_P)
+    sep_len = np.where((sep == 0) | (sep == 3), 1, 2).astype(np.int32)
+    wl = lens[tok].astype(np.int32)
+    tot = wl + sep_len
+    ends = np.cumsum(tot, dtype=np.int64)
+    total = int(ends[-1])
+    begs = ends - tot
+    out = np.empty(total, dtype=np.uint8)
+    # word bytes: out[begs[i] + k] = flat[starts[tok[i]] + k], k < wl[i]
+    nw = int(wl.sum())
+    wbeg = np.cumsum(wl, dtype=np.int64) - wl
+    k = np.arange(nw, dtype=np.int64) - np.repeat(wbeg, wl)
+    out[np.repeat(begs, wl) + k] = flat[np.repeat(starts[tok], wl) + k]
+    sp = begs + wl
+    out[sp] = np.array([0x20, 0x2C, 0x2E, 0x0A], dtype=np.uint8)[sep]
+    two = sep_len == 2
+    out[sp[two] + 1] = 0x20
+    return out
+
+
+def syn_text(size: int, seed: int = SEED) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    vocab = _vocab(rng)
+    p = 1.0 / np.arange(1, len(vocab[1]) + 1) ** 1.1
+    cdf = np.cumsum(p / p.sum())
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    blk = 8 << 20
+    while pos < size:
+        b = _text_block(rng, vocab, cdf, min(blk, size - pos))
+        k = min(len(b), size - pos)
+        out[pos:pos + k] = b[:k]
+        pos += k
+    # overwrite events, in increasing position order
+    nwords = size / 7.5
+    ncopy = int(nwords * 2e-5) + 1
+    nrun = int(nwords * 3e-5) + 1
+    ev_pos = np.sort(rng.integers(0, max(size, 1), size=ncopy + nrun))
+    ev_kind = rng.random(ncopy + nrun) < (ncopy / max(1, ncopy + nrun))
+    # span lengths: log-uniform so that most copies are short and a few are huge
+    ev_len_copy = np.exp(rng.uniform(np.log(300), np.log(200_000), size=ncopy + nrun)).astype(np.int64)
+    ev_len_run = rng.integers(70, 5001, size=ncopy + nrun)
+    ev_src = rng.random(ncopy + nrun)
+    ev_byte = rng.integers(0, 256, size=ncopy + nrun)
+    for i in range(ncopy + nrun):
+        q = int(ev_pos[i])
+        if ev_kind[i]:
+            ln = int(min(ev_len_copy[i], size - q, q))
+            if ln < 300:
+                continue
+            src = int(ev_src[i] * (q - ln + 1))
+            out[q:q + ln] = out[src:src + ln]
+        else:
+            ln = int(min(ev_len_run[i], size - q))
+            out[q:q + ln] = ev_byte[i]
+    return out
+
+
+def random_bytes(size: int, seed: int = SEED) -> np.ndarray:
+    return np.random.default_rng(seed ^ 0x5EED).integers(0, 256, size=size, dtype=np.uint8)
+
+
+def runs(size: int, seed: int = SEED) -> np.ndarray:
+    rng = np.random.default_rng(seed ^ 0x52554E)
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    while pos < size:
+        kind = rng.integers(0, 3)
+        ln = int(min(size - pos, rng.integers(1, 3000)))
+        if kind == 0:
+            out[pos:pos + ln] = rng.integers(0, 256)
+        elif kind == 1:
+            per = int(rng.integers(2, 9))
+            pat = rng.integers(0, 256, size=per, dtype=np.uint8)
+            out[pos:pos + ln] = np.resize(pat, ln)
+        else:
+            out[pos:pos + ln] = rng.integers(97, 123, size=ln, dtype=np.uint8)
+        pos += ln
+    return out
+
+
+def mixed(size: int, seed: int = SEED) -> np.ndarray:
+    """calgary.tar stand-in: text files, binary-ish records, runs, duplicated members."""
+    rng = np.random.default_rng(seed ^ 0xCA16A7)
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    member = 0
+    while pos < size:
+        ln = int(min(size - pos, rng.integers(20_000, 400_000)))
+        kind = member % 5
+        if kind in (0, 1):
+            b = syn_text(ln, seed + 17 * member + 1)
+        elif kind == 2:
+            # fixed-width binary records with small-alphabet fields
+            rec = rng.integers(0, 16, size=(ln // 16 + 1, 16), dtype=np.uint8)
+            rec[:, 0] = 0xFF
+            rec[:, 4:8] = (np.arange(rec.shape[0])[:, None] >> (8 * np.arange(4))) & 0xFF
+            b = rec.reshape(-1)[:ln]
+        elif kind == 3:
+            b = runs(ln, seed + 31 * member)
+        else:
+            src = int(rng.integers(0, max(1, pos - ln))) if pos > ln else 0
+            b = out[src:src + ln].copy() if pos > ln else random_bytes(ln, seed + member)
+        out[pos:pos + ln] = b[:ln]
+        # tar-like 512-byte header of zeros and a name
+        hdr = min(512, size - pos)
+        out[pos:pos + hdr] = 0
+        name = (b"member%04d.dat" % member)[:hdr]
+        out[pos:pos + len(name)] = np.frombuffer(name, dtype=np.uint8)
+        pos += ln
+        member += 1
+    return out
+
+
+_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed}
+
+
+def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:
+    return _GENS[kind](size, seed)
+
+
+def load(name: str) -> tuple[np.ndarray, str]:
+    """Return (bytes, provenance) for 'enwik8' | 'enwik9' | 'calgary'."""
+    d = os.environ.get("NLZM_CORPUS_DIR")
+    fname = {"calgary": "calgary.tar"}.get(name, name)
+    if d and os.path.exists(os.path.join(d, fname)):
+        return np.fromfile(os.path.join(d, fname), dtype=np.uint8), f"file:{fname}"
+    size = SIZES[name]
+    if name == "calgary":
+        return mixed(size), "synthetic:mixed"
+    return syn_text(size), "synthetic:syn_text"
