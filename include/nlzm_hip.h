@@ -1,0 +1,141 @@
+/*
+ * nlzm_hip.h -- C ABI of the MI355X (gfx950) implementation of NLZM 1.03's
+ * compress-side hot path.
+ *
+ * The reference has no library/FFI surface: its only seam for this path is
+ *
+ *     void encode_file(FILE *fin, FILE *fout, uint32 hist_bits)      NLZM.cpp:1711
+ *
+ * called from main() (NLZM.cpp:2114).  nlzm_hip_compress() replaces the body of
+ * that function -- everything between the first fread (NLZM.cpp:1774) and the
+ * terminator fwrite (NLZM.cpp:1895) -- and produces the same bytes.  The
+ * stage-level entry points below expose the same work split at the reference's
+ * internal function boundaries so each stage can be checked on its own.
+ *
+ * Conventions: plain C types only; `const uint8_t *` host buffers are owned by
+ * the caller; `void *d_*` arguments are device (HBM) pointers owned by the
+ * caller; every function returns 0 on success or a negative NLZM_HIP_E_* code
+ * (never exit()s, unlike the reference's ASSERT, NLZM.cpp:25);
+ * nlzm_hip_last_error() gives a message.  One context per process and device;
+ * calls are not re-entrant (the reference is single-threaded too).
+ */
+#ifndef NLZM_HIP_H
+#define NLZM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLZM_HIP_E_ARG        (-1)   /* bad argument                                   */
+#define NLZM_HIP_E_NODEVICE   (-2)   /* no usable gfx950 device / HIP runtime error    */
+#define NLZM_HIP_E_NOMEM      (-3)   /* device allocation failed                       */
+#define NLZM_HIP_E_CAPACITY   (-4)   /* dst_cap too small                              */
+#define NLZM_HIP_E_KERNEL     (-5)   /* kernel reported an internal error / timeout    */
+#define NLZM_HIP_E_TOOBIG     (-6)   /* input >= 2^32-2^16 bytes (32-bit positions)    */
+
+/* Operation counters: same definitions as SURVEY.md section 8d (algorithmic bytes). */
+typedef struct nlzm_hip_stats {
+    uint64_t in_bytes, out_bytes;
+    uint64_t bt_calls, bt_tests, cmp_bytes, ht_rows, rk_probes, rk_inserts;
+    uint64_t positions, nice_positions, segments;
+    uint64_t n_literal, n_dict, n_rep, rans_syms, bit_ops, frames, shifts;
+    uint64_t uncertain_positions;     /* positions whose finder set needed the master's decision */
+} nlzm_hip_stats;
+
+/* Device-side timings of the last nlzm_hip_compress*() call (HIP events on the
+ * library's own stream), in milliseconds. */
+typedef struct nlzm_hip_timing {
+    double total_ms;        /* first launch .. last launch complete                 */
+    double h2d_ms, d2h_ms;  /* copies (0 for the *_dev entry point)                 */
+    double prep_ms;         /* position-parallel pre-pass kernels                   */
+    double match_parse_ms;  /* the persistent match-find + parse + emit kernel(s)   */
+    double rans_ms;         /* frame rANS kernel(s)                                 */
+    uint32_t match_parse_launches, rans_launches, prep_launches;
+} nlzm_hip_timing;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* Select the device and create the library's stream.  Fails (NLZM_HIP_E_NODEVICE)
+ * when there is no GPU: there is no CPU fallback behind this ABI. */
+int nlzm_hip_init(int device);
+void nlzm_hip_shutdown(void);
+const char *nlzm_hip_last_error(void);
+
+/* Upper bound on the stream size for n input bytes (every frame fits a 128 KiB
+ * buffer in the reference: NLZM.cpp:1722-1724, 1738). */
+uint64_t nlzm_hip_compress_bound(uint64_t n);
+
+/* Window/frame geometry the stream will use for a file of flen bytes when
+ * `-window:hist_bits_req` was asked (auto-shrink NLZM.cpp:1716-1718, frame sizes
+ * NLZM.cpp:1722-1725). */
+void nlzm_hip_geometry(uint64_t flen, uint32_t hist_bits_req, uint32_t *hist_bits,
+                       uint32_t *frame_bits, uint32_t *chunk_size, uint32_t *feed_size);
+
+/* ---- whole path: replaces encode_file (NLZM.cpp:1711-1910) ---------------- */
+
+/* src/dst are host buffers.  hist_bits_req is the value after the CLI clamp to
+ * [15,28] (NLZM.cpp:2085).  *dst_len receives header + frames + terminator. */
+int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
+                      uint8_t *dst, uint64_t dst_cap, uint64_t *dst_len);
+
+/* Same, but input and output already live in HBM (d_src must be followed by at
+ * least 16 readable padding bytes).  Used by bench.py so the timed region starts
+ * with the input resident. */
+int nlzm_hip_compress_dev(const void *d_src, uint64_t n, uint32_t hist_bits_req,
+                          void *d_dst, uint64_t dst_cap, uint64_t *dst_len);
+
+/* Incremental form of the same call, for time-boxed runs: begin binds the input,
+ * each step compresses the next `max_chunks` chunks (one chunk = one frame's
+ * worth of input, NLZM.cpp:1724), finish appends the terminator.  The bytes
+ * produced are identical to the one-shot call. */
+int nlzm_hip_stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req,
+                          void *d_dst, uint64_t dst_cap);
+int nlzm_hip_stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished);
+int nlzm_hip_stream_finish(uint64_t *dst_len);
+
+int nlzm_hip_get_stats(nlzm_hip_stats *out);
+int nlzm_hip_get_timing(nlzm_hip_timing *out);
+
+/* ---- stage: frame coder, replaces CodeFrame::Flush (NLZM.cpp:590-640) ------ */
+
+/* For each frame f: syms[sym_off[f] .. sym_off[f+1]) are the (freq<<16)+start
+ * words buffered by WriteRange (NLZM.cpp:565); bits[bits_off[f] .. bits_off[f+1])
+ * are the raw-bit bytes INCLUDING the four pad bytes Flush appends
+ * (NLZM.cpp:591-597); num_ops[f] is the op count.  Frame f is written to
+ * out + f*out_stride and its length to out_len[f].  Host pointers. */
+int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off,
+                         const uint8_t *bits, const uint64_t *bits_off,
+                         const uint32_t *num_ops, uint32_t nframes,
+                         uint8_t *out, uint64_t out_stride, uint32_t *out_len);
+
+/* ---- stage: match finding, replaces the finder block of parse_table -------- */
+/* (NLZM.cpp:1501-1543: carry + HT2/HT3/BT4/RK256 -> the table copied to mt_carry)
+ *
+ * Runs the whole path on src but returns, for positions [pos_lo, pos_hi), the
+ * per-position match tables as records {pos, max_len, delta[2..max_len]} of
+ * uint32 words (same record format as the oracle's capture).  Host pointers. */
+int nlzm_hip_find_matches(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
+                          uint64_t pos_lo, uint64_t pos_hi,
+                          uint32_t *out_words, uint64_t cap_words, uint64_t *used_words);
+
+/* ---- stage: parse + emit, replaces parse_table's relaxations and the -------- */
+/* model_encode_* calls of the driver loop (NLZM.cpp:1545-1650, 1809-1843)
+ *
+ * Returns the symbol/bit streams of frame `frame_idx` before rANS coding:
+ * sizes_out = {nsyms, nbits_bytes (incl. pad), num_ops}.  Host pointers. */
+int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
+                        uint32_t frame_idx, uint32_t *syms, uint32_t cap_syms,
+                        uint8_t *bits, uint32_t cap_bits, uint32_t *sizes_out);
+
+/* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
+/* key: "workers" (0 = BT4 inside the master workgroup, 1 = per-head worker
+ * lanes, default 1), "batch_chunks" (chunks per persistent launch). */
+int nlzm_hip_set_option(const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,805 @@
+// nlzm_core.h -- data layout and the serial ("master") half of the compress path.
+//
+// Everything here is written once, against a wave policy `W` (lane id, wave
+// width, LDS sync, cross-lane reductions, grouped byte compares).  The kernels in
+// nlzm_kernels.hip instantiate it with the 64-lane gfx950 policy; tests/host_sim
+// instantiates the very same code with a 1-lane policy to check the logic against
+// the oracle without a GPU.  Control flow is wave-uniform: every lane carries the
+// same scalar state, lanes split only inside the `for (i = W::lane(); ...)` loops.
+//
+// Reference map (all NLZM.cpp):
+//   Master::parse_segment   parse_table                      :1464-1651
+//   Master::finders         finder block of parse_table      :1501-1543
+//   Master::ht_*            MatchFinderHT::FindAndUpdate     :910-938
+//   Master::rk_*            MatchFinderRK256::FindAndUpdate  :1055-1113
+//   bt_find_and_update      MatchFinderBT::FindAndUpdate     :978-1022
+//   Master::emit_*          model_encode_*                   :1274-1367, 1428-1439
+//   Master::run_chunk       encode_file chunk loop           :1782-1886
+#pragma once
+
+#include <stdint.h>
+
+#ifndef NLZM_HD
+#define NLZM_HD __host__ __device__ __forceinline__
+#endif
+#ifndef NLZM_HDN
+#define NLZM_HDN __host__ __device__
+#endif
+
+namespace nlzm {
+
+constexpr uint32_t kMatchMin = 2;       // :733
+constexpr uint32_t kMatchMax = 264;     // :737
+constexpr uint32_t kNice = 64;          // :734
+constexpr uint32_t kParseMax = 4096;    // :1458
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// ---- CDF contexts (Model, :1133-1146) flattened into one table -------------
+constexpr uint32_t kCtxCmd = 0;                 // CDF2
+constexpr uint32_t kCtxLitHi = 1;               // CDF4
+constexpr uint32_t kCtxLitLo = 2;               // CDF4 x16
+constexpr uint32_t kCtxLenDirect = 18;          // CDF3
+constexpr uint32_t kCtxLenExtHi = 19;           // CDF4
+constexpr uint32_t kCtxLenExtLo = 20;           // CDF4 x16
+constexpr uint32_t kCtxSlotHi = 36;             // CDF3 x4
+constexpr uint32_t kCtxSlotLo = 40;             // CDF3 x4x8
+constexpr uint32_t kNumCtx = 72;
+constexpr uint32_t kCdfStride = 18;             // 17 cells used
+
+NLZM_HD uint32_t ctx_nsyms(uint32_t ctx)
+{
+    if (ctx == kCtxCmd) return 4;
+    if (ctx == kCtxLenDirect || ctx >= kCtxSlotHi) return 8;
+    return 16;
+}
+
+struct Geom {
+    uint64_t n;             // input bytes
+    uint32_t wbits, wmask;  // window (after auto-shrink, :1716-1718)
+    uint32_t frame_bits, frame_size, chunk_size, feed;   // :1722-1725
+    uint32_t ht3_shift;     // 32 - (12 + clamp(wbits,15,17) - 15)   :1751
+    uint32_t bt_shift;      // 32 - (13 + clamp(wbits,16,20) - 16)   :1752
+    uint32_t rk_shift;      // 32 - (15 + clamp(wbits,16,22) - 16)   :1753
+    uint32_t tag_mask;      // (1 << (32 - wbits)) - 1               :899, :1036
+    uint32_t nchunks;
+};
+
+// Operation counters, accumulated per launch.
+struct Counters {
+    unsigned long long bt_calls, bt_tests, cmp_bytes, ht_rows, rk_probes, rk_inserts;
+    unsigned long long positions, nice_positions, segments;
+    unsigned long long n_literal, n_dict, n_rep, rans_syms, bit_ops, frames, shifts;
+    unsigned long long uncertain_positions;
+};
+
+// State that survives between launches (one per stream), in HBM.
+struct Persist {
+    uint16_t cdf[kNumCtx * kCdfStride];
+    uint32_t rep[4];
+    uint32_t mt_max;
+    uint32_t mt_delta[kMatchMax + 8];
+    uint32_t rk_from, rk_to, rk_len, rk_end;
+    unsigned long long reb_base;
+    uint32_t next_chunk;
+    uint32_t error;             // 0 ok; see kErr*
+    uint32_t error_info[3];
+    Counters cnt;
+};
+
+constexpr uint32_t kErrFrameOverflow = 1;
+constexpr uint32_t kErrTimeout = 2;
+constexpr uint32_t kErrInternal = 3;
+constexpr uint32_t kErrCapture = 4;
+
+struct FrameMeta {
+    uint32_t nsyms, nbits_bytes, num_ops, out_len;
+};
+
+// Everything the master needs from HBM.
+struct Globals {
+    const uint8_t *in;          // input, followed by >= 16 padding bytes
+    const uint32_t *rkhash;     // rkhash[a] = RK256 hash of in[a .. a+256)   (closed form of :798-799)
+    uint32_t *ht2, *ht3, *rk_table;
+    uint32_t *bt_heads, *bt_tree;   // absolute positions
+    Persist *persist;
+    // per-frame symbol/bit streams for the chunks of this launch (index = chunk - chunk0)
+    uint32_t *syms;  unsigned long long syms_stride;   // words per frame
+    uint8_t *bits;   unsigned long long bits_stride;   // bytes per frame
+    FrameMeta *fmeta;
+    uint32_t chunk0;
+    // optional capture of match tables (stage test)
+    uint32_t *cap_words; unsigned long long cap_cap, cap_lo, cap_hi; unsigned long long *cap_used;
+};
+
+// LDS image of the master workgroup.
+struct MasterLds {
+    uint32_t node_cost[kParseMax + 1];
+    uint32_t node_delta[kParseMax + 1];
+    uint32_t node_link[kParseMax + 1];      // from:13 | len:9<<13 | cmd:2<<22 ; from==0x1FFF: none
+    uint32_t reps[512 * 4];                 // CarriedState ring (:1460-1467)
+    uint32_t mt[512];                       // match table as a ring: entry i at (mt_base+i)&511
+    uint16_t cmdlist[kParseMax + 2];        // node indices of the chosen path
+    uint16_t cdf[kNumCtx * kCdfStride];
+    uint16_t price[kNumCtx * 16];           // log2_lut[freq>>6] per (context, symbol)  (:435-438)
+    uint16_t lut[256];                      // log2_lut (:97-124)
+};
+
+NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
+{
+    return 2u + (d >= (1u << 8)) + (d >= (1u << 12)) + (d >= (1u << 20));
+}
+NLZM_HD uint32_t hash4(uint32_t x) { return x * 987660757u; }    // :739
+NLZM_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+NLZM_HD uint32_t umax(uint32_t a, uint32_t b) { return a < b ? b : a; }
+NLZM_HD uint32_t ilog2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x | 1u); }   // the reference's "clz32", :59-75
+
+NLZM_HD uint32_t load32u(const uint8_t *p)
+{
+    uint32_t v; __builtin_memcpy(&v, p, 4); return v;
+}
+NLZM_HD unsigned long long load64u(const uint8_t *p)
+{
+    unsigned long long v; __builtin_memcpy(&v, p, 8); return v;
+}
+
+// log2 cost table, :103-124
+NLZM_HD uint16_t log2_lut_entry(uint32_t i)
+{
+    if (i == 0) i = 1;
+    uint32_t next = 1u << 16;
+    uint16_t acc = 0;
+    for (int s = 0; s < 32; s++) {
+        const uint32_t v = (i * next) >> 8;
+        const uint32_t nbits = 16u - ilog2(v);
+        acc = (uint16_t)(acc + nbits - 1);
+        next = v << (nbits - 1);
+    }
+    return acc;
+}
+
+// distance -> slot / extra bits (:1227-1243, :1299-1320)
+NLZM_HD uint32_t dist_slot(uint32_t dv, uint32_t &nextra, uint32_t &extra)
+{
+    if (dv < 4) { nextra = 0; extra = 0; return dv; }
+    const uint32_t nb = ilog2(dv) + 1, ab = nb - 2;
+    nextra = ab;
+    extra = dv & ((1u << ab) - 1);
+    return ((nb - 1) << 1) + ((dv >> ab) & 1);
+}
+
+NLZM_HD void rep_add(uint32_t r[4], uint32_t d)     // :1160-1171
+{
+    if (r[0] == d || r[1] == d || r[2] == d || r[3] == d) return;
+    r[3] = r[2]; r[2] = r[1]; r[1] = r[0]; r[0] = d;
+}
+
+// ---------------------------------------------------------------------------
+// BT4: one call = MatchFinderBT::FindAndUpdate (:978-1022) on absolute positions.
+// `Cmp` supplies the byte compare (wave-wide in the master, lane-serial in the
+// worker kernel); `Sink` receives every (distance, length) the reference would
+// pass to MatchTable::Update (:996-998).
+// ---------------------------------------------------------------------------
+template <class Cmp, class Sink>
+NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask,
+                                const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
+                                Cmp &cmp, Sink &sink, unsigned long long &n_tests)
+{
+    uint32_t pend_l = (a & wmask) << 1, pend_r = pend_l + 1;     // indices into tree[]
+    uint32_t len_l = 0, len_r = 0;
+    uint32_t sp = heads[h4 >> bt_shift];
+    heads[h4 >> bt_shift] = a;
+    uint32_t tests = 256;                                       // :777, :988 (uint16 there; never wraps)
+    while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
+        n_tests++;
+        const uint32_t pair = (sp & wmask) << 1;
+        const uint32_t r = cmp(in + sp, in + a, umin(len_l, len_r), max_len);
+        const uint32_t l = r & 0x7FFFFFFFu;
+        if (l >= match_min(a - sp)) sink(a - sp, l);
+        if (l == max_len) {                                     // :1000-1004
+            tree[pend_l] = tree[pair];
+            tree[pend_r] = tree[pair + 1];
+            return;
+        }
+        if (r >> 31) { tree[pend_l] = sp; pend_l = pair + 1; sp = tree[pend_l]; len_r = l; }
+        else         { tree[pend_r] = sp; pend_r = pair;     sp = tree[pend_r]; len_l = l; }
+    }
+    tree[pend_r] = kNone;                                       // :1020-1021
+    tree[pend_l] = kNone;
+}
+
+// ---------------------------------------------------------------------------
+// The master: walks positions in order, owns HT2/HT3/RK256 state, the match
+// table chain, the parse, the model and the symbol output.
+// ---------------------------------------------------------------------------
+template <class W>
+struct Master {
+    Geom g;
+    Globals G;
+    MasterLds *L;
+
+    // match table ring + RK scalars + window base (wave-uniform registers)
+    uint32_t mt_base, mt_max;
+    uint32_t rk_from, rk_to, rk_len, rk_end;
+    unsigned long long base;        // absolute offset of rebased 0
+    uint32_t la_end;                // rebased end of the chunk's lookahead
+    uint32_t rep[4];                // live model rep set
+
+    // frame writer (CodeFrame, :490-513)
+    uint32_t *fsyms; uint8_t *fbits;
+    uint32_t nsyms, nbits, word, word_bits, num_ops;
+
+    Counters c;
+    uint32_t err;
+
+    // ---- LDS accessors ----------------------------------------------------
+    NLZM_HD uint32_t &mt(uint32_t i) { return L->mt[(mt_base + i) & 511]; }
+
+    NLZM_HD uint32_t price(uint32_t ctx, uint32_t y) const { return L->price[ctx * 16 + y]; }
+
+    // ---- byte compare, one pair, all lanes (MatchLengthSigned, :854-877) ---
+    struct WaveCmp {
+        unsigned long long *cmp_bytes;
+        NLZM_HD uint32_t operator()(const uint8_t *s, const uint8_t *t, uint32_t init, uint32_t cap) const
+        {
+            uint32_t off = init, res = cap;
+            uint32_t lt = 0;
+            bool hit = false;
+            while (off < cap) {
+                const uint32_t my = off + W::lane() * 8;
+                uint32_t m = kNone, mylt = 0;
+                if (my < cap) {
+                    const unsigned long long x = load64u(s + my), y = load64u(t + my);
+                    const unsigned long long d = x ^ y;
+                    if (d) {
+                        const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                        if (my + nb < cap) {
+                            m = my + nb;
+                            mylt = ((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF);
+                        }
+                    }
+                }
+                const uint32_t first = W::rmin(m);
+                if (first != kNone) {
+                    lt = W::ror((m == first) ? mylt : 0u);
+                    res = first; hit = true;
+                    break;
+                }
+                off += W::width() * 8;
+            }
+            *cmp_bytes += (res - init) + (hit ? 1u : 0u);
+            return res | (lt << 31);
+        }
+    };
+
+    // ---- MatchTable::Update (:835-852) on the ring ---------------------------
+    NLZM_HD void mt_update(uint32_t d, uint32_t len)
+    {
+        for (uint32_t i = W::lane(); i <= len; i += W::width()) {
+            uint32_t &e = mt(i);
+            e = (i <= mt_max) ? umin(e, d) : d;
+        }
+        mt_max = umax(mt_max, len);
+        W::sync();
+    }
+
+    struct MtSink {
+        Master *m;
+        NLZM_HD void operator()(uint32_t d, uint32_t l) const { m->mt_update(d, l); }
+    };
+
+    // ---- model prices ------------------------------------------------------
+    NLZM_HD uint32_t price_len(uint32_t lv) const                  // :1214-1225
+    {
+        uint32_t cst = price(kCtxLenDirect, umin(lv, 7));
+        if (lv >= 7) {
+            const uint32_t e = lv - 7;
+            cst += price(kCtxLenExtHi, e >> 4) + price(kCtxLenExtLo + (e >> 4), e & 15);
+        }
+        return cst;
+    }
+    NLZM_HD uint32_t price_match(uint32_t d, uint32_t len) const   // :1208-1251
+    {
+        const uint32_t lv = len - match_min(d), lc = umin(lv, 3);
+        uint32_t nx, ex;
+        const uint32_t slot = dist_slot(d - 1, nx, ex);
+        return price(kCtxCmd, 1) + price_len(lv) + (nx << 5) + price(kCtxSlotHi + lc, slot >> 3) +
+               price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+    }
+    NLZM_HD uint32_t price_rep(uint32_t d, uint32_t len) const     // :1253-1272
+    {
+        return price(kCtxCmd, 2) + price_len(len - match_min(d)) + (2u << 5);
+    }
+    NLZM_HD uint32_t price_literal(uint32_t y) const               // :1418-1426
+    {
+        return price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15);
+    }
+
+    // ---- symbol output (WriteRange/WriteBits + cdf_update) -------------------
+    NLZM_HD void put_sym(uint32_t ctx, uint32_t y)
+    {
+        // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279)
+        const uint32_t nsy = ctx_nsyms(ctx);
+        uint16_t *cell = L->cdf + ctx * kCdfStride;
+        const uint32_t start = cell[y], freq = (uint32_t)cell[y + 1] - start;
+        if (W::lane() == 0) fsyms[nsyms] = (freq << 16) + start;
+        nsyms++; num_ops++;
+        // cdf_update (:348-382): cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsyms;
+        // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsyms)   (:284-298)
+        W::sync();
+        for (uint32_t i = W::lane(); i < nsy; i += W::width()) {
+            const int mix = (i <= y) ? (int)i : (int)(16384 + i + (127 - nsy));
+            cell[i] = (uint16_t)(cell[i] + ((mix - (int)cell[i]) >> 7));
+        }
+        W::sync();
+        for (uint32_t i = W::lane(); i < nsy; i += W::width())
+            L->price[ctx * 16 + i] = L->lut[((uint32_t)cell[i + 1] - (uint32_t)cell[i]) >> 6];
+        W::sync();
+    }
+    NLZM_HD void put_bits(uint32_t v, uint32_t nb)                  // :574-588
+    {
+        num_ops++;
+        word |= v << (32 - word_bits - nb);
+        word_bits += nb;
+        while (word_bits >= 8) {
+            if (W::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            nbits++;
+            word <<= 8;
+            word_bits -= 8;
+        }
+    }
+    NLZM_HD uint32_t emit_len(uint32_t lv)                          // :1281-1297
+    {
+        put_sym(kCtxLenDirect, umin(lv, 7));
+        if (lv >= 7) {
+            const uint32_t e = lv - 7;
+            // both WriteCDFs precede both updates in the reference; contexts differ, so equal
+            put_sym(kCtxLenExtHi, e >> 4);
+            put_sym(kCtxLenExtLo + (e >> 4), e & 15);
+        }
+        return umin(lv, 3);
+    }
+    NLZM_HD void emit_literal(uint32_t y)                           // :1428-1439
+    {
+        put_sym(kCtxCmd, 0);
+        put_sym(kCtxLitHi, y >> 4);
+        put_sym(kCtxLitLo + (y >> 4), y & 15);
+        c.n_literal++;
+    }
+    NLZM_HD void emit_match(uint32_t d, uint32_t len)               // :1274-1342
+    {
+        put_sym(kCtxCmd, 1);
+        const uint32_t lc = emit_len(len - match_min(d));
+        uint32_t nx, ex;
+        const uint32_t slot = dist_slot(d - 1, nx, ex);
+        put_sym(kCtxSlotHi + lc, slot >> 3);
+        put_sym(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+        if (d - 1 >= 4) {
+            if (nx < 4) put_bits(ex, nx);
+            else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
+        }
+        rep_add(rep, d);                                            // :1819
+        c.n_dict++;
+    }
+    NLZM_HD void emit_rep(uint32_t idx, uint32_t len)               // :1344-1367
+    {
+        put_sym(kCtxCmd, 2);
+        emit_len(len - match_min(rep[idx]));
+        put_bits(idx, 2);
+        c.n_rep++;                                                  // rep4.Add(present delta) is a no-op (:1834)
+    }
+
+    // ---- parse graph helpers -------------------------------------------------
+    NLZM_HD static uint32_t pack_link(uint32_t from, uint32_t len, uint32_t cmd) { return from | (len << 13) | (cmd << 22); }
+
+    NLZM_HD void open_nodes(uint32_t &end_p, uint32_t upto)         // :1550-1554
+    {
+        if (upto > end_p) {
+            for (uint32_t e = end_p + 1 + W::lane(); e <= upto; e += W::width()) {
+                L->node_cost[e] = kNone;
+                L->node_link[e] = 0x1FFF;
+            }
+            end_p = upto;
+            W::sync();
+        }
+    }
+
+    // relax edge p -> np by one lane (or uniformly by all lanes with equal arguments)
+    NLZM_HD void relax(uint32_t p, uint32_t np, uint32_t cost_p, uint32_t cst, uint32_t cmd, uint32_t len,
+                       uint32_t store_delta, const uint32_t rp[4], uint32_t add_delta)
+    {
+        if (L->node_cost[np] > cost_p + cst) {                      // strict: first candidate wins ties
+            L->node_cost[np] = cost_p + cst;
+            L->node_delta[np] = store_delta;
+            L->node_link[np] = pack_link(p, len, cmd);
+            uint32_t r[4] = { rp[0], rp[1], rp[2], rp[3] };
+            rep_add(r, add_delta);
+            uint32_t *dst = L->reps + (np & 511) * 4;
+            dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2]; dst[3] = r[3];
+        }
+    }
+
+    // ---- finders for one position (:1501-1543) --------------------------------
+    // q: rebased position, a: absolute position, p: parse-relative index.
+    // rp/rep_len: the node's rep set and (output) explicit rep-probe lengths.
+    NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t p, const uint32_t rp[4], uint32_t rep_cap,
+                         uint32_t rep_len[4])
+    {
+        const uint8_t *cur = G.in + a;
+        const uint32_t avail = la_end - q;
+        WaveCmp wcmp{ &c.cmp_bytes };
+
+        // carry by one (:1501-1502, CarryFrom :823-833)
+        if (mt_max <= 1) mt_max = 0;
+        else { mt_max -= 1; mt_base = (mt_base + 1) & 511; }
+        // extend the longest entry (:1503-1512)
+        if (mt_max > 0) {
+            const uint32_t d = mt(mt_max);
+            if (q >= d) {
+                const uint32_t cap = umin(kMatchMax, avail);
+                if (mt_max < cap) {
+                    unsigned long long dummy = 0;
+                    WaveCmp ext{ &dummy };
+                    const uint32_t nl = ext(cur - d, cur, mt_max, cap) & 0x7FFFFFFFu;
+                    if (nl > mt_max) {
+                        for (uint32_t i = mt_max + 1 + W::lane(); i <= nl; i += W::width()) mt(i) = d;
+                        mt_max = nl;
+                        W::sync();
+                    }
+                }
+            }
+        }
+
+        const bool nice = mt_max >= kNice;                          // :1514
+        c.nice_positions += nice ? 1 : 0;
+        const bool call = !nice || !(p & 7);                        // :1529
+        const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
+        const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
+
+        // ---- gather up to 8 compare jobs: HT2, HT3 row0/row1, RK probe, 4 rep probes
+        uint32_t job_sp[8], job_cap[8], job_len[8];
+        uint32_t valid = 0;
+        uint32_t v4 = 0, h2 = 0, h3 = 0, h4 = 0;
+        uint32_t row[3] = { 0, 0, 0 }, tag2 = 0, tag3 = 0;
+        if (have4) {
+            v4 = load32u(cur);
+            h2 = hash4(v4 & 0xFFFFu); h3 = hash4(v4 & 0xFFFFFFu); h4 = hash4(v4);   // :1516-1518
+            uint32_t *r2 = G.ht2 + (h2 >> 20);                                       // 12-bit, 1 row (:1750)
+            uint32_t *r3 = G.ht3 + (h3 >> g.ht3_shift);                              // base NOT scaled by rows (:912)
+            row[0] = r2[0]; row[1] = r3[0]; row[2] = r3[1];
+            tag2 = h2 & g.tag_mask; tag3 = h3 & g.tag_mask;
+            // rows always rotate, compare or not (:935-936); q is stored un-masked (:913)
+            if (W::lane() == 0) {
+                r2[0] = q | (tag2 << g.wbits);
+                r3[0] = q | (tag3 << g.wbits);
+                r3[1] = row[1];
+            }
+            c.ht_rows += 3;
+            const uint32_t tags[3] = { tag2, tag3, tag3 };
+            for (int k = 0; k < 3; k++) {
+                const uint32_t sp = row[k] & g.wmask;
+                if ((row[k] >> g.wbits) == tags[k] && sp < q && q - sp <= g.wmask) {   // :922-925
+                    valid |= 1u << k; job_sp[k] = a - (q - sp); job_cap[k] = max_len;
+                }
+            }
+        }
+        uint32_t rkv = 0, rkh = 0;
+        bool rk_probe = false;
+        if (have256) {
+            // carried long match (:1056-1069)
+            if (rk_len > 0) {
+                if (q - rk_to < rk_len) {
+                    const uint32_t d = rk_to - rk_from, l = rk_len - (q - rk_to);
+                    if (l >= match_min(d)) mt_update(d, umin(l, kMatchMax));
+                } else rk_len = 0;
+            }
+            // window ends passed since the last call: insert with the CALLING position (:1084-1087)
+            for (uint32_t e = (rk_end | 255u) + 1; e < q + 256; e += 256) {
+                const uint32_t hh = G.rkhash[(uint32_t)(base + e - 256)];
+                if (W::lane() == 0) G.rk_table[hh >> g.rk_shift] = q | (hh << g.wbits);
+                c.rk_inserts++;
+            }
+            rk_end = q + 256;
+            rkh = G.rkhash[a];
+            if (rk_len < 256) {                                     // :1090-1095
+                W::sync_global();
+                rkv = G.rk_table[rkh >> g.rk_shift];
+                c.rk_probes++;
+                const uint32_t sp = rkv & g.wmask;
+                if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) {
+                    rk_probe = true;
+                    valid |= 1u << 3; job_sp[3] = a - (q - sp); job_cap[3] = avail & 0xFFFFu;   // uint16 parameter (:760)
+                }
+            }
+        }
+        for (int k = 0; k < 4; k++) {                               // explicit rep probes (:1601-1606)
+            rep_len[k] = 0;
+            if (rp[k] < q) { valid |= 1u << (4 + k); job_sp[4 + k] = a - rp[k]; job_cap[4 + k] = rep_cap; }
+        }
+        W::cmp_multi(G.in, job_sp, a, job_cap, valid, job_len);
+
+        // ---- HT2 (:917-933)
+        if (have4) {
+            if ((valid & 1) && 1 < max_len) {
+                const uint32_t l = job_len[0], d = a - job_sp[0];
+                c.cmp_bytes += l + (l < max_len);
+                if (l > 1 && l >= match_min(d)) mt_update(d, l);
+            }
+            uint32_t best = 1;
+            for (int k = 1; k < 3; k++) {
+                if (!((valid >> k) & 1) || !(best < max_len)) continue;
+                const uint32_t l = job_len[k], d = a - job_sp[k];
+                c.cmp_bytes += l + (l < max_len);
+                if (l > best && l >= match_min(d)) { mt_update(d, l); best = l; }
+            }
+            if (!nice) {                                            // BT4 (:1522)
+                bt_step(a, h4, max_len);
+            }
+        }
+        if (have256) {
+            if (rk_probe) {                                         // :1096-1105
+                const uint32_t l = job_len[3], sp_abs = job_sp[3], d = a - sp_abs;
+                c.cmp_bytes += l + (l < job_cap[3]);
+                if (l >= rk_len && l >= match_min(d)) {
+                    mt_update(d, umin(l, kMatchMax));
+                    rk_from = q - d; rk_to = q; rk_len = l;
+                }
+            }
+            if (!(q & 255u)) {                                      // aligned insert after the probe (:1109-1112)
+                if (W::lane() == 0) G.rk_table[rkh >> g.rk_shift] = q | (rkh << g.wbits);
+                c.rk_inserts++;
+            }
+        }
+        for (int k = 0; k < 4; k++) if ((valid >> (4 + k)) & 1) rep_len[k] = job_len[4 + k];
+        W::sync_global();
+    }
+
+    // BT4 inside the master (workers off): wave-wide compares, uniform descent.
+    NLZM_HD void bt_step(uint32_t a, uint32_t h4, uint32_t max_len)
+    {
+        WaveCmp wcmp{ &c.cmp_bytes };
+        MtSink sink{ this };
+        c.bt_calls++;
+        BtMem mem{ G.bt_heads, G.bt_tree };
+        bt_find_and_update_uniform(mem, a, h4, max_len, wcmp, sink);
+    }
+
+    struct BtMem { uint32_t *heads, *tree; };
+
+    // same control flow as bt_find_and_update, but every store is done by lane 0 only
+    // and followed by a global sync so the wave's later (uniform) loads see it
+    template <class Cmp, class Sink>
+    NLZM_HD void bt_find_and_update_uniform(BtMem &mem, uint32_t a, uint32_t h4, uint32_t max_len, Cmp &cmp, Sink &sink)
+    {
+        uint32_t *heads = mem.heads, *tree = mem.tree;
+        const uint32_t wmask = g.wmask;
+        uint32_t pend_l = (a & wmask) << 1, pend_r = pend_l + 1;
+        uint32_t len_l = 0, len_r = 0;
+        uint32_t sp = heads[h4 >> g.bt_shift];
+        if (W::lane() == 0) heads[h4 >> g.bt_shift] = a;
+        uint32_t tests = 256;
+        while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
+            c.bt_tests++;
+            const uint32_t pair = (sp & wmask) << 1;
+            const uint32_t pl = tree[pair], pr = tree[pair + 1];
+            const uint32_t r = cmp(G.in + sp, G.in + a, umin(len_l, len_r), max_len);
+            const uint32_t l = r & 0x7FFFFFFFu;
+            if (l >= match_min(a - sp)) sink(a - sp, l);
+            if (l == max_len) {
+                if (W::lane() == 0) { tree[pend_l] = pl; tree[pend_r] = pr; }
+                W::sync_global();
+                return;
+            }
+            if (r >> 31) { if (W::lane() == 0) tree[pend_l] = sp; pend_l = pair + 1; sp = pr; len_r = l; }
+            else         { if (W::lane() == 0) tree[pend_r] = sp; pend_r = pair;     sp = pl; len_l = l; }
+        }
+        if (W::lane() == 0) { tree[pend_r] = kNone; tree[pend_l] = kNone; }
+        W::sync_global();
+    }
+
+    // ---- one parse segment (:1464-1651); returns end_p, leaves the path in cmdlist
+    NLZM_HD uint32_t parse_segment(uint32_t seg_q, uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
+    {
+        max_parse = umin(max_parse, kParseMax);
+        if (W::lane() == 0) {
+            L->node_cost[0] = 0; L->node_link[0] = 0x1FFF;
+            L->node_cost[1] = kNone; L->node_link[1] = pack_link(0, 0, 0);
+            for (int k = 0; k < 4; k++) { L->reps[k] = rep[k]; L->reps[4 + k] = rep[k]; }
+        }
+        W::sync();
+        uint32_t p = 0, end_p = 1;
+        while (p < end_p) {
+            const uint32_t q = seg_q + p, a = seg_a + p;
+            c.positions++;
+            const uint32_t cost_p = L->node_cost[p];
+            uint32_t rp[4];
+            for (int k = 0; k < 4; k++) rp[k] = L->reps[(p & 511) * 4 + k];
+
+            // literal edge (:1490-1499)
+            {
+                const uint32_t cst = price_literal(G.in[a]);
+                if (L->node_cost[p + 1] > cost_p + cst) {
+                    W::sync();
+                    if (W::lane() == 0) {
+                        L->node_cost[p + 1] = cost_p + cst;
+                        L->node_link[p + 1] = pack_link(p, 0, 0);
+                        for (int k = 0; k < 4; k++) L->reps[((p + 1) & 511) * 4 + k] = rp[k];
+                    }
+                    W::sync();
+                }
+            }
+
+            uint32_t rep_len[4];
+            finders(q, a, p, rp, umin(max_parse - p, kMatchMax), rep_len);
+            capture(a);
+
+            uint32_t max_len = umin(mt_max, max_parse - p);         // :1545-1548
+            if (max_len < kMatchMin) max_len = 0;
+            open_nodes(end_p, max_len + p);
+
+            // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2
+            uint32_t checked = 0;
+            if (max_len >= kMatchMin) {
+                uint32_t step = (max_len - kMatchMin) >> 4;
+                step += step == 0;
+                const uint32_t K = (max_len - kMatchMin) / step + 1;
+                for (uint32_t k = W::lane(); k < K; k += W::width()) {
+                    const uint32_t tl = max_len - k * step;
+                    const uint32_t d = mt(tl);
+                    if (tl < match_min(d)) continue;
+                    const uint32_t np = p + tl;
+                    relax(p, np, cost_p, price_match(d, tl), 1, tl, d, rp, d);
+                    int ri = -1;
+                    for (int j = 3; j >= 0; j--) if (rp[j] == d) ri = j;
+                    if (ri < 0) continue;
+                    checked |= 1u << ri;
+                    relax(p, np, cost_p, price_rep(d, tl), 2, tl, (uint32_t)ri, rp, d);
+                }
+                checked = W::ror(checked);
+                W::sync();
+            }
+            // explicit rep probes (:1598-1628)
+            if (checked != 15) {
+                for (uint32_t ri = 0; ri < 4; ri++) {
+                    if ((checked >> ri) & 1 || rp[ri] >= q) continue;
+                    const uint32_t l = rep_len[ri];                 // already min(len, 264)
+                    c.cmp_bytes += l + 1;
+                    if (l >= match_min(rp[ri])) {
+                        open_nodes(end_p, l + p);
+                        W::sync();
+                        if (W::lane() == 0) relax(p, p + l, cost_p, price_rep(rp[ri], l), 2, l, ri, rp, rp[ri]);
+                        W::sync();
+                    }
+                }
+            }
+            ++p;
+        }
+        // backtrack (:1633-1650): collect the node indices of the path, end first
+        uint32_t n = 0, cur = p;
+        while (cur != 0) {
+            if (W::lane() == 0) L->cmdlist[n] = (uint16_t)cur;
+            n++;
+            cur = L->node_link[cur] & 0x1FFF;
+        }
+        W::sync();
+        ncmds = n;
+        c.segments++;
+        return end_p;
+    }
+
+    NLZM_HD void capture(uint32_t a)
+    {
+        if (!G.cap_words) return;
+        if (a < G.cap_lo || a >= G.cap_hi) return;
+        // record {pos, max_len, delta[2..max_len]}
+        unsigned long long used = *G.cap_used;
+        const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
+        if (used + need > G.cap_cap) { err = kErrCapture; return; }
+        W::sync_global();
+        if (W::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
+        for (uint32_t i = 2 + W::lane(); i <= mt_max; i += W::width()) G.cap_words[used + i] = mt(i);
+        if (W::lane() == 0) *G.cap_used = used + need;
+        W::sync_global();
+    }
+
+    // ---- one chunk = one frame (:1782-1886) -----------------------------------
+    NLZM_HD void run_chunk(uint32_t ci)
+    {
+        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+        const unsigned long long remain = g.n - chunk_abs;
+        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+        const uint32_t p_end = umin(g.chunk_size, chunk_read);
+        const uint32_t W2 = 2u * (g.wmask + 1);
+
+        // frame.Init (:534-550)
+        fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
+        fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
+        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0;
+
+        if (chunk_abs - base >= W2) {                               // :1786-1792
+            base += g.wmask + 1;
+            c.shifts++;
+            if (W::lane() == 0) { G.ht2[0] = kNone; G.ht3[0] = kNone; }   // MatchFinderHT::Shift (:940-957)
+            if (rk_end >= g.wmask + 1) rk_end -= g.wmask + 1; else rk_end = 0;   // :1115-1123
+            W::sync_global();
+            // BT4 keeps absolute positions: no pass over the tree (appendix D.3)
+        }
+        const uint32_t chunk_q = (uint32_t)(chunk_abs - base);
+        la_end = chunk_q + chunk_read;
+
+        uint32_t p = 0;
+        while (p < p_end && !err) {
+            uint32_t ncmds = 0;
+            parse_segment(chunk_q + p, (uint32_t)chunk_abs + p, p_end - p, ncmds);
+            for (uint32_t k = ncmds; k-- > 0;) {                    // :1809-1843
+                const uint32_t node = L->cmdlist[k];
+                const uint32_t link = L->node_link[node];
+                const uint32_t cmd = link >> 22, len = (link >> 13) & 0x1FF;
+                if (cmd == 0) { emit_literal(G.in[(uint32_t)chunk_abs + p]); p += 1; }
+                else if (cmd == 1) { emit_match(L->node_delta[node], len); p += len; }
+                else { emit_rep(L->node_delta[node], len); p += len; }
+            }
+            if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) err = kErrFrameOverflow;
+        }
+        // bit pad of Flush (:591-597)
+        c.rans_syms += nsyms; c.bit_ops += num_ops - nsyms; c.frames++;
+        for (int i = 0; i < 4; i++) {
+            if (W::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            nbits++; word <<= 8;
+        }
+        if (W::lane() == 0) {
+            FrameMeta &fm = G.fmeta[ci - G.chunk0];
+            fm.nsyms = nsyms; fm.nbits_bytes = nbits; fm.num_ops = num_ops; fm.out_len = 0;
+        }
+    }
+
+    // ---- launch prologue / epilogue -------------------------------------------
+    NLZM_HD void load_state()
+    {
+        Persist *P = G.persist;
+        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) L->cdf[i] = P->cdf[i];
+        for (uint32_t i = W::lane(); i < 256; i += W::width()) L->lut[i] = log2_lut_entry(i);
+        W::sync();
+        for (uint32_t i = W::lane(); i < kNumCtx * 16; i += W::width()) {
+            const uint32_t ctx = i >> 4, y = i & 15;
+            const uint16_t *cell = L->cdf + ctx * kCdfStride;
+            L->price[i] = (y < ctx_nsyms(ctx)) ? L->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
+        }
+        mt_base = 0; mt_max = P->mt_max;
+        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) L->mt[i] = P->mt_delta[i];
+        for (int k = 0; k < 4; k++) rep[k] = P->rep[k];
+        rk_from = P->rk_from; rk_to = P->rk_to; rk_len = P->rk_len; rk_end = P->rk_end;
+        base = P->reb_base;
+        err = P->error;
+        Counters z = {};
+        c = z;
+        W::sync();
+    }
+    NLZM_HD void store_state(uint32_t next_chunk)
+    {
+        Persist *P = G.persist;
+        W::sync();
+        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) P->cdf[i] = L->cdf[i];
+        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = mt(i);
+        if (W::lane() == 0) {
+            P->mt_max = mt_max;
+            for (int k = 0; k < 4; k++) P->rep[k] = rep[k];
+            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
+            P->reb_base = base;
+            P->next_chunk = next_chunk;
+            P->error = err;
+            unsigned long long *dst = (unsigned long long *)&P->cnt;
+            const unsigned long long *src = (const unsigned long long *)&c;
+            for (uint32_t i = 0; i < sizeof(Counters) / 8; i++) dst[i] += src[i];
+        }
+    }
+
+    NLZM_HD void run(uint32_t c0, uint32_t c1)
+    {
+        load_state();
+        uint32_t ci = c0;
+        for (; ci < c1 && !err; ci++) run_chunk(ci);
+        store_state(ci);
+    }
+};
+
+}  // namespace nlzm

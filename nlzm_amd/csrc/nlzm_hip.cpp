@@ -1,0 +1,517 @@
+// nlzm_hip.cpp -- host pipeline behind the C ABI of include/nlzm_hip.h.
+//
+// Replaces encode_file (NLZM.cpp:1711-1910): the whole input lives in HBM as one
+// flat buffer; chunks (= frames, NLZM.cpp:1724) are processed in batches by the
+// persistent match-find/parse/emit launch, then every frame of the batch is
+// rANS-coded in parallel and gathered into the output stream.
+// There is no CPU implementation of any stage in this library.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nlzm_hip.h"
+#include "nlzm_core.h"
+
+namespace nlzm {
+void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long pos0, unsigned long long pos1,
+                    uint32_t *out, hipStream_t st);
+void launch_master(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, hipStream_t st);
+void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
+                 FrameMeta *fmeta, uint32_t *scratch, unsigned long long scratch_stride, uint8_t *out,
+                 unsigned long long out_stride, uint32_t out_cap, uint32_t nframes, hipStream_t st);
+void launch_gather(const uint8_t *frames, unsigned long long stride, const unsigned long long *dst_off,
+                   const FrameMeta *fmeta, uint8_t *dst, uint32_t nframes, hipStream_t st);
+}  // namespace nlzm
+
+using namespace nlzm;
+
+namespace {
+
+char g_err[512] = "";
+int set_err(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return set_err(e_ == hipErrorOutOfMemory ? NLZM_HIP_E_NOMEM : NLZM_HIP_E_NODEVICE,    \
+                           "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+    } while (0)
+
+inline uint32_t clampu(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Ctx {
+    bool inited = false;
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};
+
+    // options
+    int64_t opt_workers = 0;
+    int64_t opt_batch = 32;
+
+    // stream state
+    bool open = false;
+    Geom g{};
+    const uint8_t *d_in = nullptr;
+    uint8_t *d_dst = nullptr;
+    uint64_t dst_cap = 0, out_pos = 0;
+    uint32_t next_chunk = 0;
+
+    // device buffers
+    uint32_t *rkhash = nullptr, *ht2 = nullptr, *ht3 = nullptr, *rk_table = nullptr, *bt_heads = nullptr, *bt_tree = nullptr;
+    Persist *persist = nullptr;
+    uint32_t *syms = nullptr, *scratch = nullptr;
+    uint8_t *bits = nullptr, *frames = nullptr;
+    FrameMeta *fmeta = nullptr;
+    unsigned long long *dst_off = nullptr;
+    unsigned long long syms_stride = 0, bits_stride = 0, frame_stride = 0;
+    uint32_t batch = 0;
+
+    // capture (stage tests)
+    uint32_t *cap_words = nullptr; unsigned long long cap_cap = 0, cap_lo = 0, cap_hi = 0; unsigned long long *cap_used = nullptr;
+    // frame capture for parse_emit
+    int64_t want_frame = -1;
+    std::vector<uint32_t> got_syms; std::vector<uint8_t> got_bits; FrameMeta got_meta{};
+    bool got = false;
+
+    // owned copies for the host-buffer entry point
+    uint8_t *own_in = nullptr, *own_dst = nullptr;
+
+    nlzm_hip_stats stats{};
+    nlzm_hip_timing tm{};
+};
+
+Ctx C;
+
+void free_stream_buffers()
+{
+    void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
+                     C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
+    C.persist = nullptr; C.syms = C.scratch = nullptr; C.bits = C.frames = nullptr; C.fmeta = nullptr;
+    C.dst_off = nullptr; C.own_in = C.own_dst = nullptr;
+    C.open = false;
+}
+
+void make_geom(uint64_t n, uint32_t hist_bits_req, Geom &g)
+{
+    uint32_t hb = hist_bits_req;
+    while (hb > 10 && n < (1ull << (hb - 1))) --hb;                 // NLZM.cpp:1716-1718
+    g.n = n;
+    g.wbits = hb; g.wmask = (1u << hb) - 1;
+    g.frame_bits = clampu(hb - 2, 14, 17);                          // :1722
+    g.frame_size = 1u << g.frame_bits;
+    g.chunk_size = ((g.frame_size * 15) / 16) - 0x200;              // :1724
+    g.feed = g.chunk_size + kMatchMax + 1;                          // :1725
+    g.ht3_shift = 32 - (12 + clampu(hb, 15, 17) - 15);              // :1751
+    g.bt_shift = 32 - (13 + clampu(hb, 16, 20) - 16);               // :1752
+    g.rk_shift = 32 - (15 + clampu(hb, 16, 22) - 16);               // :1753
+    g.tag_mask = (uint32_t)((1ull << (32 - hb)) - 1);
+    g.nchunks = (uint32_t)((n + g.chunk_size - 1) / g.chunk_size);
+}
+
+int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
+{
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (n >= 0xFFFF0000ull) return set_err(NLZM_HIP_E_TOOBIG, "input of %llu bytes needs >32-bit positions", (unsigned long long)n);
+    if (hist_bits_req < 10 || hist_bits_req > 28) return set_err(NLZM_HIP_E_ARG, "hist_bits %u outside [10,28]", hist_bits_req);
+    if (dst_cap < 8) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap < 8");
+    {   // keep caller-visible buffers of a host-entry call alive across the reset
+        uint8_t *oi = C.own_in, *od = C.own_dst;
+        C.own_in = C.own_dst = nullptr;
+        free_stream_buffers();
+        C.own_in = oi; C.own_dst = od;
+    }
+    make_geom(n, hist_bits_req, C.g);
+    const Geom &g = C.g;
+    C.d_in = (const uint8_t *)d_src; C.d_dst = (uint8_t *)d_dst; C.dst_cap = dst_cap;
+    C.out_pos = 0; C.next_chunk = 0;
+    memset(&C.stats, 0, sizeof C.stats);
+    memset(&C.tm, 0, sizeof C.tm);
+    C.stats.in_bytes = n;
+
+    const size_t ht3_rows = (size_t)2 << (32 - g.ht3_shift);
+    HIPCHK(hipMalloc(&C.rkhash, (n + 1024) * 4 + 16));
+    HIPCHK(hipMalloc(&C.ht2, 4096 * 4));
+    HIPCHK(hipMalloc(&C.ht3, ht3_rows * 4));
+    HIPCHK(hipMalloc(&C.rk_table, (size_t)4 << (32 - g.rk_shift)));
+    HIPCHK(hipMalloc(&C.bt_heads, (size_t)4 << (32 - g.bt_shift)));
+    HIPCHK(hipMalloc(&C.bt_tree, (size_t)8 << g.wbits));
+    HIPCHK(hipMalloc(&C.persist, sizeof(Persist)));
+    HIPCHK(hipMemsetAsync(C.ht2, 0xFF, 4096 * 4, C.st));                         // :902
+    HIPCHK(hipMemsetAsync(C.ht3, 0xFF, ht3_rows * 4, C.st));
+    HIPCHK(hipMemsetAsync(C.rk_table, 0xFF, (size_t)4 << (32 - g.rk_shift), C.st));   // :1040
+    HIPCHK(hipMemsetAsync(C.bt_heads, 0xFF, (size_t)4 << (32 - g.bt_shift), C.st));   // :968
+    HIPCHK(hipMemsetAsync(C.bt_tree, 0xFF, (size_t)8 << g.wbits, C.st));              // :969
+
+    Persist P;
+    memset(&P, 0, sizeof P);
+    for (uint32_t ctx = 0; ctx < kNumCtx; ctx++) {                                // model_init :1183-1206, cdf_init :324-346
+        const uint32_t ns = (ctx == kCtxCmd) ? 4 : ((ctx == kCtxLenDirect || ctx >= kCtxSlotHi) ? 8 : 16);
+        for (uint32_t i = 0; i <= ns; i++) P.cdf[ctx * kCdfStride + i] = (uint16_t)(i * (16384 / ns));
+    }
+    for (int i = 0; i < 4; i++) P.rep[i] = (uint32_t)i + 1;                       // :1154-1158
+    HIPCHK(hipMemcpyAsync(C.persist, &P, sizeof P, hipMemcpyHostToDevice, C.st));
+
+    C.batch = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
+    if (C.batch > g.nchunks && g.nchunks) C.batch = g.nchunks;
+    if (!C.batch) C.batch = 1;
+    C.syms_stride = 3ull * g.chunk_size + 4096;          // <= 3 symbols per input byte
+    C.bits_stride = 2ull * g.chunk_size + 64;            // <= 13 raw bits per input byte
+    C.frame_stride = 12 + C.bits_stride + 16 + 2 * C.syms_stride;
+    HIPCHK(hipMalloc(&C.syms, C.batch * C.syms_stride * 4));
+    HIPCHK(hipMalloc(&C.scratch, C.batch * C.syms_stride * 4));
+    HIPCHK(hipMalloc(&C.bits, C.batch * C.bits_stride));
+    HIPCHK(hipMalloc(&C.frames, C.batch * C.frame_stride));
+    HIPCHK(hipMalloc(&C.fmeta, C.batch * sizeof(FrameMeta)));
+    HIPCHK(hipMalloc(&C.dst_off, C.batch * sizeof(unsigned long long)));
+
+    // stream header (:1762-1766)
+    const uint8_t hdr[4] = { (uint8_t)(g.wbits >> 8), (uint8_t)g.wbits, (uint8_t)(g.frame_bits >> 8), (uint8_t)g.frame_bits };
+    HIPCHK(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
+    C.out_pos = 4;
+
+    // pre-pass: RK256 hash of every window
+    HIPCHK(hipEventRecord(C.ev[0], C.st));
+    if (n >= 256) launch_rk_hash(C.d_in, n, 0, n - 255, C.rkhash, C.st);
+    HIPCHK(hipEventRecord(C.ev[1], C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, C.ev[0], C.ev[1]));
+    C.tm.prep_ms += ms; C.tm.prep_launches += n >= 256;
+    C.tm.total_ms += ms;
+    C.open = true;
+    return 0;
+}
+
+int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
+{
+    if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
+    const Geom &g = C.g;
+    uint32_t todo = g.nchunks - C.next_chunk;
+    if (max_chunks && todo > max_chunks) todo = max_chunks;
+    std::vector<FrameMeta> hm(C.batch);
+    std::vector<unsigned long long> hoff(C.batch);
+    while (todo) {
+        const uint32_t c0 = C.next_chunk, nb = todo < C.batch ? todo : C.batch, c1 = c0 + nb;
+        Globals G;
+        memset(&G, 0, sizeof G);
+        G.in = C.d_in; G.rkhash = C.rkhash; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
+        G.bt_heads = C.bt_heads; G.bt_tree = C.bt_tree; G.persist = C.persist;
+        G.syms = C.syms; G.syms_stride = C.syms_stride; G.bits = C.bits; G.bits_stride = C.bits_stride;
+        G.fmeta = C.fmeta; G.chunk0 = c0;
+        G.cap_words = C.cap_words; G.cap_cap = C.cap_cap; G.cap_lo = C.cap_lo; G.cap_hi = C.cap_hi; G.cap_used = C.cap_used;
+
+        HIPCHK(hipEventRecord(C.ev[0], C.st));
+        launch_master(g, G, c0, c1, C.st);
+        HIPCHK(hipEventRecord(C.ev[1], C.st));
+        launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
+                    C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
+        HIPCHK(hipEventRecord(C.ev[2], C.st));
+        HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
+        Persist P;
+        HIPCHK(hipMemcpyAsync(&P, C.persist, sizeof P, hipMemcpyDeviceToHost, C.st));
+        HIPCHK(hipStreamSynchronize(C.st));
+        HIPCHK(hipGetLastError());
+        if (P.error) return set_err(NLZM_HIP_E_KERNEL, "device error %u at chunk %u (info %u %u %u)", P.error, P.next_chunk,
+                                    P.error_info[0], P.error_info[1], P.error_info[2]);
+        if (P.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", P.next_chunk, c1);
+        unsigned long long pos = C.out_pos;
+        for (uint32_t f = 0; f < nb; f++) {
+            // the reference asserts that the frame fits its buffer (:592, :610); the first one is 4 bytes shorter (:1784)
+            const uint32_t room = g.frame_size - ((c0 + f) == 0 ? 4 : 0);
+            if (hm[f].out_len > room)
+                return set_err(NLZM_HIP_E_KERNEL, "frame %u is %u bytes: the reference would assert (:610)", c0 + f, hm[f].out_len);
+            hoff[f] = pos; pos += hm[f].out_len;
+        }
+        if (pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap %llu too small", (unsigned long long)C.dst_cap);
+        if (C.want_frame >= (int64_t)c0 && C.want_frame < (int64_t)c1) {
+            const uint32_t f = (uint32_t)(C.want_frame - c0);
+            C.got_meta = hm[f];
+            C.got_syms.resize(hm[f].nsyms); C.got_bits.resize(hm[f].nbits_bytes);
+            HIPCHK(hipMemcpy(C.got_syms.data(), C.syms + f * C.syms_stride, hm[f].nsyms * 4ull, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(C.got_bits.data(), C.bits + f * C.bits_stride, hm[f].nbits_bytes, hipMemcpyDeviceToHost));
+            C.got = true;
+        }
+        HIPCHK(hipMemcpyAsync(C.dst_off, hoff.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, C.st));
+        HIPCHK(hipEventRecord(C.ev[3], C.st));
+        launch_gather(C.frames, C.frame_stride, C.dst_off, C.fmeta, C.d_dst, nb, C.st);
+        HIPCHK(hipEventRecord(C.ev[4], C.st));
+        HIPCHK(hipStreamSynchronize(C.st));
+        float a = 0, b = 0, c = 0;
+        HIPCHK(hipEventElapsedTime(&a, C.ev[0], C.ev[1]));
+        HIPCHK(hipEventElapsedTime(&b, C.ev[1], C.ev[2]));
+        HIPCHK(hipEventElapsedTime(&c, C.ev[3], C.ev[4]));
+        C.tm.match_parse_ms += a; C.tm.match_parse_launches++;
+        C.tm.rans_ms += b + c; C.tm.rans_launches++;
+        C.tm.total_ms += a + b + c;
+        C.out_pos = pos;
+        C.next_chunk = c1;
+        todo -= nb;
+    }
+    if (in_done) {
+        const unsigned long long d = (unsigned long long)C.next_chunk * g.chunk_size;
+        *in_done = d < g.n ? d : g.n;
+    }
+    if (out_done) *out_done = C.out_pos;
+    if (finished) *finished = C.next_chunk >= g.nchunks;
+    return 0;
+}
+
+int stream_finish(uint64_t *dst_len)
+{
+    if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
+    if (C.next_chunk < C.g.nchunks) return set_err(NLZM_HIP_E_ARG, "stream not finished (%u of %u chunks)", C.next_chunk, C.g.nchunks);
+    if (C.out_pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap too small");
+    HIPCHK(hipMemsetAsync(C.d_dst + C.out_pos, 0, 4, C.st));        // terminator (:1891-1895)
+    C.out_pos += 4;
+    Persist P;
+    HIPCHK(hipMemcpyAsync(&P, C.persist, sizeof P, hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    nlzm_hip_stats &s = C.stats;
+    s.out_bytes = C.out_pos;
+    s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes; s.ht_rows = P.cnt.ht_rows;
+    s.rk_probes = P.cnt.rk_probes; s.rk_inserts = P.cnt.rk_inserts; s.positions = P.cnt.positions;
+    s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
+    s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
+    s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
+    if (dst_len) *dst_len = C.out_pos;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlzm_hip_init(int device)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return set_err(NLZM_HIP_E_NODEVICE, "no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return set_err(NLZM_HIP_E_ARG, "device %d out of range (%d present)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(NLZM_HIP_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if (C.inited && C.device == device) return 0;
+    if (C.inited) nlzm_hip_shutdown();
+    C.device = device;
+    HIPCHK(hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking));
+    for (auto &ev : C.ev) HIPCHK(hipEventCreate(&ev));
+    C.inited = true;
+    return 0;
+}
+
+void nlzm_hip_shutdown(void)
+{
+    if (!C.inited) return;
+    free_stream_buffers();
+    if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
+    if (C.cap_used) { (void)hipFree(C.cap_used); C.cap_used = nullptr; }
+    for (auto &ev : C.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (C.st) { (void)hipStreamDestroy(C.st); C.st = nullptr; }
+    C.inited = false;
+}
+
+const char *nlzm_hip_last_error(void) { return g_err; }
+
+uint64_t nlzm_hip_compress_bound(uint64_t n)
+{
+    // worst ratio frame_size/chunk_size is 16384/14848 (hist_bits <= 16)
+    return 16 + 131072 + (n / 14848 + 1) * 16384;
+}
+
+void nlzm_hip_geometry(uint64_t flen, uint32_t hist_bits_req, uint32_t *hist_bits, uint32_t *frame_bits,
+                       uint32_t *chunk_size, uint32_t *feed_size)
+{
+    Geom g;
+    make_geom(flen, hist_bits_req, g);
+    if (hist_bits) *hist_bits = g.wbits;
+    if (frame_bits) *frame_bits = g.frame_bits;
+    if (chunk_size) *chunk_size = g.chunk_size;
+    if (feed_size) *feed_size = g.feed;
+}
+
+int nlzm_hip_stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
+{
+    if (C.own_in) { (void)hipFree(C.own_in); C.own_in = nullptr; }
+    if (C.own_dst) { (void)hipFree(C.own_dst); C.own_dst = nullptr; }
+    return stream_begin(d_src, n, hist_bits_req, d_dst, dst_cap);
+}
+int nlzm_hip_stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
+{
+    return stream_step(max_chunks, in_done, out_done, finished);
+}
+int nlzm_hip_stream_finish(uint64_t *dst_len) { return stream_finish(dst_len); }
+
+int nlzm_hip_compress_dev(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap,
+                          uint64_t *dst_len)
+{
+    int rc = nlzm_hip_stream_begin(d_src, n, hist_bits_req, d_dst, dst_cap);
+    if (rc) return rc;
+    rc = stream_step(0, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return stream_finish(dst_len);
+}
+
+int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint8_t *dst, uint64_t dst_cap,
+                      uint64_t *dst_len)
+{
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if ((!src && n) || !dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
+    if (n >= 0xFFFF0000ull) return set_err(NLZM_HIP_E_TOOBIG, "input too large");
+    if (C.own_in) { (void)hipFree(C.own_in); C.own_in = nullptr; }
+    if (C.own_dst) { (void)hipFree(C.own_dst); C.own_dst = nullptr; }
+    const uint64_t bound = nlzm_hip_compress_bound(n);
+    HIPCHK(hipMalloc(&C.own_in, n + 64));
+    HIPCHK(hipMalloc(&C.own_dst, bound));
+    HIPCHK(hipEventRecord(C.ev[5], C.st));
+    HIPCHK(hipMemsetAsync(C.own_in + n, 0, 64, C.st));
+    if (n) HIPCHK(hipMemcpyAsync(C.own_in, src, n, hipMemcpyHostToDevice, C.st));
+    HIPCHK(hipEventRecord(C.ev[6], C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    float h2d = 0;
+    HIPCHK(hipEventElapsedTime(&h2d, C.ev[5], C.ev[6]));
+    int rc = stream_begin(C.own_in, n, hist_bits_req, C.own_dst, bound);
+    if (rc) return rc;
+    rc = stream_step(0, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    uint64_t len = 0;
+    rc = stream_finish(&len);
+    if (rc) return rc;
+    if (len > dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "stream is %llu bytes, dst_cap %llu", (unsigned long long)len, (unsigned long long)dst_cap);
+    HIPCHK(hipEventRecord(C.ev[5], C.st));
+    HIPCHK(hipMemcpyAsync(dst, C.own_dst, len, hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipEventRecord(C.ev[6], C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    float d2h = 0;
+    HIPCHK(hipEventElapsedTime(&d2h, C.ev[5], C.ev[6]));
+    C.tm.h2d_ms = h2d; C.tm.d2h_ms = d2h;
+    *dst_len = len;
+    return 0;
+}
+
+int nlzm_hip_get_stats(nlzm_hip_stats *out)
+{
+    if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
+    *out = C.stats;
+    return 0;
+}
+
+int nlzm_hip_get_timing(nlzm_hip_timing *out)
+{
+    if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
+    *out = C.tm;
+    return 0;
+}
+
+int nlzm_hip_set_option(const char *key, int64_t value)
+{
+    if (!key) return set_err(NLZM_HIP_E_ARG, "null key");
+    if (!strcmp(key, "workers")) { C.opt_workers = value; return 0; }
+    if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
+    return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
+}
+
+int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off, const uint8_t *bits, const uint64_t *bits_off,
+                         const uint32_t *num_ops, uint32_t nframes, uint8_t *out, uint64_t out_stride, uint32_t *out_len)
+{
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (!nframes) return 0;
+    if (!syms || !sym_off || !bits || !bits_off || !num_ops || !out || !out_len) return set_err(NLZM_HIP_E_ARG, "null argument");
+    uint64_t max_syms = 1, max_bits = 4;
+    for (uint32_t f = 0; f < nframes; f++) {
+        if (sym_off[f + 1] - sym_off[f] > max_syms) max_syms = sym_off[f + 1] - sym_off[f];
+        if (bits_off[f + 1] - bits_off[f] > max_bits) max_bits = bits_off[f + 1] - bits_off[f];
+    }
+    uint32_t *d_syms = nullptr, *d_scr = nullptr; uint8_t *d_bits = nullptr, *d_out = nullptr; FrameMeta *d_fm = nullptr;
+    const unsigned long long fstride = 12 + max_bits + 16 + 2 * max_syms;
+    HIPCHK(hipMalloc(&d_syms, nframes * max_syms * 4));
+    HIPCHK(hipMalloc(&d_scr, nframes * max_syms * 4));
+    HIPCHK(hipMalloc(&d_bits, nframes * max_bits));
+    HIPCHK(hipMalloc(&d_out, nframes * fstride));
+    HIPCHK(hipMalloc(&d_fm, nframes * sizeof(FrameMeta)));
+    std::vector<FrameMeta> hm(nframes);
+    for (uint32_t f = 0; f < nframes; f++) {
+        const uint64_t ns = sym_off[f + 1] - sym_off[f], nb = bits_off[f + 1] - bits_off[f];
+        hm[f].nsyms = (uint32_t)ns; hm[f].nbits_bytes = (uint32_t)nb; hm[f].num_ops = num_ops[f]; hm[f].out_len = 0;
+        if (ns) HIPCHK(hipMemcpyAsync(d_syms + f * max_syms, syms + sym_off[f], ns * 4, hipMemcpyHostToDevice, C.st));
+        if (nb) HIPCHK(hipMemcpyAsync(d_bits + f * max_bits, bits + bits_off[f], nb, hipMemcpyHostToDevice, C.st));
+    }
+    HIPCHK(hipMemcpyAsync(d_fm, hm.data(), nframes * sizeof(FrameMeta), hipMemcpyHostToDevice, C.st));
+    launch_rans(d_syms, max_syms, d_bits, max_bits, d_fm, d_scr, max_syms, d_out, fstride, (uint32_t)fstride, nframes, C.st);
+    HIPCHK(hipMemcpyAsync(hm.data(), d_fm, nframes * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    HIPCHK(hipGetLastError());
+    int rc = 0;
+    for (uint32_t f = 0; f < nframes && !rc; f++) {
+        out_len[f] = hm[f].out_len;
+        if (hm[f].out_len > out_stride) { rc = set_err(NLZM_HIP_E_CAPACITY, "frame %u needs %u bytes", f, hm[f].out_len); break; }
+        HIPCHK(hipMemcpy(out + f * out_stride, d_out + f * fstride, hm[f].out_len, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_syms); (void)hipFree(d_scr); (void)hipFree(d_bits); (void)hipFree(d_out); (void)hipFree(d_fm);
+    return rc;
+}
+
+int nlzm_hip_find_matches(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint64_t pos_lo, uint64_t pos_hi,
+                          uint32_t *out_words, uint64_t cap_words, uint64_t *used_words)
+{
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (!out_words || !used_words) return set_err(NLZM_HIP_E_ARG, "null argument");
+    if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
+    if (C.cap_used) { (void)hipFree(C.cap_used); C.cap_used = nullptr; }
+    HIPCHK(hipMalloc(&C.cap_words, (cap_words + 1) * 4));
+    HIPCHK(hipMalloc(&C.cap_used, 8));
+    HIPCHK(hipMemset(C.cap_used, 0, 8));
+    C.cap_cap = cap_words; C.cap_lo = pos_lo; C.cap_hi = pos_hi;
+    const uint64_t bound = nlzm_hip_compress_bound(n);
+    std::vector<uint8_t> tmp(bound);
+    uint64_t len = 0;
+    int rc = nlzm_hip_compress(src, n, hist_bits_req, tmp.data(), bound, &len);
+    unsigned long long used = 0;
+    if (!rc) {
+        HIPCHK(hipMemcpy(&used, C.cap_used, 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_words, C.cap_words, used * 4, hipMemcpyDeviceToHost));
+        *used_words = used;
+    }
+    (void)hipFree(C.cap_words); (void)hipFree(C.cap_used);
+    C.cap_words = nullptr; C.cap_used = nullptr; C.cap_cap = 0;
+    return rc;
+}
+
+int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint32_t frame_idx, uint32_t *syms,
+                        uint32_t cap_syms, uint8_t *bits, uint32_t cap_bits, uint32_t *sizes_out)
+{
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (!syms || !bits || !sizes_out) return set_err(NLZM_HIP_E_ARG, "null argument");
+    C.want_frame = frame_idx; C.got = false;
+    const uint64_t bound = nlzm_hip_compress_bound(n);
+    std::vector<uint8_t> tmp(bound);
+    uint64_t len = 0;
+    int rc = nlzm_hip_compress(src, n, hist_bits_req, tmp.data(), bound, &len);
+    C.want_frame = -1;
+    if (rc) return rc;
+    if (!C.got) return set_err(NLZM_HIP_E_ARG, "frame %u does not exist", frame_idx);
+    if (C.got_meta.nsyms > cap_syms || C.got_meta.nbits_bytes > cap_bits) return set_err(NLZM_HIP_E_CAPACITY, "capture buffers too small");
+    memcpy(syms, C.got_syms.data(), C.got_meta.nsyms * 4ull);
+    memcpy(bits, C.got_bits.data(), C.got_meta.nbits_bytes);
+    sizes_out[0] = C.got_meta.nsyms; sizes_out[1] = C.got_meta.nbits_bytes; sizes_out[2] = C.got_meta.num_ops;
+    return 0;
+}
+
+}  // extern "C"
