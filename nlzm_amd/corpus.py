@@ -169,7 +169,30 @@ def mixed(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
-_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed}
+def dups(size: int, seed: int = SEED) -> np.ndarray:
+    """Long duplicated spans: incompressible blocks repeated at distances that exercise the
+    RK256 finder (>= 256 B), its carried match and the uint16 truncation of its length cap
+    (spans >= 65,536 B), separated by text."""
+    rng = np.random.default_rng(seed ^ 0xD0B5)
+    out = np.empty(size, dtype=np.uint8)
+    blocks = [random_bytes(int(k), seed + i + 1) for i, k in enumerate((70_000, 300, 5_000, 66_000, 1_000))]
+    pos = 0
+    i = 0
+    while pos < size:
+        if i % 2 == 0:
+            b = syn_text(int(rng.integers(2_000, 40_000)), seed + 100 + i)
+        else:
+            b = blocks[int(rng.integers(0, len(blocks)))]
+            off = int(rng.integers(0, 3)) * 7
+            b = b[off:]
+        k = min(len(b), size - pos)
+        out[pos:pos + k] = b[:k]
+        pos += k
+        i += 1
+    return out
+
+
+_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

@@ -95,6 +95,22 @@ struct FrameMeta {
     uint32_t nsyms, nbits_bytes, num_ops, out_len;
 };
 
+// BT4 result of one position, written by a worker lane and read by the master.
+// 64 bytes: word 0 = ready, word 1 = count | tests<<16, then up to 6 (distance,
+// length) pairs -- the record-setters of the descent (descent order is by
+// increasing distance, so only a longer match changes the table: :835-852).
+// count > 6: pair 6 = {overflow block index, 0} and pairs 6.. live in that pool block.
+struct BtResult {
+    uint32_t w[16];
+};
+constexpr uint32_t kBtInline = 7;
+constexpr uint32_t kOvfBlock = 256;             // pairs per overflow block (<= 256 tests per call)
+constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
+
+struct WorkerCounters {
+    unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
+};
+
 // Everything the master needs from HBM.
 struct Globals {
     const uint8_t *in;          // input, followed by >= 16 padding bytes
@@ -109,6 +125,21 @@ struct Globals {
     uint32_t chunk0;
     // optional capture of match tables (stage test)
     uint32_t *cap_words; unsigned long long cap_cap, cap_lo, cap_hi; unsigned long long *cap_used;
+    // ---- worker mode: BT4 on per-head worker lanes ------------------------------
+    uint32_t workers;           // 0: BT4 runs inside the master workgroup
+    uint32_t batch_a0;          // absolute position of the first byte of this launch
+    BtResult *bt_res;           // [a - batch_a0]
+    uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
+    const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
+    uint32_t *ovf_pool;         // overflow blocks of kOvfBlock pairs
+    uint32_t *ovf_next;         // bump allocator (block index)
+    uint32_t ovf_blocks;
+    const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
+    const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by head, ascending
+    uint32_t nheads;
+    uint32_t *abort_word;       // nonzero: every role leaves its loops
+    WorkerCounters *wcnt;
+    void *hook_user;            // host simulation only
 };
 
 // LDS image of the master workgroup.
@@ -122,6 +153,8 @@ struct MasterLds {
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];           // log2_lut[freq>>6] per (context, symbol)  (:435-438)
     uint16_t lut[256];                      // log2_lut (:97-124)
+    uint32_t btrec[16];                     // worker result being consumed
+    uint32_t btovf[2 * kOvfBlock];
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -179,32 +212,108 @@ NLZM_HD void rep_add(uint32_t r[4], uint32_t d)     // :1160-1171
 // worker kernel); `Sink` receives every (distance, length) the reference would
 // pass to MatchTable::Update (:996-998).
 // ---------------------------------------------------------------------------
-template <class Cmp, class Sink>
+// `kWrite` = false is a dry run: the same descent (the links a call rewrites are
+// never read again by that call), all matches reported, nothing stored.
+template <bool kWrite, class Cmp, class Sink>
 NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask,
                                 const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
-                                Cmp &cmp, Sink &sink, unsigned long long &n_tests)
+                                Cmp &cmp, Sink &sink, uint32_t &n_tests)
 {
     uint32_t pend_l = (a & wmask) << 1, pend_r = pend_l + 1;     // indices into tree[]
     uint32_t len_l = 0, len_r = 0;
     uint32_t sp = heads[h4 >> bt_shift];
-    heads[h4 >> bt_shift] = a;
+    if (kWrite) heads[h4 >> bt_shift] = a;
     uint32_t tests = 256;                                       // :777, :988 (uint16 there; never wraps)
     while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
         n_tests++;
         const uint32_t pair = (sp & wmask) << 1;
+        const uint32_t pl = tree[pair], pr = tree[pair + 1];
         const uint32_t r = cmp(in + sp, in + a, umin(len_l, len_r), max_len);
         const uint32_t l = r & 0x7FFFFFFFu;
         if (l >= match_min(a - sp)) sink(a - sp, l);
         if (l == max_len) {                                     // :1000-1004
-            tree[pend_l] = tree[pair];
-            tree[pend_r] = tree[pair + 1];
+            if (kWrite) { tree[pend_l] = pl; tree[pend_r] = pr; }
             return;
         }
-        if (r >> 31) { tree[pend_l] = sp; pend_l = pair + 1; sp = tree[pend_l]; len_r = l; }
-        else         { tree[pend_r] = sp; pend_r = pair;     sp = tree[pend_r]; len_l = l; }
+        if (r >> 31) { if (kWrite) tree[pend_l] = sp; pend_l = pair + 1; sp = pr; len_r = l; }
+        else         { if (kWrite) tree[pend_r] = sp; pend_r = pair;     sp = pl; len_l = l; }
     }
-    tree[pend_r] = kNone;                                       // :1020-1021
-    tree[pend_l] = kNone;
+    if (kWrite) { tree[pend_r] = kNone; tree[pend_l] = kNone; } // :1020-1021
+}
+
+// ---------------------------------------------------------------------------
+// Worker lane: one BT4 call for absolute position `a`, lane-serial.
+// IO supplies the agent-scope stores used to hand the result to the master.
+// ---------------------------------------------------------------------------
+struct LaneCmp {
+    unsigned long long *cmp_bytes;
+    NLZM_HD uint32_t operator()(const uint8_t *s, const uint8_t *t, uint32_t init, uint32_t cap) const
+    {
+        uint32_t l = init;
+        while (l < cap) {
+            const unsigned long long x = load64u(s + l), y = load64u(t + l);
+            const unsigned long long d = x ^ y;
+            if (d) {
+                const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                if (l + nb < cap) {
+                    *cmp_bytes += (l + nb - init) + 1;
+                    return (l + nb) | ((uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF)) << 31);
+                }
+                break;
+            }
+            l += 8;
+        }
+        *cmp_bytes += cap - init;
+        return cap;
+    }
+};
+
+template <class IO>
+struct ResultSink {
+    const Globals *G;
+    uint32_t *rec;          // BtResult words of this position (nullptr: do not publish)
+    uint32_t count, best, ovf_base;
+    bool failed;
+    NLZM_HD void operator()(uint32_t d, uint32_t l)
+    {
+        if (!rec || l <= best) return;      // only record-setters change the table
+        best = l;
+        if (count < kBtInline - 1) {
+            IO::st_agent(rec + 2 + 2 * count, d);
+            IO::st_agent(rec + 3 + 2 * count, l);
+        } else {
+            if (count == kBtInline - 1) {
+                const uint32_t blk = IO::atomic_inc(G->ovf_next);
+                if (blk >= G->ovf_blocks) { failed = true; return; }
+                ovf_base = blk * kOvfBlock * 2;
+                IO::st_agent(rec + 2 + 2 * (kBtInline - 1), blk);
+                IO::st_agent(rec + 3 + 2 * (kBtInline - 1), 0);
+            }
+            const uint32_t k = count - (kBtInline - 1);
+            IO::st_agent(G->ovf_pool + ovf_base + 2 * k, d);
+            IO::st_agent(G->ovf_pool + ovf_base + 2 * k + 1, l);
+        }
+        count++;
+    }
+};
+
+// returns false when the overflow pool is exhausted
+template <class IO, bool kWrite>
+NLZM_HD bool worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, bool publish,
+                            unsigned long long &n_tests, unsigned long long &cmp_bytes)
+{
+    LaneCmp cmp{ &cmp_bytes };
+    ResultSink<IO> sink{ &G, publish ? G.bt_res[a - G.batch_a0].w : nullptr, 0, 1, 0, false };
+    uint32_t tests = 0;
+    const uint32_t h4 = hash4(load32u(G.in + a));
+    bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, G.in, a, h4, max_len, cmp, sink, tests);
+    n_tests += tests;
+    if (publish) {
+        IO::st_agent(sink.rec + 1, sink.count | (tests << 16));
+        IO::drain();                        // every payload store has left before the ready word
+        IO::st_agent(sink.rec + 0, 1u);
+    }
+    return !sink.failed;
 }
 
 // ---------------------------------------------------------------------------
@@ -229,7 +338,7 @@ struct Master {
     uint32_t nsyms, nbits, word, word_bits, num_ops;
 
     Counters c;
-    uint32_t err;
+    uint32_t err, err_info0;
 
     // ---- LDS accessors ----------------------------------------------------
     NLZM_HD uint32_t &mt(uint32_t i) { return L->mt[(mt_base + i) & 511]; }
@@ -451,6 +560,17 @@ struct Master {
 
         const bool nice = mt_max >= kNice;                          // :1514
         c.nice_positions += nice ? 1 : 0;
+        if (G.workers) {
+            // tell the worker that owns this position's BT4 head whether the call happens
+            const uint32_t bi = a - G.batch_a0;
+            if (G.unc[bi]) {
+                c.uncertain_positions++;
+                if (W::lane() == 0) W::st_agent(G.bt_flag + bi, nice ? kFlagSkip : kFlagCall);
+            } else if (nice) {
+                // the pre-filter promised that no match of 65+ bytes ends up in the table at a-1
+                err = kErrInternal; err_info0 = a;
+            }
+        }
         const bool call = !nice || !(p & 7);                        // :1529
         const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
@@ -532,7 +652,7 @@ struct Master {
                 if (l > best && l >= match_min(d)) { mt_update(d, l); best = l; }
             }
             if (!nice) {                                            // BT4 (:1522)
-                bt_step(a, h4, max_len);
+                if (G.workers) bt_consume(a); else bt_step(a, h4, max_len);
             }
         }
         if (have256) {
@@ -551,6 +671,36 @@ struct Master {
         }
         for (int k = 0; k < 4; k++) if ((valid >> (4 + k)) & 1) rep_len[k] = job_len[4 + k];
         W::sync_global();
+    }
+
+    // BT4 result of a worker lane: wait for it, then merge its pairs (MatchTable::Update, :996-998).
+    NLZM_HD void bt_consume(uint32_t a)
+    {
+        const uint32_t *rec = G.bt_res[a - G.batch_a0].w;
+        W::wait_hook(G.hook_user, a);
+        const unsigned long long t0 = W::clock();
+        uint32_t spins = 0;
+        while (W::ld_agent(rec) != 1u) {
+            if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { err = kErrTimeout; err_info0 = a; return; }
+            W::sleep();
+        }
+        // the ready word was stored after every payload word had been written through
+        W::sync();
+        for (uint32_t i = W::lane(); i < 16; i += W::width()) L->btrec[i] = W::ld_agent(rec + i);
+        W::sync();
+        const uint32_t count = L->btrec[1] & 0xFFFFu;
+        if (count > kBtInline - 1) {
+            const uint32_t *ov = G.ovf_pool + (unsigned long long)L->btrec[2 + 2 * (kBtInline - 1)] * kOvfBlock * 2;
+            const uint32_t nov = (count - (kBtInline - 1)) * 2;
+            for (uint32_t i = W::lane(); i < nov; i += W::width()) L->btovf[i] = W::ld_agent(ov + i);
+            W::sync();
+        }
+        for (uint32_t k = 0; k < count; k++) {
+            uint32_t d, l;
+            if (k < kBtInline - 1) { d = L->btrec[2 + 2 * k]; l = L->btrec[3 + 2 * k]; }
+            else { d = L->btovf[2 * (k - (kBtInline - 1))]; l = L->btovf[2 * (k - (kBtInline - 1)) + 1]; }
+            mt_update(d, l);
+        }
     }
 
     // BT4 inside the master (workers off): wave-wide compares, uniform descent.
@@ -769,7 +919,7 @@ struct Master {
         for (int k = 0; k < 4; k++) rep[k] = P->rep[k];
         rk_from = P->rk_from; rk_to = P->rk_to; rk_len = P->rk_len; rk_end = P->rk_end;
         base = P->reb_base;
-        err = P->error;
+        err = P->error; err_info0 = 0;
         Counters z = {};
         c = z;
         W::sync();
@@ -787,6 +937,7 @@ struct Master {
             P->reb_base = base;
             P->next_chunk = next_chunk;
             P->error = err;
+            if (err) { P->error_info[0] = err_info0; if (G.abort_word) W::st_agent(G.abort_word, 1u); }
             unsigned long long *dst = (unsigned long long *)&P->cnt;
             const unsigned long long *src = (const unsigned long long *)&c;
             for (uint32_t i = 0; i < sizeof(Counters) / 8; i++) dst[i] += src[i];

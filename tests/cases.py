@@ -1,0 +1,49 @@
+"""Parity cases shared by the golden-vector generator (oracle/make_golden.py) and the tests.
+
+Each case is (name, generator kind, size, seed offset, window bits as given to the CLI).
+The edge cases are the ones SURVEY.md section 8c lists: empty input, < 2 KiB input (window
+shrinks below the decoder's minimum), exactly chunk_size +-1, EOF inside the 265-byte
+overlap, input > 2W (window rebases and the p >= W masking regime of HT/RK), long
+duplicated spans (RK carry, uint16 truncation), long runs (nice-length skip, BT4 early
+return), random bytes (expansion).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from nlzm_amd import corpus
+
+# chunk_size for hist_bits <= 16 is 14,848 (NLZM.cpp:1722-1724)
+CASES = [
+    ("empty", "random", 0, 0, 22),
+    ("one_byte", "syn_text", 1, 0, 15),
+    ("tiny_1000", "syn_text", 1000, 1, 15),
+    ("under_2k", "syn_text", 2047, 2, 20),
+    ("chunk_minus1", "syn_text", 14847, 3, 15),
+    ("chunk_exact", "syn_text", 14848, 3, 15),
+    ("chunk_plus1", "syn_text", 14849, 3, 15),
+    ("overlap_264", "syn_text", 14848 + 264, 4, 15),
+    ("overlap_265", "syn_text", 14848 + 265, 4, 15),
+    ("overlap_266", "syn_text", 14848 + 266, 4, 15),
+    ("text_200k_w15", "syn_text", 200_000, 5, 15),
+    ("text_300k_w20", "syn_text", 300_000, 0, 20),
+    ("text_500k_w17", "syn_text", 500_000, 6, 17),
+    ("mixed_1m_w20", "mixed", 1_000_000, 7, 20),
+    ("dups_600k_w20", "dups", 600_000, 8, 20),
+    ("dups_400k_w16", "dups", 400_000, 9, 16),
+    ("runs_300k_w15", "runs", 300_000, 10, 15),
+    ("runs_300k_w18", "runs", 300_000, 11, 18),
+    ("random_100k_w15", "random", 100_000, 12, 15),
+    ("text_2m_w15", "syn_text", 2_000_000, 13, 15),
+]
+
+# larger cases: checked on the GPU box against the oracle run live (and golden sha)
+BIG_CASES = [
+    ("text_3m_w20", "syn_text", 3_000_000, 0, 20),
+    ("mixed_3m_w20", "mixed", 3_152_896, 0, 20),
+]
+
+
+def make_case(case) -> np.ndarray:
+    _, kind, size, seed_off, _ = case
+    return corpus.make(kind, size, corpus.SEED + seed_off)

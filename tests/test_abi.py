@@ -1,0 +1,89 @@
+"""CPU suite: the C-ABI library loads and exports exactly what include/nlzm_hip.h declares;
+without a GPU every compute entry fails loudly (there is no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import nlzm_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    nlzm_amd.build()
+    return nlzm_amd.load_library()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nlzm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlzm_hip_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(lib):
+    syms = declared_symbols()
+    assert syms == sorted(nlzm_amd.ABI_SYMBOLS)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/nlzm_hip.h but not exported"
+
+
+def test_only_c_abi_is_exported():
+    out = subprocess.run(["nm", "-D", "--defined-only", nlzm_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert all(not s.startswith("nlzm_oracle") for s in exported), "the product must not contain the oracle"
+    assert set(nlzm_amd.ABI_SYMBOLS) <= set(exported)
+
+
+def test_library_has_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          f"--input={nlzm_amd.LIB_PATH}"], capture_output=True, text=True)
+    blob = open(nlzm_amd.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"master_kernel" in blob and b"rans_frames_kernel" in blob
+
+
+def test_geometry_needs_no_device(lib):
+    g = nlzm_amd.geometry(1_000_000_000, 28)
+    assert g == {"hist_bits": 28, "frame_bits": 17, "chunk_size": 122368, "feed_size": 122633}
+    assert nlzm_amd.geometry(125_000_000, 28)["hist_bits"] == 27
+    assert nlzm_amd.geometry(0, 22)["hist_bits"] == 10
+    assert lib.nlzm_hip_compress_bound(0) >= 8
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.nlzm_hip_init(0) != 0
+    assert b"device" in lib.nlzm_hip_last_error().lower()
+    with pytest.raises(nlzm_amd.NlzmError):
+        nlzm_amd.compress(b"hello world", 15)
+
+
+def test_cli_host_side_decodes_and_refuses_to_overwrite(tmp_path, lib):
+    """`d`/`t`/`h` are host-only (NLZM.cpp:2119-2162); `c` needs the GPU."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "streams.json")))["cases"]
+    g = next(c for c in gold if c["name"] == "tiny_1000" )
+    # hist_bits < 12 here: the reference's own decoder would assert (NLZM.cpp:1918); ours accepts it
+    from tests import cases
+    data = cases.make_case(next(c for c in cases.CASES if c[0] == "tiny_1000")).tobytes()
+    stream = tmp_path / "s.nlzm"
+    stream.write_bytes(bytes.fromhex(g["stream_hex"]))
+    out = tmp_path / "o.bin"
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(stream), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and out.read_bytes() == data
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(stream), str(out)], capture_output=True, text=True)
+    assert r.returncode != 0 and "already exists" in r.stdout
+    r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(stream)], capture_output=True, text=True)
+    assert "Done (output CRC32" in r.stdout
+    r = subprocess.run([nlzm_amd.CLI_PATH, "h", str(out)], capture_output=True, text=True)
+    from tests import oracle_py
+    assert r.stdout.strip().splitlines()[-1] == f"{oracle_py.crc32(data):X}"
+    r = subprocess.run([nlzm_amd.CLI_PATH, "-bogus", "c", str(out), str(tmp_path / 'x')], capture_output=True, text=True)
+    assert r.returncode != 0 and "Unrecognized flag" in r.stdout
+    r = subprocess.run([nlzm_amd.CLI_PATH], capture_output=True, text=True)
+    assert "Commands:" in r.stdout

@@ -1,0 +1,132 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle and the
+reference's golden vectors.  Integer/byte work: the bar is bit-exact."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import nlzm_amd
+from nlzm_amd import corpus
+from tests import cases, oracle_py
+
+pytestmark = pytest.mark.gpu
+
+GOLD = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))["cases"]}
+
+
+@pytest.mark.parametrize("case", cases.CASES, ids=[c[0] for c in cases.CASES])
+def test_stream_bit_exact(gpu, case):
+    """encode_file replacement (NLZM.cpp:1711-1910): whole stream == reference golden == oracle."""
+    data = cases.make_case(case)
+    got = gpu.compress(data, case[4])
+    g = GOLD[case[0]]
+    assert len(got) == g["stream_size"]
+    assert hashlib.sha256(got).hexdigest() == g["stream_sha256"]
+    assert got == oracle_py.compress(data, case[4])
+    assert oracle_py.decompress(got) == data.tobytes()
+
+
+@pytest.mark.parametrize("case", cases.BIG_CASES, ids=[c[0] for c in cases.BIG_CASES])
+def test_stream_bit_exact_big(gpu, case):
+    data = cases.make_case(case)
+    got = gpu.compress(data, case[4])
+    g = GOLD[case[0]]
+    assert (len(got), hashlib.sha256(got).hexdigest()) == (g["stream_size"], g["stream_sha256"])
+    st = gpu.stats()
+    ost = oracle_py.compress(data, case[4], want_stats=True)[1]
+    for k in ("bt_calls", "bt_tests", "ht_rows", "rk_probes", "rk_inserts", "positions", "nice_positions", "segments",
+              "n_literal", "n_dict", "n_rep", "rans_syms", "bit_ops", "frames", "shifts"):
+        assert st[k] == ost[k], k
+
+
+def test_worker_and_inline_modes_agree(gpu):
+    """BT4 inside the master workgroup vs. per-head worker lanes: same bytes."""
+    data = corpus.dups(300_000)
+    outs = []
+    for w in (0, 1):
+        gpu.set_option("workers", w)
+        outs.append(gpu.compress(data, 17))
+    gpu.set_option("workers", 1)
+    assert outs[0] == outs[1] == oracle_py.compress(data, 17)
+
+
+def test_batching_is_invisible(gpu):
+    """State carried across persistent launches (model, finders, carry table) is exact."""
+    data = corpus.syn_text(700_000, corpus.SEED + 21)
+    want = oracle_py.compress(data, 16)
+    for b in (1, 3, 64):
+        gpu.set_option("batch_chunks", b)
+        assert gpu.compress(data, 16) == want, b
+    gpu.set_option("batch_chunks", 32)
+
+
+def test_rans_frames_stage(gpu):
+    """CodeFrame::Flush replacement (NLZM.cpp:590-640) on captured symbol/bit streams."""
+    case = next(c for c in cases.CASES if c[0] == "mixed_1m_w20")
+    data = cases.make_case(case)
+    frames, want = [], []
+    for idx in (0, 3, 8):
+        syms, bits, ops, fr = oracle_py.capture_frame(data, case[4], idx)
+        frames.append((syms, bits, ops))
+        want.append(fr)
+    # degenerate frames: no symbols at all, a single symbol, only raw bits
+    frames.append((np.zeros(0, np.uint32), np.zeros(4, np.uint8), 0))
+    frames.append((np.array([(16384 // 4) << 16], np.uint32), np.zeros(4, np.uint8), 1))
+    frames.append((np.zeros(0, np.uint32), np.array([0xAB, 0xCD, 0, 0, 0, 0], np.uint8), 2))
+    for s, b, o in frames[3:]:
+        want.append(oracle_py.flush_frame(s, b, o))
+    got = gpu.rans_frames(frames)
+    assert got == want
+
+
+def test_find_matches_stage(gpu):
+    """Finder block of parse_table (NLZM.cpp:1501-1543): per-position match tables."""
+    data = corpus.dups(200_000, corpus.SEED + 3)
+    lo, hi = 60_000, 140_000
+    got = gpu.find_matches(data, 16, lo, hi)
+    want = oracle_py.capture_tables(data, 16, lo, hi)
+    assert got.size == want.size and np.array_equal(got, want)
+
+
+def test_parse_emit_stage(gpu):
+    """Relaxations + model_encode_* (NLZM.cpp:1545-1650, 1809-1843): symbol/bit streams of a frame."""
+    data = corpus.syn_text(300_000)
+    for idx in (0, 2):
+        syms, bits, ops = gpu.parse_emit(data, 20, idx)
+        osyms, obits, oops, _ = oracle_py.capture_frame(data, 20, idx)
+        assert ops == oops and np.array_equal(syms, osyms) and np.array_equal(bits, obits)
+
+
+def test_blocks_of_a_sharded_run(gpu):
+    """k-way split: each block is an independent stream identical to the oracle's."""
+    from nlzm_amd import shard
+    data = corpus.syn_text(900_000, corpus.SEED + 5)
+    blob = b""
+    for i in range(4):
+        lo, hi = shard.block_range(data.size, 4, i)
+        s = gpu.compress(data[lo:hi], 28)
+        assert s == oracle_py.compress(data[lo:hi], 28)
+        blob += s
+    assert b"".join(oracle_py.decompress(s) for s in shard.split_streams(blob)) == data.tobytes()
+
+
+def test_cli_compress_round_trip(gpu, tmp_path):
+    data = corpus.mixed(400_000, corpus.SEED + 9)
+    inp, out, back = tmp_path / "in.bin", tmp_path / "out.nlzm", tmp_path / "back.bin"
+    data.tofile(inp)
+    r = subprocess.run([nlzm_amd.CLI_PATH, "-window:18", "c", str(inp), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"Done (input CRC32 {oracle_py.crc32(data):X}" in r.stdout
+    assert out.read_bytes() == oracle_py.compress(data, 18)
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(out), str(back)], capture_output=True, text=True)
+    assert r.returncode == 0 and back.read_bytes() == data.tobytes()
+    r = subprocess.run([nlzm_amd.CLI_PATH, "c", str(inp), str(out)], capture_output=True, text=True)
+    assert r.returncode != 0 and "already exists" in r.stdout
+
+
+def test_smoke_entry(gpu):
+    import __graft_entry__ as g
+    g.smoke()
