@@ -95,16 +95,15 @@ struct FrameMeta {
     uint32_t nsyms, nbits_bytes, num_ops, out_len;
 };
 
-// BT4 result of one position, written by a worker lane and read by the master.
-// 64 bytes: word 0 = ready, word 1 = count | tests<<16, then up to 6 (distance,
-// length) pairs -- the record-setters of the descent (descent order is by
-// increasing distance, so only a longer match changes the table: :835-852).
-// count > 6: pair 6 = {overflow block index, 0} and pairs 6.. live in that pool block.
-struct BtResult {
-    uint32_t w[16];
-};
-constexpr uint32_t kBtInline = 7;
-constexpr uint32_t kOvfBlock = 256;             // pairs per overflow block (<= 256 tests per call)
+// BT4 result of one position, written by a worker lane and read by the master:
+//   bt_ready[i] = 0 (not yet) | 0x80000000 | tests<<9 | count
+//   bt_pairs[i * 2*kBtMaxPairs ...] = `count` (distance, length) pairs -- the
+// record-setters of the descent (a descent visits candidates by increasing distance,
+// so only a longer match changes the table: :835-852).  The stride is the worst case
+// (one pair per test, <= 256 tests, :777): 2 KiB per position, sized for HBM, so no
+// allocator and no overflow path exists.
+constexpr uint32_t kBtMaxPairs = 256;
+constexpr uint32_t kBtReady = 0x80000000u;
 constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
 
 struct WorkerCounters {
@@ -128,12 +127,10 @@ struct Globals {
     // ---- worker mode: BT4 on per-head worker lanes ------------------------------
     uint32_t workers;           // 0: BT4 runs inside the master workgroup
     uint32_t batch_a0;          // absolute position of the first byte of this launch
-    BtResult *bt_res;           // [a - batch_a0]
+    uint32_t *bt_ready;         // [a - batch_a0]
+    uint32_t *bt_pairs;         // [(a - batch_a0) * 2 * kBtMaxPairs]
     uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
     const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
-    uint32_t *ovf_pool;         // overflow blocks of kOvfBlock pairs
-    uint32_t *ovf_next;         // bump allocator (block index)
-    uint32_t ovf_blocks;
     const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
     const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by head, ascending
     uint32_t nheads;
@@ -153,8 +150,7 @@ struct MasterLds {
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];           // log2_lut[freq>>6] per (context, symbol)  (:435-438)
     uint16_t lut[256];                      // log2_lut (:97-124)
-    uint32_t btrec[16];                     // worker result being consumed
-    uint32_t btovf[2 * kOvfBlock];
+    uint32_t btpairs[2 * kBtMaxPairs];      // worker result being consumed
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -270,50 +266,33 @@ struct LaneCmp {
 
 template <class IO>
 struct ResultSink {
-    const Globals *G;
-    uint32_t *rec;          // BtResult words of this position (nullptr: do not publish)
-    uint32_t count, best, ovf_base;
-    bool failed;
+    uint32_t *pairs;        // nullptr: do not publish
+    uint32_t count, best;
     NLZM_HD void operator()(uint32_t d, uint32_t l)
     {
-        if (!rec || l <= best) return;      // only record-setters change the table
+        if (!pairs || l <= best) return;    // only record-setters change the table
         best = l;
-        if (count < kBtInline - 1) {
-            IO::st_agent(rec + 2 + 2 * count, d);
-            IO::st_agent(rec + 3 + 2 * count, l);
-        } else {
-            if (count == kBtInline - 1) {
-                const uint32_t blk = IO::atomic_inc(G->ovf_next);
-                if (blk >= G->ovf_blocks) { failed = true; return; }
-                ovf_base = blk * kOvfBlock * 2;
-                IO::st_agent(rec + 2 + 2 * (kBtInline - 1), blk);
-                IO::st_agent(rec + 3 + 2 * (kBtInline - 1), 0);
-            }
-            const uint32_t k = count - (kBtInline - 1);
-            IO::st_agent(G->ovf_pool + ovf_base + 2 * k, d);
-            IO::st_agent(G->ovf_pool + ovf_base + 2 * k + 1, l);
-        }
+        IO::st_agent(pairs + 2 * count, d);
+        IO::st_agent(pairs + 2 * count + 1, l);
         count++;
     }
 };
 
-// returns false when the overflow pool is exhausted
 template <class IO, bool kWrite>
-NLZM_HD bool worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, bool publish,
+NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, bool publish,
                             unsigned long long &n_tests, unsigned long long &cmp_bytes)
 {
     LaneCmp cmp{ &cmp_bytes };
-    ResultSink<IO> sink{ &G, publish ? G.bt_res[a - G.batch_a0].w : nullptr, 0, 1, 0, false };
+    const unsigned long long bi = a - G.batch_a0;
+    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, G.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
     if (publish) {
-        IO::st_agent(sink.rec + 1, sink.count | (tests << 16));
-        IO::drain();                        // every payload store has left before the ready word
-        IO::st_agent(sink.rec + 0, 1u);
+        IO::drain();                        // every pair has been written through before the ready word
+        IO::st_agent(G.bt_ready + bi, kBtReady | (tests << 9) | sink.count);
     }
-    return !sink.failed;
 }
 
 // ---------------------------------------------------------------------------
@@ -676,31 +655,21 @@ struct Master {
     // BT4 result of a worker lane: wait for it, then merge its pairs (MatchTable::Update, :996-998).
     NLZM_HD void bt_consume(uint32_t a)
     {
-        const uint32_t *rec = G.bt_res[a - G.batch_a0].w;
+        const unsigned long long bi = a - G.batch_a0;
         W::wait_hook(G.hook_user, a);
         const unsigned long long t0 = W::clock();
-        uint32_t spins = 0;
-        while (W::ld_agent(rec) != 1u) {
+        uint32_t spins = 0, v;
+        while (!((v = W::ld_agent(G.bt_ready + bi)) & kBtReady)) {
             if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { err = kErrTimeout; err_info0 = a; return; }
             W::sleep();
         }
-        // the ready word was stored after every payload word had been written through
+        // the ready word was stored after every pair had been written through (sc1) and drained
+        const uint32_t count = v & 0x1FFu;
+        const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
         W::sync();
-        for (uint32_t i = W::lane(); i < 16; i += W::width()) L->btrec[i] = W::ld_agent(rec + i);
+        for (uint32_t i = W::lane(); i < 2 * count; i += W::width()) L->btpairs[i] = W::ld_agent(pairs + i);
         W::sync();
-        const uint32_t count = L->btrec[1] & 0xFFFFu;
-        if (count > kBtInline - 1) {
-            const uint32_t *ov = G.ovf_pool + (unsigned long long)L->btrec[2 + 2 * (kBtInline - 1)] * kOvfBlock * 2;
-            const uint32_t nov = (count - (kBtInline - 1)) * 2;
-            for (uint32_t i = W::lane(); i < nov; i += W::width()) L->btovf[i] = W::ld_agent(ov + i);
-            W::sync();
-        }
-        for (uint32_t k = 0; k < count; k++) {
-            uint32_t d, l;
-            if (k < kBtInline - 1) { d = L->btrec[2 + 2 * k]; l = L->btrec[3 + 2 * k]; }
-            else { d = L->btovf[2 * (k - (kBtInline - 1))]; l = L->btovf[2 * (k - (kBtInline - 1)) + 1]; }
-            mt_update(d, l);
-        }
+        for (uint32_t k = 0; k < count; k++) mt_update(L->btpairs[2 * k], L->btpairs[2 * k + 1]);
     }
 
     // BT4 inside the master (workers off): wave-wide compares, uniform descent.

@@ -20,7 +20,11 @@
 namespace nlzm {
 void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long pos0, unsigned long long pos1,
                     uint32_t *out, hipStream_t st);
-void launch_master(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, hipStream_t st);
+void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
+void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
+void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
+                uint32_t *pos, hipStream_t st);
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
                  FrameMeta *fmeta, uint32_t *scratch, unsigned long long scratch_stride, uint8_t *out,
                  unsigned long long out_stride, uint32_t out_cap, uint32_t nframes, hipStream_t st);
@@ -59,8 +63,9 @@ struct Ctx {
     hipEvent_t ev[8] = {};
 
     // options
-    int64_t opt_workers = 0;
+    int64_t opt_workers = 1;
     int64_t opt_batch = 32;
+    int64_t opt_worker_blocks = 448;
 
     // stream state
     bool open = false;
@@ -79,6 +84,13 @@ struct Ctx {
     unsigned long long *dst_off = nullptr;
     unsigned long long syms_stride = 0, bits_stride = 0, frame_stride = 0;
     uint32_t batch = 0;
+    // worker mode
+    bool workers = false;
+    uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
+    uint32_t t_bits = 0, m_bits = 0, nheads = 0;
+    uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
+    uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr;
+    WorkerCounters *wcnt = nullptr;
 
     // capture (stage tests)
     uint32_t *cap_words = nullptr; unsigned long long cap_cap = 0, cap_lo = 0, cap_hi = 0; unsigned long long *cap_used = nullptr;
@@ -92,6 +104,7 @@ struct Ctx {
 
     nlzm_hip_stats stats{};
     nlzm_hip_timing tm{};
+    unsigned long long last_dry_runs = 0, last_flag_waits = 0;
 };
 
 Ctx C;
@@ -99,8 +112,11 @@ Ctx C;
 void free_stream_buffers()
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
-                     C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst };
+                     C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
+                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
+    C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
     C.persist = nullptr; C.syms = C.scratch = nullptr; C.bits = C.frames = nullptr; C.fmeta = nullptr;
     C.dst_off = nullptr; C.own_in = C.own_dst = nullptr;
@@ -180,6 +196,34 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
     HIPCHK(hipMalloc(&C.fmeta, C.batch * sizeof(FrameMeta)));
     HIPCHK(hipMalloc(&C.dst_off, C.batch * sizeof(unsigned long long)));
 
+    // worker mode: pre-filter tables, per-launch hand-off arrays, bins
+    C.workers = C.opt_workers != 0;
+    C.nheads = 1u << (32 - g.bt_shift);
+    if (C.workers) {
+        const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
+        uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
+        C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
+        C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
+        HIPCHK(hipMalloc(&C.pf_T, (size_t)4 << C.t_bits));
+        HIPCHK(hipMalloc(&C.pf_M, (size_t)4 << C.m_bits));
+        HIPCHK(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
+        HIPCHK(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
+        HIPCHK(hipMalloc(&C.pf_h, bpos * 4));
+        HIPCHK(hipMalloc(&C.pf_c1, bpos));
+        HIPCHK(hipMalloc(&C.unc, bpos + 16));
+        HIPCHK(hipMalloc(&C.bt_ready, bpos * 4));
+        HIPCHK(hipMalloc(&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4)));      // worst case, 2 KiB per position
+        HIPCHK(hipMalloc(&C.bt_flag, bpos * 4));
+        HIPCHK(hipMalloc(&C.abort_word, 4));
+        HIPCHK(hipMalloc(&C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4));
+        HIPCHK(hipMalloc(&C.bin_cur, (size_t)C.batch * C.nheads * 4));
+        HIPCHK(hipMalloc(&C.bin_pos, bpos * 4));
+        HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
+        HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
+        if ((unsigned long long)C.nheads > 2ull * (unsigned long long)C.opt_worker_blocks * 256)
+            return set_err(NLZM_HIP_E_ARG, "worker_blocks %lld too small for %u heads", (long long)C.opt_worker_blocks, C.nheads);
+    }
+
     // stream header (:1762-1766)
     const uint8_t hdr[4] = { (uint8_t)(g.wbits >> 8), (uint8_t)g.wbits, (uint8_t)(g.frame_bits >> 8), (uint8_t)g.frame_bits };
     HIPCHK(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
@@ -215,9 +259,30 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
         G.syms = C.syms; G.syms_stride = C.syms_stride; G.bits = C.bits; G.bits_stride = C.bits_stride;
         G.fmeta = C.fmeta; G.chunk0 = c0;
         G.cap_words = C.cap_words; G.cap_cap = C.cap_cap; G.cap_lo = C.cap_lo; G.cap_hi = C.cap_hi; G.cap_used = C.cap_used;
+        G.workers = C.workers ? 1 : 0;
+        const unsigned long long a0 = (unsigned long long)c0 * g.chunk_size;
+        unsigned long long a1 = (unsigned long long)c1 * g.chunk_size;
+        if (a1 > g.n) a1 = g.n;
+        G.batch_a0 = (uint32_t)a0;
+        float pre_ms = 0;
+        if (C.workers) {
+            const unsigned long long cnt = a1 - a0;
+            G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
+            G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads;
+            G.abort_word = C.abort_word; G.wcnt = C.wcnt;
+            HIPCHK(hipEventRecord(C.ev[5], C.st));
+            HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4, C.st));
+            HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
+            HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
+            HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
+            launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
+                             C.pf_c1, C.unc, C.st);
+            launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
+            HIPCHK(hipEventRecord(C.ev[6], C.st));
+        }
 
         HIPCHK(hipEventRecord(C.ev[0], C.st));
-        launch_master(g, G, c0, c1, C.st);
+        launch_pipeline(g, G, c0, c1, (uint32_t)C.opt_worker_blocks, C.st);
         HIPCHK(hipEventRecord(C.ev[1], C.st));
         launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
                     C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
@@ -225,10 +290,17 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
         HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
         Persist P;
         HIPCHK(hipMemcpyAsync(&P, C.persist, sizeof P, hipMemcpyDeviceToHost, C.st));
+        uint32_t aborted = 0;
+        if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
         HIPCHK(hipStreamSynchronize(C.st));
         HIPCHK(hipGetLastError());
+        if (C.workers) {
+            HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
+            C.tm.prep_ms += pre_ms; C.tm.prep_launches += 4; C.tm.total_ms += pre_ms;
+        }
         if (P.error) return set_err(NLZM_HIP_E_KERNEL, "device error %u at chunk %u (info %u %u %u)", P.error, P.next_chunk,
                                     P.error_info[0], P.error_info[1], P.error_info[2]);
+        if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
         if (P.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", P.next_chunk, c1);
         unsigned long long pos = C.out_pos;
         for (uint32_t f = 0; f < nb; f++) {
@@ -289,6 +361,12 @@ int stream_finish(uint64_t *dst_len)
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
+    if (C.workers) {
+        WorkerCounters wc;
+        HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
+        s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
+        C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
+    }
     if (dst_len) *dst_len = C.out_pos;
     return 0;
 }
@@ -424,6 +502,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
 {
     if (!key) return set_err(NLZM_HIP_E_ARG, "null key");
     if (!strcmp(key, "workers")) { C.opt_workers = value; return 0; }
+    if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 511) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
 }

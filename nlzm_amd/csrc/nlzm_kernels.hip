@@ -3,8 +3,10 @@
 //   rk_hash_kernel      RK256 rolling hash of every 256-byte window, one thread per
 //                       position (closed form of MatchFinderRK256's roll, NLZM.cpp:798-799,
 //                       1071-1083): pure, position-parallel, input tile staged in LDS.
-//   master_kernel       the serial half (nlzm_core.h): HT2/HT3/RK256 state, match-table
-//                       chain, forward-graph parse, model, symbol emit.  One workgroup.
+//   prefilter_*_kernel  marks the positions whose BT4 call cannot be decided from the input alone
+//   bin_kernel          groups each chunk's positions by BT4 hash head
+//   pipeline_kernel     block 0: the serial half (nlzm_core.h): HT2/HT3/RK256 state, match-table
+//                       chain, forward-graph parse, model, symbol emit; blocks 1..: BT4 worker lanes
 //   rans_frames_kernel  CodeFrame::Flush (NLZM.cpp:590-640): 4 interleaved rANS states
 //                       per frame, renormalisation words placed by a prefix scan.
 //   gather_frames_kernel concatenates the frames into the output stream.
@@ -21,14 +23,29 @@ namespace nlzm {
 struct DevWave {
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
-    static __device__ __forceinline__ void sync() { __syncthreads(); }
-    static __device__ __forceinline__ void sync_global()
+    // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
+    // program order, so a workgroup-scope fence (the waits) plus a scheduling barrier
+    // is all the cross-lane ordering it needs -- no s_barrier.
+    static __device__ __forceinline__ void sync()
     {
-        // same CU, same L1: a workgroup-scope fence orders lane 0's stores before
-        // every lane's later loads
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    static __device__ __forceinline__ void sync_global() { sync(); }
+    // agent-scope (sc1, write-through / L1-bypassing) accesses for words shared with worker lanes
+    static __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
+    {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
+    {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
+    static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }      // 100 MHz
+    static __device__ __forceinline__ unsigned long long timeout_ticks() { return 2000000000ull; } // 20 s
+    static __device__ __forceinline__ void wait_hook(void *, uint32_t) {}
     static __device__ __forceinline__ uint32_t rmin(uint32_t v)
     {
 #pragma unroll
@@ -106,14 +123,270 @@ __global__ __launch_bounds__(256) void rk_hash_kernel(const uint8_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// master
+// pre-filter: which positions can have a 65+ byte match inside the window at all?
+//
+// parse_table skips BT4 at position p exactly when the table carried from p-1 is
+// >= 64 long (NLZM.cpp:1514), which needs a genuine match of >= 65 bytes at p-1
+// with distance <= W-1.  "No earlier in-window occurrence of the 65-gram at p-1"
+// is a pure function of the input, so for those positions the finder set is known
+// without running anything serial; the others are marked `unc` and wait for the
+// master.  The filter is conservative: slot collisions only add `unc` marks.
+//   T[slot]  = 1 + latest position (from earlier launches) whose 65-gram hashes there
+//   M[slot2] = earliest position of THIS launch hashing there
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void master_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
+constexpr uint32_t kPfLen = 65;
+constexpr uint32_t kPfMul = 0x9E3779B1u, kPfMul2 = 0x85EBCA77u;
+
+__global__ __launch_bounds__(256) void prefilter_hash_kernel(const uint8_t *__restrict__ in, unsigned long long n,
+                                                             uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+                                                             uint32_t m_bits, const uint32_t *__restrict__ T,
+                                                             uint32_t *__restrict__ M, uint32_t *__restrict__ hbuf,
+                                                             uint8_t *__restrict__ c1)
+{
+    __shared__ uint8_t tile[1024 + kPfLen + 15];
+    const unsigned long long blk0 = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 1024;
+    for (uint32_t i = threadIdx.x; i < 1024 + kPfLen; i += 256) {
+        const unsigned long long a = blk0 + i;
+        tile[i] = a < n ? in[a] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = threadIdx.x + 256u * k;
+        const unsigned long long a = blk0 + o;
+        if (a >= a1) continue;
+        uint32_t h = 0;
+        const bool ok = a + kPfLen <= n;
+        if (ok) {
+#pragma unroll 13
+            for (uint32_t j = 0; j < kPfLen; j++) h = (h + tile[o + j]) * 0x2F0FD693u;
+        }
+        hbuf[a - a0] = h;
+        uint8_t f = 0;
+        if (ok) {
+            const uint32_t t = T[(h * kPfMul) >> (32 - t_bits)];
+            f = t != 0 && (uint32_t)a - (t - 1) <= wmask;
+            atomicMin(&M[(h * kPfMul2) >> (32 - m_bits)], (uint32_t)a);
+        }
+        c1[a - a0] = f;
+    }
+}
+
+// unc[x+1] = C(x); unc[0] = 1 (the position before this launch is not examined)
+__global__ __launch_bounds__(256) void prefilter_mark_kernel(unsigned long long n, uint32_t a0, uint32_t a1, uint32_t m_bits,
+                                                             const uint32_t *__restrict__ M, const uint32_t *__restrict__ hbuf,
+                                                             const uint8_t *__restrict__ c1, uint8_t *__restrict__ unc)
+{
+    const unsigned long long a = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (a >= a1) return;
+    if (a == a0) unc[0] = 1;
+    uint8_t f = c1[a - a0];
+    if (a + kPfLen <= n) {
+        const uint32_t h = hbuf[a - a0];
+        f |= M[(h * kPfMul2) >> (32 - m_bits)] < (uint32_t)a;
+    }
+    if (a + 1 < a1) unc[a + 1 - a0] = f;
+}
+
+__global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long long n, uint32_t a0, uint32_t a1, uint32_t t_bits,
+                                                               uint32_t m_bits, uint32_t *__restrict__ T,
+                                                               uint32_t *__restrict__ M, const uint32_t *__restrict__ hbuf)
+{
+    const unsigned long long a = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (a >= a1 || a + kPfLen > n) return;
+    const uint32_t h = hbuf[a - a0];
+    atomicMax(&T[(h * kPfMul) >> (32 - t_bits)], (uint32_t)a + 1);
+    M[(h * kPfMul2) >> (32 - m_bits)] = kNone;
+}
+
+// ---------------------------------------------------------------------------
+// binning: positions of one chunk grouped by BT4 head (hash of 4 bytes, :1518, :983),
+// ascending inside each head.  One workgroup per chunk.
+//   cnt: [nchunks][nheads+1] zeroed by the host -> becomes the exclusive offsets
+//   cur: [nchunks][nheads]   scratch cursors
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ in, Geom g, uint32_t c0,
+                                                   uint32_t nheads, uint32_t *__restrict__ off_all,
+                                                   uint32_t *__restrict__ cur_all, uint32_t *__restrict__ pos_all)
+{
+    const uint32_t ci = c0 + blockIdx.x;
+    uint32_t *off = off_all + (unsigned long long)blockIdx.x * (nheads + 1);
+    uint32_t *cur = cur_all + (unsigned long long)blockIdx.x * nheads;
+    uint32_t *pos = pos_all + (unsigned long long)blockIdx.x * g.chunk_size;
+    const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+    const unsigned long long remain = g.n - chunk_abs;
+    const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+    const uint32_t p_end = umin(g.chunk_size, chunk_read);
+    const uint32_t n_ok = chunk_read >= 4 ? umin(p_end, chunk_read - 3) : 0;    // positions with >= 4 bytes of lookahead (:1515)
+    const uint8_t *base = in + chunk_abs;
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t heads_t[1024];
+
+    for (uint32_t p = threadIdx.x; p < n_ok; p += 1024) atomicAdd(&off[hash4(load32u(base + p)) >> g.bt_shift], 1u);
+    __syncthreads();
+    // exclusive scan over nheads counters: each thread owns a contiguous slice
+    const uint32_t per = (nheads + 1023) / 1024;
+    const uint32_t lo = umin(nheads, threadIdx.x * per), hi = umin(nheads, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t h = lo; h < hi; h++) sum += off[h];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 1024; t++) { const uint32_t v = part[t]; part[t] = run; run += v; }
+        off[nheads] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t h = lo; h < hi; h++) { const uint32_t v = off[h]; off[h] = run; cur[h] = run; run += v; }
+    __syncthreads();
+    // stable scatter, 1024 positions at a time
+    for (uint32_t t0 = 0; t0 < n_ok; t0 += 1024) {
+        const uint32_t p = t0 + threadIdx.x;
+        const bool ok = p < n_ok;
+        const uint32_t h = ok ? hash4(load32u(base + p)) >> g.bt_shift : kNone;
+        heads_t[threadIdx.x] = h;
+        __syncthreads();
+        uint32_t at = 0, after = 1;
+        if (ok) {
+            uint32_t before = 0;
+            after = 0;
+            for (uint32_t t = 0; t < 1024; t++) {
+                const uint32_t o = heads_t[t];
+                before += (o == h) & (t < threadIdx.x);
+                after += (o == h) & (t > threadIdx.x);
+            }
+            at = cur[h] + before;
+            pos[at] = (uint32_t)chunk_abs + p;
+        }
+        __syncthreads();
+        if (ok && !after) cur[h] = at + 1;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// worker lanes: BT4, one serial worker per hash head (trees of different heads are
+// disjoint: slot (p & mask)*2 is written by p's own insertion and re-linked only by
+// later positions of the same head, NLZM.cpp:979-1021).
+// ---------------------------------------------------------------------------
+struct LaneIO {
+    static __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
+    {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
+    {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every write-through store of this wave has completed (inline asm: the compiler
+    // may not drop or move it, cf. guide "Compiler hazard")
+    static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+__device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
+{
+    const uint32_t nl = (gridDim.x - 1) * blockDim.x;
+    const uint32_t gl = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    // a lane owns heads gl and gl + nl and walks their positions in ascending order:
+    // the position it may block on is then always its smallest unprocessed one
+    const uint32_t h0 = gl, h1 = gl + nl;
+    const bool has0 = h0 < G.nheads, has1 = h1 < G.nheads;
+    bool active = has0 || has1;
+    uint32_t c = c0;
+    bool loaded = false;
+    uint32_t i0 = 0, e0 = 0, i1 = 0, e1 = 0;
+    uint32_t la_end = 0;            // absolute end of the chunk's lookahead
+    uint32_t stage = 0, a = 0, max_len = 0;
+    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dummy_t = 0, dummy_c = 0;
+    unsigned long long t_wait0 = 0;
+    uint32_t idle = 0;
+    bool fail = false;
+
+    while (__any(active)) {
+        bool waiting = false;
+        if (active) {
+            if (stage == 0) {
+                if (!loaded) {
+                    if (c >= c1) active = false;
+                    else {
+                        const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
+                        if (has0) { i0 = off[h0]; e0 = off[h0 + 1]; } else { i0 = e0 = 0; }
+                        if (has1) { i1 = off[h1]; e1 = off[h1 + 1]; } else { i1 = e1 = 0; }
+                        const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
+                        const unsigned long long remain = g.n - chunk_abs;
+                        la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
+                        loaded = true;
+                    }
+                }
+                if (active) {
+                    const uint32_t *pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size;
+                    const uint32_t pa = i0 < e0 ? pos[i0] : kNone, pb = i1 < e1 ? pos[i1] : kNone;
+                    if (pa == kNone && pb == kNone) { c++; loaded = false; }
+                    else {
+                        if (pa < pb) { a = pa; i0++; } else { a = pb; i1++; }
+                        max_len = umin(la_end - a, kMatchMax);
+                        if (G.unc[a - G.batch_a0]) {
+                            // whether this call happens is decided by the master; its MATCHES do not depend
+                            // on that: report them now from a dry run, insert once the decision is in
+                            worker_bt_call<LaneIO, false>(g, G, a, max_len, true, dummy_t, dummy_c);
+                            n_dry++;
+                            stage = 1; t_wait0 = 0; idle = 0;
+                        } else {
+                            worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
+                            n_calls++;
+                        }
+                    }
+                }
+            } else {
+                const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
+                if (f == kFlagCall) {
+                    worker_bt_call<LaneIO, true>(g, G, a, max_len, false, n_tests, n_cmp);
+                    n_calls++;
+                    stage = 0;
+                } else if (f == kFlagSkip) {
+                    stage = 0;
+                } else {
+                    waiting = true;
+                    n_wait++;
+                    if ((++idle & 1023u) == 0) {
+                        if (LaneIO::ld_agent(G.abort_word)) active = false;
+                        const unsigned long long now = wall_clock64();
+                        if (!t_wait0) t_wait0 = now;
+                        else if (now - t_wait0 > 3000000000ull) { fail = true; }   // 30 s
+                    }
+                }
+            }
+            if (fail) { LaneIO::st_agent(G.abort_word, 2u); active = false; }
+        }
+        if (!__any(active && !waiting)) __builtin_amdgcn_s_sleep(8);
+    }
+    // counters: one atomic per wave
+    for (int m = 32; m >= 1; m >>= 1) {
+        n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
+        n_dry += __shfl_xor(n_dry, m, 64); n_wait += __shfl_xor(n_wait, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
+        atomicAdd(&G.wcnt->dry_runs, n_dry); atomicAdd(&G.wcnt->flag_waits, n_wait);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the persistent launch: block 0 = master (one wave), blocks 1.. = worker lanes.
+// Grid <= 2 blocks per CU (73 KB of LDS each), so every block is resident.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
 {
     __shared__ MasterLds lds;
-    Master<DevWave> m;
-    m.g = g; m.G = G; m.L = &lds;
-    m.run(c0, c1);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x >= 64) return;
+        Master<DevWave> m;
+        m.g = g; m.G = G; m.L = &lds;
+        m.run(c0, c1);
+    } else {
+        worker_role(g, G, c0, c1);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -223,9 +496,27 @@ void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long 
     hipLaunchKernelGGL(rk_hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, in, n, pos0, pos1, out);
 }
 
-void launch_master(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, hipStream_t st)
+void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(master_kernel, dim3(1), dim3(64), 0, st, g, G, c0, c1);
+    hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(256), 0, st, g, G, c0, c1);
+}
+
+void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st)
+{
+    if (a1 <= a0) return;
+    const uint32_t cnt = a1 - a0;
+    hipLaunchKernelGGL(prefilter_hash_kernel, dim3((cnt + 1023) / 1024), dim3(256), 0, st, in, n, a0, a1, wmask, t_bits, m_bits,
+                       T, M, hbuf, c1);
+    hipLaunchKernelGGL(prefilter_mark_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, m_bits, M, hbuf, c1, unc);
+    hipLaunchKernelGGL(prefilter_insert_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, t_bits, m_bits, T, M, hbuf);
+}
+
+void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
+                uint32_t *pos, hipStream_t st)
+{
+    if (!nchunks) return;
+    hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos);
 }
 
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,

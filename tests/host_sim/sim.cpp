@@ -20,7 +20,24 @@
 
 using namespace nlzm;
 
+struct SimWorkers;
+static SimWorkers *g_workers = nullptr;
+static void sim_wait_hook(uint32_t a);
+
+struct HostIO {
+    static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
+    static uint32_t ld_agent(const uint32_t *p) { return *p; }
+    static uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
+    static void drain() {}
+};
+
 struct HostWave {
+    static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
+    static uint32_t ld_agent(const uint32_t *p) { return *p; }
+    static void sleep() {}
+    static unsigned long long clock() { return 0; }
+    static unsigned long long timeout_ticks() { return ~0ull; }
+    static void wait_hook(void *, uint32_t a) { sim_wait_hook(a); }
     static uint32_t lane() { return 0; }
     static uint32_t width() { return 1; }
     static void sync() {}
@@ -54,6 +71,111 @@ static void make_geom(uint64_t n, uint32_t hist_bits_req, Geom &g)
     g.tag_mask = (uint32_t)((1ull << (32 - hb)) - 1);
     g.nchunks = (uint32_t)((n + g.chunk_size - 1) / g.chunk_size);
 }
+
+// ---- emulation of the device-side helpers around the master (tests only) -------------
+// pre-filter: same tables and phases as prefilter_*_kernel in nlzm_kernels.hip
+struct SimPrefilter {
+    uint32_t t_bits, m_bits;
+    std::vector<uint32_t> T, M;
+    void init(uint32_t wbits, unsigned long long batch_pos)
+    {
+        uint32_t lg = 1; while ((1ull << lg) < batch_pos) lg++;
+        t_bits = wbits + 5 > 32 ? 32 : (wbits + 5 < 16 ? 16 : wbits + 5);
+        if (t_bits > 26) t_bits = 26;                    // keep the simulation small; only adds `unc` marks
+        m_bits = lg + 6 > 28 ? 28 : lg + 6;
+        if (m_bits > 24) m_bits = 24;
+        T.assign((size_t)1 << t_bits, 0); M.assign((size_t)1 << m_bits, kNone);
+    }
+    void run(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, std::vector<uint8_t> &unc)
+    {
+        const uint32_t cnt = a1 - a0;
+        std::vector<uint32_t> h(cnt, 0); std::vector<uint8_t> c1(cnt, 0);
+        unc.assign(cnt + 16, 0);
+        for (uint32_t a = a0; a < a1; a++) {
+            if ((unsigned long long)a + 65 > n) continue;
+            uint32_t hh = 0;
+            for (int j = 0; j < 65; j++) hh = (hh + in[a + j]) * 0x2F0FD693u;
+            h[a - a0] = hh;
+            const uint32_t t = T[(hh * 0x9E3779B1u) >> (32 - t_bits)];
+            c1[a - a0] = t != 0 && a - (t - 1) <= wmask;
+            uint32_t &m = M[(hh * 0x85EBCA77u) >> (32 - m_bits)];
+            if (a < m) m = a;
+        }
+        if (cnt) unc[0] = 1;
+        for (uint32_t a = a0; a < a1; a++) {
+            uint8_t f = c1[a - a0];
+            if ((unsigned long long)a + 65 <= n) f |= M[(h[a - a0] * 0x85EBCA77u) >> (32 - m_bits)] < a;
+            if (a + 1 < a1) unc[a + 1 - a0] = f;
+        }
+        for (uint32_t a = a0; a < a1; a++) {
+            if ((unsigned long long)a + 65 > n) continue;
+            uint32_t &t = T[(h[a - a0] * 0x9E3779B1u) >> (32 - t_bits)];
+            if (a + 1 > t) t = a + 1;
+            M[(h[a - a0] * 0x85EBCA77u) >> (32 - m_bits)] = kNone;
+        }
+    }
+};
+
+// worker lanes, run lazily: when the master needs the result of position a, the worker of a's
+// head processes its positions up to a, exactly as worker_role does on the device
+struct SimWorkers {
+    Geom g; Globals *G;
+    std::vector<std::vector<uint32_t>> bins;   // per head: positions of this launch, ascending
+    std::vector<uint32_t> next;                // per head: next index
+    std::vector<uint8_t> published;            // per position of the launch
+    uint32_t c0 = 0;
+    unsigned long long calls = 0, tests = 0, cmp = 0, dry = 0;
+    uint32_t la_end_of(uint32_t a) const
+    {
+        const uint32_t ci = a / g.chunk_size;
+        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size, remain = g.n - chunk_abs;
+        return (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
+    }
+    void build(uint32_t a0, uint32_t a1)
+    {
+        const uint32_t nheads = 1u << (32 - g.bt_shift);
+        bins.assign(nheads, {}); next.assign(nheads, 0); published.assign(a1 - a0 + 1, 0);
+        for (uint32_t a = a0; a < a1; a++) {
+            if (la_end_of(a) - a < 4) continue;
+            bins[hash4(load32u(G->in + a)) >> g.bt_shift].push_back(a);
+        }
+    }
+    void step(uint32_t h, bool final_flush)
+    {
+        // process head h's next position; requires its flag to be known when uncertain
+        const uint32_t a = bins[h][next[h]];
+        const uint32_t max_len = umin(la_end_of(a) - a, kMatchMax);
+        unsigned long long dt = 0, dc = 0;
+        if (G->unc[a - G->batch_a0]) {
+            if (!published[a - G->batch_a0]) {
+                worker_bt_call<HostIO, false>(g, *G, a, max_len, true, dt, dc);
+                published[a - G->batch_a0] = 1; dry++;
+            }
+            const uint32_t f = G->bt_flag[a - G->batch_a0];
+            if (f == 0) { if (final_flush) { printf("sim: flag of uncertain position %u never published\n", a); exit(1); } return; }
+            if (f == kFlagCall) { worker_bt_call<HostIO, true>(g, *G, a, max_len, false, tests, cmp); calls++; }
+        } else {
+            worker_bt_call<HostIO, true>(g, *G, a, max_len, true, tests, cmp);
+            published[a - G->batch_a0] = 1; calls++;
+        }
+        next[h]++;
+    }
+    void need(uint32_t a)
+    {
+        const uint32_t h = hash4(load32u(G->in + a)) >> g.bt_shift;
+        while (next[h] < bins[h].size() && bins[h][next[h]] <= a) {
+            const uint32_t before = next[h];
+            step(h, false);
+            if (next[h] == before) break;       // blocked on its own flag: only legal for a itself
+        }
+        // the dry run of `a` itself may have just been published while its flag is already in
+    }
+    void finish()
+    {
+        for (uint32_t h = 0; h < bins.size(); h++) while (next[h] < bins[h].size()) step(h, true);
+    }
+};
+static void sim_wait_hook(uint32_t a) { if (g_workers) g_workers->need(a); }
 
 struct Check {
     const std::vector<uint32_t> *syms; const std::vector<uint8_t> *bits; const std::vector<FrameMeta> *fm;
@@ -108,6 +230,7 @@ int main(int argc, char **argv)
     fclose(f);
     const uint32_t hb = (uint32_t)atoi(argv[2]);
     const int check_tables = argc > 3 ? atoi(argv[3]) : 0;
+    const int use_workers = argc > 4 ? atoi(argv[4]) : 0;
 
     Geom g; make_geom((uint64_t)n, hb, g);
     std::vector<uint32_t> rkhash((size_t)n + 1, 0);
@@ -140,9 +263,35 @@ int main(int argc, char **argv)
     if (check_tables) { m.G.cap_words = cap.data(); m.G.cap_cap = cap.size(); m.G.cap_lo = 0; m.G.cap_hi = ~0ull; m.G.cap_used = &cap_used; }
     // two launches, to exercise the state save/restore path
     const uint32_t half = g.nchunks / 2;
-    m.run(0, half);
-    m.run(half, g.nchunks);
-    if (P.error) { printf("sim error %u\n", P.error); return 1; }
+    SimPrefilter pf; SimWorkers wk; std::vector<uint8_t> unc; std::vector<uint32_t> ready, pairs, flag;
+    uint32_t abort_word = 0; WorkerCounters wc = {};
+    unsigned long long unc_total = 0;
+    if (use_workers) { pf.init(g.wbits, (unsigned long long)(g.nchunks - half + 1) * g.chunk_size); wk.g = g; wk.G = &m.G; g_workers = &wk; }
+    const uint32_t ranges[3] = { 0, half, g.nchunks };
+    for (int r = 0; r < 2; r++) {
+        const uint32_t c0 = ranges[r], c1 = ranges[r + 1];
+        if (c0 == c1) continue;
+        m.G.chunk0 = 0;     // frame buffers are indexed from chunk 0 in the simulation
+        if (use_workers) {
+            const unsigned long long a0 = (unsigned long long)c0 * g.chunk_size;
+            unsigned long long a1 = (unsigned long long)c1 * g.chunk_size; if (a1 > (unsigned long long)n) a1 = n;
+            pf.run(in.data(), (unsigned long long)n, (uint32_t)a0, (uint32_t)a1, g.wmask, unc);
+            for (unsigned long long i = 0; i < a1 - a0; i++) unc_total += unc[i];
+            ready.assign(a1 - a0 + 1, 0); pairs.resize((size_t)(a1 - a0 + 1) * 2 * kBtMaxPairs); flag.assign(a1 - a0 + 1, 0);
+            m.G.workers = 1; m.G.batch_a0 = (uint32_t)a0; m.G.bt_ready = ready.data(); m.G.bt_pairs = pairs.data(); m.G.bt_flag = flag.data(); m.G.unc = unc.data();
+            m.G.nheads = 1u << (32 - g.bt_shift);
+            m.G.abort_word = &abort_word; m.G.wcnt = &wc;
+            wk.build((uint32_t)a0, (uint32_t)a1);
+        }
+        m.run(c0, c1);
+        if (use_workers) wk.finish();
+        if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
+    }
+    if (use_workers) {
+        P.cnt.bt_tests += wk.tests; P.cnt.bt_calls += wk.calls; P.cnt.cmp_bytes += wk.cmp;
+        printf("workers: uncertain marks %llu (%.2f%%), master-seen uncertain %llu, dry runs %llu\n", unc_total,
+               100.0 * unc_total / (n ? n : 1), P.cnt.uncertain_positions, wk.dry);
+    }
 
     Check c; c.syms = &syms; c.bits = &bits; c.fm = &fm; c.syms_stride = ss; c.bits_stride = bs;
     c.cap = cap.data(); c.cap_used = cap_used; c.check_tables = check_tables;
