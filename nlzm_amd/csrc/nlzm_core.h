@@ -33,6 +33,11 @@ constexpr uint32_t kMatchMax = 264;     // :737
 constexpr uint32_t kNice = 64;          // :734
 constexpr uint32_t kParseMax = 4096;    // :1458
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kPf = 64;            // look-ahead depth of the master (positions)
+constexpr uint32_t kWinTail = 288;
+constexpr uint32_t kRc = 8;             // rep-distance cache entries
+constexpr uint32_t kRcLen = 256;        // bytes per entry
+constexpr uint32_t kRcCmp = 16;         // bytes compared from the cache; longer matches take the exact path
 
 // ---- CDF contexts (Model, :1133-1146) flattened into one table -------------
 constexpr uint32_t kCtxCmd = 0;                 // CDF2
@@ -62,6 +67,12 @@ struct Geom {
     uint32_t rk_shift;      // 32 - (15 + clamp(wbits,16,22) - 16)   :1753
     uint32_t tag_mask;      // (1 << (32 - wbits)) - 1               :899, :1036
     uint32_t nchunks;
+    // BT4 node slots.  The reference indexes nodes by p & (W-1): position p+W reuses p's
+    // slot, which is harmless there because p is out of every later window (:989 checks the
+    // distance before it reads the pair).  Worker lanes of different heads run up to one
+    // launch apart, so the slot space is widened to >= W + positions per launch: a lane that
+    // is ahead can then never overwrite a node a lagging lane may still visit.
+    uint32_t bt_tmask;
 };
 
 // Operation counters, accumulated per launch.
@@ -84,6 +95,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
+    unsigned long long prof[16];    // cycles per master phase (diagnostic builds: NLZM_PROFILE)
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -151,6 +163,22 @@ struct MasterLds {
     uint16_t price[kNumCtx * 16];           // log2_lut[freq>>6] per (context, symbol)  (:435-438)
     uint16_t lut[256];                      // log2_lut (:97-124)
     uint32_t btpairs[2 * kBtMaxPairs];      // worker result being consumed
+    Counters cnt;                           // operation counters of this launch (LDS adds, nothing to wait for)
+    // look-ahead: kPf positions are evaluated by the lanes in parallel against the finder
+    // tables as they stand, then consumed in order (Master::pf_fill / finders_fast)
+    uint32_t pf_v4[kPf];                    // the position's 4 input bytes
+    uint32_t pf_idx[kPf];                   // HT2 bucket | HT3 bucket << 16
+    uint32_t pf_row[3 * kPf];               // HT2 row, HT3 row 0, HT3 row 1 as read
+    uint32_t pf_len[kPf];                   // match lengths of the three HT candidates, 9 bits each
+    uint32_t pf_rkh[kPf], pf_rkv[kPf], pf_rkl[kPf];
+    uint32_t pf_ready[kPf];                 // bt_ready word as read
+    uint32_t pf_pairs[8 * kPf];             // first 4 pairs when the result was ready
+    uint8_t pf_flags[kPf];                  // bits 0..3 candidate valid (HT2, HT3 r0, HT3 r1, RK); 4: RK length inexact; 5: unc
+    uint8_t pf_stale[kPf];                  // 1: an HT row it read was rewritten since; 4: its RK slot was
+    uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
+    // bytes in front of recently probed rep distances (explicit rep probes, :1598-1628)
+    uint32_t rc_d[kRc], rc_lo[kRc];
+    uint8_t rc_data[kRc * kRcLen];
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -211,18 +239,18 @@ NLZM_HD void rep_add(uint32_t r[4], uint32_t d)     // :1160-1171
 // `kWrite` = false is a dry run: the same descent (the links a call rewrites are
 // never read again by that call), all matches reported, nothing stored.
 template <bool kWrite, class Cmp, class Sink>
-NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask,
+NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask, uint32_t tmask,
                                 const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
                                 Cmp &cmp, Sink &sink, uint32_t &n_tests)
 {
-    uint32_t pend_l = (a & wmask) << 1, pend_r = pend_l + 1;     // indices into tree[]
+    uint32_t pend_l = (a & tmask) << 1, pend_r = pend_l + 1;     // indices into tree[]
     uint32_t len_l = 0, len_r = 0;
     uint32_t sp = heads[h4 >> bt_shift];
     if (kWrite) heads[h4 >> bt_shift] = a;
     uint32_t tests = 256;                                       // :777, :988 (uint16 there; never wraps)
     while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
         n_tests++;
-        const uint32_t pair = (sp & wmask) << 1;
+        const uint32_t pair = (sp & tmask) << 1;
         const uint32_t pl = tree[pair], pr = tree[pair + 1];
         const uint32_t r = cmp(in + sp, in + a, umin(len_l, len_r), max_len);
         const uint32_t l = r & 0x7FFFFFFFu;
@@ -287,7 +315,7 @@ NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_
     ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
-    bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, G.in, a, h4, max_len, cmp, sink, tests);
+    bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
     if (publish) {
         IO::drain();                        // every pair has been written through before the ready word
@@ -303,10 +331,15 @@ template <class W>
 struct Master {
     Geom g;
     Globals G;
-    MasterLds *L;
 
     // match table ring + RK scalars + window base (wave-uniform registers)
     uint32_t mt_base, mt_max;
+    uint32_t top_d;                 // distance stored at mt(mt_max)
+    bool top_open;                  // false: that entry is known not to extend (mismatch at its end)
+    bool rk_open;                   // the carried RK match ran into its length cap
+    uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
+    uint32_t rc_next;
+    uint32_t chunk_q_, chunk_pend_; // rebased start and length of the current chunk
     uint32_t rk_from, rk_to, rk_len, rk_end;
     unsigned long long base;        // absolute offset of rebased 0
     uint32_t la_end;                // rebased end of the chunk's lookahead
@@ -316,63 +349,81 @@ struct Master {
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops;
 
-    Counters c;
     uint32_t err, err_info0;
+#ifdef NLZM_PROFILE
+    unsigned long long prof[16];
+    unsigned long long prof_t;
+    NLZM_HD void prof_start() { prof_t = W::tick(); }
+    NLZM_HD void prof_mark(int k) { const unsigned long long t = W::tick(); prof[k] += t - prof_t; prof_t = t; }
+#else
+    NLZM_HD void prof_start() {}
+    NLZM_HD void prof_mark(int) {}
+#endif
 
     // ---- LDS accessors ----------------------------------------------------
-    NLZM_HD uint32_t &mt(uint32_t i) { return L->mt[(mt_base + i) & 511]; }
+    NLZM_HD uint32_t &mt(uint32_t i) { return W::lds()->mt[(mt_base + i) & 511]; }
 
-    NLZM_HD uint32_t price(uint32_t ctx, uint32_t y) const { return L->price[ctx * 16 + y]; }
+    NLZM_HD uint32_t price(uint32_t ctx, uint32_t y) const { return W::lds()->price[ctx * 16 + y]; }
 
     // ---- byte compare, one pair, all lanes (MatchLengthSigned, :854-877) ---
-    struct WaveCmp {
-        unsigned long long *cmp_bytes;
-        NLZM_HD uint32_t operator()(const uint8_t *s, const uint8_t *t, uint32_t init, uint32_t cap) const
-        {
-            uint32_t off = init, res = cap;
-            uint32_t lt = 0;
-            bool hit = false;
-            while (off < cap) {
-                const uint32_t my = off + W::lane() * 8;
-                uint32_t m = kNone, mylt = 0;
-                if (my < cap) {
-                    const unsigned long long x = load64u(s + my), y = load64u(t + my);
-                    const unsigned long long d = x ^ y;
-                    if (d) {
-                        const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
-                        if (my + nb < cap) {
-                            m = my + nb;
-                            mylt = ((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF);
-                        }
+    // returns length | (s-byte < t-byte at the mismatch) << 31; kCount adds the bytes looked at to cmp_bytes
+    template <bool kCount>
+    static NLZM_HD uint32_t wave_cmp(const uint8_t *s, const uint8_t *t, uint32_t init, uint32_t cap)
+    {
+        uint32_t off = init, res = cap;
+        uint32_t lt = 0;
+        bool hit = false;
+        while (off < cap) {
+            const uint32_t my = off + W::lane() * 8;
+            uint32_t m = kNone, mylt = 0;
+            if (my < cap) {
+                const unsigned long long x = load64u(s + my), y = load64u(t + my);
+                const unsigned long long d = x ^ y;
+                if (d) {
+                    const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                    if (my + nb < cap) {
+                        m = my + nb;
+                        mylt = ((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF);
                     }
                 }
-                const uint32_t first = W::rmin(m);
-                if (first != kNone) {
-                    lt = W::ror((m == first) ? mylt : 0u);
-                    res = first; hit = true;
-                    break;
-                }
-                off += W::width() * 8;
             }
-            *cmp_bytes += (res - init) + (hit ? 1u : 0u);
-            return res | (lt << 31);
+            const uint32_t first = W::rmin(m);
+            if (first != kNone) {
+                lt = W::ror((m == first) ? mylt : 0u);
+                res = first; hit = true;
+                break;
+            }
+            off += W::width() * 8;
+        }
+        if (kCount) W::cnt_add(&W::lds()->cnt.cmp_bytes, (res - init) + (hit ? 1u : 0u));
+        return res | (lt << 31);
+    }
+    struct WaveCmp {
+        NLZM_HD uint32_t operator()(const uint8_t *s, const uint8_t *t, uint32_t init, uint32_t cap) const
+        {
+            return wave_cmp<true>(s, t, init, cap);
         }
     };
 
     // ---- MatchTable::Update (:835-852) on the ring ---------------------------
-    NLZM_HD void mt_update(uint32_t d, uint32_t len)
+    // No read-modify-write round trip: entries below the old maximum take an LDS
+    // atomic min, entries above it a plain store.  `open`: the match ran into its
+    // length cap, so the carried entry may extend at the next position (:1503-1512).
+    NLZM_HD void mt_update(uint32_t d, uint32_t len, bool open)
     {
         for (uint32_t i = W::lane(); i <= len; i += W::width()) {
-            uint32_t &e = mt(i);
-            e = (i <= mt_max) ? umin(e, d) : d;
+            uint32_t *e = &mt(i);
+            if (i <= mt_max) W::lds_min(e, d); else *e = d;
         }
-        mt_max = umax(mt_max, len);
+        if (len > mt_max) { mt_max = len; top_d = d; top_open = open; }
+        else if (len == mt_max) { top_d = umin(top_d, d); top_open = top_open || open; }
         W::sync();
     }
 
     struct MtSink {
         Master *m;
-        NLZM_HD void operator()(uint32_t d, uint32_t l) const { m->mt_update(d, l); }
+        uint32_t max_len;
+        NLZM_HD void operator()(uint32_t d, uint32_t l) const { m->mt_update(d, l, l >= max_len); }
     };
 
     // ---- model prices ------------------------------------------------------
@@ -407,7 +458,7 @@ struct Master {
     {
         // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279)
         const uint32_t nsy = ctx_nsyms(ctx);
-        uint16_t *cell = L->cdf + ctx * kCdfStride;
+        uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
         const uint32_t start = cell[y], freq = (uint32_t)cell[y + 1] - start;
         if (W::lane() == 0) fsyms[nsyms] = (freq << 16) + start;
         nsyms++; num_ops++;
@@ -420,7 +471,7 @@ struct Master {
         }
         W::sync();
         for (uint32_t i = W::lane(); i < nsy; i += W::width())
-            L->price[ctx * 16 + i] = L->lut[((uint32_t)cell[i + 1] - (uint32_t)cell[i]) >> 6];
+            W::lds()->price[ctx * 16 + i] = W::lds()->lut[((uint32_t)cell[i + 1] - (uint32_t)cell[i]) >> 6];
         W::sync();
     }
     NLZM_HD void put_bits(uint32_t v, uint32_t nb)                  // :574-588
@@ -451,7 +502,7 @@ struct Master {
         put_sym(kCtxCmd, 0);
         put_sym(kCtxLitHi, y >> 4);
         put_sym(kCtxLitLo + (y >> 4), y & 15);
-        c.n_literal++;
+        W::cnt_add(&W::lds()->cnt.n_literal, 1);
     }
     NLZM_HD void emit_match(uint32_t d, uint32_t len)               // :1274-1342
     {
@@ -466,14 +517,14 @@ struct Master {
             else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
         }
         rep_add(rep, d);                                            // :1819
-        c.n_dict++;
+        W::cnt_add(&W::lds()->cnt.n_dict, 1);
     }
     NLZM_HD void emit_rep(uint32_t idx, uint32_t len)               // :1344-1367
     {
         put_sym(kCtxCmd, 2);
         emit_len(len - match_min(rep[idx]));
         put_bits(idx, 2);
-        c.n_rep++;                                                  // rep4.Add(present delta) is a no-op (:1834)
+        W::cnt_add(&W::lds()->cnt.n_rep, 1);                                                  // rep4.Add(present delta) is a no-op (:1834)
     }
 
     // ---- parse graph helpers -------------------------------------------------
@@ -483,8 +534,8 @@ struct Master {
     {
         if (upto > end_p) {
             for (uint32_t e = end_p + 1 + W::lane(); e <= upto; e += W::width()) {
-                L->node_cost[e] = kNone;
-                L->node_link[e] = 0x1FFF;
+                W::lds()->node_cost[e] = kNone;
+                W::lds()->node_link[e] = 0x1FFF;
             }
             end_p = upto;
             W::sync();
@@ -495,14 +546,163 @@ struct Master {
     NLZM_HD void relax(uint32_t p, uint32_t np, uint32_t cost_p, uint32_t cst, uint32_t cmd, uint32_t len,
                        uint32_t store_delta, const uint32_t rp[4], uint32_t add_delta)
     {
-        if (L->node_cost[np] > cost_p + cst) {                      // strict: first candidate wins ties
-            L->node_cost[np] = cost_p + cst;
-            L->node_delta[np] = store_delta;
-            L->node_link[np] = pack_link(p, len, cmd);
+        if (W::lds()->node_cost[np] > cost_p + cst) {                      // strict: first candidate wins ties
+            W::lds()->node_cost[np] = cost_p + cst;
+            W::lds()->node_delta[np] = store_delta;
+            W::lds()->node_link[np] = pack_link(p, len, cmd);
             uint32_t r[4] = { rp[0], rp[1], rp[2], rp[3] };
             rep_add(r, add_delta);
-            uint32_t *dst = L->reps + (np & 511) * 4;
+            uint32_t *dst = W::lds()->reps + (np & 511) * 4;
             dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2]; dst[3] = r[3];
+        }
+    }
+
+    // ---- look-ahead ------------------------------------------------------------
+    // Lane j evaluates position pf_base + j against the finder tables as they stand
+    // now: HT2/HT3 rows and the RK256 slot are read, their candidates compared (lane-
+    // serial, 8 bytes at a time), the BT4 result of the worker lanes fetched if it is
+    // there already.  Positions are consumed in order afterwards; a table store made
+    // by an earlier position marks the later slots that read the same row `stale`,
+    // and those take the direct path again.
+    NLZM_HD void pf_fill(uint32_t a_start, uint32_t pos_end_abs, uint32_t la_end_abs)
+    {
+        W::sync_global();                       // every table store so far has landed
+        pf_base = a_start;
+        pf_n = umin(kPf, pos_end_abs - a_start);
+        for (uint32_t i = W::lane(); i < kPf + kWinTail; i += W::width())
+            W::lds()->win[i] = (unsigned long long)a_start + i < g.n ? G.in[a_start + i] : 0;
+        for (uint32_t j = W::lane(); j < pf_n; j += W::width()) {
+            const uint32_t x = a_start + j, q = (uint32_t)(x - base), avail = la_end_abs - x;
+            const uint8_t *cur = G.in + x;
+            uint32_t flags = 0, lens = 0, v4 = 0, idx = 0;
+            uint32_t row[3] = { 0, 0, 0 };
+            unsigned long long dummy = 0;
+            LaneCmp lcmp{ &dummy };
+            if (avail >= 4) {
+                v4 = load32u(cur);
+                const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu);
+                const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;
+                idx = i2 | (i3 << 16);
+                row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1];
+                const uint32_t max_len = umin(avail, kMatchMax);
+                const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t sp = row[k] & g.wmask;
+                    if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) {
+                        flags |= 1u << k;
+                        lens |= (lcmp(cur - (q - sp), cur, 0, max_len) & 0x1FFu) << (9 * k);
+                    }
+                }
+            }
+            uint32_t rkh = 0, rkv = 0, rkl = 0;
+            if (avail >= 256) {
+                rkh = G.rkhash[x];
+                rkv = G.rk_table[rkh >> g.rk_shift];
+                const uint32_t sp = rkv & g.wmask;
+                if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) {
+                    flags |= 8u;
+                    const uint32_t cap = avail & 0xFFFFu, lim = umin(cap, kMatchMax + 8);
+                    rkl = lcmp(cur - (q - sp), cur, 0, lim) & 0x7FFFFFFFu;
+                    if (rkl == lim && lim < cap) flags |= 16u;      // longer than we looked: exact length on demand
+                }
+            }
+            uint32_t ready = 0;
+            if (G.workers) {
+                const unsigned long long bi = x - G.batch_a0;
+                if (G.unc[bi]) flags |= 32u;
+                W::wait_hook(G.hook_user, x);
+                ready = W::ld_agent(G.bt_ready + bi);
+                if (ready & kBtReady) {
+                    const uint32_t n2 = 2 * umin(ready & 0x1FFu, 4u);
+                    const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+                    for (uint32_t k = 0; k < n2; k++) W::lds()->pf_pairs[8 * j + k] = W::ld_agent(pairs + k);
+                }
+            }
+            W::lds()->pf_v4[j] = v4; W::lds()->pf_idx[j] = idx;
+            W::lds()->pf_row[3 * j] = row[0]; W::lds()->pf_row[3 * j + 1] = row[1]; W::lds()->pf_row[3 * j + 2] = row[2];
+            W::lds()->pf_len[j] = lens; W::lds()->pf_rkh[j] = rkh; W::lds()->pf_rkv[j] = rkv; W::lds()->pf_rkl[j] = rkl;
+            W::lds()->pf_ready[j] = ready; W::lds()->pf_flags[j] = (uint8_t)flags; W::lds()->pf_stale[j] = 0;
+        }
+        W::sync();
+    }
+
+    // a store to HT2 row i2 / HT3 rows i3, i3+1 (bucket b reads rows b and b+1, :912) invalidates
+    // what later look-ahead slots read from them
+    NLZM_HD void pf_mark_ht(uint32_t s, uint32_t i2, uint32_t i3)
+    {
+        for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width()) {
+            const uint32_t o = W::lds()->pf_idx[j], o2 = o & 0xFFFFu, o3 = o >> 16;
+            if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) W::lds()->pf_stale[j] |= 1;
+        }
+    }
+    NLZM_HD void pf_mark_rk(uint32_t s, uint32_t slot)
+    {
+        for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width())
+            if ((W::lds()->pf_rkh[j] >> g.rk_shift) == slot) W::lds()->pf_stale[j] |= 4;
+    }
+
+    // ---- explicit rep probes (:1598-1628): common prefix of in[a-d..] and in[a..] -------------
+    // The bytes in front of the few distances that keep being probed sit in LDS (rc_*),
+    // the bytes at the position in `win`; only matches longer than kRcCmp bytes go to HBM.
+    NLZM_HD void rep_lens(uint32_t a, uint32_t q, const uint32_t rp[4], uint32_t rep_cap, uint32_t rep_len[4])
+    {
+        uint32_t ent[4];
+        const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+        // which cache entry covers each probe: 4 probes x kRc entries checked by 32 lanes at once
+        const unsigned long long hits = W::mask64([=](uint32_t i) {
+            if (i >= 4 * kRc) return false;
+            const uint32_t k = i >> 3, e = i & 7;
+            const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+            const uint32_t lo = a - d, elo = W::lds()->rc_lo[e];
+            return W::lds()->rc_d[e] == d && elo <= lo && lo + kRcCmp <= elo + kRcLen;
+        });
+        uint32_t evicted = 0;
+        for (int k = 0; k < 4; k++) {
+            rep_len[k] = 0; ent[k] = kNone;
+            if (!(rp[k] < q) || rep_cap == 0) continue;
+            const uint32_t lo = a - rp[k];
+            const uint32_t f = (uint32_t)(hits >> (8 * k)) & 0xFFu & ~evicted;
+            if (f) ent[k] = (uint32_t)__builtin_ctz(f);
+            if (ent[k] == kNone) {                                  // miss: load kRcLen bytes from a-d on
+                bool again = false;
+                for (int m = 0; m < k; m++) if (rp[m] == rp[k] && ent[m] < kRc) { ent[k] = ent[m]; again = true; }
+                if (again) continue;
+                const uint32_t e = rc_next; rc_next = (rc_next + 1) % kRc;
+                evicted |= 1u << e;
+                for (int m = 0; m < 4; m++) if (m != k && ent[m] == e) ent[m] = kNone - 1;   // evicted under another probe: exact path
+                W::sync();
+                for (uint32_t i = W::lane(); i < kRcLen; i += W::width()) {
+                    const unsigned long long src = (unsigned long long)lo + i;
+                    W::lds()->rc_data[e * kRcLen + i] = src < g.n ? G.in[src] : 0;
+                }
+                W::lds()->rc_d[e] = rp[k]; W::lds()->rc_lo[e] = lo;
+                W::sync();
+                ent[k] = e;
+            }
+        }
+        // 4 probes x kRcCmp bytes in one pass: bit (16k + b) set = byte b of probe k differs
+        const uint32_t wo = a - pf_base;
+        uint32_t off[4];
+        for (int k = 0; k < 4; k++) off[k] = ent[k] < kRc ? ent[k] * kRcLen + ((a - rp[k]) - W::lds()->rc_lo[ent[k]]) : 0;
+        const uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3], o0 = off[0], o1 = off[1], o2 = off[2], o3 = off[3];
+        const unsigned long long diff = W::mask64([=](uint32_t i) {
+            const uint32_t k = i >> 4, b = i & 15;
+            const uint32_t ek = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : e3));
+            const uint32_t ok = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+            return ek < kRc && W::lds()->rc_data[ok + b] != W::lds()->win[wo + b];
+        });
+        for (int k = 0; k < 4; k++) {
+            if (ent[k] == kNone) continue;
+            uint32_t l;
+            if (ent[k] < kRc) {
+                const uint32_t f = (uint32_t)(diff >> (16 * k)) & 0xFFFFu;
+                l = f ? (uint32_t)__builtin_ctz(f) : kRcCmp;
+                if (l >= rep_cap) l = rep_cap;
+                else if (l == kRcCmp) l = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRcCmp, rep_cap) & 0x7FFFFFFFu;
+            } else {
+                l = wave_cmp<false>(G.in + a - rp[k], G.in + a, 0, rep_cap) & 0x7FFFFFFFu;
+            }
+            rep_len[k] = l;
         }
     }
 
@@ -510,41 +710,43 @@ struct Master {
     // q: rebased position, a: absolute position, p: parse-relative index.
     // rp/rep_len: the node's rep set and (output) explicit rep-probe lengths.
     NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t p, const uint32_t rp[4], uint32_t rep_cap,
-                         uint32_t rep_len[4])
+                         uint32_t rep_len[4], uint32_t pos_end_abs)
     {
         const uint8_t *cur = G.in + a;
         const uint32_t avail = la_end - q;
-        WaveCmp wcmp{ &c.cmp_bytes };
+        prof_mark(0);
+        if (a - pf_base >= pf_n) pf_fill(a, pos_end_abs, a + avail);
+        const uint32_t s = a - pf_base;
+        const uint32_t pflags = W::lds()->pf_flags[s], pstale = W::lds()->pf_stale[s];
 
         // carry by one (:1501-1502, CarryFrom :823-833)
-        if (mt_max <= 1) mt_max = 0;
+        if (mt_max <= 1) { mt_max = 0; top_open = false; }
         else { mt_max -= 1; mt_base = (mt_base + 1) & 511; }
-        // extend the longest entry (:1503-1512)
-        if (mt_max > 0) {
-            const uint32_t d = mt(mt_max);
+        // extend the longest entry (:1503-1512); skipped when that entry is known to end in a mismatch
+        if (mt_max > 0 && top_open) {
+            const uint32_t d = top_d;
             if (q >= d) {
                 const uint32_t cap = umin(kMatchMax, avail);
                 if (mt_max < cap) {
-                    unsigned long long dummy = 0;
-                    WaveCmp ext{ &dummy };
-                    const uint32_t nl = ext(cur - d, cur, mt_max, cap) & 0x7FFFFFFFu;
+                    const uint32_t nl = wave_cmp<false>(cur - d, cur, mt_max, cap) & 0x7FFFFFFFu;
                     if (nl > mt_max) {
                         for (uint32_t i = mt_max + 1 + W::lane(); i <= nl; i += W::width()) mt(i) = d;
                         mt_max = nl;
                         W::sync();
                     }
+                    top_open = nl >= cap;
                 }
             }
         }
 
+        prof_mark(1);
         const bool nice = mt_max >= kNice;                          // :1514
-        c.nice_positions += nice ? 1 : 0;
+        W::cnt_add(&W::lds()->cnt.nice_positions, nice ? 1 : 0);
         if (G.workers) {
             // tell the worker that owns this position's BT4 head whether the call happens
-            const uint32_t bi = a - G.batch_a0;
-            if (G.unc[bi]) {
-                c.uncertain_positions++;
-                if (W::lane() == 0) W::st_agent(G.bt_flag + bi, nice ? kFlagSkip : kFlagCall);
+            if (pflags & 32u) {
+                W::cnt_add(&W::lds()->cnt.uncertain_positions, 1);
+                if (W::lane() == 0) W::st_agent(G.bt_flag + (a - G.batch_a0), nice ? kFlagSkip : kFlagCall);
             } else if (nice) {
                 // the pre-filter promised that no match of 65+ bytes ends up in the table at a-1
                 err = kErrInternal; err_info0 = a;
@@ -554,106 +756,126 @@ struct Master {
         const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
 
-        // ---- gather up to 8 compare jobs: HT2, HT3 row0/row1, RK probe, 4 rep probes
-        uint32_t job_sp[8], job_cap[8], job_len[8];
-        uint32_t valid = 0;
-        uint32_t v4 = 0, h2 = 0, h3 = 0, h4 = 0;
-        uint32_t row[3] = { 0, 0, 0 }, tag2 = 0, tag3 = 0;
         if (have4) {
-            v4 = load32u(cur);
-            h2 = hash4(v4 & 0xFFFFu); h3 = hash4(v4 & 0xFFFFFFu); h4 = hash4(v4);   // :1516-1518
-            uint32_t *r2 = G.ht2 + (h2 >> 20);                                       // 12-bit, 1 row (:1750)
-            uint32_t *r3 = G.ht3 + (h3 >> g.ht3_shift);                              // base NOT scaled by rows (:912)
-            row[0] = r2[0]; row[1] = r3[0]; row[2] = r3[1];
-            tag2 = h2 & g.tag_mask; tag3 = h3 & g.tag_mask;
+            const uint32_t v4 = W::lds()->pf_v4[s];
+            const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu), h4 = hash4(v4);   // :1516-1518
+            const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;   // bucket base NOT scaled by rows (:912)
+            const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
+            uint32_t row[3], len[3], valid = 0;
+            if (!(pstale & 1)) {
+                row[0] = W::lds()->pf_row[3 * s]; row[1] = W::lds()->pf_row[3 * s + 1]; row[2] = W::lds()->pf_row[3 * s + 2];
+                const uint32_t pl = W::lds()->pf_len[s];
+                len[0] = pl & 0x1FF; len[1] = (pl >> 9) & 0x1FF; len[2] = (pl >> 18) & 0x1FF;
+                valid = pflags & 7u;
+            } else {
+                // an earlier position rewrote a row this slot had read: read them again, compare now
+                W::sync_global();
+                row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1];
+                uint32_t job_sp[8], job_cap[8], job_len[8];
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t sp = row[k] & g.wmask;
+                    if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) {   // :922-925
+                        valid |= 1u << k; job_sp[k] = a - (q - sp); job_cap[k] = max_len;
+                    }
+                }
+                W::cmp_multi(G.in, job_sp, a, job_cap, valid, job_len);
+                for (int k = 0; k < 3; k++) len[k] = job_len[k];
+            }
             // rows always rotate, compare or not (:935-936); q is stored un-masked (:913)
             if (W::lane() == 0) {
-                r2[0] = q | (tag2 << g.wbits);
-                r3[0] = q | (tag3 << g.wbits);
-                r3[1] = row[1];
+                G.ht2[i2] = q | (tag2 << g.wbits);
+                G.ht3[i3] = q | (tag3 << g.wbits);
+                G.ht3[i3 + 1] = row[1];
             }
-            c.ht_rows += 3;
-            const uint32_t tags[3] = { tag2, tag3, tag3 };
-            for (int k = 0; k < 3; k++) {
-                const uint32_t sp = row[k] & g.wmask;
-                if ((row[k] >> g.wbits) == tags[k] && sp < q && q - sp <= g.wmask) {   // :922-925
-                    valid |= 1u << k; job_sp[k] = a - (q - sp); job_cap[k] = max_len;
-                }
+            pf_mark_ht(s, i2, i3);
+            W::cnt_add(&W::lds()->cnt.ht_rows, 3);
+            prof_mark(2);
+            // HT2 (:917-933)
+            if ((valid & 1) && 1 < max_len) {
+                const uint32_t l = len[0], d = q - (row[0] & g.wmask);
+                W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < max_len));
+                if (l > 1 && l >= match_min(d)) mt_update(d, l, l >= max_len);
             }
+            // HT3, two rows, `best` gates the second (:917-933)
+            uint32_t best = 1;
+            for (int k = 1; k < 3; k++) {
+                if (!((valid >> k) & 1) || !(best < max_len)) continue;
+                const uint32_t l = len[k], d = q - (row[k] & g.wmask);
+                W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < max_len));
+                if (l > best && l >= match_min(d)) { mt_update(d, l, l >= max_len); best = l; }
+            }
+            prof_mark(4);
+            if (!nice) {                                            // BT4 (:1522)
+                if (G.workers) {
+                    const uint32_t ready = W::lds()->pf_ready[s], cnt = ready & 0x1FFu;
+#ifdef NLZM_SIM_DEBUG
+                    if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[a - G.batch_a0]);
+#endif
+                    if ((ready & kBtReady) && cnt <= 4) {
+                        for (uint32_t k = 0; k < cnt; k++) {
+                            const uint32_t l = W::lds()->pf_pairs[8 * s + 2 * k + 1];
+                            mt_update(W::lds()->pf_pairs[8 * s + 2 * k], l, l >= max_len);
+                        }
+                    } else bt_consume(a, max_len);
+                } else bt_step(a, h4, max_len);
+            }
+            prof_mark(5);
         }
-        uint32_t rkv = 0, rkh = 0;
-        bool rk_probe = false;
         if (have256) {
             // carried long match (:1056-1069)
             if (rk_len > 0) {
                 if (q - rk_to < rk_len) {
                     const uint32_t d = rk_to - rk_from, l = rk_len - (q - rk_to);
-                    if (l >= match_min(d)) mt_update(d, umin(l, kMatchMax));
+                    if (l >= match_min(d)) mt_update(d, umin(l, kMatchMax), rk_open || l >= kMatchMax);
                 } else rk_len = 0;
             }
+            const uint32_t rkh = W::lds()->pf_rkh[s], myslot = rkh >> g.rk_shift;
+            bool fresh = !(pstale & 4);
             // window ends passed since the last call: insert with the CALLING position (:1084-1087)
             for (uint32_t e = (rk_end | 255u) + 1; e < q + 256; e += 256) {
                 const uint32_t hh = G.rkhash[(uint32_t)(base + e - 256)];
                 if (W::lane() == 0) G.rk_table[hh >> g.rk_shift] = q | (hh << g.wbits);
-                c.rk_inserts++;
+                pf_mark_rk(s, hh >> g.rk_shift);
+                if ((hh >> g.rk_shift) == myslot) fresh = false;
+                W::cnt_add(&W::lds()->cnt.rk_inserts, 1);
             }
             rk_end = q + 256;
-            rkh = G.rkhash[a];
-            if (rk_len < 256) {                                     // :1090-1095
-                W::sync_global();
-                rkv = G.rk_table[rkh >> g.rk_shift];
-                c.rk_probes++;
-                const uint32_t sp = rkv & g.wmask;
-                if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) {
-                    rk_probe = true;
-                    valid |= 1u << 3; job_sp[3] = a - (q - sp); job_cap[3] = avail & 0xFFFFu;   // uint16 parameter (:760)
+            if (rk_len < 256) {                                     // :1090-1107
+                W::cnt_add(&W::lds()->cnt.rk_probes, 1);
+                uint32_t rkv, l = 0;
+                bool ok, exact = true;
+                if (fresh) { rkv = W::lds()->pf_rkv[s]; ok = (pflags & 8u) != 0; l = W::lds()->pf_rkl[s]; exact = !(pflags & 16u); }
+                else {
+                    W::sync_global();
+                    rkv = G.rk_table[myslot];
+                    const uint32_t sp = rkv & g.wmask;
+                    ok = (rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask;
+                    exact = false;
                 }
-            }
-        }
-        for (int k = 0; k < 4; k++) {                               // explicit rep probes (:1601-1606)
-            rep_len[k] = 0;
-            if (rp[k] < q) { valid |= 1u << (4 + k); job_sp[4 + k] = a - rp[k]; job_cap[4 + k] = rep_cap; }
-        }
-        W::cmp_multi(G.in, job_sp, a, job_cap, valid, job_len);
-
-        // ---- HT2 (:917-933)
-        if (have4) {
-            if ((valid & 1) && 1 < max_len) {
-                const uint32_t l = job_len[0], d = a - job_sp[0];
-                c.cmp_bytes += l + (l < max_len);
-                if (l > 1 && l >= match_min(d)) mt_update(d, l);
-            }
-            uint32_t best = 1;
-            for (int k = 1; k < 3; k++) {
-                if (!((valid >> k) & 1) || !(best < max_len)) continue;
-                const uint32_t l = job_len[k], d = a - job_sp[k];
-                c.cmp_bytes += l + (l < max_len);
-                if (l > best && l >= match_min(d)) { mt_update(d, l); best = l; }
-            }
-            if (!nice) {                                            // BT4 (:1522)
-                if (G.workers) bt_consume(a); else bt_step(a, h4, max_len);
-            }
-        }
-        if (have256) {
-            if (rk_probe) {                                         // :1096-1105
-                const uint32_t l = job_len[3], sp_abs = job_sp[3], d = a - sp_abs;
-                c.cmp_bytes += l + (l < job_cap[3]);
-                if (l >= rk_len && l >= match_min(d)) {
-                    mt_update(d, umin(l, kMatchMax));
-                    rk_from = q - d; rk_to = q; rk_len = l;
+                if (ok) {
+                    const uint32_t d = q - (rkv & g.wmask), cap = avail & 0xFFFFu;   // uint16 parameter (:760)
+                    if (!exact) l = wave_cmp<false>(cur - d, cur, 0, cap) & 0x7FFFFFFFu;
+                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < cap));
+                    if (l >= rk_len && l >= match_min(d)) {
+                        rk_open = l >= cap;
+                        mt_update(d, umin(l, kMatchMax), rk_open || l >= kMatchMax);
+                        rk_from = q - d; rk_to = q; rk_len = l;
+                    }
                 }
             }
             if (!(q & 255u)) {                                      // aligned insert after the probe (:1109-1112)
-                if (W::lane() == 0) G.rk_table[rkh >> g.rk_shift] = q | (rkh << g.wbits);
-                c.rk_inserts++;
+                if (W::lane() == 0) G.rk_table[myslot] = q | (rkh << g.wbits);
+                pf_mark_rk(s, myslot);
+                W::cnt_add(&W::lds()->cnt.rk_inserts, 1);
             }
         }
-        for (int k = 0; k < 4; k++) if ((valid >> (4 + k)) & 1) rep_len[k] = job_len[4 + k];
-        W::sync_global();
+        prof_mark(6);
+        rep_lens(a, q, rp, rep_cap, rep_len);
+        prof_mark(3);
     }
 
     // BT4 result of a worker lane: wait for it, then merge its pairs (MatchTable::Update, :996-998).
-    NLZM_HD void bt_consume(uint32_t a)
+    NLZM_HD void bt_consume(uint32_t a, uint32_t max_len)
     {
         const unsigned long long bi = a - G.batch_a0;
         W::wait_hook(G.hook_user, a);
@@ -667,17 +889,17 @@ struct Master {
         const uint32_t count = v & 0x1FFu;
         const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
         W::sync();
-        for (uint32_t i = W::lane(); i < 2 * count; i += W::width()) L->btpairs[i] = W::ld_agent(pairs + i);
+        for (uint32_t i = W::lane(); i < 2 * count; i += W::width()) W::lds()->btpairs[i] = W::ld_agent(pairs + i);
         W::sync();
-        for (uint32_t k = 0; k < count; k++) mt_update(L->btpairs[2 * k], L->btpairs[2 * k + 1]);
+        for (uint32_t k = 0; k < count; k++) mt_update(W::lds()->btpairs[2 * k], W::lds()->btpairs[2 * k + 1], W::lds()->btpairs[2 * k + 1] >= max_len);
     }
 
     // BT4 inside the master (workers off): wave-wide compares, uniform descent.
     NLZM_HD void bt_step(uint32_t a, uint32_t h4, uint32_t max_len)
     {
-        WaveCmp wcmp{ &c.cmp_bytes };
-        MtSink sink{ this };
-        c.bt_calls++;
+        WaveCmp wcmp;
+        MtSink sink{ this, max_len };
+        W::cnt_add(&W::lds()->cnt.bt_calls, 1);
         BtMem mem{ G.bt_heads, G.bt_tree };
         bt_find_and_update_uniform(mem, a, h4, max_len, wcmp, sink);
     }
@@ -690,15 +912,15 @@ struct Master {
     NLZM_HD void bt_find_and_update_uniform(BtMem &mem, uint32_t a, uint32_t h4, uint32_t max_len, Cmp &cmp, Sink &sink)
     {
         uint32_t *heads = mem.heads, *tree = mem.tree;
-        const uint32_t wmask = g.wmask;
-        uint32_t pend_l = (a & wmask) << 1, pend_r = pend_l + 1;
+        const uint32_t wmask = g.wmask, tmask = g.bt_tmask;
+        uint32_t pend_l = (a & tmask) << 1, pend_r = pend_l + 1;
         uint32_t len_l = 0, len_r = 0;
         uint32_t sp = heads[h4 >> g.bt_shift];
         if (W::lane() == 0) heads[h4 >> g.bt_shift] = a;
         uint32_t tests = 256;
         while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
-            c.bt_tests++;
-            const uint32_t pair = (sp & wmask) << 1;
+            W::cnt_add(&W::lds()->cnt.bt_tests, 1);
+            const uint32_t pair = (sp & tmask) << 1;
             const uint32_t pl = tree[pair], pr = tree[pair + 1];
             const uint32_t r = cmp(G.in + sp, G.in + a, umin(len_l, len_r), max_len);
             const uint32_t l = r & 0x7FFFFFFFu;
@@ -720,35 +942,36 @@ struct Master {
     {
         max_parse = umin(max_parse, kParseMax);
         if (W::lane() == 0) {
-            L->node_cost[0] = 0; L->node_link[0] = 0x1FFF;
-            L->node_cost[1] = kNone; L->node_link[1] = pack_link(0, 0, 0);
-            for (int k = 0; k < 4; k++) { L->reps[k] = rep[k]; L->reps[4 + k] = rep[k]; }
+            W::lds()->node_cost[0] = 0; W::lds()->node_link[0] = 0x1FFF;
+            W::lds()->node_cost[1] = kNone; W::lds()->node_link[1] = pack_link(0, 0, 0);
+            for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
         }
         W::sync();
         uint32_t p = 0, end_p = 1;
         while (p < end_p) {
             const uint32_t q = seg_q + p, a = seg_a + p;
-            c.positions++;
-            const uint32_t cost_p = L->node_cost[p];
+            W::cnt_add(&W::lds()->cnt.positions, 1);
+            const uint32_t cost_p = W::lds()->node_cost[p];
             uint32_t rp[4];
-            for (int k = 0; k < 4; k++) rp[k] = L->reps[(p & 511) * 4 + k];
+            for (int k = 0; k < 4; k++) rp[k] = W::lds()->reps[(p & 511) * 4 + k];
 
             // literal edge (:1490-1499)
             {
                 const uint32_t cst = price_literal(G.in[a]);
-                if (L->node_cost[p + 1] > cost_p + cst) {
+                if (W::lds()->node_cost[p + 1] > cost_p + cst) {
                     W::sync();
                     if (W::lane() == 0) {
-                        L->node_cost[p + 1] = cost_p + cst;
-                        L->node_link[p + 1] = pack_link(p, 0, 0);
-                        for (int k = 0; k < 4; k++) L->reps[((p + 1) & 511) * 4 + k] = rp[k];
+                        W::lds()->node_cost[p + 1] = cost_p + cst;
+                        W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
+                        for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
                     }
                     W::sync();
                 }
             }
 
             uint32_t rep_len[4];
-            finders(q, a, p, rp, umin(max_parse - p, kMatchMax), rep_len);
+            prof_mark(7);
+            finders(q, a, p, rp, umin(max_parse - p, kMatchMax), rep_len, seg_a - (seg_q - chunk_q_) + chunk_pend_);
             capture(a);
 
             uint32_t max_len = umin(mt_max, max_parse - p);         // :1545-1548
@@ -776,12 +999,13 @@ struct Master {
                 checked = W::ror(checked);
                 W::sync();
             }
+            prof_mark(8);
             // explicit rep probes (:1598-1628)
             if (checked != 15) {
                 for (uint32_t ri = 0; ri < 4; ri++) {
                     if ((checked >> ri) & 1 || rp[ri] >= q) continue;
                     const uint32_t l = rep_len[ri];                 // already min(len, 264)
-                    c.cmp_bytes += l + 1;
+                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + 1);
                     if (l >= match_min(rp[ri])) {
                         open_nodes(end_p, l + p);
                         W::sync();
@@ -790,18 +1014,20 @@ struct Master {
                     }
                 }
             }
+            prof_mark(9);
             ++p;
         }
         // backtrack (:1633-1650): collect the node indices of the path, end first
         uint32_t n = 0, cur = p;
         while (cur != 0) {
-            if (W::lane() == 0) L->cmdlist[n] = (uint16_t)cur;
+            if (W::lane() == 0) W::lds()->cmdlist[n] = (uint16_t)cur;
             n++;
-            cur = L->node_link[cur] & 0x1FFF;
+            cur = W::lds()->node_link[cur] & 0x1FFF;
         }
         W::sync();
+        prof_mark(10);
         ncmds = n;
-        c.segments++;
+        W::cnt_add(&W::lds()->cnt.segments, 1);
         return end_p;
     }
 
@@ -836,7 +1062,7 @@ struct Master {
 
         if (chunk_abs - base >= W2) {                               // :1786-1792
             base += g.wmask + 1;
-            c.shifts++;
+            W::cnt_add(&W::lds()->cnt.shifts, 1);
             if (W::lane() == 0) { G.ht2[0] = kNone; G.ht3[0] = kNone; }   // MatchFinderHT::Shift (:940-957)
             if (rk_end >= g.wmask + 1) rk_end -= g.wmask + 1; else rk_end = 0;   // :1115-1123
             W::sync_global();
@@ -844,23 +1070,26 @@ struct Master {
         }
         const uint32_t chunk_q = (uint32_t)(chunk_abs - base);
         la_end = chunk_q + chunk_read;
+        chunk_q_ = chunk_q; chunk_pend_ = p_end;
+        pf_n = 0;                           // the look-ahead never crosses a chunk (lookahead limit, rebase)
 
         uint32_t p = 0;
         while (p < p_end && !err) {
             uint32_t ncmds = 0;
             parse_segment(chunk_q + p, (uint32_t)chunk_abs + p, p_end - p, ncmds);
             for (uint32_t k = ncmds; k-- > 0;) {                    // :1809-1843
-                const uint32_t node = L->cmdlist[k];
-                const uint32_t link = L->node_link[node];
+                const uint32_t node = W::lds()->cmdlist[k];
+                const uint32_t link = W::lds()->node_link[node];
                 const uint32_t cmd = link >> 22, len = (link >> 13) & 0x1FF;
                 if (cmd == 0) { emit_literal(G.in[(uint32_t)chunk_abs + p]); p += 1; }
-                else if (cmd == 1) { emit_match(L->node_delta[node], len); p += len; }
-                else { emit_rep(L->node_delta[node], len); p += len; }
+                else if (cmd == 1) { emit_match(W::lds()->node_delta[node], len); p += len; }
+                else { emit_rep(W::lds()->node_delta[node], len); p += len; }
             }
+            prof_mark(11);
             if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) err = kErrFrameOverflow;
         }
         // bit pad of Flush (:591-597)
-        c.rans_syms += nsyms; c.bit_ops += num_ops - nsyms; c.frames++;
+        W::cnt_add(&W::lds()->cnt.rans_syms, nsyms); W::cnt_add(&W::lds()->cnt.bit_ops, num_ops - nsyms); W::cnt_add(&W::lds()->cnt.frames, 1);
         for (int i = 0; i < 4; i++) {
             if (W::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
             nbits++; word <<= 8;
@@ -875,29 +1104,35 @@ struct Master {
     NLZM_HD void load_state()
     {
         Persist *P = G.persist;
-        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) L->cdf[i] = P->cdf[i];
-        for (uint32_t i = W::lane(); i < 256; i += W::width()) L->lut[i] = log2_lut_entry(i);
+        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) W::lds()->cdf[i] = P->cdf[i];
+        for (uint32_t i = W::lane(); i < 256; i += W::width()) W::lds()->lut[i] = log2_lut_entry(i);
         W::sync();
         for (uint32_t i = W::lane(); i < kNumCtx * 16; i += W::width()) {
             const uint32_t ctx = i >> 4, y = i & 15;
-            const uint16_t *cell = L->cdf + ctx * kCdfStride;
-            L->price[i] = (y < ctx_nsyms(ctx)) ? L->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
+            const uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
+            W::lds()->price[i] = (y < ctx_nsyms(ctx)) ? W::lds()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
         }
         mt_base = 0; mt_max = P->mt_max;
-        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) L->mt[i] = P->mt_delta[i];
+        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) W::lds()->mt[i] = P->mt_delta[i];
+        top_d = P->mt_delta[mt_max]; top_open = true; rk_open = true;     // conservative across launches
+        pf_base = 0; pf_n = 0; rc_next = 0;
+        for (uint32_t i = W::lane(); i < kRc; i += W::width()) { W::lds()->rc_d[i] = 0; W::lds()->rc_lo[i] = 0; }
         for (int k = 0; k < 4; k++) rep[k] = P->rep[k];
         rk_from = P->rk_from; rk_to = P->rk_to; rk_len = P->rk_len; rk_end = P->rk_end;
         base = P->reb_base;
         err = P->error; err_info0 = 0;
-        Counters z = {};
-        c = z;
+        for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 16; k++) prof[k] = 0;
+        prof_start();
+#endif
         W::sync();
     }
     NLZM_HD void store_state(uint32_t next_chunk)
     {
         Persist *P = G.persist;
         W::sync();
-        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) P->cdf[i] = L->cdf[i];
+        for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) P->cdf[i] = W::lds()->cdf[i];
         for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = mt(i);
         if (W::lane() == 0) {
             P->mt_max = mt_max;
@@ -907,8 +1142,11 @@ struct Master {
             P->next_chunk = next_chunk;
             P->error = err;
             if (err) { P->error_info[0] = err_info0; if (G.abort_word) W::st_agent(G.abort_word, 1u); }
+#ifdef NLZM_PROFILE
+            for (int k = 0; k < 16; k++) P->prof[k] += prof[k];
+#endif
             unsigned long long *dst = (unsigned long long *)&P->cnt;
-            const unsigned long long *src = (const unsigned long long *)&c;
+            const unsigned long long *src = (const unsigned long long *)&W::lds()->cnt;
             for (uint32_t i = 0; i < sizeof(Counters) / 8; i++) dst[i] += src[i];
         }
     }

@@ -10,6 +10,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -65,7 +66,7 @@ struct Ctx {
     // options
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
-    int64_t opt_worker_blocks = 448;
+    int64_t opt_worker_blocks = 240;        // + the master block: below the 256 CUs, one 512-thread block per CU
 
     // stream state
     bool open = false;
@@ -138,6 +139,7 @@ void make_geom(uint64_t n, uint32_t hist_bits_req, Geom &g)
     g.rk_shift = 32 - (15 + clampu(hb, 16, 22) - 16);               // :1753
     g.tag_mask = (uint32_t)((1ull << (32 - hb)) - 1);
     g.nchunks = (uint32_t)((n + g.chunk_size - 1) / g.chunk_size);
+    g.bt_tmask = g.wmask;       // widened by stream_begin once the launch size is known
 }
 
 int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
@@ -166,13 +168,22 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
     HIPCHK(hipMalloc(&C.ht3, ht3_rows * 4));
     HIPCHK(hipMalloc(&C.rk_table, (size_t)4 << (32 - g.rk_shift)));
     HIPCHK(hipMalloc(&C.bt_heads, (size_t)4 << (32 - g.bt_shift)));
-    HIPCHK(hipMalloc(&C.bt_tree, (size_t)8 << g.wbits));
+    {
+        // node slots >= W + positions per launch (see Geom::bt_tmask)
+        uint32_t b = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
+        if (g.nchunks && b > g.nchunks) b = g.nchunks;
+        const unsigned long long need = (1ull << g.wbits) + (unsigned long long)b * g.chunk_size;
+        unsigned long long slots = 1ull << g.wbits;
+        while (slots < need) slots <<= 1;
+        C.g.bt_tmask = (uint32_t)(slots - 1);
+    }
+    HIPCHK(hipMalloc(&C.bt_tree, ((size_t)C.g.bt_tmask + 1) * 8));
     HIPCHK(hipMalloc(&C.persist, sizeof(Persist)));
     HIPCHK(hipMemsetAsync(C.ht2, 0xFF, 4096 * 4, C.st));                         // :902
     HIPCHK(hipMemsetAsync(C.ht3, 0xFF, ht3_rows * 4, C.st));
     HIPCHK(hipMemsetAsync(C.rk_table, 0xFF, (size_t)4 << (32 - g.rk_shift), C.st));   // :1040
     HIPCHK(hipMemsetAsync(C.bt_heads, 0xFF, (size_t)4 << (32 - g.bt_shift), C.st));   // :968
-    HIPCHK(hipMemsetAsync(C.bt_tree, 0xFF, (size_t)8 << g.wbits, C.st));              // :969
+    HIPCHK(hipMemsetAsync(C.bt_tree, 0xFF, ((size_t)C.g.bt_tmask + 1) * 8, C.st));     // :969
 
     Persist P;
     memset(&P, 0, sizeof P);
@@ -220,7 +231,7 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
         HIPCHK(hipMalloc(&C.bin_pos, bpos * 4));
         HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
         HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
-        if ((unsigned long long)C.nheads > 2ull * (unsigned long long)C.opt_worker_blocks * 256)
+        if ((unsigned long long)C.nheads > 2ull * (unsigned long long)C.opt_worker_blocks * 512)
             return set_err(NLZM_HIP_E_ARG, "worker_blocks %lld too small for %u heads", (long long)C.opt_worker_blocks, C.nheads);
     }
 
@@ -229,15 +240,7 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
     HIPCHK(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
     C.out_pos = 4;
 
-    // pre-pass: RK256 hash of every window
-    HIPCHK(hipEventRecord(C.ev[0], C.st));
-    if (n >= 256) launch_rk_hash(C.d_in, n, 0, n - 255, C.rkhash, C.st);
-    HIPCHK(hipEventRecord(C.ev[1], C.st));
     HIPCHK(hipStreamSynchronize(C.st));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, C.ev[0], C.ev[1]));
-    C.tm.prep_ms += ms; C.tm.prep_launches += n >= 256;
-    C.tm.total_ms += ms;
     C.open = true;
     return 0;
 }
@@ -264,7 +267,14 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
         unsigned long long a1 = (unsigned long long)c1 * g.chunk_size;
         if (a1 > g.n) a1 = g.n;
         G.batch_a0 = (uint32_t)a0;
-        float pre_ms = 0;
+        float pre_ms = 0, rk_ms = 0;
+        {   // pre-pass: RK256 hash of every window the launch can touch (catch-up inserts reach back < 512 bytes)
+            const unsigned long long lo = a0 > 1024 ? a0 - 1024 : 0;
+            unsigned long long hi = a1 + g.feed + 256;
+            if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
+            HIPCHK(hipEventRecord(C.ev[7], C.st));
+            if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash, C.st);
+        }
         if (C.workers) {
             const unsigned long long cnt = a1 - a0;
             G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
@@ -294,6 +304,8 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
         if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
         HIPCHK(hipStreamSynchronize(C.st));
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventElapsedTime(&rk_ms, C.ev[7], C.workers ? C.ev[5] : C.ev[0]));
+        C.tm.prep_ms += rk_ms; C.tm.prep_launches += 1; C.tm.total_ms += rk_ms;
         if (C.workers) {
             HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
             C.tm.prep_ms += pre_ms; C.tm.prep_launches += 4; C.tm.total_ms += pre_ms;
@@ -344,16 +356,10 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
     return 0;
 }
 
-int stream_finish(uint64_t *dst_len)
+int refresh_stats()
 {
-    if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
-    if (C.next_chunk < C.g.nchunks) return set_err(NLZM_HIP_E_ARG, "stream not finished (%u of %u chunks)", C.next_chunk, C.g.nchunks);
-    if (C.out_pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap too small");
-    HIPCHK(hipMemsetAsync(C.d_dst + C.out_pos, 0, 4, C.st));        // terminator (:1891-1895)
-    C.out_pos += 4;
     Persist P;
-    HIPCHK(hipMemcpyAsync(&P, C.persist, sizeof P, hipMemcpyDeviceToHost, C.st));
-    HIPCHK(hipStreamSynchronize(C.st));
+    HIPCHK(hipMemcpy(&P, C.persist, sizeof P, hipMemcpyDeviceToHost));
     nlzm_hip_stats &s = C.stats;
     s.out_bytes = C.out_pos;
     s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes; s.ht_rows = P.cnt.ht_rows;
@@ -361,12 +367,33 @@ int stream_finish(uint64_t *dst_len)
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
+    if (getenv("NLZM_PROFILE_PRINT")) {
+        static const char *names[12] = { "loop-top/literal", "carry+extend", "HT consume", "rep probes", "HT logic", "BT consume",
+                                         "RK", "node read", "sampled relax", "rep relax", "backtrack", "emit" };
+        unsigned long long tot = 0;
+        for (int k = 0; k < 12; k++) tot += P.prof[k];
+        for (int k = 0; k < 12; k++) fprintf(stderr, "prof %-18s %12llu cyc  %5.1f%%  %7.1f cyc/pos\n", names[k], P.prof[k],
+                                             100.0 * P.prof[k] / (tot ? tot : 1), (double)P.prof[k] / (P.cnt.positions ? P.cnt.positions : 1));
+    }
     if (C.workers) {
         WorkerCounters wc;
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
     }
+    return 0;
+}
+
+int stream_finish(uint64_t *dst_len)
+{
+    if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
+    if (C.next_chunk < C.g.nchunks) return set_err(NLZM_HIP_E_ARG, "stream not finished (%u of %u chunks)", C.next_chunk, C.g.nchunks);
+    if (C.out_pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap too small");
+    HIPCHK(hipMemsetAsync(C.d_dst + C.out_pos, 0, 4, C.st));        // terminator (:1891-1895)
+    C.out_pos += 4;
+    HIPCHK(hipStreamSynchronize(C.st));
+    const int rc = refresh_stats();
+    if (rc) return rc;
     if (dst_len) *dst_len = C.out_pos;
     return 0;
 }
@@ -487,6 +514,7 @@ int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, ui
 int nlzm_hip_get_stats(nlzm_hip_stats *out)
 {
     if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
+    if (C.open) { const int rc = refresh_stats(); if (rc) return rc; }
     *out = C.stats;
     return 0;
 }
@@ -502,7 +530,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
 {
     if (!key) return set_err(NLZM_HIP_E_ARG, "null key");
     if (!strcmp(key, "workers")) { C.opt_workers = value; return 0; }
-    if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 511) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
+    if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
 }

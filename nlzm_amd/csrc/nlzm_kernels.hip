@@ -20,7 +20,16 @@ namespace nlzm {
 // ---------------------------------------------------------------------------
 // 64-lane wave policy for the master (block = one wave)
 // ---------------------------------------------------------------------------
+// LDS image of the master: a file-scope __shared__ object, so every access is a ds_* instruction
+// (a pointer kept in a struct would degrade to flat_* accesses and their full waits)
+__shared__ MasterLds g_master_lds;
+
 struct DevWave {
+    static __device__ __forceinline__ MasterLds *lds() { return &g_master_lds; }
+    static __device__ __forceinline__ void cnt_add(unsigned long long *p, unsigned long long v)
+    {
+        if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
     // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
@@ -28,11 +37,18 @@ struct DevWave {
     // is all the cross-lane ordering it needs -- no s_barrier.
     static __device__ __forceinline__ void sync()
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // LDS only: DS operations of one wave execute in order, so other lanes' earlier LDS
+        // writes are visible to later reads without any wait; only the compiler must not
+        // move or cache LDS accesses across this point
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    static __device__ __forceinline__ void sync_global() { sync(); }
+    static __device__ __forceinline__ void sync_global()
+    {
+        // lane 0's global stores (HT rows, RK table, BT links) before every lane's later loads
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     // agent-scope (sc1, write-through / L1-bypassing) accesses for words shared with worker lanes
     static __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
     {
@@ -42,10 +58,18 @@ struct DevWave {
     {
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    static __device__ __forceinline__ void lds_min(uint32_t *p, uint32_t v)
+    {
+        // result unused: a ds_min_u32 without return, nothing to wait for
+        (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    template <class F>
+    static __device__ __forceinline__ unsigned long long mask64(F f) { return __ballot(f(lane())); }
     static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
     static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }      // 100 MHz
     static __device__ __forceinline__ unsigned long long timeout_ticks() { return 2000000000ull; } // 20 s
     static __device__ __forceinline__ void wait_hook(void *, uint32_t) {}
+    static __device__ __forceinline__ unsigned long long tick() { return __builtin_readcyclecounter(); }
     static __device__ __forceinline__ uint32_t rmin(uint32_t v)
     {
 #pragma unroll
@@ -374,15 +398,15 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
 
 // ---------------------------------------------------------------------------
 // the persistent launch: block 0 = master (one wave), blocks 1.. = worker lanes.
-// Grid <= 2 blocks per CU (73 KB of LDS each), so every block is resident.
+// 512-thread blocks with ~81 KB of LDS: exactly one block per CU, and the grid is kept
+// below the CU count, so every block is resident at once (the roles wait on each other).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
+__global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
 {
-    __shared__ MasterLds lds;
     if (blockIdx.x == 0) {
         if (threadIdx.x >= 64) return;
         Master<DevWave> m;
-        m.g = g; m.G = G; m.L = &lds;
+        m.g = g; m.G = G;
         m.run(c0, c1);
     } else {
         worker_role(g, G, c0, c1);
@@ -498,7 +522,7 @@ void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long 
 
 void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(256), 0, st, g, G, c0, c1);
+    hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(512), 0, st, g, G, c0, c1);
 }
 
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,

@@ -31,13 +31,20 @@ struct HostIO {
     static void drain() {}
 };
 
+static MasterLds *g_lds = nullptr;
 struct HostWave {
+    static MasterLds *lds() { return g_lds; }
+    static void cnt_add(unsigned long long *p, unsigned long long v) { *p += v; }
     static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
     static uint32_t ld_agent(const uint32_t *p) { return *p; }
     static void sleep() {}
     static unsigned long long clock() { return 0; }
     static unsigned long long timeout_ticks() { return ~0ull; }
     static void wait_hook(void *, uint32_t a) { sim_wait_hook(a); }
+    static unsigned long long tick() { return 0; }
+    static void lds_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
+    template <class F>
+    static unsigned long long mask64(F f) { unsigned long long m = 0; for (uint32_t i = 0; i < 64; i++) if (f(i)) m |= 1ull << i; return m; }
     static uint32_t lane() { return 0; }
     static uint32_t width() { return 1; }
     static void sync() {}
@@ -70,6 +77,12 @@ static void make_geom(uint64_t n, uint32_t hist_bits_req, Geom &g)
     g.rk_shift = 32 - (15 + clampu(hb, 16, 22) - 16);
     g.tag_mask = (uint32_t)((1ull << (32 - hb)) - 1);
     g.nchunks = (uint32_t)((n + g.chunk_size - 1) / g.chunk_size);
+    {   // node slots >= W + positions of the larger launch (the simulation runs two)
+        const unsigned long long need = (1ull << hb) + (unsigned long long)(g.nchunks - g.nchunks / 2 + 1) * g.chunk_size;
+        unsigned long long slots = 1ull << hb;
+        while (slots < need) slots <<= 1;
+        g.bt_tmask = (uint32_t)(slots - 1);
+    }
 }
 
 // ---- emulation of the device-side helpers around the master (tests only) -------------
@@ -160,9 +173,14 @@ struct SimWorkers {
         }
         next[h]++;
     }
+    bool eager_mode = false;
     void need(uint32_t a)
     {
         const uint32_t h = hash4(load32u(G->in + a)) >> g.bt_shift;
+        if (eager_mode) {   // after a decision arrives the lane runs on as far as it can
+            while (next[h] < bins[h].size()) { const uint32_t b = next[h]; step(h, false); if (next[h] == b) break; }
+            return;
+        }
         while (next[h] < bins[h].size() && bins[h][next[h]] <= a) {
             const uint32_t before = next[h];
             step(h, false);
@@ -170,6 +188,13 @@ struct SimWorkers {
         }
         // the dry run of `a` itself may have just been published while its flag is already in
     }
+    // every lane infinitely fast: run each head until it blocks on a decision of the master
+    void eager()
+    {
+        for (uint32_t h = 0; h < bins.size(); h++)
+            while (next[h] < bins[h].size()) { const uint32_t b = next[h]; step(h, false); if (next[h] == b) break; }
+    }
+    void need_all(uint32_t) {}
     void finish()
     {
         for (uint32_t h = 0; h < bins.size(); h++) while (next[h] < bins[h].size()) step(h, true);
@@ -239,7 +264,7 @@ int main(int argc, char **argv)
         else rkhash[a] = (in[a + 255] + rkhash[a - 1] - in[a - 1] * 0x0E4EA401u) * 0x2F0FD693u;
     }
     std::vector<uint32_t> ht2(4096, kNone), ht3((size_t)2 << (32 - g.ht3_shift), kNone), rkt((size_t)1 << (32 - g.rk_shift), kNone),
-        heads((size_t)1 << (32 - g.bt_shift), kNone), tree((size_t)2 << g.wbits, kNone);
+        heads((size_t)1 << (32 - g.bt_shift), kNone), tree(((size_t)g.bt_tmask + 1) * 2, kNone);
     Persist P; memset(&P, 0, sizeof P);
     for (uint32_t ctx = 0; ctx < kNumCtx; ctx++) {
         const uint32_t ns = ctx_nsyms(ctx);
@@ -253,9 +278,9 @@ int main(int argc, char **argv)
     std::vector<uint32_t> cap; unsigned long long cap_used = 0;
     if (check_tables) cap.resize((size_t)n * 270 + 1024);
 
-    MasterLds *lds = new MasterLds;
+    g_lds = new MasterLds;
     Master<HostWave> m;
-    m.g = g; m.L = lds;
+    m.g = g;
     memset(&m.G, 0, sizeof m.G);
     m.G.in = in.data(); m.G.rkhash = rkhash.data(); m.G.ht2 = ht2.data(); m.G.ht3 = ht3.data(); m.G.rk_table = rkt.data();
     m.G.bt_heads = heads.data(); m.G.bt_tree = tree.data(); m.G.persist = &P;
@@ -282,6 +307,8 @@ int main(int argc, char **argv)
             m.G.nheads = 1u << (32 - g.bt_shift);
             m.G.abort_word = &abort_word; m.G.wcnt = &wc;
             wk.build((uint32_t)a0, (uint32_t)a1);
+            wk.eager_mode = use_workers == 2;
+            if (use_workers == 2) wk.eager();
         }
         m.run(c0, c1);
         if (use_workers) wk.finish();

@@ -18,10 +18,14 @@ def sim():
     return SIM
 
 
-@pytest.mark.parametrize("name", ["overlap_265", "text_200k_w15", "dups_400k_w16", "runs_300k_w18", "random_100k_w15"])
-def test_master_logic_matches_oracle(sim, name, tmp_path):
+# worker emulation: 0 = BT4 inside the master, 1 = worker lanes as slow as possible (results computed only when
+# the master asks), 2 = worker lanes infinitely fast (each head runs until it blocks on a decision of the master)
+@pytest.mark.parametrize("workers", [0, 1, 2])
+@pytest.mark.parametrize("name", ["overlap_265", "text_200k_w15", "dups_400k_w16", "runs_300k_w18", "random_100k_w15",
+                                  "text_2m_w15"])
+def test_master_logic_matches_oracle(sim, name, workers, tmp_path):
     case = next(c for c in cases.CASES if c[0] == name)
     p = tmp_path / "in.bin"
     cases.make_case(case).tofile(p)
-    r = subprocess.run([sim, str(p), str(case[4]), "1"], capture_output=True, text=True)
+    r = subprocess.run([sim, str(p), str(case[4]), "1", str(workers)], capture_output=True, text=True)
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout + r.stderr
