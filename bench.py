@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-chunks", type=int, default=16)
+    ap.add_argument("--batch-chunks", type=int, default=8)
     ap.add_argument("--full", action="store_true", help="compress the whole stream (steps = all batches, warmup 0)")
     ap.add_argument("--cpu-sample-mb", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -204,6 +204,17 @@ def main():
                           "rans_gather": round(tm1["rans_ms"] - tm0["rans_ms"], 3)},
             "counters": d,
         }
+        # HBM traffic of the same command, measured in separate rocprofv3 --pmc passes (tests/prof_run.sh) and
+        # committed under profiles/: bench.py itself cannot read PMC counters
+        try:
+            import glob
+            prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            pj = json.load(open(prof))
+            if pj["bench_line_under_profiler"]["config"]["batch_chunks"] == B and world == 1:
+                res["roofline"]["traffic"] = int(pj["traffic_bytes_per_launch"]["total_with_fetch_x2"])
+                res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT)
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu:
             sample_n = int(min(need, args.cpu_sample_mb * 1e6))
             res["cpu_baseline"] = cpu_baseline(host[:sample_n])

@@ -387,9 +387,9 @@ struct Master {
                     }
                 }
             }
-            const uint32_t first = W::rmin(m);
+            const uint32_t first = W::uni(W::rmin(m));
             if (first != kNone) {
-                lt = W::ror((m == first) ? mylt : 0u);
+                lt = W::uni(W::ror((m == first) ? mylt : 0u));
                 res = first; hit = true;
                 break;
             }
@@ -450,7 +450,7 @@ struct Master {
     }
     NLZM_HD uint32_t price_literal(uint32_t y) const               // :1418-1426
     {
-        return price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15);
+        return W::uni(price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15));
     }
 
     // ---- symbol output (WriteRange/WriteBits + cdf_update) -------------------
@@ -459,7 +459,7 @@ struct Master {
         // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279)
         const uint32_t nsy = ctx_nsyms(ctx);
         uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
-        const uint32_t start = cell[y], freq = (uint32_t)cell[y + 1] - start;
+        const uint32_t start = W::uni(cell[y]), freq = W::uni(cell[y + 1]) - start;
         if (W::lane() == 0) fsyms[nsyms] = (freq << 16) + start;
         nsyms++; num_ops++;
         // cdf_update (:348-382): cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsyms;
@@ -683,7 +683,7 @@ struct Master {
         // 4 probes x kRcCmp bytes in one pass: bit (16k + b) set = byte b of probe k differs
         const uint32_t wo = a - pf_base;
         uint32_t off[4];
-        for (int k = 0; k < 4; k++) off[k] = ent[k] < kRc ? ent[k] * kRcLen + ((a - rp[k]) - W::lds()->rc_lo[ent[k]]) : 0;
+        for (int k = 0; k < 4; k++) off[k] = ent[k] < kRc ? ent[k] * kRcLen + ((a - rp[k]) - W::uni(W::lds()->rc_lo[ent[k]])) : 0;
         const uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3], o0 = off[0], o1 = off[1], o2 = off[2], o3 = off[3];
         const unsigned long long diff = W::mask64([=](uint32_t i) {
             const uint32_t k = i >> 4, b = i & 15;
@@ -715,9 +715,8 @@ struct Master {
         const uint8_t *cur = G.in + a;
         const uint32_t avail = la_end - q;
         prof_mark(0);
-        if (a - pf_base >= pf_n) pf_fill(a, pos_end_abs, a + avail);
         const uint32_t s = a - pf_base;
-        const uint32_t pflags = W::lds()->pf_flags[s], pstale = W::lds()->pf_stale[s];
+        const uint32_t pflags = W::uni(W::lds()->pf_flags[s]), pstale = W::uni(W::lds()->pf_stale[s]);
 
         // carry by one (:1501-1502, CarryFrom :823-833)
         if (mt_max <= 1) { mt_max = 0; top_open = false; }
@@ -757,20 +756,20 @@ struct Master {
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
 
         if (have4) {
-            const uint32_t v4 = W::lds()->pf_v4[s];
+            const uint32_t v4 = W::uni(W::lds()->pf_v4[s]);
             const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu), h4 = hash4(v4);   // :1516-1518
             const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;   // bucket base NOT scaled by rows (:912)
             const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
             uint32_t row[3], len[3], valid = 0;
             if (!(pstale & 1)) {
-                row[0] = W::lds()->pf_row[3 * s]; row[1] = W::lds()->pf_row[3 * s + 1]; row[2] = W::lds()->pf_row[3 * s + 2];
-                const uint32_t pl = W::lds()->pf_len[s];
+                row[0] = W::uni(W::lds()->pf_row[3 * s]); row[1] = W::uni(W::lds()->pf_row[3 * s + 1]); row[2] = W::uni(W::lds()->pf_row[3 * s + 2]);
+                const uint32_t pl = W::uni(W::lds()->pf_len[s]);
                 len[0] = pl & 0x1FF; len[1] = (pl >> 9) & 0x1FF; len[2] = (pl >> 18) & 0x1FF;
                 valid = pflags & 7u;
             } else {
                 // an earlier position rewrote a row this slot had read: read them again, compare now
                 W::sync_global();
-                row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1];
+                row[0] = W::uni(G.ht2[i2]); row[1] = W::uni(G.ht3[i3]); row[2] = W::uni(G.ht3[i3 + 1]);
                 uint32_t job_sp[8], job_cap[8], job_len[8];
                 for (int k = 0; k < 3; k++) {
                     const uint32_t sp = row[k] & g.wmask;
@@ -779,7 +778,7 @@ struct Master {
                     }
                 }
                 W::cmp_multi(G.in, job_sp, a, job_cap, valid, job_len);
-                for (int k = 0; k < 3; k++) len[k] = job_len[k];
+                for (int k = 0; k < 3; k++) len[k] = W::uni(job_len[k]);
             }
             // rows always rotate, compare or not (:935-936); q is stored un-masked (:913)
             if (W::lane() == 0) {
@@ -807,14 +806,14 @@ struct Master {
             prof_mark(4);
             if (!nice) {                                            // BT4 (:1522)
                 if (G.workers) {
-                    const uint32_t ready = W::lds()->pf_ready[s], cnt = ready & 0x1FFu;
+                    const uint32_t ready = W::uni(W::lds()->pf_ready[s]), cnt = ready & 0x1FFu;
 #ifdef NLZM_SIM_DEBUG
                     if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[a - G.batch_a0]);
 #endif
                     if ((ready & kBtReady) && cnt <= 4) {
                         for (uint32_t k = 0; k < cnt; k++) {
-                            const uint32_t l = W::lds()->pf_pairs[8 * s + 2 * k + 1];
-                            mt_update(W::lds()->pf_pairs[8 * s + 2 * k], l, l >= max_len);
+                            const uint32_t l = W::uni(W::lds()->pf_pairs[8 * s + 2 * k + 1]);
+                            mt_update(W::uni(W::lds()->pf_pairs[8 * s + 2 * k]), l, l >= max_len);
                         }
                     } else bt_consume(a, max_len);
                 } else bt_step(a, h4, max_len);
@@ -829,11 +828,11 @@ struct Master {
                     if (l >= match_min(d)) mt_update(d, umin(l, kMatchMax), rk_open || l >= kMatchMax);
                 } else rk_len = 0;
             }
-            const uint32_t rkh = W::lds()->pf_rkh[s], myslot = rkh >> g.rk_shift;
+            const uint32_t rkh = W::uni(W::lds()->pf_rkh[s]), myslot = rkh >> g.rk_shift;
             bool fresh = !(pstale & 4);
             // window ends passed since the last call: insert with the CALLING position (:1084-1087)
             for (uint32_t e = (rk_end | 255u) + 1; e < q + 256; e += 256) {
-                const uint32_t hh = G.rkhash[(uint32_t)(base + e - 256)];
+                const uint32_t hh = W::uni(G.rkhash[(uint32_t)(base + e - 256)]);
                 if (W::lane() == 0) G.rk_table[hh >> g.rk_shift] = q | (hh << g.wbits);
                 pf_mark_rk(s, hh >> g.rk_shift);
                 if ((hh >> g.rk_shift) == myslot) fresh = false;
@@ -844,10 +843,10 @@ struct Master {
                 W::cnt_add(&W::lds()->cnt.rk_probes, 1);
                 uint32_t rkv, l = 0;
                 bool ok, exact = true;
-                if (fresh) { rkv = W::lds()->pf_rkv[s]; ok = (pflags & 8u) != 0; l = W::lds()->pf_rkl[s]; exact = !(pflags & 16u); }
+                if (fresh) { rkv = W::uni(W::lds()->pf_rkv[s]); ok = (pflags & 8u) != 0; l = W::uni(W::lds()->pf_rkl[s]); exact = !(pflags & 16u); }
                 else {
                     W::sync_global();
-                    rkv = G.rk_table[myslot];
+                    rkv = W::uni(G.rk_table[myslot]);
                     const uint32_t sp = rkv & g.wmask;
                     ok = (rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask;
                     exact = false;
@@ -881,7 +880,7 @@ struct Master {
         W::wait_hook(G.hook_user, a);
         const unsigned long long t0 = W::clock();
         uint32_t spins = 0, v;
-        while (!((v = W::ld_agent(G.bt_ready + bi)) & kBtReady)) {
+        while (!((v = W::uni(W::ld_agent(G.bt_ready + bi))) & kBtReady)) {
             if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { err = kErrTimeout; err_info0 = a; return; }
             W::sleep();
         }
@@ -891,7 +890,10 @@ struct Master {
         W::sync();
         for (uint32_t i = W::lane(); i < 2 * count; i += W::width()) W::lds()->btpairs[i] = W::ld_agent(pairs + i);
         W::sync();
-        for (uint32_t k = 0; k < count; k++) mt_update(W::lds()->btpairs[2 * k], W::lds()->btpairs[2 * k + 1], W::lds()->btpairs[2 * k + 1] >= max_len);
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t d = W::uni(W::lds()->btpairs[2 * k]), l = W::uni(W::lds()->btpairs[2 * k + 1]);
+            mt_update(d, l, l >= max_len);
+        }
     }
 
     // BT4 inside the master (workers off): wave-wide compares, uniform descent.
@@ -951,17 +953,20 @@ struct Master {
         while (p < end_p) {
             const uint32_t q = seg_q + p, a = seg_a + p;
             W::cnt_add(&W::lds()->cnt.positions, 1);
-            const uint32_t cost_p = W::lds()->node_cost[p];
+            const uint32_t cost_p = W::uni(W::lds()->node_cost[p]);
             uint32_t rp[4];
-            for (int k = 0; k < 4; k++) rp[k] = W::lds()->reps[(p & 511) * 4 + k];
+            for (int k = 0; k < 4; k++) rp[k] = W::uni(W::lds()->reps[(p & 511) * 4 + k]);
 
+            if (a - pf_base >= pf_n) pf_fill(a, seg_a - (seg_q - chunk_q_) + chunk_pend_, seg_a - seg_q + la_end);
             // literal edge (:1490-1499)
             {
-                const uint32_t cst = price_literal(G.in[a]);
-                if (W::lds()->node_cost[p + 1] > cost_p + cst) {
+                const uint32_t lit = W::uni(W::lds()->win[a - pf_base]);
+                const uint32_t cst = price_literal(lit);
+                if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst) {
                     W::sync();
                     if (W::lane() == 0) {
                         W::lds()->node_cost[p + 1] = cost_p + cst;
+                        W::lds()->node_delta[p + 1] = lit;          // the byte itself, for the emitter
                         W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
                         for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
                     }
@@ -996,7 +1001,7 @@ struct Master {
                     checked |= 1u << ri;
                     relax(p, np, cost_p, price_rep(d, tl), 2, tl, (uint32_t)ri, rp, d);
                 }
-                checked = W::ror(checked);
+                checked = W::uni(W::ror(checked));
                 W::sync();
             }
             prof_mark(8);
@@ -1022,7 +1027,7 @@ struct Master {
         while (cur != 0) {
             if (W::lane() == 0) W::lds()->cmdlist[n] = (uint16_t)cur;
             n++;
-            cur = W::lds()->node_link[cur] & 0x1FFF;
+            cur = W::uni(W::lds()->node_link[cur]) & 0x1FFF;
         }
         W::sync();
         prof_mark(10);
@@ -1078,12 +1083,12 @@ struct Master {
             uint32_t ncmds = 0;
             parse_segment(chunk_q + p, (uint32_t)chunk_abs + p, p_end - p, ncmds);
             for (uint32_t k = ncmds; k-- > 0;) {                    // :1809-1843
-                const uint32_t node = W::lds()->cmdlist[k];
-                const uint32_t link = W::lds()->node_link[node];
+                const uint32_t node = W::uni(W::lds()->cmdlist[k]);
+                const uint32_t link = W::uni(W::lds()->node_link[node]);
                 const uint32_t cmd = link >> 22, len = (link >> 13) & 0x1FF;
-                if (cmd == 0) { emit_literal(G.in[(uint32_t)chunk_abs + p]); p += 1; }
-                else if (cmd == 1) { emit_match(W::lds()->node_delta[node], len); p += len; }
-                else { emit_rep(W::lds()->node_delta[node], len); p += len; }
+                if (cmd == 0) { emit_literal(W::uni(W::lds()->node_delta[node])); p += 1; }
+                else if (cmd == 1) { emit_match(W::uni(W::lds()->node_delta[node]), len); p += len; }
+                else { emit_rep(W::uni(W::lds()->node_delta[node]), len); p += len; }
             }
             prof_mark(11);
             if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) err = kErrFrameOverflow;

@@ -32,6 +32,9 @@ struct DevWave {
     }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
+    // the value is the same in every lane: move it to a scalar register so that the arithmetic and
+    // the branches that depend on it run on the scalar unit
+    static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
     // program order, so a workgroup-scope fence (the waits) plus a scheduling barrier
     // is all the cross-lane ordering it needs -- no s_barrier.

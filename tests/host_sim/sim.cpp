@@ -45,6 +45,7 @@ struct HostWave {
     static void lds_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
     template <class F>
     static unsigned long long mask64(F f) { unsigned long long m = 0; for (uint32_t i = 0; i < 64; i++) if (f(i)) m |= 1ull << i; return m; }
+    static uint32_t uni(uint32_t v) { return v; }
     static uint32_t lane() { return 0; }
     static uint32_t width() { return 1; }
     static void sync() {}
