@@ -166,14 +166,12 @@ struct MasterLds {
     Counters cnt;                           // operation counters of this launch (LDS adds, nothing to wait for)
     // look-ahead: kPf positions are evaluated by the lanes in parallel against the finder
     // tables as they stand, then consumed in order (Master::pf_fill / finders_fast)
-    uint32_t pf_v4[kPf];                    // the position's 4 input bytes
-    uint32_t pf_idx[kPf];                   // HT2 bucket | HT3 bucket << 16
-    uint32_t pf_row[3 * kPf];               // HT2 row, HT3 row 0, HT3 row 1 as read
-    uint32_t pf_len[kPf];                   // match lengths of the three HT candidates, 9 bits each
-    uint32_t pf_rkh[kPf], pf_rkv[kPf], pf_rkl[kPf];
-    uint32_t pf_ready[kPf];                 // bt_ready word as read
-    uint32_t pf_pairs[8 * kPf];             // first 4 pairs when the result was ready
-    uint8_t pf_flags[kPf];                  // bits 0..3 candidate valid (HT2, HT3 r0, HT3 r1, RK); 4: RK length inexact; 5: unc
+    // one 32-word record per slot, fetched with ONE LDS read (lane k takes word k) when the slot is consumed:
+    //   0 input bytes (4)   1 HT2 bucket | HT3 bucket << 16   2 HT3 row 0 as read   3 flags
+    //   4 number of HT updates | bytes compared << 8          5..10 HT updates: distance, length | open << 31
+    //   11 RK hash   12 RK slot as read   13 RK candidate length   14 bt_ready as read   15..22 first 4 BT4 pairs
+    // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
+    uint32_t pf_rec[32 * kPf];
     uint8_t pf_stale[kPf];                  // 1: an HT row it read was rewritten since; 4: its RK slot was
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
     // bytes in front of recently probed rep distances (explicit rep probes, :1598-1628)
@@ -340,6 +338,17 @@ struct Master {
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
     uint32_t rc_next;
     uint32_t chunk_q_, chunk_pend_; // rebased start and length of the current chunk
+    // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
+    uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
+    NLZM_HD void counts_zero() { n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = 0; }
+    NLZM_HD void counts_flush()
+    {
+        Counters &c = W::lds()->cnt;
+        W::cnt_add(&c.positions, n_pos); W::cnt_add(&c.nice_positions, n_nice); W::cnt_add(&c.uncertain_positions, n_unc);
+        W::cnt_add(&c.ht_rows, 3ull * n_ht); W::cnt_add(&c.rk_probes, n_rkp); W::cnt_add(&c.rk_inserts, n_rki);
+        W::cnt_add(&c.cmp_bytes, n_cmp);
+        counts_zero();
+    }
     uint32_t rk_from, rk_to, rk_len, rk_end;
     unsigned long long base;        // absolute offset of rebased 0
     uint32_t la_end;                // rebased end of the chunk's lookahead
@@ -406,18 +415,26 @@ struct Master {
     };
 
     // ---- MatchTable::Update (:835-852) on the ring ---------------------------
-    // No read-modify-write round trip: entries below the old maximum take an LDS
-    // atomic min, entries above it a plain store.  `open`: the match ran into its
-    // length cap, so the carried entry may extend at the next position (:1503-1512).
+    // Invariant: every ring entry above mt_max holds kNone, so the element-wise
+    // min-merge is ONE predicated LDS atomic min per lane (no read, nothing to wait
+    // for) whether the entry existed or not.  `open`: the match ran into its length
+    // cap, so the carried entry may extend at the next position (:1503-1512).
     NLZM_HD void mt_update(uint32_t d, uint32_t len, bool open)
     {
-        for (uint32_t i = W::lane(); i <= len; i += W::width()) {
-            uint32_t *e = &mt(i);
-            if (i <= mt_max) W::lds_min(e, d); else *e = d;
-        }
+        for (uint32_t i = W::lane(); i <= len; i += W::width()) W::lds_min(&mt(i), d);
         if (len > mt_max) { mt_max = len; top_d = d; top_open = open; }
         else if (len == mt_max) { top_d = umin(top_d, d); top_open = top_open || open; }
-        W::sync();
+    }
+    // carry by one position (CarryFrom with shift 1, :823-833) keeping the invariant
+    NLZM_HD void mt_carry()
+    {
+        if (mt_max <= 1) {
+            for (uint32_t i = W::lane(); i < 2; i += W::width()) mt(i) = kNone;
+            mt_max = 0; top_open = false;
+        } else {
+            mt(0) = kNone;                              // becomes relative index 511 after the shift
+            mt_max -= 1; mt_base = (mt_base + 1) & 511;
+        }
     }
 
     struct MtSink {
@@ -460,7 +477,7 @@ struct Master {
         const uint32_t nsy = ctx_nsyms(ctx);
         uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
         const uint32_t start = W::uni(cell[y]), freq = W::uni(cell[y + 1]) - start;
-        if (W::lane() == 0) fsyms[nsyms] = (freq << 16) + start;
+        fsyms[nsyms] = (freq << 16) + start;            // wave-uniform store: same address, same value in every lane
         nsyms++; num_ops++;
         // cdf_update (:348-382): cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsyms;
         // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsyms)   (:284-298)
@@ -480,7 +497,7 @@ struct Master {
         word |= v << (32 - word_bits - nb);
         word_bits += nb;
         while (word_bits >= 8) {
-            if (W::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            fbits[nbits] = (uint8_t)(word >> 24);
             nbits++;
             word <<= 8;
             word_bits -= 8;
@@ -522,7 +539,7 @@ struct Master {
     NLZM_HD void emit_rep(uint32_t idx, uint32_t len)               // :1344-1367
     {
         put_sym(kCtxCmd, 2);
-        emit_len(len - match_min(rep[idx]));
+        emit_len(len - match_min(idx == 0 ? rep[0] : (idx == 1 ? rep[1] : (idx == 2 ? rep[2] : rep[3]))));
         put_bits(idx, 2);
         W::cnt_add(&W::lds()->cnt.n_rep, 1);                                                  // rep4.Add(present delta) is a no-op (:1834)
     }
@@ -574,6 +591,7 @@ struct Master {
         for (uint32_t j = W::lane(); j < pf_n; j += W::width()) {
             const uint32_t x = a_start + j, q = (uint32_t)(x - base), avail = la_end_abs - x;
             const uint8_t *cur = G.in + x;
+            uint32_t *rec = W::lds()->pf_rec + 32 * j;
             uint32_t flags = 0, lens = 0, v4 = 0, idx = 0;
             uint32_t row[3] = { 0, 0, 0 };
             unsigned long long dummy = 0;
@@ -586,13 +604,26 @@ struct Master {
                 row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1];
                 const uint32_t max_len = umin(avail, kMatchMax);
                 const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
+                // MatchFinderHT::FindAndUpdate (:917-933) for HT2 then HT3, as a list of table updates
+                uint32_t np = 0, cmpb = 0, best = 1;
                 for (int k = 0; k < 3; k++) {
+                    if (k == 1) best = 1;                           // HT3 is its own call
                     const uint32_t sp = row[k] & g.wmask;
                     if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) {
                         flags |= 1u << k;
-                        lens |= (lcmp(cur - (q - sp), cur, 0, max_len) & 0x1FFu) << (9 * k);
+                        if (best < max_len) {
+                            const uint32_t l = lcmp(cur - (q - sp), cur, 0, max_len) & 0x1FFu, d = q - sp;
+                            lens |= l << (9 * k);
+                            cmpb += l + (l < max_len);
+                            if (l > best && l >= match_min(d)) {
+                                rec[5 + 2 * np] = d;
+                                rec[6 + 2 * np] = l | ((uint32_t)(l >= max_len) << 31);
+                                np++; best = l;
+                            }
+                        }
                     }
                 }
+                rec[4] = np | (cmpb << 8);
             }
             uint32_t rkh = 0, rkv = 0, rkl = 0;
             if (avail >= 256) {
@@ -615,13 +646,12 @@ struct Master {
                 if (ready & kBtReady) {
                     const uint32_t n2 = 2 * umin(ready & 0x1FFu, 4u);
                     const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-                    for (uint32_t k = 0; k < n2; k++) W::lds()->pf_pairs[8 * j + k] = W::ld_agent(pairs + k);
+                    for (uint32_t k = 0; k < n2; k++) rec[15 + k] = W::ld_agent(pairs + k);
                 }
             }
-            W::lds()->pf_v4[j] = v4; W::lds()->pf_idx[j] = idx;
-            W::lds()->pf_row[3 * j] = row[0]; W::lds()->pf_row[3 * j + 1] = row[1]; W::lds()->pf_row[3 * j + 2] = row[2];
-            W::lds()->pf_len[j] = lens; W::lds()->pf_rkh[j] = rkh; W::lds()->pf_rkv[j] = rkv; W::lds()->pf_rkl[j] = rkl;
-            W::lds()->pf_ready[j] = ready; W::lds()->pf_flags[j] = (uint8_t)flags; W::lds()->pf_stale[j] = 0;
+            rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags;
+            rec[11] = rkh; rec[12] = rkv; rec[13] = rkl; rec[14] = ready;
+            W::lds()->pf_stale[j] = 0;
         }
         W::sync();
     }
@@ -631,14 +661,14 @@ struct Master {
     NLZM_HD void pf_mark_ht(uint32_t s, uint32_t i2, uint32_t i3)
     {
         for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width()) {
-            const uint32_t o = W::lds()->pf_idx[j], o2 = o & 0xFFFFu, o3 = o >> 16;
+            const uint32_t o = W::lds()->pf_rec[32 * j + 1], o2 = o & 0xFFFFu, o3 = o >> 16;
             if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) W::lds()->pf_stale[j] |= 1;
         }
     }
     NLZM_HD void pf_mark_rk(uint32_t s, uint32_t slot)
     {
         for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width())
-            if ((W::lds()->pf_rkh[j] >> g.rk_shift) == slot) W::lds()->pf_stale[j] |= 4;
+            if ((W::lds()->pf_rec[32 * j + 11] >> g.rk_shift) == slot) W::lds()->pf_stale[j] |= 4;
     }
 
     // ---- explicit rep probes (:1598-1628): common prefix of in[a-d..] and in[a..] -------------
@@ -646,62 +676,50 @@ struct Master {
     // the bytes at the position in `win`; only matches longer than kRcCmp bytes go to HBM.
     NLZM_HD void rep_lens(uint32_t a, uint32_t q, const uint32_t rp[4], uint32_t rep_cap, uint32_t rep_len[4])
     {
-        uint32_t ent[4];
         const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+        uint32_t need = 0;
+        for (int k = 0; k < 4; k++) { rep_len[k] = 0; if (rp[k] < q && rep_cap) need |= 1u << k; }
+        if (!need) return;
         // which cache entry covers each probe: 4 probes x kRc entries checked by 32 lanes at once
-        const unsigned long long hits = W::mask64([=](uint32_t i) {
-            if (i >= 4 * kRc) return false;
-            const uint32_t k = i >> 3, e = i & 7;
-            const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
-            const uint32_t lo = a - d, elo = W::lds()->rc_lo[e];
-            return W::lds()->rc_d[e] == d && elo <= lo && lo + kRcCmp <= elo + kRcLen;
-        });
-        uint32_t evicted = 0;
-        for (int k = 0; k < 4; k++) {
-            rep_len[k] = 0; ent[k] = kNone;
-            if (!(rp[k] < q) || rep_cap == 0) continue;
-            const uint32_t lo = a - rp[k];
-            const uint32_t f = (uint32_t)(hits >> (8 * k)) & 0xFFu & ~evicted;
-            if (f) ent[k] = (uint32_t)__builtin_ctz(f);
-            if (ent[k] == kNone) {                                  // miss: load kRcLen bytes from a-d on
-                bool again = false;
-                for (int m = 0; m < k; m++) if (rp[m] == rp[k] && ent[m] < kRc) { ent[k] = ent[m]; again = true; }
-                if (again) continue;
-                const uint32_t e = rc_next; rc_next = (rc_next + 1) % kRc;
-                evicted |= 1u << e;
-                for (int m = 0; m < 4; m++) if (m != k && ent[m] == e) ent[m] = kNone - 1;   // evicted under another probe: exact path
-                W::sync();
-                for (uint32_t i = W::lane(); i < kRcLen; i += W::width()) {
-                    const unsigned long long src = (unsigned long long)lo + i;
-                    W::lds()->rc_data[e * kRcLen + i] = src < g.n ? G.in[src] : 0;
-                }
-                W::lds()->rc_d[e] = rp[k]; W::lds()->rc_lo[e] = lo;
-                W::sync();
-                ent[k] = e;
+        unsigned long long hits;
+        for (;;) {
+            hits = W::mask64([=](uint32_t i) {
+                if (i >= 4 * kRc) return false;
+                const uint32_t k = i >> 3, e = i & 7;
+                const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+                const uint32_t lo = a - d, elo = W::lds()->rc_lo[e];
+                return W::lds()->rc_d[e] == d && elo <= lo && lo + kRcCmp <= elo + kRcLen;
+            });
+            int miss = -1;
+            for (int k = 3; k >= 0; k--) if (((need >> k) & 1) && !((hits >> (8 * k)) & 0xFF)) miss = k;
+            if (miss < 0) break;
+            // load kRcLen bytes from a-d on into the next entry (round robin), then look again
+            const uint32_t e = rc_next; rc_next = (rc_next + 1) % kRc;
+            const uint32_t lo = a - rp[miss];
+            W::sync();
+            for (uint32_t i = W::lane(); i < kRcLen; i += W::width()) {
+                const unsigned long long src = (unsigned long long)lo + i;
+                W::lds()->rc_data[e * kRcLen + i] = src < g.n ? G.in[src] : 0;
             }
+            if (W::lane() == 0) { W::lds()->rc_d[e] = rp[miss]; W::lds()->rc_lo[e] = lo; }
+            W::sync();
         }
         // 4 probes x kRcCmp bytes in one pass: bit (16k + b) set = byte b of probe k differs
         const uint32_t wo = a - pf_base;
-        uint32_t off[4];
-        for (int k = 0; k < 4; k++) off[k] = ent[k] < kRc ? ent[k] * kRcLen + ((a - rp[k]) - W::uni(W::lds()->rc_lo[ent[k]])) : 0;
-        const uint32_t e0 = ent[0], e1 = ent[1], e2 = ent[2], e3 = ent[3], o0 = off[0], o1 = off[1], o2 = off[2], o3 = off[3];
         const unsigned long long diff = W::mask64([=](uint32_t i) {
             const uint32_t k = i >> 4, b = i & 15;
-            const uint32_t ek = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-            const uint32_t ok = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
-            return ek < kRc && W::lds()->rc_data[ok + b] != W::lds()->win[wo + b];
+            const uint32_t h = (uint32_t)(hits >> (8 * k)) & 0xFFu;
+            if (!h) return false;
+            const uint32_t e = (uint32_t)__builtin_ctz(h);
+            const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+            return W::lds()->rc_data[e * kRcLen + ((a - d) - W::lds()->rc_lo[e]) + b] != W::lds()->win[wo + b];
         });
         for (int k = 0; k < 4; k++) {
-            if (ent[k] == kNone) continue;
-            uint32_t l;
-            if (ent[k] < kRc) {
-                const uint32_t f = (uint32_t)(diff >> (16 * k)) & 0xFFFFu;
-                l = f ? (uint32_t)__builtin_ctz(f) : kRcCmp;
-                if (l >= rep_cap) l = rep_cap;
-                else if (l == kRcCmp) l = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRcCmp, rep_cap) & 0x7FFFFFFFu;
-            } else {
-                l = wave_cmp<false>(G.in + a - rp[k], G.in + a, 0, rep_cap) & 0x7FFFFFFFu;
-            }
+            if (!((need >> k) & 1)) continue;
+            const uint32_t f = (uint32_t)(diff >> (16 * k)) & 0xFFFFu;
+            uint32_t l = f ? (uint32_t)__builtin_ctz(f) : kRcCmp;
+            if (l >= rep_cap) l = rep_cap;
+            else if (l == kRcCmp) l = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRcCmp, rep_cap) & 0x7FFFFFFFu;
             rep_len[k] = l;
         }
     }
@@ -716,11 +734,11 @@ struct Master {
         const uint32_t avail = la_end - q;
         prof_mark(0);
         const uint32_t s = a - pf_base;
-        const uint32_t pflags = W::uni(W::lds()->pf_flags[s]), pstale = W::uni(W::lds()->pf_stale[s]);
+        const typename W::Rec rec = W::rec_load(W::lds()->pf_rec + 32 * s);
+        const uint32_t pflags = W::rec_get(rec, 3), pstale = W::uni(W::lds()->pf_stale[s]);
 
         // carry by one (:1501-1502, CarryFrom :823-833)
-        if (mt_max <= 1) { mt_max = 0; top_open = false; }
-        else { mt_max -= 1; mt_base = (mt_base + 1) & 511; }
+        mt_carry();
         // extend the longest entry (:1503-1512); skipped when that entry is known to end in a mismatch
         if (mt_max > 0 && top_open) {
             const uint32_t d = top_d;
@@ -731,7 +749,6 @@ struct Master {
                     if (nl > mt_max) {
                         for (uint32_t i = mt_max + 1 + W::lane(); i <= nl; i += W::width()) mt(i) = d;
                         mt_max = nl;
-                        W::sync();
                     }
                     top_open = nl >= cap;
                 }
@@ -740,11 +757,11 @@ struct Master {
 
         prof_mark(1);
         const bool nice = mt_max >= kNice;                          // :1514
-        W::cnt_add(&W::lds()->cnt.nice_positions, nice ? 1 : 0);
+        n_nice += nice ? 1 : 0;
         if (G.workers) {
             // tell the worker that owns this position's BT4 head whether the call happens
             if (pflags & 32u) {
-                W::cnt_add(&W::lds()->cnt.uncertain_positions, 1);
+                n_unc++;
                 if (W::lane() == 0) W::st_agent(G.bt_flag + (a - G.batch_a0), nice ? kFlagSkip : kFlagCall);
             } else if (nice) {
                 // the pre-filter promised that no match of 65+ bytes ends up in the table at a-1
@@ -756,16 +773,14 @@ struct Master {
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
 
         if (have4) {
-            const uint32_t v4 = W::uni(W::lds()->pf_v4[s]);
+            const uint32_t v4 = W::rec_get(rec, 0);
             const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu), h4 = hash4(v4);   // :1516-1518
             const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;   // bucket base NOT scaled by rows (:912)
             const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
             uint32_t row[3], len[3], valid = 0;
-            if (!(pstale & 1)) {
-                row[0] = W::uni(W::lds()->pf_row[3 * s]); row[1] = W::uni(W::lds()->pf_row[3 * s + 1]); row[2] = W::uni(W::lds()->pf_row[3 * s + 2]);
-                const uint32_t pl = W::uni(W::lds()->pf_len[s]);
-                len[0] = pl & 0x1FF; len[1] = (pl >> 9) & 0x1FF; len[2] = (pl >> 18) & 0x1FF;
-                valid = pflags & 7u;
+            const bool fresh_ht = !(pstale & 1);
+            if (fresh_ht) {
+                row[1] = W::rec_get(rec, 2);                        // HT3 row 0 moves down one row
             } else {
                 // an earlier position rewrote a row this slot had read: read them again, compare now
                 W::sync_global();
@@ -781,18 +796,25 @@ struct Master {
                 for (int k = 0; k < 3; k++) len[k] = W::uni(job_len[k]);
             }
             // rows always rotate, compare or not (:935-936); q is stored un-masked (:913)
-            if (W::lane() == 0) {
-                G.ht2[i2] = q | (tag2 << g.wbits);
-                G.ht3[i3] = q | (tag3 << g.wbits);
-                G.ht3[i3 + 1] = row[1];
-            }
+            G.ht2[i2] = q | (tag2 << g.wbits);                  // wave-uniform stores
+            G.ht3[i3] = q | (tag3 << g.wbits);
+            G.ht3[i3 + 1] = row[1];
             pf_mark_ht(s, i2, i3);
-            W::cnt_add(&W::lds()->cnt.ht_rows, 3);
+            n_ht++;
             prof_mark(2);
+            if (fresh_ht) {
+                // the lane that looked at this position already ran the HT2/HT3 logic
+                const uint32_t np = W::rec_get(rec, 4);
+                n_cmp += np >> 8;
+                for (uint32_t k = 0; k < (np & 0xFFu); k++) {
+                    const uint32_t lo = W::rec_get(rec, 6 + 2 * k);
+                    mt_update(W::rec_get(rec, 5 + 2 * k), lo & 0x1FFu, (lo >> 31) != 0);
+                }
+            } else {
             // HT2 (:917-933)
             if ((valid & 1) && 1 < max_len) {
                 const uint32_t l = len[0], d = q - (row[0] & g.wmask);
-                W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < max_len));
+                n_cmp += l + (l < max_len);
                 if (l > 1 && l >= match_min(d)) mt_update(d, l, l >= max_len);
             }
             // HT3, two rows, `best` gates the second (:917-933)
@@ -800,20 +822,21 @@ struct Master {
             for (int k = 1; k < 3; k++) {
                 if (!((valid >> k) & 1) || !(best < max_len)) continue;
                 const uint32_t l = len[k], d = q - (row[k] & g.wmask);
-                W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < max_len));
+                n_cmp += l + (l < max_len);
                 if (l > best && l >= match_min(d)) { mt_update(d, l, l >= max_len); best = l; }
+            }
             }
             prof_mark(4);
             if (!nice) {                                            // BT4 (:1522)
                 if (G.workers) {
-                    const uint32_t ready = W::uni(W::lds()->pf_ready[s]), cnt = ready & 0x1FFu;
+                    const uint32_t ready = W::rec_get(rec, 14), cnt = ready & 0x1FFu;
 #ifdef NLZM_SIM_DEBUG
                     if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[a - G.batch_a0]);
 #endif
                     if ((ready & kBtReady) && cnt <= 4) {
                         for (uint32_t k = 0; k < cnt; k++) {
-                            const uint32_t l = W::uni(W::lds()->pf_pairs[8 * s + 2 * k + 1]);
-                            mt_update(W::uni(W::lds()->pf_pairs[8 * s + 2 * k]), l, l >= max_len);
+                            const uint32_t l = W::rec_get(rec, 16 + 2 * k);
+                            mt_update(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
                         }
                     } else bt_consume(a, max_len);
                 } else bt_step(a, h4, max_len);
@@ -828,22 +851,22 @@ struct Master {
                     if (l >= match_min(d)) mt_update(d, umin(l, kMatchMax), rk_open || l >= kMatchMax);
                 } else rk_len = 0;
             }
-            const uint32_t rkh = W::uni(W::lds()->pf_rkh[s]), myslot = rkh >> g.rk_shift;
+            const uint32_t rkh = W::rec_get(rec, 11), myslot = rkh >> g.rk_shift;
             bool fresh = !(pstale & 4);
             // window ends passed since the last call: insert with the CALLING position (:1084-1087)
             for (uint32_t e = (rk_end | 255u) + 1; e < q + 256; e += 256) {
                 const uint32_t hh = W::uni(G.rkhash[(uint32_t)(base + e - 256)]);
-                if (W::lane() == 0) G.rk_table[hh >> g.rk_shift] = q | (hh << g.wbits);
+                G.rk_table[hh >> g.rk_shift] = q | (hh << g.wbits);
                 pf_mark_rk(s, hh >> g.rk_shift);
                 if ((hh >> g.rk_shift) == myslot) fresh = false;
-                W::cnt_add(&W::lds()->cnt.rk_inserts, 1);
+                n_rki++;
             }
             rk_end = q + 256;
             if (rk_len < 256) {                                     // :1090-1107
-                W::cnt_add(&W::lds()->cnt.rk_probes, 1);
+                n_rkp++;
                 uint32_t rkv, l = 0;
                 bool ok, exact = true;
-                if (fresh) { rkv = W::uni(W::lds()->pf_rkv[s]); ok = (pflags & 8u) != 0; l = W::uni(W::lds()->pf_rkl[s]); exact = !(pflags & 16u); }
+                if (fresh) { rkv = W::rec_get(rec, 12); ok = (pflags & 8u) != 0; l = W::rec_get(rec, 13); exact = !(pflags & 16u); }
                 else {
                     W::sync_global();
                     rkv = W::uni(G.rk_table[myslot]);
@@ -854,7 +877,7 @@ struct Master {
                 if (ok) {
                     const uint32_t d = q - (rkv & g.wmask), cap = avail & 0xFFFFu;   // uint16 parameter (:760)
                     if (!exact) l = wave_cmp<false>(cur - d, cur, 0, cap) & 0x7FFFFFFFu;
-                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + (l < cap));
+                    n_cmp += l + (l < cap);
                     if (l >= rk_len && l >= match_min(d)) {
                         rk_open = l >= cap;
                         mt_update(d, umin(l, kMatchMax), rk_open || l >= kMatchMax);
@@ -863,9 +886,9 @@ struct Master {
                 }
             }
             if (!(q & 255u)) {                                      // aligned insert after the probe (:1109-1112)
-                if (W::lane() == 0) G.rk_table[myslot] = q | (rkh << g.wbits);
+                G.rk_table[myslot] = q | (rkh << g.wbits);
                 pf_mark_rk(s, myslot);
-                W::cnt_add(&W::lds()->cnt.rk_inserts, 1);
+                n_rki++;
             }
         }
         prof_mark(6);
@@ -943,34 +966,32 @@ struct Master {
     NLZM_HD uint32_t parse_segment(uint32_t seg_q, uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
     {
         max_parse = umin(max_parse, kParseMax);
-        if (W::lane() == 0) {
-            W::lds()->node_cost[0] = 0; W::lds()->node_link[0] = 0x1FFF;
-            W::lds()->node_cost[1] = kNone; W::lds()->node_link[1] = pack_link(0, 0, 0);
-            for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
-        }
+        W::lds()->node_cost[0] = 0; W::lds()->node_link[0] = 0x1FFF;
+        W::lds()->node_cost[1] = kNone; W::lds()->node_link[1] = pack_link(0, 0, 0);
+        for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
         W::sync();
         uint32_t p = 0, end_p = 1;
         while (p < end_p) {
             const uint32_t q = seg_q + p, a = seg_a + p;
-            W::cnt_add(&W::lds()->cnt.positions, 1);
-            const uint32_t cost_p = W::uni(W::lds()->node_cost[p]);
+            n_pos++;
+            // cost and rep set of node p, cost of node p+1: one LDS read (lane 0 / 1..4 / 5), then lane picks
+            const typename W::Rec nrec = W::rec_load_fn([=](uint32_t i) {
+                return i == 0 ? W::lds()->node_cost[p] : (i < 5 ? W::lds()->reps[(p & 511) * 4 + ((i - 1) & 3)] : W::lds()->node_cost[p + 1]);
+            });
+            const uint32_t cost_p = W::rec_get(nrec, 0);
             uint32_t rp[4];
-            for (int k = 0; k < 4; k++) rp[k] = W::uni(W::lds()->reps[(p & 511) * 4 + k]);
+            for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
 
             if (a - pf_base >= pf_n) pf_fill(a, seg_a - (seg_q - chunk_q_) + chunk_pend_, seg_a - seg_q + la_end);
             // literal edge (:1490-1499)
             {
                 const uint32_t lit = W::uni(W::lds()->win[a - pf_base]);
                 const uint32_t cst = price_literal(lit);
-                if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst) {
-                    W::sync();
-                    if (W::lane() == 0) {
-                        W::lds()->node_cost[p + 1] = cost_p + cst;
-                        W::lds()->node_delta[p + 1] = lit;          // the byte itself, for the emitter
-                        W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
-                        for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
-                    }
-                    W::sync();
+                if (W::rec_get(nrec, 5) > cost_p + cst) {
+                    W::lds()->node_cost[p + 1] = cost_p + cst;
+                    W::lds()->node_delta[p + 1] = lit;              // the byte itself, for the emitter
+                    W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
+                    for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
                 }
             }
 
@@ -985,6 +1006,7 @@ struct Master {
 
             // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2
             uint32_t checked = 0;
+            W::sync();                                              // table updates above, table reads below
             if (max_len >= kMatchMin) {
                 uint32_t step = (max_len - kMatchMin) >> 4;
                 step += step == 0;
@@ -1010,11 +1032,11 @@ struct Master {
                 for (uint32_t ri = 0; ri < 4; ri++) {
                     if ((checked >> ri) & 1 || rp[ri] >= q) continue;
                     const uint32_t l = rep_len[ri];                 // already min(len, 264)
-                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + 1);
+                    n_cmp += l + 1;
                     if (l >= match_min(rp[ri])) {
                         open_nodes(end_p, l + p);
                         W::sync();
-                        if (W::lane() == 0) relax(p, p + l, cost_p, price_rep(rp[ri], l), 2, l, ri, rp, rp[ri]);
+                        relax(p, p + l, cost_p, price_rep(rp[ri], l), 2, l, ri, rp, rp[ri]);   // wave-uniform
                         W::sync();
                     }
                 }
@@ -1025,7 +1047,7 @@ struct Master {
         // backtrack (:1633-1650): collect the node indices of the path, end first
         uint32_t n = 0, cur = p;
         while (cur != 0) {
-            if (W::lane() == 0) W::lds()->cmdlist[n] = (uint16_t)cur;
+            W::lds()->cmdlist[n] = (uint16_t)cur;
             n++;
             cur = W::uni(W::lds()->node_link[cur]) & 0x1FFF;
         }
@@ -1045,6 +1067,7 @@ struct Master {
         const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
         if (used + need > G.cap_cap) { err = kErrCapture; return; }
         W::sync_global();
+        W::sync();
         if (W::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
         for (uint32_t i = 2 + W::lane(); i <= mt_max; i += W::width()) G.cap_words[used + i] = mt(i);
         if (W::lane() == 0) *G.cap_used = used + need;
@@ -1077,6 +1100,7 @@ struct Master {
         la_end = chunk_q + chunk_read;
         chunk_q_ = chunk_q; chunk_pend_ = p_end;
         pf_n = 0;                           // the look-ahead never crosses a chunk (lookahead limit, rebase)
+        counts_zero();
 
         uint32_t p = 0;
         while (p < p_end && !err) {
@@ -1093,6 +1117,7 @@ struct Master {
             prof_mark(11);
             if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) err = kErrFrameOverflow;
         }
+        counts_flush();
         // bit pad of Flush (:591-597)
         W::cnt_add(&W::lds()->cnt.rans_syms, nsyms); W::cnt_add(&W::lds()->cnt.bit_ops, num_ops - nsyms); W::cnt_add(&W::lds()->cnt.frames, 1);
         for (int i = 0; i < 4; i++) {
@@ -1117,15 +1142,15 @@ struct Master {
             const uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
             W::lds()->price[i] = (y < ctx_nsyms(ctx)) ? W::lds()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
         }
-        mt_base = 0; mt_max = P->mt_max;
-        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) W::lds()->mt[i] = P->mt_delta[i];
-        top_d = P->mt_delta[mt_max]; top_open = true; rk_open = true;     // conservative across launches
+        mt_base = 0; mt_max = W::uni(P->mt_max);
+        for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
+        top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
         pf_base = 0; pf_n = 0; rc_next = 0;
         for (uint32_t i = W::lane(); i < kRc; i += W::width()) { W::lds()->rc_d[i] = 0; W::lds()->rc_lo[i] = 0; }
-        for (int k = 0; k < 4; k++) rep[k] = P->rep[k];
-        rk_from = P->rk_from; rk_to = P->rk_to; rk_len = P->rk_len; rk_end = P->rk_end;
-        base = P->reb_base;
-        err = P->error; err_info0 = 0;
+        for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
+        rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
+        base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
+        err = W::uni(P->error); err_info0 = 0;
         for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;
 #ifdef NLZM_PROFILE
         for (int k = 0; k < 16; k++) prof[k] = 0;

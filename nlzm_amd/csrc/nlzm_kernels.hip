@@ -34,6 +34,12 @@ struct DevWave {
     static __device__ __forceinline__ uint32_t width() { return 64u; }
     // the value is the same in every lane: move it to a scalar register so that the arithmetic and
     // the branches that depend on it run on the scalar unit
+    // a small record read with ONE LDS instruction (lane k holds word k), its words picked by v_readlane
+    struct Rec { uint32_t v; };
+    static __device__ __forceinline__ Rec rec_load(const uint32_t *base) { return Rec{ base[lane() & 31u] }; }
+    template <class F>
+    static __device__ __forceinline__ Rec rec_load_fn(F f) { return Rec{ f(lane() & 7u) }; }
+    static __device__ __forceinline__ uint32_t rec_get(Rec r, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)r.v, (int)k); }
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
     // program order, so a workgroup-scope fence (the waits) plus a scheduling barrier

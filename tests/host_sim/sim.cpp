@@ -45,6 +45,11 @@ struct HostWave {
     static void lds_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
     template <class F>
     static unsigned long long mask64(F f) { unsigned long long m = 0; for (uint32_t i = 0; i < 64; i++) if (f(i)) m |= 1ull << i; return m; }
+    struct Rec { uint32_t w[32]; };
+    static Rec rec_load(const uint32_t *base) { Rec r; for (int i = 0; i < 32; i++) r.w[i] = base[i]; return r; }
+    template <class F>
+    static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
+    static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
     static uint32_t uni(uint32_t v) { return v; }
     static uint32_t lane() { return 0; }
     static uint32_t width() { return 1; }
