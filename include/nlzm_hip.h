@@ -82,7 +82,7 @@ int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
                       uint8_t *dst, uint64_t dst_cap, uint64_t *dst_len);
 
 /* Same, but input and output already live in HBM (d_src must be followed by at
- * least 16 readable padding bytes).  Used by bench.py so the timed region starts
+ * least 128 readable padding bytes).  Used by bench.py so the timed region starts
  * with the input resident. */
 int nlzm_hip_compress_dev(const void *d_src, uint64_t n, uint32_t hist_bits_req,
                           void *d_dst, uint64_t dst_cap, uint64_t *dst_len);

@@ -35,9 +35,7 @@ constexpr uint32_t kParseMax = 4096;    // :1458
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kPf = 64;            // look-ahead depth of the master (positions)
 constexpr uint32_t kWinTail = 288;
-constexpr uint32_t kRc = 8;             // rep-distance cache entries
-constexpr uint32_t kRcLen = 256;        // bytes per entry
-constexpr uint32_t kRcCmp = 16;         // bytes compared from the cache; longer matches take the exact path
+constexpr uint32_t kRepPf = 64;         // bytes fetched ahead per explicit rep probe; longer matches take the exact path
 
 // ---- CDF contexts (Model, :1133-1146) flattened into one table -------------
 constexpr uint32_t kCtxCmd = 0;                 // CDF2
@@ -153,7 +151,7 @@ struct Globals {
 
 // LDS image of the master workgroup.
 struct MasterLds {
-    uint32_t node_cost[kParseMax + 1];
+    uint32_t node_cost[kParseMax + 2];
     uint32_t node_delta[kParseMax + 1];
     uint32_t node_link[kParseMax + 1];      // from:13 | len:9<<13 | cmd:2<<22 ; from==0x1FFF: none
     uint32_t reps[512 * 4];                 // CarriedState ring (:1460-1467)
@@ -174,9 +172,6 @@ struct MasterLds {
     uint32_t pf_rec[32 * kPf];
     uint8_t pf_stale[kPf];                  // 1: an HT row it read was rewritten since; 4: its RK slot was
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
-    // bytes in front of recently probed rep distances (explicit rep probes, :1598-1628)
-    uint32_t rc_d[kRc], rc_lo[kRc];
-    uint8_t rc_data[kRc * kRcLen];
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -336,7 +331,6 @@ struct Master {
     bool top_open;                  // false: that entry is known not to extend (mismatch at its end)
     bool rk_open;                   // the carried RK match ran into its length cap
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
-    uint32_t rc_next;
     uint32_t chunk_q_, chunk_pend_; // rebased start and length of the current chunk
     // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
     uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
@@ -671,64 +665,10 @@ struct Master {
             if ((W::lds()->pf_rec[32 * j + 11] >> g.rk_shift) == slot) W::lds()->pf_stale[j] |= 4;
     }
 
-    // ---- explicit rep probes (:1598-1628): common prefix of in[a-d..] and in[a..] -------------
-    // The bytes in front of the few distances that keep being probed sit in LDS (rc_*),
-    // the bytes at the position in `win`; only matches longer than kRcCmp bytes go to HBM.
-    NLZM_HD void rep_lens(uint32_t a, uint32_t q, const uint32_t rp[4], uint32_t rep_cap, uint32_t rep_len[4])
-    {
-        const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-        uint32_t need = 0;
-        for (int k = 0; k < 4; k++) { rep_len[k] = 0; if (rp[k] < q && rep_cap) need |= 1u << k; }
-        if (!need) return;
-        // which cache entry covers each probe: 4 probes x kRc entries checked by 32 lanes at once
-        unsigned long long hits;
-        for (;;) {
-            hits = W::mask64([=](uint32_t i) {
-                if (i >= 4 * kRc) return false;
-                const uint32_t k = i >> 3, e = i & 7;
-                const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
-                const uint32_t lo = a - d, elo = W::lds()->rc_lo[e];
-                return W::lds()->rc_d[e] == d && elo <= lo && lo + kRcCmp <= elo + kRcLen;
-            });
-            int miss = -1;
-            for (int k = 3; k >= 0; k--) if (((need >> k) & 1) && !((hits >> (8 * k)) & 0xFF)) miss = k;
-            if (miss < 0) break;
-            // load kRcLen bytes from a-d on into the next entry (round robin), then look again
-            const uint32_t e = rc_next; rc_next = (rc_next + 1) % kRc;
-            const uint32_t lo = a - rp[miss];
-            W::sync();
-            for (uint32_t i = W::lane(); i < kRcLen; i += W::width()) {
-                const unsigned long long src = (unsigned long long)lo + i;
-                W::lds()->rc_data[e * kRcLen + i] = src < g.n ? G.in[src] : 0;
-            }
-            if (W::lane() == 0) { W::lds()->rc_d[e] = rp[miss]; W::lds()->rc_lo[e] = lo; }
-            W::sync();
-        }
-        // 4 probes x kRcCmp bytes in one pass: bit (16k + b) set = byte b of probe k differs
-        const uint32_t wo = a - pf_base;
-        const unsigned long long diff = W::mask64([=](uint32_t i) {
-            const uint32_t k = i >> 4, b = i & 15;
-            const uint32_t h = (uint32_t)(hits >> (8 * k)) & 0xFFu;
-            if (!h) return false;
-            const uint32_t e = (uint32_t)__builtin_ctz(h);
-            const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
-            return W::lds()->rc_data[e * kRcLen + ((a - d) - W::lds()->rc_lo[e]) + b] != W::lds()->win[wo + b];
-        });
-        for (int k = 0; k < 4; k++) {
-            if (!((need >> k) & 1)) continue;
-            const uint32_t f = (uint32_t)(diff >> (16 * k)) & 0xFFFFu;
-            uint32_t l = f ? (uint32_t)__builtin_ctz(f) : kRcCmp;
-            if (l >= rep_cap) l = rep_cap;
-            else if (l == kRcCmp) l = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRcCmp, rep_cap) & 0x7FFFFFFFu;
-            rep_len[k] = l;
-        }
-    }
-
     // ---- finders for one position (:1501-1543) --------------------------------
     // q: rebased position, a: absolute position, p: parse-relative index.
     // rp/rep_len: the node's rep set and (output) explicit rep-probe lengths.
-    NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t p, const uint32_t rp[4], uint32_t rep_cap,
-                         uint32_t rep_len[4], uint32_t pos_end_abs)
+    NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t p, uint32_t pos_end_abs)
     {
         const uint8_t *cur = G.in + a;
         const uint32_t avail = la_end - q;
@@ -892,8 +832,6 @@ struct Master {
             }
         }
         prof_mark(6);
-        rep_lens(a, q, rp, rep_cap, rep_len);
-        prof_mark(3);
     }
 
     // BT4 result of a worker lane: wait for it, then merge its pairs (MatchTable::Update, :996-998).
@@ -971,13 +909,21 @@ struct Master {
         for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
         W::sync();
         uint32_t p = 0, end_p = 1;
+        // Node p (cost, rep set) and the cost of node p+1 are read with one LDS instruction at the END of the
+        // previous iteration; right behind it the bytes the explicit rep probes of node p will compare
+        // (kRepPf bytes in front of each of its 4 rep distances, and at the position) are requested from HBM,
+        // so that their latency is covered by the literal edge and the finders of the same position.
+        auto node_read = [&](uint32_t pp) {
+            return W::rec_load_fn([=](uint32_t i) {
+                return i == 0 ? W::lds()->node_cost[pp] : (i < 5 ? W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)] : W::lds()->node_cost[pp + 1]);
+            });
+        };
+        W::sync();
+        typename W::Rec nrec = node_read(0);
+        typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, seg_a, W::rec_get(nrec, 1), W::rec_get(nrec, 2), W::rec_get(nrec, 3), W::rec_get(nrec, 4));
         while (p < end_p) {
             const uint32_t q = seg_q + p, a = seg_a + p;
             n_pos++;
-            // cost and rep set of node p, cost of node p+1: one LDS read (lane 0 / 1..4 / 5), then lane picks
-            const typename W::Rec nrec = W::rec_load_fn([=](uint32_t i) {
-                return i == 0 ? W::lds()->node_cost[p] : (i < 5 ? W::lds()->reps[(p & 511) * 4 + ((i - 1) & 3)] : W::lds()->node_cost[p + 1]);
-            });
             const uint32_t cost_p = W::rec_get(nrec, 0);
             uint32_t rp[4];
             for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
@@ -995,35 +941,68 @@ struct Master {
                 }
             }
 
-            uint32_t rep_len[4];
             prof_mark(7);
-            finders(q, a, p, rp, umin(max_parse - p, kMatchMax), rep_len, seg_a - (seg_q - chunk_q_) + chunk_pend_);
+            finders(q, a, p, seg_a - (seg_q - chunk_q_) + chunk_pend_);
             capture(a);
+            // explicit rep probe lengths (:1605-1606) from the bytes requested one iteration ago
+            uint32_t rep_len[4];
+            {
+                const uint32_t rep_cap = umin(max_parse - p, kMatchMax);
+                W::rep_lengths(rpf, rep_len);
+                for (int k = 0; k < 4; k++) {
+                    if (!(rp[k] < q)) { rep_len[k] = 0; continue; }
+                    if (rep_len[k] >= rep_cap) rep_len[k] = rep_cap;
+                    else if (rep_len[k] == kRepPf) rep_len[k] = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                }
+            }
+            prof_mark(3);
 
             uint32_t max_len = umin(mt_max, max_parse - p);         // :1545-1548
             if (max_len < kMatchMin) max_len = 0;
             open_nodes(end_p, max_len + p);
 
-            // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2
+            // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2, one lane per length.
+            // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
+            // one compare-and-store; the targets of different lanes are distinct nodes.
             uint32_t checked = 0;
             W::sync();                                              // table updates above, table reads below
             if (max_len >= kMatchMin) {
                 uint32_t step = (max_len - kMatchMin) >> 4;
                 step += step == 0;
                 const uint32_t K = (max_len - kMatchMin) / step + 1;
+                const uint32_t pc_dict = W::uni(price(kCtxCmd, 1)), pc_rep = W::uni(price(kCtxCmd, 2));
+                uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
                 for (uint32_t k = W::lane(); k < K; k += W::width()) {
                     const uint32_t tl = max_len - k * step;
                     const uint32_t d = mt(tl);
-                    if (tl < match_min(d)) continue;
-                    const uint32_t np = p + tl;
-                    relax(p, np, cost_p, price_match(d, tl), 1, tl, d, rp, d);
-                    int ri = -1;
-                    for (int j = 3; j >= 0; j--) if (rp[j] == d) ri = j;
-                    if (ri < 0) continue;
-                    checked |= 1u << ri;
-                    relax(p, np, cost_p, price_rep(d, tl), 2, tl, (uint32_t)ri, rp, d);
+                    const uint32_t mm = match_min(d);
+                    if (tl < mm) continue;
+                    const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
+                    uint32_t nx, ex;
+                    const uint32_t slot = dist_slot(d - 1, nx, ex);
+                    const uint32_t plen = price_len(lv);
+                    const uint32_t pdist = (nx << 5) + price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+                    uint32_t best = W::lds()->node_cost[np], sel = 0;
+                    const uint32_t ri = rp[0] == d ? 0u : (rp[1] == d ? 1u : (rp[2] == d ? 2u : (rp[3] == d ? 3u : 4u)));
+                    const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
+                    if (ca < best) { best = ca; sel = 1; }
+                    if (ri < 4 && cb < best) { best = cb; sel = 2; }
+                    if (sel) {
+                        W::lds()->node_cost[np] = best;
+                        W::lds()->node_delta[np] = sel == 1 ? d : ri;
+                        W::lds()->node_link[np] = pack_link(p, tl, sel);
+                        uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
+                        const bool has = ri < 4;
+                        dst[0] = has ? rp[0] : d; dst[1] = has ? rp[1] : rp[0]; dst[2] = has ? rp[2] : rp[1]; dst[3] = has ? rp[3] : rp[2];
+                    }
+                    myri = ri;
+                    if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
                 }
-                checked = W::uni(W::ror(checked));
+                if (W::width() != 1) {
+                    const uint32_t m = myri;
+                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
+                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
+                }
                 W::sync();
             }
             prof_mark(8);
@@ -1036,13 +1015,16 @@ struct Master {
                     if (l >= match_min(rp[ri])) {
                         open_nodes(end_p, l + p);
                         W::sync();
-                        relax(p, p + l, cost_p, price_rep(rp[ri], l), 2, l, ri, rp, rp[ri]);   // wave-uniform
+                        relax(p, p + l, cost_p, W::uni(price_rep(rp[ri], l)), 2, l, ri, rp, rp[ri]);   // wave-uniform
                         W::sync();
                     }
                 }
             }
             prof_mark(9);
             ++p;
+            W::sync();
+            nrec = node_read(p);                                    // p <= end_p <= 4096: node p+1 is inside the arrays
+            rpf = W::rep_prefetch(G.in, g.n, seg_a + p, W::rec_get(nrec, 1), W::rec_get(nrec, 2), W::rec_get(nrec, 3), W::rec_get(nrec, 4));
         }
         // backtrack (:1633-1650): collect the node indices of the path, end first
         uint32_t n = 0, cur = p;
@@ -1145,8 +1127,7 @@ struct Master {
         mt_base = 0; mt_max = W::uni(P->mt_max);
         for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
         top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
-        pf_base = 0; pf_n = 0; rc_next = 0;
-        for (uint32_t i = W::lane(); i < kRc; i += W::width()) { W::lds()->rc_d[i] = 0; W::lds()->rc_lo[i] = 0; }
+        pf_base = 0; pf_n = 0;
         for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
         rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);

@@ -483,10 +483,10 @@ int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, ui
     if (C.own_in) { (void)hipFree(C.own_in); C.own_in = nullptr; }
     if (C.own_dst) { (void)hipFree(C.own_dst); C.own_dst = nullptr; }
     const uint64_t bound = nlzm_hip_compress_bound(n);
-    HIPCHK(hipMalloc(&C.own_in, n + 64));
+    HIPCHK(hipMalloc(&C.own_in, n + 512));
     HIPCHK(hipMalloc(&C.own_dst, bound));
     HIPCHK(hipEventRecord(C.ev[5], C.st));
-    HIPCHK(hipMemsetAsync(C.own_in + n, 0, 64, C.st));
+    HIPCHK(hipMemsetAsync(C.own_in + n, 0, 512, C.st));
     if (n) HIPCHK(hipMemcpyAsync(C.own_in, src, n, hipMemcpyHostToDevice, C.st));
     HIPCHK(hipEventRecord(C.ev[6], C.st));
     HIPCHK(hipStreamSynchronize(C.st));

@@ -32,6 +32,32 @@ struct DevWave {
     }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
+    // explicit rep probes: lane i = probe i>>4, dword i&15 of the kRepPf bytes in front of the distance and at the position
+    struct RepPf { uint32_t s, c; };
+    static __device__ __forceinline__ RepPf rep_prefetch(const uint8_t *in, unsigned long long n, uint32_t a, uint32_t r0, uint32_t r1,
+                                                         uint32_t r2, uint32_t r3)
+    {
+        const uint32_t i = lane(), k = i >> 4, j = (i & 15u) * 4;
+        const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+        RepPf r;
+        r.c = (unsigned long long)a + j + 4 <= n + 64 ? load32u(in + a + j) : 0;        // the input is followed by >= 128 bytes
+        r.s = d <= a ? load32u(in + (a - d) + j) : ~r.c;                                 // distance beyond the start: no match
+        return r;
+    }
+    static __device__ __forceinline__ void rep_lengths(RepPf r, uint32_t len[4])
+    {
+        const uint32_t x = r.s ^ r.c;
+        const unsigned long long bal = __ballot(x != 0);
+        const uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t f = (uint32_t)(bal >> (16 * k)) & 0xFFFFu;
+            if (f) {
+                const uint32_t l = (uint32_t)__builtin_ctz(f);
+                len[k] = 4 * l + (uint32_t)__builtin_amdgcn_readlane((int)nb, 16 * k + (int)l);
+            } else len[k] = kRepPf;
+        }
+    }
     // the value is the same in every lane: move it to a scalar register so that the arithmetic and
     // the branches that depend on it run on the scalar unit
     // a small record read with ONE LDS instruction (lane k holds word k), its words picked by v_readlane

@@ -50,6 +50,19 @@ struct HostWave {
     template <class F>
     static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
+    struct RepPf { const uint8_t *in; unsigned long long n; uint32_t a, r[4]; };
+    static RepPf rep_prefetch(const uint8_t *in, unsigned long long n, uint32_t a, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
+    {
+        return RepPf{ in, n, a, { r0, r1, r2, r3 } };
+    }
+    static void rep_lengths(const RepPf &r, uint32_t len[4])
+    {
+        for (int k = 0; k < 4; k++) {
+            uint32_t l = 0;
+            if (r.r[k] <= r.a) while (l < kRepPf && r.a + l < r.n + 64 && r.in[r.a - r.r[k] + l] == r.in[r.a + l]) l++;
+            len[k] = l;
+        }
+    }
     static uint32_t uni(uint32_t v) { return v; }
     static uint32_t lane() { return 0; }
     static uint32_t width() { return 1; }
