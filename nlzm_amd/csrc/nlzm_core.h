@@ -35,6 +35,8 @@ constexpr uint32_t kParseMax = 4096;    // :1458
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kPf = 64;            // look-ahead depth of the master (positions)
 constexpr uint32_t kWinTail = 288;
+constexpr uint32_t kEr = 64;            // hand-off ring between the two master waves (positions)
+constexpr uint32_t kErLong = 4;         // of them with a table longer than 63 entries
 constexpr uint32_t kRepPf = 64;         // bytes fetched ahead per explicit rep probe; longer matches take the exact path
 
 // ---- CDF contexts (Model, :1133-1146) flattened into one table -------------
@@ -172,6 +174,17 @@ struct MasterLds {
     uint32_t pf_rec[32 * kPf];
     uint8_t pf_stale[kPf];                  // 1: an HT row it read was rewritten since; 4: its RK slot was
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
+    // ---- hand-off between the two waves of the master (Master::run_finder / run_parser) ----
+    // Wave A (finders) publishes, per position a, slot a % kEr: word 0 = table length | (long slot + 1) << 16,
+    // word 1 = the input byte, words 2..63 = table entries 2..63; longer tables go to er_long whole.
+    uint32_t er_tab[kEr * 64];
+    uint32_t er_long[kErLong * (kMatchMax + 8)];
+    uint32_t x_apos;                        // A: positions < x_apos are published
+    uint32_t x_bpos;                        // B: positions < x_bpos are parsed (their slots are free again)
+    uint32_t x_bseg;                        // B: start of the segment that contains x_bpos
+    uint32_t x_long_free;                   // B: long slots given back (monotonic)
+    uint32_t x_err;                         // either: error code, both waves leave their loops
+    uint32_t x_adone;                       // A: finished the launch
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -331,7 +344,7 @@ struct Master {
     bool top_open;                  // false: that entry is known not to extend (mismatch at its end)
     bool rk_open;                   // the carried RK match ran into its length cap
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
-    uint32_t chunk_q_, chunk_pend_; // rebased start and length of the current chunk
+    uint32_t a_long, b_long;        // long hand-off slots taken (finder wave) / given back (parser wave)
     // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
     uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
     NLZM_HD void counts_zero() { n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = 0; }
@@ -668,7 +681,7 @@ struct Master {
     // ---- finders for one position (:1501-1543) --------------------------------
     // q: rebased position, a: absolute position, p: parse-relative index.
     // rp/rep_len: the node's rep set and (output) explicit rep-probe lengths.
-    NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t p, uint32_t pos_end_abs)
+    NLZM_HD void finders(uint32_t q, uint32_t a, uint32_t pos_end_abs)
     {
         const uint8_t *cur = G.in + a;
         const uint32_t avail = la_end - q;
@@ -705,10 +718,16 @@ struct Master {
                 if (W::lane() == 0) W::st_agent(G.bt_flag + (a - G.batch_a0), nice ? kFlagSkip : kFlagCall);
             } else if (nice) {
                 // the pre-filter promised that no match of 65+ bytes ends up in the table at a-1
-                err = kErrInternal; err_info0 = a;
+                fail(kErrInternal, a);
             }
         }
-        const bool call = !nice || !(p & 7);                        // :1529
+        // inside a nice region the finders run at every 8th PARSE-RELATIVE position (:1529): the segment
+        // start is the parser wave's knowledge, final for `a` once it has parsed every earlier position
+        bool call = true;
+        if (nice) {
+            if (!wait_ge(&W::lds()->x_bpos, a)) return;
+            call = !((a - W::xw_load(&W::lds()->x_bseg)) & 7u);
+        }
         const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
 
@@ -842,7 +861,8 @@ struct Master {
         const unsigned long long t0 = W::clock();
         uint32_t spins = 0, v;
         while (!((v = W::uni(W::ld_agent(G.bt_ready + bi))) & kBtReady)) {
-            if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { err = kErrTimeout; err_info0 = a; return; }
+            if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return; }
+            if ((spins & 255u) == 0 && W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
             W::sleep();
         }
         // the ready word was stored after every pair had been written through (sc1) and drained
@@ -900,19 +920,143 @@ struct Master {
         W::sync_global();
     }
 
-    // ---- one parse segment (:1464-1651); returns end_p, leaves the path in cmdlist
+    // ---- cross-wave waits (both waves of the master share the CU's LDS; DS operations of a wave
+    // execute in order, so a reader that sees a counter also sees what was written before it) -------
+    NLZM_HD bool wait_ge(const uint32_t *w, uint32_t v)             // until *w >= v
+    {
+        if (W::xw_load(w) >= v) return true;
+        const unsigned long long t0 = W::clock();
+        uint32_t spins = 0;
+        for (;;) {
+            if (W::xw_load(w) >= v) return true;
+            if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
+            if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, v); return false; }
+            W::xw_pause();
+        }
+    }
+    NLZM_HD bool wait_space(uint32_t a)                             // until position a - kEr has been parsed
+    {
+        const unsigned long long t0 = W::clock();
+        uint32_t spins = 0;
+        while (a - W::xw_load(&W::lds()->x_bpos) >= kEr) {
+            if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
+            if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return false; }
+            W::xw_pause();
+        }
+        return true;
+    }
+    NLZM_HD void fail(uint32_t code, uint32_t info)
+    {
+        err = code; err_info0 = info;
+        W::xw_store(&W::lds()->x_err, code);
+    }
+
+    // =========================== wave A: finders ===========================================
+    // publish position a: table length, input byte, table entries (MatchTable as mt_carry holds it, :1543)
+    NLZM_HD void a_publish(uint32_t a)
+    {
+        uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
+        uint32_t hdr = mt_max;
+        W::sync();
+        if (mt_max > 63) {
+            if (!wait_ge(&W::lds()->x_long_free, a_long + 1)) return;      // x_long_free starts at kErLong
+            uint32_t *l = W::lds()->er_long + (a_long % kErLong) * (kMatchMax + 8);
+            for (uint32_t i = W::lane(); i <= mt_max; i += W::width()) l[i] = mt(i);
+            hdr |= ((a_long % kErLong) + 1) << 16;
+            a_long++;
+        }
+        for (uint32_t i = 2 + W::lane(); i < 64; i += W::width()) e[i] = mt(i);
+        e[0] = hdr;
+        e[1] = W::lds()->win[a - pf_base];
+        W::sync();
+        W::xw_store(&W::lds()->x_apos, a + 1);
+    }
+
+    NLZM_HD void run_chunk_finder(uint32_t ci)
+    {
+        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+        const unsigned long long remain = g.n - chunk_abs;
+        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+        const uint32_t p_end = umin(g.chunk_size, chunk_read);
+        const uint32_t W2 = 2u * (g.wmask + 1);
+        if (chunk_abs - base >= W2) {                               // :1786-1792
+            base += g.wmask + 1;
+            W::cnt_add(&W::lds()->cnt.shifts, 1);
+            G.ht2[0] = kNone; G.ht3[0] = kNone;                     // MatchFinderHT::Shift (:940-957)
+            if (rk_end >= g.wmask + 1) rk_end -= g.wmask + 1; else rk_end = 0;   // :1115-1123
+            W::sync_global();
+            // BT4 keeps absolute positions: no pass over the tree (appendix D.3)
+        }
+        const uint32_t chunk_q = (uint32_t)(chunk_abs - base);
+        la_end = chunk_q + chunk_read;
+        pf_n = 0;                           // the look-ahead never crosses a chunk (lookahead limit, rebase)
+        counts_zero();
+        const uint32_t a0 = (uint32_t)chunk_abs, a1 = a0 + p_end;
+        for (uint32_t a = a0; a < a1 && !err; a++) {
+            if (!wait_space(a)) break;                              // slot a % kEr is free again
+            if (a - pf_base >= pf_n) pf_fill(a, a1, a0 + chunk_read);
+            prof_start();
+            finders(chunk_q + (a - a0), a, a1);
+            if (err) break;
+            capture(a);
+            a_publish(a);
+            prof_mark(12);
+        }
+        counts_flush();
+    }
+
+    NLZM_HD void run_finder(uint32_t c0, uint32_t c1)
+    {
+        Persist *P = G.persist;
+        mt_base = 0; mt_max = W::uni(P->mt_max);
+        for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
+        top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
+        pf_base = 0; pf_n = 0; a_long = 0;
+        rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
+        base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
+        err = W::uni(P->error); err_info0 = 0;
+        counts_zero();
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 16; k++) prof[k] = 0;
+#endif
+        W::sync();
+        uint32_t ci = c0;
+        for (; ci < c1 && !err; ci++) run_chunk_finder(ci);
+        W::sync();
+        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = i <= mt_max ? mt(i) : 0;
+        if (W::lane() == 0) {
+            P->mt_max = mt_max;
+            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
+            P->reb_base = base;
+            if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 1; }
+#ifdef NLZM_PROFILE
+            for (int k = 0; k < 7; k++) P->prof[k] += prof[k];
+            P->prof[12] += prof[12];
+#endif
+        }
+        W::sync_global();
+        W::xw_store(&W::lds()->x_adone, 1u);
+    }
+
+    // =========================== wave B: parse + emit ======================================
+    // table entry `tl` of the position whose hand-off header is `hdr`
+    NLZM_HD uint32_t tab(const uint32_t *e, uint32_t hdr, uint32_t tl) const
+    {
+        return tl < 64 ? e[tl] : W::lds()->er_long[((hdr >> 16) - 1) * (kMatchMax + 8) + tl];
+    }
+
+    // one parse segment (:1464-1651); returns end_p, leaves the path in cmdlist
     NLZM_HD uint32_t parse_segment(uint32_t seg_q, uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
     {
         max_parse = umin(max_parse, kParseMax);
         W::lds()->node_cost[0] = 0; W::lds()->node_link[0] = 0x1FFF;
         W::lds()->node_cost[1] = kNone; W::lds()->node_link[1] = pack_link(0, 0, 0);
         for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
-        W::sync();
         uint32_t p = 0, end_p = 1;
         // Node p (cost, rep set) and the cost of node p+1 are read with one LDS instruction at the END of the
         // previous iteration; right behind it the bytes the explicit rep probes of node p will compare
         // (kRepPf bytes in front of each of its 4 rep distances, and at the position) are requested from HBM,
-        // so that their latency is covered by the literal edge and the finders of the same position.
+        // so that their latency is covered by the rest of the loop.
         auto node_read = [&](uint32_t pp) {
             return W::rec_load_fn([=](uint32_t i) {
                 return i == 0 ? W::lds()->node_cost[pp] : (i < 5 ? W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)] : W::lds()->node_cost[pp + 1]);
@@ -928,10 +1072,15 @@ struct Master {
             uint32_t rp[4];
             for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
 
-            if (a - pf_base >= pf_n) pf_fill(a, seg_a - (seg_q - chunk_q_) + chunk_pend_, seg_a - seg_q + la_end);
+            // the finder wave's result for this position
+            if (!wait_ge(&W::lds()->x_apos, a + 1)) break;
+            const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
+            const typename W::Rec hrec = W::rec_load(e);
+            const uint32_t hdr = W::rec_get(hrec, 0), tmax = hdr & 0xFFFFu;
+
             // literal edge (:1490-1499)
             {
-                const uint32_t lit = W::uni(W::lds()->win[a - pf_base]);
+                const uint32_t lit = W::rec_get(hrec, 1);
                 const uint32_t cst = price_literal(lit);
                 if (W::rec_get(nrec, 5) > cost_p + cst) {
                     W::lds()->node_cost[p + 1] = cost_p + cst;
@@ -940,10 +1089,7 @@ struct Master {
                     for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
                 }
             }
-
             prof_mark(7);
-            finders(q, a, p, seg_a - (seg_q - chunk_q_) + chunk_pend_);
-            capture(a);
             // explicit rep probe lengths (:1605-1606) from the bytes requested one iteration ago
             uint32_t rep_len[4];
             {
@@ -957,7 +1103,7 @@ struct Master {
             }
             prof_mark(3);
 
-            uint32_t max_len = umin(mt_max, max_parse - p);         // :1545-1548
+            uint32_t max_len = umin(tmax, max_parse - p);           // :1545-1548
             if (max_len < kMatchMin) max_len = 0;
             open_nodes(end_p, max_len + p);
 
@@ -965,7 +1111,6 @@ struct Master {
             // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
             // one compare-and-store; the targets of different lanes are distinct nodes.
             uint32_t checked = 0;
-            W::sync();                                              // table updates above, table reads below
             if (max_len >= kMatchMin) {
                 uint32_t step = (max_len - kMatchMin) >> 4;
                 step += step == 0;
@@ -974,7 +1119,7 @@ struct Master {
                 uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
                 for (uint32_t k = W::lane(); k < K; k += W::width()) {
                     const uint32_t tl = max_len - k * step;
-                    const uint32_t d = mt(tl);
+                    const uint32_t d = tab(e, hdr, tl);
                     const uint32_t mm = match_min(d);
                     if (tl < mm) continue;
                     const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
@@ -1023,12 +1168,16 @@ struct Master {
             prof_mark(9);
             ++p;
             W::sync();
+            // hand the slot back; a segment that ends here is announced BEFORE the position count
+            if (hdr >> 16) W::xw_store(&W::lds()->x_long_free, kErLong + (++b_long));
+            if (p == end_p) W::xw_store(&W::lds()->x_bseg, seg_a + p);
+            W::xw_store(&W::lds()->x_bpos, seg_a + p);
             nrec = node_read(p);                                    // p <= end_p <= 4096: node p+1 is inside the arrays
             rpf = W::rep_prefetch(G.in, g.n, seg_a + p, W::rec_get(nrec, 1), W::rec_get(nrec, 2), W::rec_get(nrec, 3), W::rec_get(nrec, 4));
         }
         // backtrack (:1633-1650): collect the node indices of the path, end first
         uint32_t n = 0, cur = p;
-        while (cur != 0) {
+        while (cur != 0 && !err) {
             W::lds()->cmdlist[n] = (uint16_t)cur;
             n++;
             cur = W::uni(W::lds()->node_link[cur]) & 0x1FFF;
@@ -1047,7 +1196,7 @@ struct Master {
         // record {pos, max_len, delta[2..max_len]}
         unsigned long long used = *G.cap_used;
         const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
-        if (used + need > G.cap_cap) { err = kErrCapture; return; }
+        if (used + need > G.cap_cap) { fail(kErrCapture, a); return; }
         W::sync_global();
         W::sync();
         if (W::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
@@ -1056,8 +1205,8 @@ struct Master {
         W::sync_global();
     }
 
-    // ---- one chunk = one frame (:1782-1886) -----------------------------------
-    NLZM_HD void run_chunk(uint32_t ci)
+    // one chunk = one frame (:1782-1886)
+    NLZM_HD void run_chunk_parser(uint32_t ci)
     {
         const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
         const unsigned long long remain = g.n - chunk_abs;
@@ -1069,25 +1218,15 @@ struct Master {
         fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
         fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
         nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0;
-
-        if (chunk_abs - base >= W2) {                               // :1786-1792
-            base += g.wmask + 1;
-            W::cnt_add(&W::lds()->cnt.shifts, 1);
-            if (W::lane() == 0) { G.ht2[0] = kNone; G.ht3[0] = kNone; }   // MatchFinderHT::Shift (:940-957)
-            if (rk_end >= g.wmask + 1) rk_end -= g.wmask + 1; else rk_end = 0;   // :1115-1123
-            W::sync_global();
-            // BT4 keeps absolute positions: no pass over the tree (appendix D.3)
-        }
+        if (chunk_abs - base >= W2) base += g.wmask + 1;            // same rebase schedule as the finder wave (:1786)
         const uint32_t chunk_q = (uint32_t)(chunk_abs - base);
-        la_end = chunk_q + chunk_read;
-        chunk_q_ = chunk_q; chunk_pend_ = p_end;
-        pf_n = 0;                           // the look-ahead never crosses a chunk (lookahead limit, rebase)
         counts_zero();
 
         uint32_t p = 0;
         while (p < p_end && !err) {
             uint32_t ncmds = 0;
             parse_segment(chunk_q + p, (uint32_t)chunk_abs + p, p_end - p, ncmds);
+            if (err) break;
             for (uint32_t k = ncmds; k-- > 0;) {                    // :1809-1843
                 const uint32_t node = W::uni(W::lds()->cmdlist[k]);
                 const uint32_t link = W::uni(W::lds()->node_link[node]);
@@ -1097,13 +1236,13 @@ struct Master {
                 else { emit_rep(W::uni(W::lds()->node_delta[node]), len); p += len; }
             }
             prof_mark(11);
-            if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) err = kErrFrameOverflow;
+            if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
         }
         counts_flush();
         // bit pad of Flush (:591-597)
         W::cnt_add(&W::lds()->cnt.rans_syms, nsyms); W::cnt_add(&W::lds()->cnt.bit_ops, num_ops - nsyms); W::cnt_add(&W::lds()->cnt.frames, 1);
         for (int i = 0; i < 4; i++) {
-            if (W::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            fbits[nbits] = (uint8_t)(word >> 24);
             nbits++; word <<= 8;
         }
         if (W::lane() == 0) {
@@ -1112,8 +1251,7 @@ struct Master {
         }
     }
 
-    // ---- launch prologue / epilogue -------------------------------------------
-    NLZM_HD void load_state()
+    NLZM_HD void run_parser(uint32_t c0, uint32_t c1)
     {
         Persist *P = G.persist;
         for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) W::lds()->cdf[i] = P->cdf[i];
@@ -1124,37 +1262,31 @@ struct Master {
             const uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
             W::lds()->price[i] = (y < ctx_nsyms(ctx)) ? W::lds()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
         }
-        mt_base = 0; mt_max = W::uni(P->mt_max);
-        for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
-        top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
-        pf_base = 0; pf_n = 0;
         for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
-        rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
-        for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;
+        b_long = 0;
+        counts_zero();
 #ifdef NLZM_PROFILE
         for (int k = 0; k < 16; k++) prof[k] = 0;
         prof_start();
 #endif
         W::sync();
-    }
-    NLZM_HD void store_state(uint32_t next_chunk)
-    {
-        Persist *P = G.persist;
+        uint32_t ci = c0;
+        for (; ci < c1 && !err; ci++) run_chunk_parser(ci);
+        // the finder wave has stored its part of the state and its counters
+        for (uint32_t spins = 0; !W::xw_load(&W::lds()->x_adone) && spins < (1u << 28); spins++) W::xw_pause();
         W::sync();
         for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) P->cdf[i] = W::lds()->cdf[i];
-        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = mt(i);
         if (W::lane() == 0) {
-            P->mt_max = mt_max;
             for (int k = 0; k < 4; k++) P->rep[k] = rep[k];
-            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
-            P->reb_base = base;
-            P->next_chunk = next_chunk;
-            P->error = err;
-            if (err) { P->error_info[0] = err_info0; if (G.abort_word) W::st_agent(G.abort_word, 1u); }
+            P->next_chunk = ci;
+            if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 2; }
+            const uint32_t xe = W::xw_load(&W::lds()->x_err);
+            if (xe && !P->error) P->error = xe;
+            if ((err || xe) && G.abort_word) W::st_agent(G.abort_word, 1u);
 #ifdef NLZM_PROFILE
-            for (int k = 0; k < 16; k++) P->prof[k] += prof[k];
+            for (int k = 7; k < 12; k++) P->prof[k] += prof[k];
 #endif
             unsigned long long *dst = (unsigned long long *)&P->cnt;
             const unsigned long long *src = (const unsigned long long *)&W::lds()->cnt;
@@ -1162,12 +1294,15 @@ struct Master {
         }
     }
 
-    NLZM_HD void run(uint32_t c0, uint32_t c1)
+    // shared start-up, run by ONE of the two waves before either role starts
+    NLZM_HD static void init_shared(const Globals &G, uint32_t a0)
     {
-        load_state();
-        uint32_t ci = c0;
-        for (; ci < c1 && !err; ci++) run_chunk(ci);
-        store_state(ci);
+        for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;
+        if (W::lane() == 0) {
+            W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0;
+            W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
+        }
+        (void)G;
     }
 };
 

@@ -100,6 +100,19 @@ struct DevWave {
     }
     template <class F>
     static __device__ __forceinline__ unsigned long long mask64(F f) { return __ballot(f(lane())); }
+    // words shared by the two master waves (same CU, LDS)
+    static __device__ __forceinline__ void xw_store(uint32_t *p, uint32_t v)
+    {
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static __device__ __forceinline__ uint32_t xw_load(const uint32_t *p)
+    {
+        const uint32_t v = uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        asm volatile("" ::: "memory");
+        return v;
+    }
+    static __device__ __forceinline__ void xw_pause() { __builtin_amdgcn_s_sleep(1); }
     static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
     static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }      // 100 MHz
     static __device__ __forceinline__ unsigned long long timeout_ticks() { return 2000000000ull; } // 20 s
@@ -439,10 +452,14 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
 __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
 {
     if (blockIdx.x == 0) {
-        if (threadIdx.x >= 64) return;
+        // wave 0: finders (HT2/HT3/RK256 state, match-table chain, decisions for the worker lanes)
+        // wave 1: forward-graph parse, model, symbol emit; waves 2..7 leave
+        if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
+        __syncthreads();
+        if (threadIdx.x >= 128) return;
         Master<DevWave> m;
         m.g = g; m.G = G;
-        m.run(c0, c1);
+        if (threadIdx.x < 64) m.run_finder(c0, c1); else m.run_parser(c0, c1);
     } else {
         worker_role(g, G, c0, c1);
     }

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #define NLZM_HD inline
@@ -34,12 +35,15 @@ struct HostIO {
 static MasterLds *g_lds = nullptr;
 struct HostWave {
     static MasterLds *lds() { return g_lds; }
-    static void cnt_add(unsigned long long *p, unsigned long long v) { *p += v; }
+    static void cnt_add(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+    static void xw_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+    static uint32_t xw_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void xw_pause() { std::this_thread::yield(); }
     static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
     static uint32_t ld_agent(const uint32_t *p) { return *p; }
     static void sleep() {}
     static unsigned long long clock() { return 0; }
-    static unsigned long long timeout_ticks() { return ~0ull; }
+    static unsigned long long timeout_ticks() { return ~0ull >> 1; }
     static void wait_hook(void *, uint32_t a) { sim_wait_hook(a); }
     static unsigned long long tick() { return 0; }
     static void lds_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
@@ -329,7 +333,12 @@ int main(int argc, char **argv)
             wk.eager_mode = use_workers == 2;
             if (use_workers == 2) wk.eager();
         }
-        m.run(c0, c1);
+        // the two master waves as two threads
+        Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
+        Master<HostWave> mb = m;
+        std::thread tb([&] { mb.run_parser(c0, c1); });
+        m.run_finder(c0, c1);
+        tb.join();
         if (use_workers) wk.finish();
         if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
     }
