@@ -172,7 +172,6 @@ struct MasterLds {
     //   11 RK hash   12 RK slot as read   13 RK candidate length   14 bt_ready as read   15..22 first 4 BT4 pairs
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[32 * kPf];
-    uint8_t pf_stale[kPf];                  // 1: an HT row it read was rewritten since; 4: its RK slot was
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
     // ---- hand-off between the two waves of the master (Master::run_finder / run_parser) ----
     // Wave A (finders) publishes, per position a, slot a % kEr: word 0 = table length | (long slot + 1) << 16,
@@ -344,6 +343,7 @@ struct Master {
     bool top_open;                  // false: that entry is known not to extend (mismatch at its end)
     bool rk_open;                   // the carried RK match ran into its length cap
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
+    typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
     uint32_t a_long, b_long;        // long hand-off slots taken (finder wave) / given back (parser wave)
     // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
     uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
@@ -431,6 +431,26 @@ struct Master {
         for (uint32_t i = W::lane(); i <= len; i += W::width()) W::lds_min(&mt(i), d);
         if (len > mt_max) { mt_max = len; top_d = d; top_open = open; }
         else if (len == mt_max) { top_d = umin(top_d, d); top_open = top_open || open; }
+    }
+    // The HT2/HT3 (and, when they were there in time, BT4) updates of one position in ONE pass: lane i takes
+    // min{d_k : l_k >= i}.  Pairs k < nh sit at record words 5.., the next nb at words 15..; (sl, sd) is their
+    // summary as the look-ahead lane computed it (longest length | open << 31, smallest distance among the longest).
+    NLZM_HD void mt_apply_set(const typename W::Rec &rec, uint32_t nh, uint32_t nb, uint32_t sl, uint32_t sd)
+    {
+        const uint32_t n = nh + nb, lm = sl & 0x1FFu;
+        uint32_t d[7], l[7];
+        for (uint32_t k = 0; k < 7; k++) {
+            const uint32_t w = k < nh ? 5 + 2 * k : 15 + 2 * (k - nh);
+            d[k] = k < n ? W::rec_get(rec, w) : kNone;
+            l[k] = k < n ? W::rec_get(rec, w + 1) & 0x1FFu : 0;
+        }
+        for (uint32_t i = W::lane(); i <= lm; i += W::width()) {
+            uint32_t v = kNone;
+            for (uint32_t k = 0; k < 7; k++) v = (i <= l[k]) ? umin(v, d[k]) : v;
+            W::lds_min(&mt(i), v);
+        }
+        if (lm > mt_max) { mt_max = lm; top_d = sd; top_open = (sl >> 31) != 0; }
+        else if (lm == mt_max) { top_d = umin(top_d, sd); top_open = top_open || (sl >> 31) != 0; }
     }
     // carry by one position (CarryFrom with shift 1, :823-833) keeping the invariant
     NLZM_HD void mt_carry()
@@ -631,7 +651,7 @@ struct Master {
                     }
                 }
                 rec[4] = np | (cmpb << 8);
-            }
+            } else rec[4] = 0;
             uint32_t rkh = 0, rkv = 0, rkl = 0;
             if (avail >= 256) {
                 rkh = G.rkhash[x];
@@ -645,38 +665,42 @@ struct Master {
                 }
             }
             uint32_t ready = 0;
+            // summary of a set of table updates: longest length | open << 31, smallest distance among the longest
+            uint32_t sl = 0, sd = kNone;
+            auto summarise = [&](uint32_t d, uint32_t lo) {
+                const uint32_t l = lo & 0x1FFu;
+                if (l > (sl & 0x1FFu)) { sl = lo; sd = d; }
+                else if (l == (sl & 0x1FFu)) { sl |= lo & 0x80000000u; sd = umin(sd, d); }
+            };
+            if (avail >= 4) for (uint32_t k = 0; k < (rec[4] & 0xFFu); k++) summarise(rec[5 + 2 * k], rec[6 + 2 * k]);
+            rec[23] = sl; rec[24] = sd;
             if (G.workers) {
                 const unsigned long long bi = x - G.batch_a0;
                 if (G.unc[bi]) flags |= 32u;
                 W::wait_hook(G.hook_user, x);
                 ready = W::ld_agent(G.bt_ready + bi);
-                if (ready & kBtReady) {
-                    const uint32_t n2 = 2 * umin(ready & 0x1FFu, 4u);
+                if ((ready & kBtReady) && avail >= 4) {
+                    const uint32_t nb = umin(ready & 0x1FFu, 4u), max_len = umin(avail, kMatchMax);
                     const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-                    for (uint32_t k = 0; k < n2; k++) rec[15 + k] = W::ld_agent(pairs + k);
+                    for (uint32_t k = 0; k < nb; k++) {
+                        const uint32_t d = W::ld_agent(pairs + 2 * k), l = W::ld_agent(pairs + 2 * k + 1);
+                        rec[15 + 2 * k] = d; rec[16 + 2 * k] = l | ((uint32_t)(l >= max_len) << 31);
+                        summarise(d, rec[16 + 2 * k]);
+                    }
                 }
             }
+            rec[25] = sl; rec[26] = sd;
             rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags;
             rec[11] = rkh; rec[12] = rkv; rec[13] = rkl; rec[14] = ready;
-            W::lds()->pf_stale[j] = 0;
+            W::pfl_set(pfl, j, idx, rkh >> g.rk_shift);
         }
         W::sync();
     }
 
     // a store to HT2 row i2 / HT3 rows i3, i3+1 (bucket b reads rows b and b+1, :912) invalidates
     // what later look-ahead slots read from them
-    NLZM_HD void pf_mark_ht(uint32_t s, uint32_t i2, uint32_t i3)
-    {
-        for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width()) {
-            const uint32_t o = W::lds()->pf_rec[32 * j + 1], o2 = o & 0xFFFFu, o3 = o >> 16;
-            if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) W::lds()->pf_stale[j] |= 1;
-        }
-    }
-    NLZM_HD void pf_mark_rk(uint32_t s, uint32_t slot)
-    {
-        for (uint32_t j = s + 1 + W::lane(); j < pf_n; j += W::width())
-            if ((W::lds()->pf_rec[32 * j + 11] >> g.rk_shift) == slot) W::lds()->pf_stale[j] |= 4;
-    }
+    NLZM_HD void pf_mark_ht(uint32_t s, uint32_t i2, uint32_t i3) { W::pfl_mark_ht(pfl, s, pf_n, i2, i3); }
+    NLZM_HD void pf_mark_rk(uint32_t s, uint32_t slot) { W::pfl_mark_rk(pfl, s, pf_n, slot); }
 
     // ---- finders for one position (:1501-1543) --------------------------------
     // q: rebased position, a: absolute position, p: parse-relative index.
@@ -688,7 +712,7 @@ struct Master {
         prof_mark(0);
         const uint32_t s = a - pf_base;
         const typename W::Rec rec = W::rec_load(W::lds()->pf_rec + 32 * s);
-        const uint32_t pflags = W::rec_get(rec, 3), pstale = W::uni(W::lds()->pf_stale[s]);
+        const uint32_t pflags = W::rec_get(rec, 3), pstale = W::pfl_stale(pfl, s);
 
         // carry by one (:1501-1502, CarryFrom :823-833)
         mt_carry();
@@ -761,14 +785,15 @@ struct Master {
             pf_mark_ht(s, i2, i3);
             n_ht++;
             prof_mark(2);
+            bool bt_done = false;
             if (fresh_ht) {
-                // the lane that looked at this position already ran the HT2/HT3 logic
-                const uint32_t np = W::rec_get(rec, 4);
+                // the lane that looked at this position already ran the HT2/HT3 logic (and fetched the BT4 result
+                // of the worker lanes if it was there): all table updates of the position in one pass
+                const uint32_t np = W::rec_get(rec, 4), ready = W::rec_get(rec, 14), cnt = ready & 0x1FFu;
                 n_cmp += np >> 8;
-                for (uint32_t k = 0; k < (np & 0xFFu); k++) {
-                    const uint32_t lo = W::rec_get(rec, 6 + 2 * k);
-                    mt_update(W::rec_get(rec, 5 + 2 * k), lo & 0x1FFu, (lo >> 31) != 0);
-                }
+                bt_done = !nice && G.workers && (ready & kBtReady) && cnt <= 4;
+                const uint32_t nh = np & 0xFFu, nb = bt_done ? cnt : 0;
+                if (nh + nb) mt_apply_set(rec, nh, nb, W::rec_get(rec, bt_done ? 25 : 23), W::rec_get(rec, bt_done ? 26 : 24));
             } else {
             // HT2 (:917-933)
             if ((valid & 1) && 1 < max_len) {
@@ -786,7 +811,7 @@ struct Master {
             }
             }
             prof_mark(4);
-            if (!nice) {                                            // BT4 (:1522)
+            if (!nice && !bt_done) {                                // BT4 (:1522)
                 if (G.workers) {
                     const uint32_t ready = W::rec_get(rec, 14), cnt = ready & 0x1FFu;
 #ifdef NLZM_SIM_DEBUG
@@ -794,7 +819,7 @@ struct Master {
 #endif
                     if ((ready & kBtReady) && cnt <= 4) {
                         for (uint32_t k = 0; k < cnt; k++) {
-                            const uint32_t l = W::rec_get(rec, 16 + 2 * k);
+                            const uint32_t l = W::rec_get(rec, 16 + 2 * k) & 0x1FFu;
                             mt_update(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
                         }
                     } else bt_consume(a, max_len);

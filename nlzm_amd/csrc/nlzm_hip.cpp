@@ -368,11 +368,11 @@ int refresh_stats()
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
     if (getenv("NLZM_PROFILE_PRINT")) {
-        static const char *names[12] = { "loop-top/literal", "carry+extend", "HT consume", "rep probes", "HT logic", "BT consume",
-                                         "RK", "node read", "sampled relax", "rep relax", "backtrack", "emit" };
+        static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
+                                         "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
         unsigned long long tot = 0;
-        for (int k = 0; k < 12; k++) tot += P.prof[k];
-        for (int k = 0; k < 12; k++) fprintf(stderr, "prof %-18s %12llu cyc  %5.1f%%  %7.1f cyc/pos\n", names[k], P.prof[k],
+        for (int k = 0; k < 13; k++) tot += P.prof[k];
+        for (int k = 0; k < 13; k++) fprintf(stderr, "prof %-18s %12llu cyc  %5.1f%%  %7.1f cyc/pos\n", names[k], P.prof[k],
                                              100.0 * P.prof[k] / (tot ? tot : 1), (double)P.prof[k] / (P.cnt.positions ? P.cnt.positions : 1));
     }
     if (C.workers) {

@@ -32,6 +32,19 @@ struct DevWave {
     }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
+    // per look-ahead slot state kept in the lane that evaluated the slot (slot j = lane j, kPf == 64)
+    struct PfLane { uint32_t idx, rkslot, stale; };
+    static __device__ __forceinline__ void pfl_set(PfLane &p, uint32_t, uint32_t idx, uint32_t rkslot) { p.idx = idx; p.rkslot = rkslot; p.stale = 0; }
+    static __device__ __forceinline__ void pfl_mark_ht(PfLane &p, uint32_t s, uint32_t n, uint32_t i2, uint32_t i3)
+    {
+        const uint32_t o2 = p.idx & 0xFFFFu, o3 = p.idx >> 16;
+        p.stale |= (lane() > s && lane() < n && (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3)) ? 1u : 0u;
+    }
+    static __device__ __forceinline__ void pfl_mark_rk(PfLane &p, uint32_t s, uint32_t n, uint32_t slot)
+    {
+        p.stale |= (lane() > s && lane() < n && p.rkslot == slot) ? 4u : 0u;
+    }
+    static __device__ __forceinline__ uint32_t pfl_stale(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.stale, (int)s); }
     // explicit rep probes: lane i = probe i>>4, dword i&15 of the kRepPf bytes in front of the distance and at the position
     struct RepPf { uint32_t s, c; };
     static __device__ __forceinline__ RepPf rep_prefetch(const uint8_t *in, unsigned long long n, uint32_t a, uint32_t r0, uint32_t r1,

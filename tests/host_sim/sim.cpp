@@ -54,6 +54,17 @@ struct HostWave {
     template <class F>
     static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
+    struct PfLane { uint32_t idx[64], rkslot[64], stale[64]; };
+    static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot) { p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; }
+    static void pfl_mark_ht(PfLane &p, uint32_t s, uint32_t n, uint32_t i2, uint32_t i3)
+    {
+        for (uint32_t j = s + 1; j < n; j++) {
+            const uint32_t o2 = p.idx[j] & 0xFFFFu, o3 = p.idx[j] >> 16;
+            if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) p.stale[j] |= 1;
+        }
+    }
+    static void pfl_mark_rk(PfLane &p, uint32_t s, uint32_t n, uint32_t slot) { for (uint32_t j = s + 1; j < n; j++) if (p.rkslot[j] == slot) p.stale[j] |= 4; }
+    static uint32_t pfl_stale(const PfLane &p, uint32_t s) { return p.stale[s]; }
     struct RepPf { const uint8_t *in; unsigned long long n; uint32_t a, r[4]; };
     static RepPf rep_prefetch(const uint8_t *in, unsigned long long n, uint32_t a, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
     {
