@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnlzm_hip.so")
+LIB_PATH = os.environ.get("NLZM_LIB", os.path.join(_HERE, "libnlzm_hip.so"))     # override: diagnostic builds only
 CLI_PATH = os.path.join(_HERE, "nlzm")
 
 # every symbol include/nlzm_hip.h declares

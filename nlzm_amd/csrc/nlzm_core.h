@@ -35,7 +35,8 @@ constexpr uint32_t kParseMax = 4096;    // :1458
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kPf = 64;            // look-ahead depth of the master (positions)
 constexpr uint32_t kWinTail = 288;
-constexpr uint32_t kEr = 64;            // hand-off ring between the two master waves (positions)
+constexpr uint32_t kCq = 512;           // table-command queue between the finder wave and the table wave
+constexpr uint32_t kEr = 64;            // hand-off ring between the table wave and the parser wave (positions)
 constexpr uint32_t kErLong = 4;         // of them with a table longer than 63 entries
 constexpr uint32_t kRepPf = 64;         // bytes fetched ahead per explicit rep probe; longer matches take the exact path
 
@@ -173,17 +174,22 @@ struct MasterLds {
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[32 * kPf];
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
-    // ---- hand-off between the two waves of the master (Master::run_finder / run_parser) ----
-    // Wave A (finders) publishes, per position a, slot a % kEr: word 0 = table length | (long slot + 1) << 16,
-    // word 1 = the input byte, words 2..63 = table entries 2..63; longer tables go to er_long whole.
+    // ---- hand-off between the three waves of the master (run_finder -> run_table -> run_parser) ----
+    // Wave A (finders) keeps only the table's length and top entry in registers and sends what happens to
+    // the table as commands (cq); wave T owns the table ring, applies them and publishes, per position a,
+    // slot a % kEr: word 0 = table length | (long slot + 1) << 16, word 1 = the input byte,
+    // words 2..63 = table entries 2..63 (longer tables go to er_long whole); wave B parses.
+    uint32_t cq[kCq * 2];                   // op | arg << 8, value
+    uint32_t x_cpos;                        // A: commands < x_cpos are written
+    uint32_t x_tpos;                        // T: commands < x_tpos are consumed
     uint32_t er_tab[kEr * 64];
     uint32_t er_long[kErLong * (kMatchMax + 8)];
-    uint32_t x_apos;                        // A: positions < x_apos are published
+    uint32_t x_apos;                        // T: positions < x_apos are published
     uint32_t x_bpos;                        // B: positions < x_bpos are parsed (their slots are free again)
     uint32_t x_bseg;                        // B: start of the segment that contains x_bpos
     uint32_t x_long_free;                   // B: long slots given back (monotonic)
     uint32_t x_err;                         // either: error code, both waves leave their loops
-    uint32_t x_adone;                       // A: finished the launch
+    uint32_t x_adone;                       // A, T: finished the launch (count)
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -344,7 +350,10 @@ struct Master {
     bool rk_open;                   // the carried RK match ran into its length cap
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
     typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
-    uint32_t a_long, b_long;        // long hand-off slots taken (finder wave) / given back (parser wave)
+    uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
+    uint32_t cq_n, cq_seen;         // finder wave: commands written / consumed count last seen
+    uint32_t seg_s, seg_cut;        // finder wave, inside a nice region: segment start and its forced cut
+    bool prev_nice;
     // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
     uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
     NLZM_HD void counts_zero() { n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = 0; }
@@ -421,47 +430,76 @@ struct Master {
         }
     };
 
-    // ---- MatchTable::Update (:835-852) on the ring ---------------------------
-    // Invariant: every ring entry above mt_max holds kNone, so the element-wise
-    // min-merge is ONE predicated LDS atomic min per lane (no read, nothing to wait
-    // for) whether the entry existed or not.  `open`: the match ran into its length
-    // cap, so the carried entry may extend at the next position (:1503-1512).
+    // ---- table commands (finder wave) ---------------------------------------------
+    // The finder wave needs only the table's length and its top entry (for the nice decision :1514 and
+    // the extension :1503-1512); every change is forwarded to the table wave in program order.
+    static constexpr uint32_t kOpCarry = 1, kOpExt = 2, kOpUpd = 3, kOpEnd = 4;
+    NLZM_HD void cq_push(uint32_t op, uint32_t arg, uint32_t val)
+    {
+        if (cq_n - cq_seen >= kCq) {                    // queue full as far as we know: look again / wait
+            const unsigned long long t0 = W::clock();
+            uint32_t spins = 0;
+            while (cq_n - (cq_seen = W::xw_load(&W::lds()->x_tpos)) >= kCq) {
+                if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
+                if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, cq_n); return; }
+                W::xw_pause();
+            }
+        }
+        uint32_t *c = W::lds()->cq + (cq_n & (kCq - 1)) * 2;
+        c[0] = op | (arg << 8); c[1] = val;
+        cq_n++;
+    }
+    NLZM_HD void cq_flush() { W::xw_store(&W::lds()->x_cpos, cq_n); }
+
+    // MatchTable::Update (:835-852).  `open`: the match ran into its length cap, so the carried entry may
+    // extend at the next position (:1503-1512).
     NLZM_HD void mt_update(uint32_t d, uint32_t len, bool open)
     {
-        for (uint32_t i = W::lane(); i <= len; i += W::width()) W::lds_min(&mt(i), d);
+        cq_push(kOpUpd, len, d);
         if (len > mt_max) { mt_max = len; top_d = d; top_open = open; }
         else if (len == mt_max) { top_d = umin(top_d, d); top_open = top_open || open; }
     }
-    // The HT2/HT3 (and, when they were there in time, BT4) updates of one position in ONE pass: lane i takes
-    // min{d_k : l_k >= i}.  Pairs k < nh sit at record words 5.., the next nb at words 15..; (sl, sd) is their
-    // summary as the look-ahead lane computed it (longest length | open << 31, smallest distance among the longest).
+    // The HT2/HT3 (and, when they were there in time, BT4) updates of one position; pairs k < nh sit at record
+    // words 5.., the next nb at words 15..; (sl, sd) is their summary as the look-ahead lane computed it
+    // (longest length | open << 31, smallest distance among the longest).
     NLZM_HD void mt_apply_set(const typename W::Rec &rec, uint32_t nh, uint32_t nb, uint32_t sl, uint32_t sd)
     {
-        const uint32_t n = nh + nb, lm = sl & 0x1FFu;
-        uint32_t d[7], l[7];
-        for (uint32_t k = 0; k < 7; k++) {
-            const uint32_t w = k < nh ? 5 + 2 * k : 15 + 2 * (k - nh);
-            d[k] = k < n ? W::rec_get(rec, w) : kNone;
-            l[k] = k < n ? W::rec_get(rec, w + 1) & 0x1FFu : 0;
-        }
-        for (uint32_t i = W::lane(); i <= lm; i += W::width()) {
-            uint32_t v = kNone;
-            for (uint32_t k = 0; k < 7; k++) v = (i <= l[k]) ? umin(v, d[k]) : v;
-            W::lds_min(&mt(i), v);
-        }
+        const uint32_t lm = sl & 0x1FFu;
+        for (uint32_t k = 0; k < nh; k++) cq_push(kOpUpd, W::rec_get(rec, 6 + 2 * k) & 0x1FFu, W::rec_get(rec, 5 + 2 * k));
+        for (uint32_t k = 0; k < nb; k++) cq_push(kOpUpd, W::rec_get(rec, 16 + 2 * k) & 0x1FFu, W::rec_get(rec, 15 + 2 * k));
         if (lm > mt_max) { mt_max = lm; top_d = sd; top_open = (sl >> 31) != 0; }
         else if (lm == mt_max) { top_d = umin(top_d, sd); top_open = top_open || (sl >> 31) != 0; }
     }
-    // carry by one position (CarryFrom with shift 1, :823-833) keeping the invariant
+    // carry by one position (CarryFrom with shift 1, :823-833)
     NLZM_HD void mt_carry()
+    {
+        cq_push(kOpCarry, 0, 0);
+        if (mt_max <= 1) { mt_max = 0; top_open = false; }
+        else mt_max -= 1;
+    }
+
+    // ---- the table itself (table wave) ----------------------------------------------
+    // Invariant: every ring entry above t_max holds kNone, so the element-wise min-merge of Update is ONE
+    // predicated LDS atomic min per lane (no read, nothing to wait for) whether the entry existed or not.
+    NLZM_HD void t_update(uint32_t d, uint32_t len)
+    {
+        for (uint32_t i = W::lane(); i <= len; i += W::width()) W::lds_min(&mt(i), d);
+        mt_max = umax(mt_max, len);
+    }
+    NLZM_HD void t_carry()
     {
         if (mt_max <= 1) {
             for (uint32_t i = W::lane(); i < 2; i += W::width()) mt(i) = kNone;
-            mt_max = 0; top_open = false;
+            mt_max = 0;
         } else {
             mt(0) = kNone;                              // becomes relative index 511 after the shift
             mt_max -= 1; mt_base = (mt_base + 1) & 511;
         }
+    }
+    NLZM_HD void t_extend(uint32_t d, uint32_t nl)
+    {
+        for (uint32_t i = mt_max + 1 + W::lane(); i <= nl; i += W::width()) mt(i) = d;
+        mt_max = nl;
     }
 
     struct MtSink {
@@ -723,10 +761,7 @@ struct Master {
                 const uint32_t cap = umin(kMatchMax, avail);
                 if (mt_max < cap) {
                     const uint32_t nl = wave_cmp<false>(cur - d, cur, mt_max, cap) & 0x7FFFFFFFu;
-                    if (nl > mt_max) {
-                        for (uint32_t i = mt_max + 1 + W::lane(); i <= nl; i += W::width()) mt(i) = d;
-                        mt_max = nl;
-                    }
+                    if (nl > mt_max) { cq_push(kOpExt, nl, d); mt_max = nl; }
                     top_open = nl >= cap;
                 }
             }
@@ -747,11 +782,19 @@ struct Master {
         }
         // inside a nice region the finders run at every 8th PARSE-RELATIVE position (:1529): the segment
         // start is the parser wave's knowledge, final for `a` once it has parsed every earlier position
+        // A segment cannot end inside a nice region (the table of the previous position reaches >= 64 further,
+        // :1550-1554) except at the forced cut -- 4096 positions (:1469) or the chunk end (:1802) -- so the parser is
+        // asked once per region and the forced cut is followed here.
         bool call = true;
         if (nice) {
-            if (!wait_ge(&W::lds()->x_bpos, a)) return;
-            call = !((a - W::xw_load(&W::lds()->x_bseg)) & 7u);
+            if (!prev_nice) {
+                if (!wait_ge(&W::lds()->x_bpos, a)) return;
+                seg_s = W::xw_load(&W::lds()->x_bseg);
+            } else if (a == seg_cut) seg_s = a;
+            seg_cut = seg_s + umin(kParseMax, pos_end_abs - seg_s);
+            call = !((a - seg_s) & 7u);
         }
+        prev_nice = nice;
         const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
 
@@ -951,9 +994,17 @@ struct Master {
     {
         if (W::xw_load(w) >= v) return true;
         const unsigned long long t0 = W::clock();
+#ifdef NLZM_PROFILE
+        const unsigned long long c0 = W::tick();
+#endif
         uint32_t spins = 0;
         for (;;) {
-            if (W::xw_load(w) >= v) return true;
+            if (W::xw_load(w) >= v) {
+#ifdef NLZM_PROFILE
+                prof[13] += W::tick() - c0;
+#endif
+                return true;
+            }
             if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
             if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, v); return false; }
             W::xw_pause();
@@ -978,7 +1029,7 @@ struct Master {
 
     // =========================== wave A: finders ===========================================
     // publish position a: table length, input byte, table entries (MatchTable as mt_carry holds it, :1543)
-    NLZM_HD void a_publish(uint32_t a)
+    NLZM_HD void t_publish(uint32_t a, uint32_t lit)
     {
         uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
         uint32_t hdr = mt_max;
@@ -992,7 +1043,7 @@ struct Master {
         }
         for (uint32_t i = 2 + W::lane(); i < 64; i += W::width()) e[i] = mt(i);
         e[0] = hdr;
-        e[1] = W::lds()->win[a - pf_base];
+        e[1] = lit;
         W::sync();
         W::xw_store(&W::lds()->x_apos, a + 1);
     }
@@ -1018,13 +1069,12 @@ struct Master {
         counts_zero();
         const uint32_t a0 = (uint32_t)chunk_abs, a1 = a0 + p_end;
         for (uint32_t a = a0; a < a1 && !err; a++) {
-            if (!wait_space(a)) break;                              // slot a % kEr is free again
             if (a - pf_base >= pf_n) pf_fill(a, a1, a0 + chunk_read);
             prof_start();
             finders(chunk_q + (a - a0), a, a1);
             if (err) break;
-            capture(a);
-            a_publish(a);
+            cq_push(kOpEnd, W::lds()->win[a - pf_base], a);       // the table of position a is complete (:1543)
+            cq_flush();
             prof_mark(12);
         }
         counts_flush();
@@ -1033,10 +1083,9 @@ struct Master {
     NLZM_HD void run_finder(uint32_t c0, uint32_t c1)
     {
         Persist *P = G.persist;
-        mt_base = 0; mt_max = W::uni(P->mt_max);
-        for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
+        mt_max = W::uni(P->mt_max);
         top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
-        pf_base = 0; pf_n = 0; a_long = 0;
+        pf_base = 0; pf_n = 0; cq_n = 0; cq_seen = 0; prev_nice = false; seg_s = 0; seg_cut = 0;
         rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
@@ -1048,19 +1097,71 @@ struct Master {
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk_finder(ci);
         W::sync();
-        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = i <= mt_max ? mt(i) : 0;
         if (W::lane() == 0) {
-            P->mt_max = mt_max;
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
             P->reb_base = base;
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 1; }
 #ifdef NLZM_PROFILE
             for (int k = 0; k < 7; k++) P->prof[k] += prof[k];
-            P->prof[12] += prof[12];
+            P->prof[12] += prof[12]; P->prof[14] += prof[13];
 #endif
         }
         W::sync_global();
-        W::xw_store(&W::lds()->x_adone, 1u);
+        W::xw_add(&W::lds()->x_adone, 1u);
+    }
+
+    // =========================== wave T: the match table ===================================
+    NLZM_HD void run_table(uint32_t c0, uint32_t c1)
+    {
+        Persist *P = G.persist;
+        mt_base = 0; mt_max = W::uni(P->mt_max);
+        for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
+        err = W::uni(P->error); err_info0 = 0;
+        a_long = 0; pf_base = 0;
+        W::sync();
+        unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
+        if (a_end > g.n) a_end = g.n;
+        const uint32_t last = (uint32_t)a_end;              // one END command per position of the launch
+        uint32_t done = 0, have = 0, ended = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        while (ended < last && !err) {
+            if (done == have) {                             // fetch what the finder wave has written meanwhile
+                const unsigned long long t0 = W::clock();
+                uint32_t spins = 0;
+                while ((have = W::xw_load(&W::lds()->x_cpos)) == done) {
+                    if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; break; }
+                    if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, done); break; }
+                    W::xw_pause();
+                }
+                if (err) break;
+            }
+            // up to 32 commands with one LDS read each for the two words, then picked by lane
+            const uint32_t nb = umin(have - done, 32u);
+            const uint32_t first = done;
+            const typename W::Rec r0 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->cq[((first + i) & (kCq - 1)) * 2]; });
+            const typename W::Rec r1 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->cq[((first + i) & (kCq - 1)) * 2 + 1]; });
+            for (uint32_t k = 0; k < nb && !err; k++) {
+                const uint32_t c = W::rec_get(r0, k), v = W::rec_get(r1, k), op = c & 0xFFu, arg = c >> 8;
+                if (op == kOpUpd) t_update(v, arg);
+                else if (op == kOpCarry) t_carry();
+                else if (op == kOpExt) t_extend(v, arg);
+                else {                                      // kOpEnd: publish position v, input byte arg
+                    if (!wait_space(v)) break;              // slot v % kEr is free again
+                    capture(v);
+                    t_publish(v, arg);
+                    ended = v + 1;
+                }
+            }
+            done += nb;
+            W::xw_store(&W::lds()->x_tpos, done);
+        }
+        W::sync();
+        for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = i <= mt_max ? mt(i) : 0;
+        if (W::lane() == 0) {
+            P->mt_max = mt_max;
+            if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 3; }
+        }
+        W::sync_global();
+        W::xw_add(&W::lds()->x_adone, 1u);
     }
 
     // =========================== wave B: parse + emit ======================================
@@ -1300,7 +1401,7 @@ struct Master {
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk_parser(ci);
         // the finder wave has stored its part of the state and its counters
-        for (uint32_t spins = 0; !W::xw_load(&W::lds()->x_adone) && spins < (1u << 28); spins++) W::xw_pause();
+        for (uint32_t spins = 0; W::xw_load(&W::lds()->x_adone) < 2 && spins < (1u << 28); spins++) W::xw_pause();
         W::sync();
         for (uint32_t i = W::lane(); i < kNumCtx * kCdfStride; i += W::width()) P->cdf[i] = W::lds()->cdf[i];
         if (W::lane() == 0) {
@@ -1312,6 +1413,7 @@ struct Master {
             if ((err || xe) && G.abort_word) W::st_agent(G.abort_word, 1u);
 #ifdef NLZM_PROFILE
             for (int k = 7; k < 12; k++) P->prof[k] += prof[k];
+            P->prof[13] += prof[13];
 #endif
             unsigned long long *dst = (unsigned long long *)&P->cnt;
             const unsigned long long *src = (const unsigned long long *)&W::lds()->cnt;
@@ -1326,6 +1428,7 @@ struct Master {
         if (W::lane() == 0) {
             W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0;
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
+            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0;
         }
         (void)G;
     }

@@ -368,6 +368,8 @@ int refresh_stats()
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
     if (getenv("NLZM_PROFILE_PRINT")) {
+        fprintf(stderr, "waits: B on A %.1f cyc/pos, A on B (nice phase, ring space excluded) %.1f cyc/pos\n",
+                (double)P.prof[13] / (P.cnt.positions ? P.cnt.positions : 1), (double)P.prof[14] / (P.cnt.positions ? P.cnt.positions : 1));
         static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
                                          "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
         unsigned long long tot = 0;

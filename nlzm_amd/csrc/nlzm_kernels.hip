@@ -78,6 +78,8 @@ struct DevWave {
     static __device__ __forceinline__ Rec rec_load(const uint32_t *base) { return Rec{ base[lane() & 31u] }; }
     template <class F>
     static __device__ __forceinline__ Rec rec_load_fn(F f) { return Rec{ f(lane() & 7u) }; }
+    template <class F>
+    static __device__ __forceinline__ Rec rec_load_fn32(F f) { return Rec{ f(lane() & 31u) }; }
     static __device__ __forceinline__ uint32_t rec_get(Rec r, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)r.v, (int)k); }
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
@@ -124,6 +126,11 @@ struct DevWave {
         const uint32_t v = uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         asm volatile("" ::: "memory");
         return v;
+    }
+    static __device__ __forceinline__ void xw_add(uint32_t *p, uint32_t v)
+    {
+        asm volatile("" ::: "memory");
+        if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     static __device__ __forceinline__ void xw_pause() { __builtin_amdgcn_s_sleep(1); }
     static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
@@ -465,14 +472,17 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
 __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
 {
     if (blockIdx.x == 0) {
-        // wave 0: finders (HT2/HT3/RK256 state, match-table chain, decisions for the worker lanes)
-        // wave 1: forward-graph parse, model, symbol emit; waves 2..7 leave
+        // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
+        // wave 1: the match table (carry / extend / update), published per position
+        // wave 2: forward-graph parse, model, symbol emit; waves 3..7 leave
         if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         __syncthreads();
-        if (threadIdx.x >= 128) return;
+        if (threadIdx.x >= 192) return;
         Master<DevWave> m;
         m.g = g; m.G = G;
-        if (threadIdx.x < 64) m.run_finder(c0, c1); else m.run_parser(c0, c1);
+        if (threadIdx.x < 64) m.run_finder(c0, c1);
+        else if (threadIdx.x < 128) m.run_table(c0, c1);
+        else m.run_parser(c0, c1);
     } else {
         worker_role(g, G, c0, c1);
     }

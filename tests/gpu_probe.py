@@ -1,5 +1,5 @@
 """Ad-hoc GPU probe (not a test): python tests/gpu_probe.py [size_mb] [window] [workers]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 import nlzm_amd
@@ -10,7 +10,7 @@ size = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 3_000_000
 hb = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 modes = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]
 kind = sys.argv[4] if len(sys.argv) > 4 else "syn_text"
-check = size <= 20_000_000
+check = size <= 20_000_000 and "NLZM_LIB" not in os.environ
 nlzm_amd.init(0)
 data = corpus.make(kind, size)
 want = oracle_py.compress(data, hb) if check else None

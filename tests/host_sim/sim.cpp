@@ -38,6 +38,7 @@ struct HostWave {
     static void cnt_add(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
     static void xw_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
     static uint32_t xw_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void xw_add(uint32_t *p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
     static void xw_pause() { std::this_thread::yield(); }
     static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
     static uint32_t ld_agent(const uint32_t *p) { return *p; }
@@ -53,6 +54,8 @@ struct HostWave {
     static Rec rec_load(const uint32_t *base) { Rec r; for (int i = 0; i < 32; i++) r.w[i] = base[i]; return r; }
     template <class F>
     static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
+    template <class F>
+    static Rec rec_load_fn32(F f) { Rec r; for (uint32_t i = 0; i < 32; i++) r.w[i] = f(i); return r; }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
     struct PfLane { uint32_t idx[64], rkslot[64], stale[64]; };
     static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot) { p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; }
@@ -346,9 +349,11 @@ int main(int argc, char **argv)
         }
         // the two master waves as two threads
         Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
-        Master<HostWave> mb = m;
+        Master<HostWave> mb = m, mt = m;
         std::thread tb([&] { mb.run_parser(c0, c1); });
+        std::thread tt([&] { mt.run_table(c0, c1); });
         m.run_finder(c0, c1);
+        tt.join();
         tb.join();
         if (use_workers) wk.finish();
         if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
