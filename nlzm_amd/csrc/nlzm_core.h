@@ -96,7 +96,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[16];    // cycles per master phase (diagnostic builds: NLZM_PROFILE)
+    unsigned long long prof[24];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -163,6 +163,8 @@ struct MasterLds {
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];           // log2_lut[freq>>6] per (context, symbol)  (:435-438)
     uint16_t lut[256];                      // log2_lut (:97-124)
+    uint16_t seg_len_price[kMatchMax + 8];  // price of the length symbols by length value (:1214-1225), current model
+    uint16_t seg_slot_price[4 * 64];        // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t btpairs[2 * kBtMaxPairs];      // worker result being consumed
     Counters cnt;                           // operation counters of this launch (LDS adds, nothing to wait for)
     // look-ahead: kPf positions are evaluated by the lanes in parallel against the finder
@@ -351,6 +353,7 @@ struct Master {
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
     typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
     uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
+    bool seg_tab_dirty;             // parser wave: a length/distance context changed since the price tables were built
     uint32_t cq_n, cq_seen;         // finder wave: commands written / consumed count last seen
     uint32_t seg_s, seg_cut;        // finder wave, inside a nice region: segment start and its forced cut
     bool prev_nice;
@@ -375,6 +378,7 @@ struct Master {
     uint32_t nsyms, nbits, word, word_bits, num_ops;
 
     uint32_t err, err_info0;
+    unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
 #ifdef NLZM_PROFILE
     unsigned long long prof[16];
     unsigned long long prof_t;
@@ -438,12 +442,14 @@ struct Master {
     {
         if (cq_n - cq_seen >= kCq) {                    // queue full as far as we know: look again / wait
             const unsigned long long t0 = W::clock();
+            const unsigned long long c0 = W::tick();
             uint32_t spins = 0;
             while (cq_n - (cq_seen = W::xw_load(&W::lds()->x_tpos)) >= kCq) {
                 if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
                 if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, cq_n); return; }
                 W::xw_pause();
             }
+            wait_cyc += W::tick() - c0;
         }
         uint32_t *c = W::lds()->cq + (cq_n & (kCq - 1)) * 2;
         c[0] = op | (arg << 8); c[1] = val;
@@ -530,6 +536,20 @@ struct Master {
     {
         return price(kCtxCmd, 2) + price_len(len - match_min(d)) + (2u << 5);
     }
+    // per-model price tables for the match edges: rebuilt (by all lanes) only after an emit touched a length or
+    // distance context; literal-only segments leave them valid
+    NLZM_HD void seg_tables()
+    {
+        if (!seg_tab_dirty) return;
+        W::sync();
+        for (uint32_t lv = W::lane(); lv <= kMatchMax; lv += W::width()) W::lds()->seg_len_price[lv] = (uint16_t)price_len(lv);
+        for (uint32_t i = W::lane(); i < 4 * 64; i += W::width()) {
+            const uint32_t lc = i >> 6, slot = i & 63;
+            W::lds()->seg_slot_price[i] = slot < 56 ? (uint16_t)(price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7)) : 0;
+        }
+        W::sync();
+        seg_tab_dirty = false;
+    }
     NLZM_HD uint32_t price_literal(uint32_t y) const               // :1418-1426
     {
         return W::uni(price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15));
@@ -570,6 +590,7 @@ struct Master {
     }
     NLZM_HD uint32_t emit_len(uint32_t lv)                          // :1281-1297
     {
+        seg_tab_dirty = true;
         put_sym(kCtxLenDirect, umin(lv, 7));
         if (lv >= 7) {
             const uint32_t e = lv - 7;
@@ -928,11 +949,13 @@ struct Master {
         W::wait_hook(G.hook_user, a);
         const unsigned long long t0 = W::clock();
         uint32_t spins = 0, v;
+        const unsigned long long c0 = W::tick();
         while (!((v = W::uni(W::ld_agent(G.bt_ready + bi))) & kBtReady)) {
             if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return; }
             if ((spins & 255u) == 0 && W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
             W::sleep();
         }
+        wait_cyc += W::tick() - c0;
         // the ready word was stored after every pair had been written through (sc1) and drained
         const uint32_t count = v & 0x1FFu;
         const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
@@ -994,14 +1017,14 @@ struct Master {
     {
         if (W::xw_load(w) >= v) return true;
         const unsigned long long t0 = W::clock();
-#ifdef NLZM_PROFILE
+#if defined(NLZM_PROFILE) || defined(NLZM_WAITPROF)
         const unsigned long long c0 = W::tick();
 #endif
         uint32_t spins = 0;
         for (;;) {
             if (W::xw_load(w) >= v) {
-#ifdef NLZM_PROFILE
-                prof[13] += W::tick() - c0;
+#if defined(NLZM_PROFILE) || defined(NLZM_WAITPROF)
+                wait_cyc += W::tick() - c0;
 #endif
                 return true;
             }
@@ -1012,13 +1035,16 @@ struct Master {
     }
     NLZM_HD bool wait_space(uint32_t a)                             // until position a - kEr has been parsed
     {
+        if (a - W::xw_load(&W::lds()->x_bpos) < kEr) return true;
         const unsigned long long t0 = W::clock();
+        const unsigned long long c0 = W::tick();
         uint32_t spins = 0;
         while (a - W::xw_load(&W::lds()->x_bpos) >= kEr) {
             if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
             if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return false; }
             W::xw_pause();
         }
+        wait_cyc += W::tick() - c0;
         return true;
     }
     NLZM_HD void fail(uint32_t code, uint32_t info)
@@ -1086,6 +1112,7 @@ struct Master {
         mt_max = W::uni(P->mt_max);
         top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
         pf_base = 0; pf_n = 0; cq_n = 0; cq_seen = 0; prev_nice = false; seg_s = 0; seg_cut = 0;
+        wait_cyc = 0; role_t0 = W::tick();
         rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
@@ -1100,6 +1127,7 @@ struct Master {
         if (W::lane() == 0) {
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
             P->reb_base = base;
+            P->prof[16] += wait_cyc; P->prof[17] += W::tick() - role_t0;
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 1; }
 #ifdef NLZM_PROFILE
             for (int k = 0; k < 7; k++) P->prof[k] += prof[k];
@@ -1118,6 +1146,7 @@ struct Master {
         for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
         err = W::uni(P->error); err_info0 = 0;
         a_long = 0; pf_base = 0;
+        wait_cyc = 0; role_t0 = W::tick();
         W::sync();
         unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
         if (a_end > g.n) a_end = g.n;
@@ -1126,12 +1155,14 @@ struct Master {
         while (ended < last && !err) {
             if (done == have) {                             // fetch what the finder wave has written meanwhile
                 const unsigned long long t0 = W::clock();
+                const unsigned long long c0 = W::tick();
                 uint32_t spins = 0;
                 while ((have = W::xw_load(&W::lds()->x_cpos)) == done) {
                     if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; break; }
                     if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, done); break; }
                     W::xw_pause();
                 }
+                wait_cyc += W::tick() - c0;
                 if (err) break;
             }
             // up to 32 commands with one LDS read each for the two words, then picked by lane
@@ -1158,6 +1189,7 @@ struct Master {
         for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = i <= mt_max ? mt(i) : 0;
         if (W::lane() == 0) {
             P->mt_max = mt_max;
+            P->prof[18] += wait_cyc; P->prof[19] += W::tick() - role_t0;
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 3; }
         }
         W::sync_global();
@@ -1238,6 +1270,7 @@ struct Master {
             // one compare-and-store; the targets of different lanes are distinct nodes.
             uint32_t checked = 0;
             if (max_len >= kMatchMin) {
+                seg_tables();
                 uint32_t step = (max_len - kMatchMin) >> 4;
                 step += step == 0;
                 const uint32_t K = (max_len - kMatchMin) / step + 1;
@@ -1251,8 +1284,8 @@ struct Master {
                     const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
                     uint32_t nx, ex;
                     const uint32_t slot = dist_slot(d - 1, nx, ex);
-                    const uint32_t plen = price_len(lv);
-                    const uint32_t pdist = (nx << 5) + price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+                    const uint32_t plen = W::lds()->seg_len_price[lv];
+                    const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + slot];
                     uint32_t best = W::lds()->node_cost[np], sel = 0;
                     const uint32_t ri = rp[0] == d ? 0u : (rp[1] == d ? 1u : (rp[2] == d ? 2u : (rp[3] == d ? 3u : 4u)));
                     const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
@@ -1391,7 +1424,8 @@ struct Master {
         for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
-        b_long = 0;
+        b_long = 0; seg_tab_dirty = true;
+        wait_cyc = 0; role_t0 = W::tick();
         counts_zero();
 #ifdef NLZM_PROFILE
         for (int k = 0; k < 16; k++) prof[k] = 0;
@@ -1400,6 +1434,7 @@ struct Master {
         W::sync();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk_parser(ci);
+        const unsigned long long role_t1 = W::tick();
         // the finder wave has stored its part of the state and its counters
         for (uint32_t spins = 0; W::xw_load(&W::lds()->x_adone) < 2 && spins < (1u << 28); spins++) W::xw_pause();
         W::sync();
@@ -1407,6 +1442,7 @@ struct Master {
         if (W::lane() == 0) {
             for (int k = 0; k < 4; k++) P->rep[k] = rep[k];
             P->next_chunk = ci;
+            P->prof[20] += wait_cyc; P->prof[21] += role_t1 - role_t0;
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 2; }
             const uint32_t xe = W::xw_load(&W::lds()->x_err);
             if (xe && !P->error) P->error = xe;

@@ -367,6 +367,11 @@ int refresh_stats()
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
+    if (getenv("NLZM_WAIT_PRINT")) {
+        const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
+        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f\n",
+                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n);
+    }
     if (getenv("NLZM_PROFILE_PRINT")) {
         fprintf(stderr, "waits: B on A %.1f cyc/pos, A on B (nice phase, ring space excluded) %.1f cyc/pos\n",
                 (double)P.prof[13] / (P.cnt.positions ? P.cnt.positions : 1), (double)P.prof[14] / (P.cnt.positions ? P.cnt.positions : 1));
