@@ -4,11 +4,12 @@ import csv, glob, json, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{R}"
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)[0]
+newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)[-1]
+ks = newest(f"{src}/trace/**/*_kernel_stats.csv")
 shutil.copy(ks, f"profiles/{R}_kernel_stats.csv")
 out = {"round": R, "command": "python3 bench.py --no-cpu", "kernel": "pipeline_kernel"}
 for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    f = glob.glob(f"{src}/{name}/**/*_counter_collection.csv", recursive=True)[0]
+    f = newest(f"{src}/{name}/**/*_counter_collection.csv")
     agg, n = {}, {}
     for r in csv.DictReader(open(f)):
         if "pipeline_kernel" in r["Kernel_Name"]:
