@@ -121,8 +121,9 @@ def main():
         host = np.fromfile(real, dtype=np.uint8, count=need, offset=lo)
         data_kind = "file:enwik9"
     else:
-        # every rank generates the same stream prefix it needs: blocks start at lo
-        host = corpus.syn_text(lo + need)[lo:] if lo else corpus.syn_text(need)
+        # N = 1: the prefix of the 1e9-byte stand-in; N > 1: every block is its own seeded text of the same kind
+        # (blocks are independent streams anyway, and this avoids generating up to 875 MB per rank to skip over)
+        host = corpus.syn_text(need, corpus.SEED + rank)
         data_kind = "synthetic"
     d_in = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)     # bytes past `need` are never read by the timed steps
     d_in[:need].copy_(torch.from_numpy(host[:need]))
