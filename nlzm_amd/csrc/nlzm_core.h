@@ -192,6 +192,11 @@ struct MasterLds {
     uint32_t x_long_free;                   // B: long slots given back (monotonic)
     uint32_t x_err;                         // either: error code, both waves leave their loops
     uint32_t x_adone;                       // A, T: finished the launch (count)
+    // parser -> sampler wave: relax the sampled-length edges of one node (request), and back (result)
+    uint32_t sq_req[12];                    // a, p, cost_p, rep set (4), max_len, end_p, hand-off header
+    uint32_t sq_res[2];                     // checked rep mask, end_p
+    uint32_t x_spos;                        // parser: request for position x_spos - 1 is posted (0xFFFFFFFF: leave)
+    uint32_t x_sdone;                       // sampler: request for position x_sdone - 1 is done
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -1196,6 +1201,85 @@ struct Master {
         W::xw_add(&W::lds()->x_adone, 1u);
     }
 
+    // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2, one lane per length.
+    // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
+    // one compare-and-store; the targets of different lanes are distinct nodes.
+    NLZM_HD uint32_t sampled_relax(uint32_t p, uint32_t cost_p, const uint32_t rp[4], const uint32_t *e, uint32_t hdr,
+                                   uint32_t max_len)
+    {
+        uint32_t checked = 0;
+        uint32_t step = (max_len - kMatchMin) >> 4;
+        step += step == 0;
+        const uint32_t K = (max_len - kMatchMin) / step + 1;
+        const uint32_t pc_dict = W::uni(price(kCtxCmd, 1)), pc_rep = W::uni(price(kCtxCmd, 2));
+        uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
+        for (uint32_t k = W::lane(); k < K; k += W::width()) {
+            const uint32_t tl = max_len - k * step;
+            const uint32_t d = tab(e, hdr, tl);
+            const uint32_t mm = match_min(d);
+            if (tl < mm) continue;
+            const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
+            uint32_t nx, ex;
+            const uint32_t slot = dist_slot(d - 1, nx, ex);
+            const uint32_t plen = W::lds()->seg_len_price[lv];
+            const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + slot];
+            uint32_t best = W::lds()->node_cost[np], sel = 0;
+            const uint32_t ri = rp[0] == d ? 0u : (rp[1] == d ? 1u : (rp[2] == d ? 2u : (rp[3] == d ? 3u : 4u)));
+            const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
+            if (ca < best) { best = ca; sel = 1; }
+            if (ri < 4 && cb < best) { best = cb; sel = 2; }
+            if (sel) {
+                W::lds()->node_cost[np] = best;
+                W::lds()->node_delta[np] = sel == 1 ? d : ri;
+                W::lds()->node_link[np] = pack_link(p, tl, sel);
+                uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
+                const bool has = ri < 4;
+                dst[0] = has ? rp[0] : d; dst[1] = has ? rp[1] : rp[0]; dst[2] = has ? rp[2] : rp[1]; dst[3] = has ? rp[3] : rp[2];
+            }
+            myri = ri;
+            if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
+        }
+        if (W::width() != 1) {
+            const uint32_t m = myri;
+            checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
+                      (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
+        }
+        W::sync();
+        return checked;
+    }
+
+    // =========================== wave S: sampled-length edges ==============================
+    NLZM_HD void run_sampler()
+    {
+        err = 0; err_info0 = 0; wait_cyc = 0;
+        uint32_t last = 0;
+        for (;;) {
+            // next request (or the order to leave)
+            uint32_t v;
+            {
+                const unsigned long long t0 = W::clock();
+                uint32_t spins = 0;
+                while ((v = W::xw_load(&W::lds()->x_spos)) == last) {
+                    if (W::xw_load(&W::lds()->x_err)) return;
+                    if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return;
+                    W::xw_pause();
+                }
+            }
+            if (v == kNone) return;
+            last = v;
+            const typename W::Rec q = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[i < 12 ? i : 0]; });
+            const uint32_t a = W::rec_get(q, 0), p = W::rec_get(q, 1), cost_p = W::rec_get(q, 2);
+            const uint32_t rp[4] = { W::rec_get(q, 3), W::rec_get(q, 4), W::rec_get(q, 5), W::rec_get(q, 6) };
+            const uint32_t max_len = W::rec_get(q, 7), hdr = W::rec_get(q, 9);
+            uint32_t end_p = W::rec_get(q, 8);
+            open_nodes(end_p, max_len + p);                         // :1550-1554
+            const uint32_t checked = sampled_relax(p, cost_p, rp, W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len);
+            W::lds()->sq_res[0] = checked; W::lds()->sq_res[1] = end_p;
+            W::sync();
+            W::xw_store(&W::lds()->x_sdone, a + 1);
+        }
+    }
+
     // =========================== wave B: parse + emit ======================================
     // table entry `tl` of the position whose hand-off header is `hdr`
     NLZM_HD uint32_t tab(const uint32_t *e, uint32_t hdr, uint32_t tl) const
@@ -1236,6 +1320,16 @@ struct Master {
             const typename W::Rec hrec = W::rec_load(e);
             const uint32_t hdr = W::rec_get(hrec, 0), tmax = hdr & 0xFFFFu;
 
+            uint32_t max_len = umin(tmax, max_parse - p);           // :1545-1548
+            if (max_len < kMatchMin) max_len = 0;
+            if (max_len) {
+                seg_tables();
+                uint32_t *r = W::lds()->sq_req;
+                r[0] = a; r[1] = p; r[2] = cost_p; r[3] = rp[0]; r[4] = rp[1]; r[5] = rp[2]; r[6] = rp[3];
+                r[7] = max_len; r[8] = end_p; r[9] = hdr;
+                W::sync();
+                W::xw_store(&W::lds()->x_spos, a + 1);
+            }
             // literal edge (:1490-1499)
             {
                 const uint32_t lit = W::rec_get(hrec, 1);
@@ -1261,53 +1355,13 @@ struct Master {
             }
             prof_mark(3);
 
-            uint32_t max_len = umin(tmax, max_parse - p);           // :1545-1548
-            if (max_len < kMatchMin) max_len = 0;
-            open_nodes(end_p, max_len + p);
-
-            // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2, one lane per length.
-            // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
-            // one compare-and-store; the targets of different lanes are distinct nodes.
+            // sampled lengths (:1558-1596): relaxed by the sampler wave while this wave did the literal edge and
+            // the rep-probe lengths; the explicit rep probes (:1598) come after them in the reference's order
             uint32_t checked = 0;
-            if (max_len >= kMatchMin) {
-                seg_tables();
-                uint32_t step = (max_len - kMatchMin) >> 4;
-                step += step == 0;
-                const uint32_t K = (max_len - kMatchMin) / step + 1;
-                const uint32_t pc_dict = W::uni(price(kCtxCmd, 1)), pc_rep = W::uni(price(kCtxCmd, 2));
-                uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
-                for (uint32_t k = W::lane(); k < K; k += W::width()) {
-                    const uint32_t tl = max_len - k * step;
-                    const uint32_t d = tab(e, hdr, tl);
-                    const uint32_t mm = match_min(d);
-                    if (tl < mm) continue;
-                    const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
-                    uint32_t nx, ex;
-                    const uint32_t slot = dist_slot(d - 1, nx, ex);
-                    const uint32_t plen = W::lds()->seg_len_price[lv];
-                    const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + slot];
-                    uint32_t best = W::lds()->node_cost[np], sel = 0;
-                    const uint32_t ri = rp[0] == d ? 0u : (rp[1] == d ? 1u : (rp[2] == d ? 2u : (rp[3] == d ? 3u : 4u)));
-                    const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
-                    if (ca < best) { best = ca; sel = 1; }
-                    if (ri < 4 && cb < best) { best = cb; sel = 2; }
-                    if (sel) {
-                        W::lds()->node_cost[np] = best;
-                        W::lds()->node_delta[np] = sel == 1 ? d : ri;
-                        W::lds()->node_link[np] = pack_link(p, tl, sel);
-                        uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
-                        const bool has = ri < 4;
-                        dst[0] = has ? rp[0] : d; dst[1] = has ? rp[1] : rp[0]; dst[2] = has ? rp[2] : rp[1]; dst[3] = has ? rp[3] : rp[2];
-                    }
-                    myri = ri;
-                    if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
-                }
-                if (W::width() != 1) {
-                    const uint32_t m = myri;
-                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
-                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
-                }
-                W::sync();
+            if (max_len) {
+                if (!wait_ge(&W::lds()->x_sdone, a + 1)) break;
+                checked = W::xw_load(&W::lds()->sq_res[0]);
+                end_p = W::xw_load(&W::lds()->sq_res[1]);
             }
             prof_mark(8);
             // explicit rep probes (:1598-1628)
@@ -1434,6 +1488,7 @@ struct Master {
         W::sync();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk_parser(ci);
+        W::xw_store(&W::lds()->x_spos, kNone);                      // the sampler wave may leave
         const unsigned long long role_t1 = W::tick();
         // the finder wave has stored its part of the state and its counters
         for (uint32_t spins = 0; W::xw_load(&W::lds()->x_adone) < 2 && spins < (1u << 28); spins++) W::xw_pause();
@@ -1464,7 +1519,7 @@ struct Master {
         if (W::lane() == 0) {
             W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0;
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
-            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0;
+            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = 0; W::lds()->x_sdone = 0;
         }
         (void)G;
     }

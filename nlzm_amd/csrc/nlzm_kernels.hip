@@ -474,15 +474,17 @@ __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32
     if (blockIdx.x == 0) {
         // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
         // wave 1: the match table (carry / extend / update), published per position
-        // wave 2: forward-graph parse, model, symbol emit; waves 3..7 leave
+        // wave 2: forward-graph parse, model, symbol emit
+        // wave 3: relaxes the sampled-length edges of each node for the parser; waves 4..7 leave
         if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         __syncthreads();
-        if (threadIdx.x >= 192) return;
+        if (threadIdx.x >= 256) return;
         Master<DevWave> m;
         m.g = g; m.G = G;
         if (threadIdx.x < 64) m.run_finder(c0, c1);
         else if (threadIdx.x < 128) m.run_table(c0, c1);
-        else m.run_parser(c0, c1);
+        else if (threadIdx.x < 192) m.run_parser(c0, c1);
+        else m.run_sampler();
     } else {
         worker_role(g, G, c0, c1);
     }
