@@ -82,6 +82,7 @@ struct Counters {
     unsigned long long positions, nice_positions, segments;
     unsigned long long n_literal, n_dict, n_rep, rans_syms, bit_ops, frames, shifts;
     unsigned long long uncertain_positions;
+    unsigned long long stale_ht, stale_rk, bt_slow;     // look-ahead slots that had to take the direct path (diagnostics)
 };
 
 // State that survives between launches (one per stream), in HBM.
@@ -363,14 +364,15 @@ struct Master {
     uint32_t seg_s, seg_cut;        // finder wave, inside a nice region: segment start and its forced cut
     bool prev_nice;
     // per-chunk operation counts kept in scalar registers, flushed to the LDS counters per chunk
-    uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp;
-    NLZM_HD void counts_zero() { n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = 0; }
+    uint32_t n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_sht, n_srk, n_sbt;
+    NLZM_HD void counts_zero() { n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = n_sht = n_srk = n_sbt = 0; }
     NLZM_HD void counts_flush()
     {
         Counters &c = W::lds()->cnt;
         W::cnt_add(&c.positions, n_pos); W::cnt_add(&c.nice_positions, n_nice); W::cnt_add(&c.uncertain_positions, n_unc);
         W::cnt_add(&c.ht_rows, 3ull * n_ht); W::cnt_add(&c.rk_probes, n_rkp); W::cnt_add(&c.rk_inserts, n_rki);
         W::cnt_add(&c.cmp_bytes, n_cmp);
+        W::cnt_add(&c.stale_ht, n_sht); W::cnt_add(&c.stale_rk, n_srk); W::cnt_add(&c.bt_slow, n_sbt);
         counts_zero();
     }
     uint32_t rk_from, rk_to, rk_len, rk_end;
@@ -835,6 +837,7 @@ struct Master {
                 row[1] = W::rec_get(rec, 2);                        // HT3 row 0 moves down one row
             } else {
                 // an earlier position rewrote a row this slot had read: read them again, compare now
+                n_sht++;
                 W::sync_global();
                 row[0] = W::uni(G.ht2[i2]); row[1] = W::uni(G.ht3[i3]); row[2] = W::uni(G.ht3[i3 + 1]);
                 uint32_t job_sp[8], job_cap[8], job_len[8];
@@ -891,7 +894,7 @@ struct Master {
                             const uint32_t l = W::rec_get(rec, 16 + 2 * k) & 0x1FFu;
                             mt_update(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
                         }
-                    } else bt_consume(a, max_len);
+                    } else { n_sbt++; bt_consume(a, max_len); }
                 } else bt_step(a, h4, max_len);
             }
             prof_mark(5);
@@ -921,6 +924,7 @@ struct Master {
                 bool ok, exact = true;
                 if (fresh) { rkv = W::rec_get(rec, 12); ok = (pflags & 8u) != 0; l = W::rec_get(rec, 13); exact = !(pflags & 16u); }
                 else {
+                    n_srk++;
                     W::sync_global();
                     rkv = W::uni(G.rk_table[myslot]);
                     const uint32_t sp = rkv & g.wmask;

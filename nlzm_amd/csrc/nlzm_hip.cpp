@@ -371,6 +371,8 @@ int refresh_stats()
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
         fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f\n",
                 P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n);
+        fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
+                1e3 * P.cnt.stale_ht / n, 1e3 * P.cnt.stale_rk / n, 1e3 * P.cnt.bt_slow / n);
     }
     if (getenv("NLZM_PROFILE_PRINT")) {
         fprintf(stderr, "waits: B on A %.1f cyc/pos, A on B (nice phase, ring space excluded) %.1f cyc/pos\n",

@@ -374,6 +374,8 @@ int main(int argc, char **argv)
     uint64_t out_n = 0; nlzm_oracle_stats st;
     int rc = nlzm_oracle_compress(in.data(), (uint64_t)n, hb, out.data(), out.size(), &out_n, &st, &hk);
     if (rc) { printf("oracle failed %d\n", rc); return 1; }
+    printf("direct-path slots per 1000 positions: HT %.1f RK %.1f BT %.1f\n", 1e3 * P.cnt.stale_ht / (double)(n ? n : 1),
+           1e3 * P.cnt.stale_rk / (double)(n ? n : 1), 1e3 * P.cnt.bt_slow / (double)(n ? n : 1));
     printf("%s: %s  (chunks %u, positions sim %llu oracle %llu, bt_tests sim %llu oracle %llu, cmp_bytes sim %llu oracle %llu)\n",
            argv[1], c.bad ? "MISMATCH" : "OK", g.nchunks, P.cnt.positions, (unsigned long long)st.positions, P.cnt.bt_tests,
            (unsigned long long)st.bt_tests, P.cnt.cmp_bytes, (unsigned long long)st.cmp_bytes);

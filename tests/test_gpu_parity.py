@@ -100,6 +100,21 @@ def test_parse_emit_stage(gpu):
         assert ops == oops and np.array_equal(syms, osyms) and np.array_equal(bits, obits)
 
 
+def test_large_window_properties(gpu):
+    """BASELINE window (-window:28 -> 25 after auto-shrink for this size, 2^17 BT4 heads, 2^21 RK slots, frame_bits 17):
+    size-independent properties on an input the CPU suite does not reach -- decode(encode(x)) == x through the
+    host decoder of the CLI, frame structure, and the stream equal to the oracle's."""
+    from nlzm_amd import shard
+    data = corpus.syn_text(20_000_000, corpus.SEED + 77)
+    got = gpu.compress(data, 28)
+    assert got[:4] == bytes([0, 25, 0, 17])
+    assert len(shard.split_streams(got)) == 1
+    assert oracle_py.decompress(got) == data.tobytes()
+    st = gpu.stats()
+    assert st["positions"] == data.size and st["frames"] == -(-data.size // 122368)
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(oracle_py.compress(data, 28)).hexdigest()
+
+
 def test_blocks_of_a_sharded_run(gpu):
     """k-way split: each block is an independent stream identical to the oracle's."""
     from nlzm_amd import shard
