@@ -97,7 +97,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[24];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
+    unsigned long long prof[32];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -146,8 +146,8 @@ struct Globals {
     uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
     const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
     const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
-    const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by head, ascending
-    uint32_t nheads;
+    const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by bin, ascending
+    uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     WorkerCounters *wcnt;
     void *hook_user;            // host simulation only
@@ -190,14 +190,15 @@ struct MasterLds {
     uint32_t x_apos;                        // T: positions < x_apos are published
     uint32_t x_bpos;                        // B: positions < x_bpos are parsed (their slots are free again)
     uint32_t x_bseg;                        // B: start of the segment that contains x_bpos
+    uint32_t x_bcover;                      // B: positions < x_bcover are known to lie inside the segment that starts at x_bseg
     uint32_t x_long_free;                   // B: long slots given back (monotonic)
     uint32_t x_err;                         // either: error code, both waves leave their loops
     uint32_t x_adone;                       // A, T: finished the launch (count)
-    // parser -> sampler wave: relax the sampled-length edges of one node (request), and back (result)
-    uint32_t sq_req[12];                    // a, p, cost_p, rep set (4), max_len, end_p, hand-off header
-    uint32_t sq_res[2];                     // checked rep mask, end_p
-    uint32_t x_spos;                        // parser: request for position x_spos - 1 is posted (0xFFFFFFFF: leave)
-    uint32_t x_sdone;                       // sampler: request for position x_sdone - 1 is done
+    // parser -> edge wave: relax the match and rep edges that leave one node (request, slot a & 1), and back
+    uint32_t sq_req[2 * 16];                // a, p, cost_p, rep set (4), max_len, -, hand-off header, q, rep cap
+    uint32_t sq_res[2];                     // per slot: end_p after the node's edges
+    uint32_t x_spos;                        // parser: requests for positions < x_spos are posted (0xFFFFFFFF: leave)
+    uint32_t x_sdone;                       // edge wave: requests for positions < x_sdone are done
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -816,7 +817,9 @@ struct Master {
         bool call = true;
         if (nice) {
             if (!prev_nice) {
-                if (!wait_ge(&W::lds()->x_bpos, a)) return;
+                // which segment is `a` in: known once the parser has seen an edge that reaches beyond a (the table of
+                // a-1 does), or has ended a segment exactly at a
+                if (W::xw_load(&W::lds()->x_bcover) <= a && !wait_ge(&W::lds()->x_bpos, a, &W::lds()->x_bcover, a + 1)) return;
                 seg_s = W::xw_load(&W::lds()->x_bseg);
             } else if (a == seg_cut) seg_s = a;
             seg_cut = seg_s + umin(kParseMax, pos_end_abs - seg_s);
@@ -1022,19 +1025,15 @@ struct Master {
 
     // ---- cross-wave waits (both waves of the master share the CU's LDS; DS operations of a wave
     // execute in order, so a reader that sees a counter also sees what was written before it) -------
-    NLZM_HD bool wait_ge(const uint32_t *w, uint32_t v)             // until *w >= v
+    NLZM_HD bool wait_ge(const uint32_t *w, uint32_t v, const uint32_t *w2 = nullptr, uint32_t v2 = 0)   // until *w >= v (or *w2 >= v2)
     {
         if (W::xw_load(w) >= v) return true;
         const unsigned long long t0 = W::clock();
-#if defined(NLZM_PROFILE) || defined(NLZM_WAITPROF)
         const unsigned long long c0 = W::tick();
-#endif
         uint32_t spins = 0;
         for (;;) {
-            if (W::xw_load(w) >= v) {
-#if defined(NLZM_PROFILE) || defined(NLZM_WAITPROF)
+            if (W::xw_load(w) >= v || (w2 && W::xw_load(w2) >= v2)) {
                 wait_cyc += W::tick() - c0;
-#endif
                 return true;
             }
             if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
@@ -1208,27 +1207,27 @@ struct Master {
     // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2, one lane per length.
     // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
     // one compare-and-store; the targets of different lanes are distinct nodes.
-    NLZM_HD uint32_t sampled_relax(uint32_t p, uint32_t cost_p, const uint32_t rp[4], const uint32_t *e, uint32_t hdr,
-                                   uint32_t max_len)
+    NLZM_HD uint32_t sampled_relax(uint32_t p, uint32_t cost_p, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
+                                   const uint32_t *e, uint32_t hdr, uint32_t max_len)
     {
         uint32_t checked = 0;
         uint32_t step = (max_len - kMatchMin) >> 4;
         step += step == 0;
-        const uint32_t K = (max_len - kMatchMin) / step + 1;
         const uint32_t pc_dict = W::uni(price(kCtxCmd, 1)), pc_rep = W::uni(price(kCtxCmd, 2));
         uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
-        for (uint32_t k = W::lane(); k < K; k += W::width()) {
+        // lane k takes tl = max_len - k*step while tl >= kMatchMin: at most 17 lengths (k*step <= max_len - kMatchMin)
+        auto edge = [&](uint32_t k) {
             const uint32_t tl = max_len - k * step;
             const uint32_t d = tab(e, hdr, tl);
             const uint32_t mm = match_min(d);
-            if (tl < mm) continue;
+            if (tl < mm) return;
             const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
             uint32_t nx, ex;
             const uint32_t slot = dist_slot(d - 1, nx, ex);
             const uint32_t plen = W::lds()->seg_len_price[lv];
             const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + slot];
             uint32_t best = W::lds()->node_cost[np], sel = 0;
-            const uint32_t ri = rp[0] == d ? 0u : (rp[1] == d ? 1u : (rp[2] == d ? 2u : (rp[3] == d ? 3u : 4u)));
+            const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
             const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
             if (ca < best) { best = ca; sel = 1; }
             if (ri < 4 && cb < best) { best = cb; sel = 2; }
@@ -1237,12 +1236,16 @@ struct Master {
                 W::lds()->node_delta[np] = sel == 1 ? d : ri;
                 W::lds()->node_link[np] = pack_link(p, tl, sel);
                 uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
-                const bool has = ri < 4;
-                dst[0] = has ? rp[0] : d; dst[1] = has ? rp[1] : rp[0]; dst[2] = has ? rp[2] : rp[1]; dst[3] = has ? rp[3] : rp[2];
+                // selects on scalars (an array indexed by `has` would live in scratch memory)
+                uint32_t w0 = d, w1 = r0, w2 = r1, w3 = r2;
+                if (ri < 4) { w0 = r0; w1 = r1; w2 = r2; w3 = r3; }
+                dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
             }
             myri = ri;
             if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
-        }
+        };
+        if (W::width() == 1) { for (uint32_t k = 0; k * step <= max_len - kMatchMin; k++) edge(k); }
+        else if (W::lane() * step <= max_len - kMatchMin) edge(W::lane());
         if (W::width() != 1) {
             const uint32_t m = myri;
             checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
@@ -1252,35 +1255,95 @@ struct Master {
         return checked;
     }
 
-    // =========================== wave S: sampled-length edges ==============================
-    NLZM_HD void run_sampler()
+    // =========================== wave S: the edges that leave a node ========================
+    // The parser wave finalises node p (its cost and rep set are complete once the literal edge of p-1 and the
+    // match edges of every node <= p-2 have been relaxed) and posts it; this wave relaxes its sampled-length
+    // edges (:1558-1596) and then its explicit rep probes (:1598-1628), all of which end at nodes >= p+2.
+    // The parser meanwhile relaxes the literal edge of p (after the edges of p-1 are in: the reference's order
+    // at node p+1) and finalises node p+1, so the two waves work on neighbouring nodes at the same time.
+    NLZM_HD void run_sampler(uint32_t a_first)
     {
-        err = 0; err_info0 = 0; wait_cyc = 0;
-        uint32_t last = 0;
+        err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 16; k++) prof[k] = 0;
+#endif
+        uint32_t next = a_first, end_p = 1;
+        typename W::RepPf rpf_next{};
+        bool have_pf = false;
         for (;;) {
-            // next request (or the order to leave)
-            uint32_t v;
-            {
-                const unsigned long long t0 = W::clock();
+            if (W::xw_load(&W::lds()->x_spos) <= next) {
+                const unsigned long long t0 = W::clock(), c0 = W::tick();
                 uint32_t spins = 0;
-                while ((v = W::xw_load(&W::lds()->x_spos)) == last) {
+                while (W::xw_load(&W::lds()->x_spos) <= next) {
                     if (W::xw_load(&W::lds()->x_err)) return;
                     if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return;
                     W::xw_pause();
                 }
+                wait_cyc += W::tick() - c0;
             }
-            if (v == kNone) return;
-            last = v;
-            const typename W::Rec q = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[i < 12 ? i : 0]; });
-            const uint32_t a = W::rec_get(q, 0), p = W::rec_get(q, 1), cost_p = W::rec_get(q, 2);
-            const uint32_t rp[4] = { W::rec_get(q, 3), W::rec_get(q, 4), W::rec_get(q, 5), W::rec_get(q, 6) };
-            const uint32_t max_len = W::rec_get(q, 7), hdr = W::rec_get(q, 9);
-            uint32_t end_p = W::rec_get(q, 8);
-            open_nodes(end_p, max_len + p);                         // :1550-1554
-            const uint32_t checked = sampled_relax(p, cost_p, rp, W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len);
-            W::lds()->sq_res[0] = checked; W::lds()->sq_res[1] = end_p;
+            if (W::xw_load(&W::lds()->x_spos) == kNone) {
+                if (W::lane() == 0) {
+                    G.persist->prof[22] += wait_cyc; G.persist->prof[23] += W::tick() - role_t0;
+#ifdef NLZM_PROFILE
+                    for (int k = 0; k < 6; k++) G.persist->prof[24 + k] += prof[k];
+#endif
+                }
+                return;
+            }
+            prof_start();
+            const uint32_t slot = next & 1u;
+            const typename W::Rec rq = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[slot * 16 + (i & 15u)]; });
+            const uint32_t a = W::rec_get(rq, 0), p = W::rec_get(rq, 1), cost_p = W::rec_get(rq, 2);
+            const uint32_t rp[4] = { W::rec_get(rq, 3), W::rec_get(rq, 4), W::rec_get(rq, 5), W::rec_get(rq, 6) };
+            const uint32_t max_len = W::rec_get(rq, 7), hdr = W::rec_get(rq, 9), q = W::rec_get(rq, 10), rep_cap = W::rec_get(rq, 11);
+            // the bytes the rep probes compare (kRepPf in front of each rep distance and at the position) were
+            // requested from HBM while the previous node was worked on, if this node had been posted by then
+            const typename W::RepPf rpf = have_pf ? rpf_next : W::rep_prefetch(G.in, g.n, a, rp[0], rp[1], rp[2], rp[3]);
+            have_pf = false;
+            if (p == 0) end_p = 1;
+            prof_mark(0);
+            uint32_t checked = 0;
+            if (max_len) {
+                open_nodes(end_p, max_len + p);                     // :1550-1554
+                checked = sampled_relax(p, cost_p, rp[0], rp[1], rp[2], rp[3], W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len);
+            }
+            prof_mark(1);
+            uint32_t rep_len[4];
+            W::rep_lengths(rpf, rep_len);
+            prof_mark(2);
+            auto look_ahead = [&]() {
+                const uint32_t v = W::xw_load(&W::lds()->x_spos);
+                if (have_pf || v == kNone || v <= next + 1) return;
+                const uint32_t s2 = (next + 1) & 1u;
+                const typename W::Rec r2 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[s2 * 16 + (i & 7u)]; });
+                rpf_next = W::rep_prefetch(G.in, g.n, W::rec_get(r2, 0), W::rec_get(r2, 3), W::rec_get(r2, 4), W::rec_get(r2, 5), W::rec_get(r2, 6));
+                have_pf = true;
+            };
+            look_ahead();
+            prof_mark(3);
+            if (checked != 15) {
+                // written out per rep index: the arrays stay in scalar registers (a loop would index them in scratch)
+                auto probe = [&](uint32_t ri, uint32_t d, uint32_t l) {
+                    if ((checked >> ri) & 1 || d >= q) return;
+                    if (l >= rep_cap) l = rep_cap;
+                    else if (l == kRepPf) l = wave_cmp<false>(G.in + a - d, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + 1);
+                    if (l >= match_min(d)) {
+                        open_nodes(end_p, l + p);
+                        W::sync();
+                        relax(p, p + l, cost_p, W::uni(price_rep(d, l)), 2, l, ri, rp, d);   // wave-uniform
+                        W::sync();
+                    }
+                };
+                probe(0, rp[0], rep_len[0]); probe(1, rp[1], rep_len[1]); probe(2, rp[2], rep_len[2]); probe(3, rp[3], rep_len[3]);
+            }
+            prof_mark(4);
+            look_ahead();
+            W::lds()->sq_res[slot] = end_p;
             W::sync();
-            W::xw_store(&W::lds()->x_sdone, a + 1);
+            next++;
+            W::xw_store(&W::lds()->x_sdone, next);
+            prof_mark(5);
         }
     }
 
@@ -1299,26 +1362,35 @@ struct Master {
         W::lds()->node_cost[1] = kNone; W::lds()->node_link[1] = pack_link(0, 0, 0);
         for (int k = 0; k < 4; k++) { W::lds()->reps[k] = rep[k]; W::lds()->reps[4 + k] = rep[k]; }
         uint32_t p = 0, end_p = 1;
-        // Node p (cost, rep set) and the cost of node p+1 are read with one LDS instruction at the END of the
-        // previous iteration; right behind it the bytes the explicit rep probes of node p will compare
-        // (kRepPf bytes in front of each of its 4 rep distances, and at the position) are requested from HBM,
-        // so that their latency is covered by the rest of the loop.
+        uint32_t settled = 0, pend_long = 0;            // nodes whose edges are in / long hand-off slots they still hold
+        // edges of every node < upto are relaxed: take over end_p, give the hand-off slots back
+        auto settle = [&](uint32_t upto, bool publish) -> bool {
+            if (settled >= upto) return true;
+            if (!wait_ge(&W::lds()->x_sdone, seg_a + upto)) return false;
+            const uint32_t se = W::xw_load(&W::lds()->sq_res[(seg_a + upto - 1) & 1u]);
+            if (se > end_p) { end_p = se; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
+            settled = upto;
+            if (pend_long) { b_long += pend_long; pend_long = 0; W::xw_store(&W::lds()->x_long_free, kErLong + b_long); }
+            if (publish) W::xw_store(&W::lds()->x_bpos, seg_a + upto);
+            return true;
+        };
+        // node p: cost and rep set with one LDS instruction
         auto node_read = [&](uint32_t pp) {
             return W::rec_load_fn([=](uint32_t i) {
-                return i == 0 ? W::lds()->node_cost[pp] : (i < 5 ? W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)] : W::lds()->node_cost[pp + 1]);
+                return i == 0 ? W::lds()->node_cost[pp] : W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)];
             });
         };
         W::sync();
+        W::xw_store(&W::lds()->x_bcover, seg_a + 1);
         typename W::Rec nrec = node_read(0);
-        typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, seg_a, W::rec_get(nrec, 1), W::rec_get(nrec, 2), W::rec_get(nrec, 3), W::rec_get(nrec, 4));
-        while (p < end_p) {
+        for (;;) {                                                  // p < end_p
             const uint32_t q = seg_q + p, a = seg_a + p;
             n_pos++;
             const uint32_t cost_p = W::rec_get(nrec, 0);
             uint32_t rp[4];
             for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
 
-            // the finder wave's result for this position
+            // the table wave's result for this position
             if (!wait_ge(&W::lds()->x_apos, a + 1)) break;
             const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
             const typename W::Rec hrec = W::rec_load(e);
@@ -1326,72 +1398,47 @@ struct Master {
 
             uint32_t max_len = umin(tmax, max_parse - p);           // :1545-1548
             if (max_len < kMatchMin) max_len = 0;
-            if (max_len) {
-                seg_tables();
-                uint32_t *r = W::lds()->sq_req;
+            if (max_len) seg_tables();
+            {   // node p is final: its match and rep edges go to the edge wave (slot a & 1 is free: node p-2 is settled)
+                uint32_t *r = W::lds()->sq_req + (a & 1u) * 16;
                 r[0] = a; r[1] = p; r[2] = cost_p; r[3] = rp[0]; r[4] = rp[1]; r[5] = rp[2]; r[6] = rp[3];
-                r[7] = max_len; r[8] = end_p; r[9] = hdr;
+                r[7] = max_len; r[9] = hdr; r[10] = q; r[11] = umin(max_parse - p, kMatchMax);
                 W::sync();
                 W::xw_store(&W::lds()->x_spos, a + 1);
             }
+            if (max_len && p + max_len > end_p) { end_p = p + max_len; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
+            const uint32_t pend_long_next = (hdr >> 16) ? 1u : 0u;
+            prof_mark(7);
+            // node p+1 takes the edges of p-1 before the literal edge of p (the reference's order, strict '<')
+            if (!settle(p, true)) break;
+            pend_long += pend_long_next;
+            prof_mark(8);
             // literal edge (:1490-1499)
             {
                 const uint32_t lit = W::rec_get(hrec, 1);
                 const uint32_t cst = price_literal(lit);
-                if (W::rec_get(nrec, 5) > cost_p + cst) {
+                if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst) {
                     W::lds()->node_cost[p + 1] = cost_p + cst;
                     W::lds()->node_delta[p + 1] = lit;              // the byte itself, for the emitter
                     W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
                     for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
                 }
             }
-            prof_mark(7);
-            // explicit rep probe lengths (:1605-1606) from the bytes requested one iteration ago
-            uint32_t rep_len[4];
-            {
-                const uint32_t rep_cap = umin(max_parse - p, kMatchMax);
-                W::rep_lengths(rpf, rep_len);
-                for (int k = 0; k < 4; k++) {
-                    if (!(rp[k] < q)) { rep_len[k] = 0; continue; }
-                    if (rep_len[k] >= rep_cap) rep_len[k] = rep_cap;
-                    else if (rep_len[k] == kRepPf) rep_len[k] = wave_cmp<false>(G.in + a - rp[k], G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
-                }
-            }
-            prof_mark(3);
-
-            // sampled lengths (:1558-1596): relaxed by the sampler wave while this wave did the literal edge and
-            // the rep-probe lengths; the explicit rep probes (:1598) come after them in the reference's order
-            uint32_t checked = 0;
-            if (max_len) {
-                if (!wait_ge(&W::lds()->x_sdone, a + 1)) break;
-                checked = W::xw_load(&W::lds()->sq_res[0]);
-                end_p = W::xw_load(&W::lds()->sq_res[1]);
-            }
-            prof_mark(8);
-            // explicit rep probes (:1598-1628)
-            if (checked != 15) {
-                for (uint32_t ri = 0; ri < 4; ri++) {
-                    if ((checked >> ri) & 1 || rp[ri] >= q) continue;
-                    const uint32_t l = rep_len[ri];                 // already min(len, 264)
-                    n_cmp += l + 1;
-                    if (l >= match_min(rp[ri])) {
-                        open_nodes(end_p, l + p);
-                        W::sync();
-                        relax(p, p + l, cost_p, W::uni(price_rep(rp[ri], l)), 2, l, ri, rp, rp[ri]);   // wave-uniform
-                        W::sync();
-                    }
-                }
-            }
-            prof_mark(9);
             ++p;
             W::sync();
-            // hand the slot back; a segment that ends here is announced BEFORE the position count
-            if (hdr >> 16) W::xw_store(&W::lds()->x_long_free, kErLong + (++b_long));
-            if (p == end_p) W::xw_store(&W::lds()->x_bseg, seg_a + p);
-            W::xw_store(&W::lds()->x_bpos, seg_a + p);
-            nrec = node_read(p);                                    // p <= end_p <= 4096: node p+1 is inside the arrays
-            rpf = W::rep_prefetch(G.in, g.n, seg_a + p, W::rec_get(nrec, 1), W::rec_get(nrec, 2), W::rec_get(nrec, 3), W::rec_get(nrec, 4));
+            if (p >= end_p) {
+                // only a rep probe of the node just posted can still extend the segment
+                if (!settle(p, false)) break;
+                if (p >= end_p) break;
+                W::xw_store(&W::lds()->x_bpos, seg_a + p);
+            }
+            nrec = node_read(p);                                    // p < end_p <= 4096
+            prof_mark(9);
         }
+        if (!err) settle(p, false);
+        // a segment that ends here is announced BEFORE the position count
+        W::xw_store(&W::lds()->x_bseg, seg_a + p);
+        W::xw_store(&W::lds()->x_bpos, seg_a + p);
         // backtrack (:1633-1650): collect the node indices of the path, end first
         uint32_t n = 0, cur = p;
         while (cur != 0 && !err) {
@@ -1521,9 +1568,9 @@ struct Master {
     {
         for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;
         if (W::lane() == 0) {
-            W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0;
+            W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0; W::lds()->x_bcover = a0 + 1;
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
-            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = 0; W::lds()->x_sdone = 0;
+            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = a0; W::lds()->x_sdone = a0;
         }
         (void)G;
     }

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long lon
 //   cur: [nchunks][nheads]   scratch cursors
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ in, Geom g, uint32_t c0,
-                                                   uint32_t nheads, uint32_t *__restrict__ off_all,
+                                                   uint32_t nheads /* = bins */, uint32_t *__restrict__ off_all,
                                                    uint32_t *__restrict__ cur_all, uint32_t *__restrict__ pos_all)
 {
     const uint32_t ci = c0 + blockIdx.x;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     __shared__ uint32_t part[1024];
     __shared__ uint32_t heads_t[1024];
 
-    for (uint32_t p = threadIdx.x; p < n_ok; p += 1024) atomicAdd(&off[hash4(load32u(base + p)) >> g.bt_shift], 1u);
+    for (uint32_t p = threadIdx.x; p < n_ok; p += 1024) atomicAdd(&off[(hash4(load32u(base + p)) >> g.bt_shift) % nheads], 1u);
     __syncthreads();
     // exclusive scan over nheads counters: each thread owns a contiguous slice
     const uint32_t per = (nheads + 1023) / 1024;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     for (uint32_t t0 = 0; t0 < n_ok; t0 += 1024) {
         const uint32_t p = t0 + threadIdx.x;
         const bool ok = p < n_ok;
-        const uint32_t h = ok ? hash4(load32u(base + p)) >> g.bt_shift : kNone;
+        const uint32_t h = ok ? (hash4(load32u(base + p)) >> g.bt_shift) % nheads : kNone;
         heads_t[threadIdx.x] = h;
         __syncthreads();
         uint32_t at = 0, after = 1;
@@ -380,14 +380,12 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
 {
     const uint32_t nl = (gridDim.x - 1) * blockDim.x;
     const uint32_t gl = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
-    // a lane owns heads gl and gl + nl and walks their positions in ascending order:
-    // the position it may block on is then always its smallest unprocessed one
-    const uint32_t h0 = gl, h1 = gl + nl;
-    const bool has0 = h0 < G.nheads, has1 = h1 < G.nheads;
-    bool active = has0 || has1;
+    // Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it,
+    // so the position a lane may block on is always its smallest unprocessed one.
+    bool active = gl < G.nheads;
     uint32_t c = c0;
     bool loaded = false;
-    uint32_t i0 = 0, e0 = 0, i1 = 0, e1 = 0;
+    uint32_t i0 = 0, e0 = 0;
     uint32_t la_end = 0;            // absolute end of the chunk's lookahead
     uint32_t stage = 0, a = 0, max_len = 0;
     unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dummy_t = 0, dummy_c = 0;
@@ -403,8 +401,7 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
                     if (c >= c1) active = false;
                     else {
                         const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
-                        if (has0) { i0 = off[h0]; e0 = off[h0 + 1]; } else { i0 = e0 = 0; }
-                        if (has1) { i1 = off[h1]; e1 = off[h1 + 1]; } else { i1 = e1 = 0; }
+                        i0 = off[gl]; e0 = off[gl + 1];
                         const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
                         const unsigned long long remain = g.n - chunk_abs;
                         la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
@@ -413,10 +410,9 @@ __device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32
                 }
                 if (active) {
                     const uint32_t *pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size;
-                    const uint32_t pa = i0 < e0 ? pos[i0] : kNone, pb = i1 < e1 ? pos[i1] : kNone;
-                    if (pa == kNone && pb == kNone) { c++; loaded = false; }
+                    if (i0 >= e0) { c++; loaded = false; }
                     else {
-                        if (pa < pb) { a = pa; i0++; } else { a = pb; i1++; }
+                        a = pos[i0++];
                         max_len = umin(la_end - a, kMatchMax);
                         if (G.unc[a - G.batch_a0]) {
                             // whether this call happens is decided by the master; its MATCHES do not depend
@@ -479,12 +475,14 @@ __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32
         if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         __syncthreads();
         if (threadIdx.x >= 256) return;
+        if ((threadIdx.x & 63u) == 0)       // diagnostics: which SIMD each role's wave landed on (HW_ID bits 5:4)
+            atomicOr(&G.persist->prof[30], (unsigned long long)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFFu) << (16 * (threadIdx.x >> 6)));
         Master<DevWave> m;
         m.g = g; m.G = G;
         if (threadIdx.x < 64) m.run_finder(c0, c1);
         else if (threadIdx.x < 128) m.run_table(c0, c1);
         else if (threadIdx.x < 192) m.run_parser(c0, c1);
-        else m.run_sampler();
+        else m.run_sampler((uint32_t)((unsigned long long)c0 * g.chunk_size));
     } else {
         worker_role(g, G, c0, c1);
     }

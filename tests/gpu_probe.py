@@ -12,6 +12,8 @@ modes = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]
 kind = sys.argv[4] if len(sys.argv) > 4 else "syn_text"
 check = size <= 20_000_000 and "NLZM_LIB" not in os.environ
 nlzm_amd.init(0)
+if os.environ.get("NLZM_WB"):
+    nlzm_amd.set_option("worker_blocks", int(os.environ["NLZM_WB"]))
 data = corpus.make(kind, size)
 want = oracle_py.compress(data, hb) if check else None
 for w in modes:

@@ -350,7 +350,7 @@ int main(int argc, char **argv)
         // the two master waves as two threads
         Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         Master<HostWave> mb = m, mt = m, ms = m;
-        std::thread ts([&] { ms.run_sampler(); });
+        std::thread ts([&] { ms.run_sampler((uint32_t)((unsigned long long)c0 * g.chunk_size)); });
         std::thread tb([&] { mb.run_parser(c0, c1); });
         std::thread tt([&] { mt.run_table(c0, c1); });
         m.run_finder(c0, c1);
