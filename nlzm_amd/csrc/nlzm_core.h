@@ -347,6 +347,9 @@ NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_
 // The master: walks positions in order, owns HT2/HT3/RK256 state, the match
 // table chain, the parse, the model and the symbol output.
 // ---------------------------------------------------------------------------
+#ifdef NLZM_SIM_COUNT
+static unsigned long long g_dbg[8];
+#endif
 template <class W>
 struct Master {
     Geom g;
@@ -424,10 +427,10 @@ struct Master {
                     }
                 }
             }
-            const uint32_t first = W::uni(W::rmin(m));
-            if (first != kNone) {
-                lt = W::uni(W::ror((m == first) ? mylt : 0u));
-                res = first; hit = true;
+            const unsigned long long bal = W::mask64([=](uint32_t) { return m != kNone; });
+            if (bal) {                                  // lanes look at ascending offsets: the lowest lane wins
+                const uint32_t fl = (uint32_t)__builtin_ctzll(bal);
+                res = W::pick(m, fl); lt = W::pick(mylt, fl); hit = true;
                 break;
             }
             off += W::width() * 8;
@@ -655,16 +658,15 @@ struct Master {
 
     // relax edge p -> np by one lane (or uniformly by all lanes with equal arguments)
     NLZM_HD void relax(uint32_t p, uint32_t np, uint32_t cost_p, uint32_t cst, uint32_t cmd, uint32_t len,
-                       uint32_t store_delta, const uint32_t rp[4], uint32_t add_delta)
+                       uint32_t store_delta, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t add_delta)
     {
         if (W::lds()->node_cost[np] > cost_p + cst) {                      // strict: first candidate wins ties
             W::lds()->node_cost[np] = cost_p + cst;
             W::lds()->node_delta[np] = store_delta;
             W::lds()->node_link[np] = pack_link(p, len, cmd);
-            uint32_t r[4] = { rp[0], rp[1], rp[2], rp[3] };
-            rep_add(r, add_delta);
+            const bool has = r0 == add_delta || r1 == add_delta || r2 == add_delta || r3 == add_delta;   // RepModel::Add (:1160-1171)
             uint32_t *dst = W::lds()->reps + (np & 511) * 4;
-            dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2]; dst[3] = r[3];
+            dst[0] = has ? r0 : add_delta; dst[1] = has ? r1 : r0; dst[2] = has ? r2 : r1; dst[3] = has ? r3 : r2;
         }
     }
 
@@ -1208,12 +1210,11 @@ struct Master {
     // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
     // one compare-and-store; the targets of different lanes are distinct nodes.
     NLZM_HD uint32_t sampled_relax(uint32_t p, uint32_t cost_p, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
-                                   const uint32_t *e, uint32_t hdr, uint32_t max_len)
+                                   const uint32_t *e, uint32_t hdr, uint32_t max_len, uint32_t pc_dict, uint32_t pc_rep)
     {
         uint32_t checked = 0;
         uint32_t step = (max_len - kMatchMin) >> 4;
         step += step == 0;
-        const uint32_t pc_dict = W::uni(price(kCtxCmd, 1)), pc_rep = W::uni(price(kCtxCmd, 2));
         uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
         // lane k takes tl = max_len - k*step while tl >= kMatchMin: at most 17 lengths (k*step <= max_len - kMatchMin)
         auto edge = [&](uint32_t k) {
@@ -1270,18 +1271,33 @@ struct Master {
         uint32_t next = a_first, end_p = 1;
         typename W::RepPf rpf_next{};
         bool have_pf = false;
+        uint32_t pf_a = 0, pf_r0 = 0, pf_r1 = 0, pf_r2 = 0, pf_r3 = 0;      // what rpf_next was requested for
         for (;;) {
-            if (W::xw_load(&W::lds()->x_spos) <= next) {
+            // post count, error word, the two command prices and the request slot with ONE LDS read; the count sits in
+            // the lowest lane (a host emulation reads the lanes in ascending order: count before data)
+            const uint32_t slot = next & 1u;
+            auto fetch = [=]() {
+                return W::rec_load_fn32([=](uint32_t i) {
+                    return i == 0 ? W::lds()->x_spos : (i == 1 ? W::lds()->x_err : (i < 4 ? ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)]
+                                                                                      : W::lds()->sq_req[slot * 16 + ((i - 4) & 15u)]));
+                });
+            };
+            typename W::Rec rq = fetch();
+            // (posted: the count has passed this position; the slot then holds it -- word 0 -- and not the node two back)
+            if (W::rec_get(rq, 0) <= next || W::rec_get(rq, 4) != next) {
                 const unsigned long long t0 = W::clock(), c0 = W::tick();
                 uint32_t spins = 0;
-                while (W::xw_load(&W::lds()->x_spos) <= next) {
-                    if (W::xw_load(&W::lds()->x_err)) return;
+                for (;;) {
+                    rq = fetch();
+                    if (W::rec_get(rq, 0) > next && (W::rec_get(rq, 4) == next || W::rec_get(rq, 0) == kNone)) break;
+                    if (W::rec_get(rq, 1)) return;
                     if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return;
                     W::xw_pause();
                 }
+                rq = fetch();                           // count and slot came with the same read: take the slot again
                 wait_cyc += W::tick() - c0;
             }
-            if (W::xw_load(&W::lds()->x_spos) == kNone) {
+            if (W::rec_get(rq, 0) == kNone) {
                 if (W::lane() == 0) {
                     G.persist->prof[22] += wait_cyc; G.persist->prof[23] += W::tick() - role_t0;
 #ifdef NLZM_PROFILE
@@ -1291,51 +1307,65 @@ struct Master {
                 return;
             }
             prof_start();
-            const uint32_t slot = next & 1u;
-            const typename W::Rec rq = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[slot * 16 + (i & 15u)]; });
-            const uint32_t a = W::rec_get(rq, 0), p = W::rec_get(rq, 1), cost_p = W::rec_get(rq, 2);
-            const uint32_t rp[4] = { W::rec_get(rq, 3), W::rec_get(rq, 4), W::rec_get(rq, 5), W::rec_get(rq, 6) };
-            const uint32_t max_len = W::rec_get(rq, 7), hdr = W::rec_get(rq, 9), q = W::rec_get(rq, 10), rep_cap = W::rec_get(rq, 11);
+            const uint32_t a = W::rec_get(rq, 4), p = W::rec_get(rq, 5), cost_p = W::rec_get(rq, 6);
+            const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
+            const uint32_t max_len = W::rec_get(rq, 11), hdr = W::rec_get(rq, 13), q = W::rec_get(rq, 14), rep_cap = W::rec_get(rq, 15);
+            const uint32_t pc_dict = W::rec_get(rq, 2) >> 16, pc_rep = W::rec_get(rq, 3) & 0xFFFFu;     // price(kCtxCmd, 1), (kCtxCmd, 2)
             // the bytes the rep probes compare (kRepPf in front of each rep distance and at the position) were
             // requested from HBM while the previous node was worked on, if this node had been posted by then
-            const typename W::RepPf rpf = have_pf ? rpf_next : W::rep_prefetch(G.in, g.n, a, rp[0], rp[1], rp[2], rp[3]);
+            const bool pf_ok = have_pf && pf_a == a && pf_r0 == rp0 && pf_r1 == rp1 && pf_r2 == rp2 && pf_r3 == rp3;
+            const typename W::RepPf rpf = pf_ok ? rpf_next : W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
             have_pf = false;
             if (p == 0) end_p = 1;
             prof_mark(0);
             uint32_t checked = 0;
             if (max_len) {
                 open_nodes(end_p, max_len + p);                     // :1550-1554
-                checked = sampled_relax(p, cost_p, rp[0], rp[1], rp[2], rp[3], W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len);
+                checked = sampled_relax(p, cost_p, rp0, rp1, rp2, rp3, W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len, pc_dict, pc_rep);
             }
             prof_mark(1);
             uint32_t rep_len[4];
             W::rep_lengths(rpf, rep_len);
             prof_mark(2);
             auto look_ahead = [&]() {
-                const uint32_t v = W::xw_load(&W::lds()->x_spos);
-                if (have_pf || v == kNone || v <= next + 1) return;
-                const uint32_t s2 = (next + 1) & 1u;
-                const typename W::Rec r2 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->sq_req[s2 * 16 + (i & 7u)]; });
-                rpf_next = W::rep_prefetch(G.in, g.n, W::rec_get(r2, 0), W::rec_get(r2, 3), W::rec_get(r2, 4), W::rec_get(r2, 5), W::rec_get(r2, 6));
+                if (have_pf) return;
+                const uint32_t s2 = slot ^ 1u;
+                const typename W::Rec r2 = W::rec_load_fn32([=](uint32_t i) { return i == 0 ? W::lds()->x_spos : W::lds()->sq_req[s2 * 16 + ((i - 1) & 7u)]; });
+                const uint32_t v = W::rec_get(r2, 0);
+                if (v == kNone || v <= next + 1 || W::rec_get(r2, 1) != next + 1) return;
+                pf_a = W::rec_get(r2, 1); pf_r0 = W::rec_get(r2, 4); pf_r1 = W::rec_get(r2, 5); pf_r2 = W::rec_get(r2, 6); pf_r3 = W::rec_get(r2, 7);
+                rpf_next = W::rep_prefetch(G.in, g.n, pf_a, pf_r0, pf_r1, pf_r2, pf_r3);
                 have_pf = true;
             };
             look_ahead();
             prof_mark(3);
             if (checked != 15) {
-                // written out per rep index: the arrays stay in scalar registers (a loop would index them in scratch)
-                auto probe = [&](uint32_t ri, uint32_t d, uint32_t l) {
-                    if ((checked >> ri) & 1 || d >= q) return;
-                    if (l >= rep_cap) l = rep_cap;
+                // explicit rep probes (:1598-1628): all four decided on the scalar unit; the usual case (no probe long
+                // enough to relax) costs one counter update
+                uint32_t l0 = rep_len[0], l1 = rep_len[1], l2 = rep_len[2], l3 = rep_len[3];
+                uint32_t rm = 0, csum = 0;
+                auto probe = [&](uint32_t k, uint32_t d, uint32_t &l) {
+                    if (((checked >> k) & 1u) || d >= q) return;
+                    if (l >= rep_cap) l = rep_cap;                  // min(len, 264)
                     else if (l == kRepPf) l = wave_cmp<false>(G.in + a - d, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
-                    W::cnt_add(&W::lds()->cnt.cmp_bytes, l + 1);
-                    if (l >= match_min(d)) {
-                        open_nodes(end_p, l + p);
-                        W::sync();
-                        relax(p, p + l, cost_p, W::uni(price_rep(d, l)), 2, l, ri, rp, d);   // wave-uniform
-                        W::sync();
-                    }
+                    csum += l + 1;
+                    if (l >= match_min(d)) rm |= 1u << k;
                 };
-                probe(0, rp[0], rep_len[0]); probe(1, rp[1], rep_len[1]); probe(2, rp[2], rep_len[2]); probe(3, rp[3], rep_len[3]);
+                probe(0, rp0, l0); probe(1, rp1, l1); probe(2, rp2, l2); probe(3, rp3, l3);
+                if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
+#ifdef NLZM_SIM_COUNT
+                g_dbg[1] += __builtin_popcount(rm); g_dbg[2]++;
+#endif
+                while (rm) {
+                    const uint32_t ri = (uint32_t)__builtin_ctz(rm);
+                    rm &= rm - 1;
+                    const uint32_t d = ri == 0 ? rp0 : (ri == 1 ? rp1 : (ri == 2 ? rp2 : rp3));
+                    const uint32_t l = ri == 0 ? l0 : (ri == 1 ? l1 : (ri == 2 ? l2 : l3));
+                    open_nodes(end_p, l + p);
+                    W::sync();
+                    relax(p, p + l, cost_p, W::uni(pc_rep + price_len(l - match_min(d)) + (2u << 5)), 2, l, ri, rp0, rp1, rp2, rp3, d);   // wave-uniform
+                    W::sync();
+                }
             }
             prof_mark(4);
             look_ahead();

@@ -30,6 +30,15 @@ struct DevWave {
     {
         if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // lane i < n adds f(i) (one exec-masked LDS atomic for all of them)
+    template <class F>
+    static __device__ __forceinline__ void cnt_add_fn(unsigned long long *p, uint32_t n, F f)
+    {
+        const uint32_t v = f(lane());
+        if (lane() < n && v) (void)__hip_atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // value of lane l (wave-uniform l)
+    static __device__ __forceinline__ uint32_t pick(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
     // per look-ahead slot state kept in the lane that evaluated the slot (slot j = lane j, kPf == 64)

@@ -36,6 +36,9 @@ static MasterLds *g_lds = nullptr;
 struct HostWave {
     static MasterLds *lds() { return g_lds; }
     static void cnt_add(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+    template <class F>
+    static void cnt_add_fn(unsigned long long *p, uint32_t n, F f) { for (uint32_t i = 0; i < n; i++) cnt_add(p, f(i)); }
+    static uint32_t pick(uint32_t v, uint32_t) { return v; }
     static void xw_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
     static uint32_t xw_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
     static void xw_add(uint32_t *p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
@@ -55,7 +58,12 @@ struct HostWave {
     template <class F>
     static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
     template <class F>
-    static Rec rec_load_fn32(F f) { Rec r; for (uint32_t i = 0; i < 32; i++) r.w[i] = f(i); return r; }
+    static Rec rec_load_fn32(F f)       // ascending lane order, one load at a time: a count in lane 0 is read before the data it covers
+    {
+        Rec r;
+        for (uint32_t i = 0; i < 32; i++) { r.w[i] = f(i); __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+        return r;
+    }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
     struct PfLane { uint32_t idx[64], rkslot[64], stale[64]; };
     static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot) { p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; }
@@ -358,6 +366,9 @@ int main(int argc, char **argv)
         tb.join();
         ts.join();
         if (use_workers) wk.finish();
+#ifdef NLZM_SIM_COUNT
+        fprintf(stderr, "dbg: long rep compares %llu (of %llu checks), relaxed rep probes %llu (of %llu nodes)\n", g_dbg[0], g_dbg[3], g_dbg[1], g_dbg[2]);
+#endif
         if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
     }
     if (use_workers) {
