@@ -175,7 +175,7 @@ struct MasterLds {
     //   4 number of HT updates | bytes compared << 8          5..10 HT updates: distance, length | open << 31
     //   11 RK hash   12 RK slot as read   13 RK candidate length   14 bt_ready as read   15..22 first 4 BT4 pairs
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
-    uint32_t pf_rec[32 * kPf];
+    uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
     // ---- hand-off between the three waves of the master (run_finder -> run_table -> run_parser) ----
     // Wave A (finders) keeps only the table's length and top entry in registers and sends what happens to
@@ -361,6 +361,7 @@ struct Master {
     bool top_open;                  // false: that entry is known not to extend (mismatch at its end)
     bool rk_open;                   // the carried RK match ran into its length cap
     uint32_t pf_base, pf_n;         // look-ahead window [pf_base, pf_base + pf_n)
+    uint32_t pf_buf, pf_mark0, pf_mark1;    // record buffer in use; command count when buffer 0 / 1 was last left
     typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
     uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
     bool seg_tab_dirty;             // parser wave: a length/distance context changed since the price tables were built
@@ -448,7 +449,7 @@ struct Master {
     // ---- table commands (finder wave) ---------------------------------------------
     // The finder wave needs only the table's length and its top entry (for the nice decision :1514 and
     // the extension :1503-1512); every change is forwarded to the table wave in program order.
-    static constexpr uint32_t kOpCarry = 1, kOpExt = 2, kOpUpd = 3, kOpEnd = 4;
+    static constexpr uint32_t kOpCarry = 1, kOpExt = 2, kOpUpd = 3, kOpEnd = 4, kOpRun = 5;
     NLZM_HD void cq_push(uint32_t op, uint32_t arg, uint32_t val)
     {
         if (cq_n - cq_seen >= kCq) {                    // queue full as far as we know: look again / wait
@@ -680,6 +681,23 @@ struct Master {
     NLZM_HD void pf_fill(uint32_t a_start, uint32_t pos_end_abs, uint32_t la_end_abs)
     {
         W::sync_global();                       // every table store so far has landed
+        // the other record buffer: the table wave must be done with the runs of the batch that used it
+        if (pf_buf) pf_mark1 = cq_n; else pf_mark0 = cq_n;
+        pf_buf ^= 1u;
+        {
+            const uint32_t need = pf_buf ? pf_mark1 : pf_mark0;
+            if ((int32_t)(W::xw_load(&W::lds()->x_tpos) - need) < 0) {
+                cq_flush();
+                const unsigned long long t0 = W::clock(), c0 = W::tick();
+                uint32_t spins = 0;
+                while ((int32_t)(W::xw_load(&W::lds()->x_tpos) - need) < 0) {
+                    if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
+                    if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, need); return; }
+                    W::xw_pause();
+                }
+                wait_cyc += W::tick() - c0;
+            }
+        }
         pf_base = a_start;
         pf_n = umin(kPf, pos_end_abs - a_start);
         for (uint32_t i = W::lane(); i < kPf + kWinTail; i += W::width())
@@ -687,8 +705,8 @@ struct Master {
         for (uint32_t j = W::lane(); j < pf_n; j += W::width()) {
             const uint32_t x = a_start + j, q = (uint32_t)(x - base), avail = la_end_abs - x;
             const uint8_t *cur = G.in + x;
-            uint32_t *rec = W::lds()->pf_rec + 32 * j;
-            uint32_t flags = 0, lens = 0, v4 = 0, idx = 0;
+            uint32_t *rec = W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * j;
+            uint32_t flags = 0, lens = 0, v4 = 0, idx = 0xFFFFFFFFu;
             uint32_t row[3] = { 0, 0, 0 };
             unsigned long long dummy = 0;
             LaneCmp lcmp{ &dummy };
@@ -761,14 +779,19 @@ struct Master {
             rec[25] = sl; rec[26] = sd;
             rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags;
             rec[11] = rkh; rec[12] = rkv; rec[13] = rkl; rec[14] = ready;
-            W::pfl_set(pfl, j, idx, rkh >> g.rk_shift);
+            // a slot is `simple` when the look-ahead has settled everything about it: the BT4 call happens (not
+            // `unc`), its result is here (<= 4 pairs), no RK candidate, no RK insert falls on it, none of its table
+            // updates can extend at the next position.  Whether an earlier slot rewrites its HT rows is added below.
+            const bool simple = G.workers && avail >= 256 && !(flags & (32u | 8u)) && (q & 255u) != 0 && (ready & kBtReady) &&
+                                (ready & 0x1FFu) <= 4 && !(sl >> 31);
+            W::pfl_set(pfl, j, idx, rkh >> g.rk_shift, v4, row[1], sl, sd, rec[4] >> 8, simple);
         }
+        W::pfl_conflicts(pfl, pf_n);
         W::sync();
     }
 
     // a store to HT2 row i2 / HT3 rows i3, i3+1 (bucket b reads rows b and b+1, :912) invalidates
     // what later look-ahead slots read from them
-    NLZM_HD void pf_mark_ht(uint32_t s, uint32_t i2, uint32_t i3) { W::pfl_mark_ht(pfl, s, pf_n, i2, i3); }
     NLZM_HD void pf_mark_rk(uint32_t s, uint32_t slot) { W::pfl_mark_rk(pfl, s, pf_n, slot); }
 
     // ---- finders for one position (:1501-1543) --------------------------------
@@ -780,7 +803,7 @@ struct Master {
         const uint32_t avail = la_end - q;
         prof_mark(0);
         const uint32_t s = a - pf_base;
-        const typename W::Rec rec = W::rec_load(W::lds()->pf_rec + 32 * s);
+        const typename W::Rec rec = W::rec_load(W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * s);
         const uint32_t pflags = W::rec_get(rec, 3), pstale = W::pfl_stale(pfl, s);
 
         // carry by one (:1501-1502, CarryFrom :823-833)
@@ -859,7 +882,6 @@ struct Master {
             G.ht2[i2] = q | (tag2 << g.wbits);                  // wave-uniform stores
             G.ht3[i3] = q | (tag3 << g.wbits);
             G.ht3[i3 + 1] = row[1];
-            pf_mark_ht(s, i2, i3);
             n_ht++;
             prof_mark(2);
             bool bt_done = false;
@@ -1084,6 +1106,31 @@ struct Master {
         W::xw_store(&W::lds()->x_apos, a + 1);
     }
 
+    // slots [s, s+n) of the look-ahead are `simple`: carry, HT2/HT3/BT4 updates as the records list them, nothing from
+    // RK256, no extension, not nice.  The table wave replays them from the records; here only the rows rotate (all
+    // slots at once) and the table's length / top entry are followed.
+    NLZM_HD void fast_run(uint32_t q, uint32_t a, uint32_t s, uint32_t n)
+    {
+#ifdef NLZM_SIM_COUNT
+        g_dbg[4] += n; g_dbg[5]++;
+#endif
+        cq_push(kOpRun, s | ((n - 1) << 6) | (pf_buf << 12), a);
+        cq_flush();
+        W::pfl_run_store(pfl, s, n, G.ht2, G.ht3, q, g.wbits, g.tag_mask, g.ht3_shift);
+        uint32_t cmpb = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            mt_max = mt_max > 1 ? mt_max - 1 : 0;                   // carry (:823-833)
+            if (mt_max >= kNice) { fail(kErrInternal, a + i); return; }   // the pre-filter promised otherwise
+            const uint32_t sl = W::pfl_sl(pfl, s + i), lm = sl & 0x1FFu;
+            if (lm > mt_max) { mt_max = lm; top_d = W::pfl_sd(pfl, s + i); }
+            else if (lm && lm == mt_max) top_d = umin(top_d, W::pfl_sd(pfl, s + i));
+            cmpb += W::pfl_cmpb(pfl, s + i);
+        }
+        n_cmp += cmpb; n_ht += n; n_rkp += n;
+        rk_end = q + n - 1 + 256;
+        prev_nice = false;
+    }
+
     NLZM_HD void run_chunk_finder(uint32_t ci)
     {
         const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
@@ -1104,14 +1151,23 @@ struct Master {
         pf_n = 0;                           // the look-ahead never crosses a chunk (lookahead limit, rebase)
         counts_zero();
         const uint32_t a0 = (uint32_t)chunk_abs, a1 = a0 + p_end;
-        for (uint32_t a = a0; a < a1 && !err; a++) {
-            if (a - pf_base >= pf_n) pf_fill(a, a1, a0 + chunk_read);
+        uint32_t a = a0;
+        while (a < a1 && !err) {
+            if (a - pf_base >= pf_n) { pf_fill(a, a1, a0 + chunk_read); if (err) break; }
+            const uint32_t s = a - pf_base, q = chunk_q + (a - a0);
+            // a run of slots the look-ahead has settled completely: passed to the table wave as ONE command
+            if (rk_len == 0 && !top_open && rk_end == q + 255) {
+                const unsigned long long m = W::pfl_run_mask(pfl, pf_n) >> s;
+                const uint32_t n = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;
+                if (n) { fast_run(q, a, s, n); a += n; continue; }
+            }
             prof_start();
-            finders(chunk_q + (a - a0), a, a1);
+            finders(q, a, a1);
             if (err) break;
             cq_push(kOpEnd, W::lds()->win[a - pf_base], a);       // the table of position a is complete (:1543)
             cq_flush();
             prof_mark(12);
+            a++;
         }
         counts_flush();
     }
@@ -1122,6 +1178,7 @@ struct Master {
         mt_max = W::uni(P->mt_max);
         top_d = W::uni(P->mt_delta[mt_max]); top_open = true; rk_open = true;     // conservative across launches
         pf_base = 0; pf_n = 0; cq_n = 0; cq_seen = 0; prev_nice = false; seg_s = 0; seg_cut = 0;
+        pf_buf = 0; pf_mark0 = 0; pf_mark1 = 0;
         wait_cyc = 0; role_t0 = W::tick();
         rk_from = W::uni(P->rk_from); rk_to = W::uni(P->rk_to); rk_len = W::uni(P->rk_len); rk_end = W::uni(P->rk_end);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
@@ -1185,6 +1242,20 @@ struct Master {
                 if (op == kOpUpd) t_update(v, arg);
                 else if (op == kOpCarry) t_carry();
                 else if (op == kOpExt) t_extend(v, arg);
+                else if (op == kOpRun) {                    // slots [s0, s0+n) of a look-ahead batch, first position v
+                    const uint32_t s0 = arg & 63u, n = ((arg >> 6) & 63u) + 1, buf = (arg >> 12) & 1u;
+                    for (uint32_t i = 0; i < n && !err; i++) {
+                        const typename W::Rec r = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + i));
+                        t_carry();
+                        const uint32_t nh = W::rec_get(r, 4) & 0xFFu, nb = W::rec_get(r, 14) & 0x1FFu;
+                        for (uint32_t j = 0; j < nh; j++) t_update(W::rec_get(r, 5 + 2 * j), W::rec_get(r, 6 + 2 * j) & 0x1FFu);
+                        for (uint32_t j = 0; j < nb; j++) t_update(W::rec_get(r, 15 + 2 * j), W::rec_get(r, 16 + 2 * j) & 0x1FFu);
+                        if (!wait_space(v + i)) break;
+                        capture(v + i);
+                        t_publish(v + i, W::rec_get(r, 0) & 0xFFu);
+                        ended = v + i + 1;
+                    }
+                }
                 else {                                      // kOpEnd: publish position v, input byte arg
                     if (!wait_space(v)) break;              // slot v % kEr is free again
                     capture(v);

@@ -42,13 +42,47 @@ struct DevWave {
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
     // per look-ahead slot state kept in the lane that evaluated the slot (slot j = lane j, kPf == 64)
-    struct PfLane { uint32_t idx, rkslot, stale; };
-    static __device__ __forceinline__ void pfl_set(PfLane &p, uint32_t, uint32_t idx, uint32_t rkslot) { p.idx = idx; p.rkslot = rkslot; p.stale = 0; }
-    static __device__ __forceinline__ void pfl_mark_ht(PfLane &p, uint32_t s, uint32_t n, uint32_t i2, uint32_t i3)
+    struct PfLane { uint32_t idx, rkslot, stale, v4, row1, sl, sd, cmpb, simple; };
+    // idx: HT2 bucket | HT3 bucket << 16 (0xFFFFFFFF: the slot touches no HT row); sl/sd: summary of its table updates;
+    // simple: everything about the slot was settled by the look-ahead (see Master::pf_fill)
+    static __device__ __forceinline__ void pfl_set(PfLane &p, uint32_t, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1,
+                                                   uint32_t sl, uint32_t sd, uint32_t cmpb, bool simple)
+    {
+        p.idx = idx; p.rkslot = rkslot; p.stale = 0; p.v4 = v4; p.row1 = row1; p.sl = sl; p.sd = sd; p.cmpb = cmpb; p.simple = simple;
+    }
+    // stale bit 1: an earlier slot of the batch writes an HT row this slot has read (bucket b owns rows b and b+1, :912)
+    static __device__ __forceinline__ void pfl_conflicts(PfLane &p, uint32_t n)
     {
         const uint32_t o2 = p.idx & 0xFFFFu, o3 = p.idx >> 16;
-        p.stale |= (lane() > s && lane() < n && (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3)) ? 1u : 0u;
+        bool conf = false;
+        for (uint32_t k = 0; k + 1 < n; k++) {
+            const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)p.idx, (int)k);
+            const uint32_t i2 = ik & 0xFFFFu, i3 = ik >> 16;
+            conf = conf || (lane() > k && ik != 0xFFFFFFFFu && (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3));
+        }
+        p.stale |= (conf && lane() < n) ? 1u : 0u;
     }
+    // slots the finder wave may pass over without looking at them one by one
+    static __device__ __forceinline__ unsigned long long pfl_run_mask(const PfLane &p, uint32_t n)
+    {
+        return __ballot(lane() < n && p.simple && !(p.stale & 5u));
+    }
+    // HT2/HT3 rows of slots [s0, s0+cnt) rotate (:935-936); no two of them, nor an earlier slot of the batch, share a row
+    static __device__ __forceinline__ void pfl_run_store(const PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3,
+                                                         uint32_t q0, uint32_t wbits, uint32_t tag_mask, uint32_t ht3_shift)
+    {
+        if (lane() >= s0 && lane() < s0 + cnt) {
+            const uint32_t q = q0 + (lane() - s0);
+            const uint32_t h2 = hash4(p.v4 & 0xFFFFu), h3 = hash4(p.v4 & 0xFFFFFFu);
+            const uint32_t i2 = h2 >> 20, i3 = h3 >> ht3_shift;
+            ht2[i2] = q | ((h2 & tag_mask) << wbits);
+            ht3[i3] = q | ((h3 & tag_mask) << wbits);
+            ht3[i3 + 1] = p.row1;
+        }
+    }
+    static __device__ __forceinline__ uint32_t pfl_sl(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sl, (int)s); }
+    static __device__ __forceinline__ uint32_t pfl_sd(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sd, (int)s); }
+    static __device__ __forceinline__ uint32_t pfl_cmpb(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.cmpb, (int)s); }
     static __device__ __forceinline__ void pfl_mark_rk(PfLane &p, uint32_t s, uint32_t n, uint32_t slot)
     {
         p.stale |= (lane() > s && lane() < n && p.rkslot == slot) ? 4u : 0u;

@@ -65,15 +65,45 @@ struct HostWave {
         return r;
     }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
-    struct PfLane { uint32_t idx[64], rkslot[64], stale[64]; };
-    static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot) { p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; }
-    static void pfl_mark_ht(PfLane &p, uint32_t s, uint32_t n, uint32_t i2, uint32_t i3)
+    struct PfLane { uint32_t idx[64], rkslot[64], stale[64], v4[64], row1[64], sl[64], sd[64], cmpb[64], simple[64]; };
+    static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1, uint32_t sl, uint32_t sd,
+                        uint32_t cmpb, bool simple)
     {
-        for (uint32_t j = s + 1; j < n; j++) {
+        p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; p.v4[j] = v4; p.row1[j] = row1; p.sl[j] = sl; p.sd[j] = sd; p.cmpb[j] = cmpb;
+        p.simple[j] = simple;
+    }
+    static void pfl_conflicts(PfLane &p, uint32_t n)
+    {
+        for (uint32_t j = 0; j < n; j++) {
             const uint32_t o2 = p.idx[j] & 0xFFFFu, o3 = p.idx[j] >> 16;
-            if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) p.stale[j] |= 1;
+            for (uint32_t k = 0; k < j; k++) {
+                if (p.idx[k] == 0xFFFFFFFFu) continue;
+                const uint32_t i2 = p.idx[k] & 0xFFFFu, i3 = p.idx[k] >> 16;
+                if (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3) p.stale[j] |= 1;
+            }
         }
     }
+    static unsigned long long pfl_run_mask(const PfLane &p, uint32_t n)
+    {
+        unsigned long long m = 0;
+        for (uint32_t j = 0; j < n; j++) if (p.simple[j] && !(p.stale[j] & 5u)) m |= 1ull << j;
+        return m;
+    }
+    static void pfl_run_store(const PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3, uint32_t q0, uint32_t wbits,
+                              uint32_t tag_mask, uint32_t ht3_shift)
+    {
+        for (uint32_t j = s0; j < s0 + cnt; j++) {
+            const uint32_t q = q0 + (j - s0);
+            const uint32_t h2 = hash4(p.v4[j] & 0xFFFFu), h3 = hash4(p.v4[j] & 0xFFFFFFu);
+            const uint32_t i2 = h2 >> 20, i3 = h3 >> ht3_shift;
+            ht2[i2] = q | ((h2 & tag_mask) << wbits);
+            ht3[i3] = q | ((h3 & tag_mask) << wbits);
+            ht3[i3 + 1] = p.row1[j];
+        }
+    }
+    static uint32_t pfl_sl(const PfLane &p, uint32_t s) { return p.sl[s]; }
+    static uint32_t pfl_sd(const PfLane &p, uint32_t s) { return p.sd[s]; }
+    static uint32_t pfl_cmpb(const PfLane &p, uint32_t s) { return p.cmpb[s]; }
     static void pfl_mark_rk(PfLane &p, uint32_t s, uint32_t n, uint32_t slot) { for (uint32_t j = s + 1; j < n; j++) if (p.rkslot[j] == slot) p.stale[j] |= 4; }
     static uint32_t pfl_stale(const PfLane &p, uint32_t s) { return p.stale[s]; }
     struct RepPf { const uint8_t *in; unsigned long long n; uint32_t a, r[4]; };
@@ -368,6 +398,7 @@ int main(int argc, char **argv)
         if (use_workers) wk.finish();
 #ifdef NLZM_SIM_COUNT
         fprintf(stderr, "dbg: long rep compares %llu (of %llu checks), relaxed rep probes %llu (of %llu nodes)\n", g_dbg[0], g_dbg[3], g_dbg[1], g_dbg[2]);
+        fprintf(stderr, "dbg: %llu positions in %llu runs\n", g_dbg[4], g_dbg[5]);
 #endif
         if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
     }
