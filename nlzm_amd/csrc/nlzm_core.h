@@ -198,7 +198,13 @@ struct MasterLds {
     uint32_t sq_req[2 * 16];                // a, p, cost_p, rep set (4), max_len, -, hand-off header, q, rep cap
     uint32_t sq_res[2];                     // per slot: end_p after the node's edges
     uint32_t x_spos;                        // parser: requests for positions < x_spos are posted (0xFFFFFFFF: leave)
-    uint32_t x_sdone;                       // edge wave: requests for positions < x_sdone are done
+    uint32_t x_sdone;                       // apply wave: the edges of positions < x_sdone are relaxed
+    // the two list waves -> apply wave, per request slot: candidate edges of the node
+    uint32_t ea[2 * 64 * 4];                // sampled lengths, lane k: cost as dict edge, cost as rep edge (or none), distance,
+                                            // length | rep index << 9 | valid << 12
+    uint32_t ea_checked[2];                 // rep indices met by a sampled edge (:1573-1584)
+    uint32_t eb[2 * 8];                     // explicit rep probes, rep k: length | relaxable << 30 | valid << 31, node cost through it
+    uint32_t x_eadone, x_ebdone[2];         // lists of positions < x are written (rep probes: per position parity)
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -1277,174 +1283,209 @@ struct Master {
         W::xw_add(&W::lds()->x_adone, 1u);
     }
 
-    // sampled lengths (:1558-1596): tl_k = max_len - k*step while >= 2, one lane per length.
-    // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into
-    // one compare-and-store; the targets of different lanes are distinct nodes.
-    NLZM_HD uint32_t sampled_relax(uint32_t p, uint32_t cost_p, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
-                                   const uint32_t *e, uint32_t hdr, uint32_t max_len, uint32_t pc_dict, uint32_t pc_rep)
+    // =========================== waves E1a, E1b, E2: the edges that leave a node ============
+    // The parser wave finalises node p (its cost and rep set are complete once the literal edge of p-1 and the
+    // match edges of every node <= p-2 have been relaxed) and posts it.  Its sampled-length edges (:1558-1596)
+    // and its explicit rep probes (:1598-1628) all end at nodes >= p+2:
+    //   E1a lists the sampled edges (length, distance, cost as dict edge and as rep edge),
+    //   E1b lists the rep probes (match length at each rep distance, cost),
+    //   E2  relaxes both lists in the reference's order -- it is the only writer of nodes >= p+2.
+    // The parser meanwhile relaxes the literal edge of p (after E2 is done with p-1: the reference's order at
+    // node p+1) and posts node p+1, so the lists of p+1 are made while the edges of p are applied.
+    //
+    // One LDS read: lane 0 post count, 1 error word, 2/3 the command prices, 4..19 the request slot, 20 `extra`.
+    // The count sits in the lowest lane (a host emulation reads the lanes in ascending order: count before data).
+    NLZM_HD typename W::Rec edge_fetch(uint32_t slot, const uint32_t *extra)
     {
-        uint32_t checked = 0;
-        uint32_t step = (max_len - kMatchMin) >> 4;
-        step += step == 0;
-        uint32_t myri = 4;                                  // rep index matched by this lane's edge (4: none)
-        // lane k takes tl = max_len - k*step while tl >= kMatchMin: at most 17 lengths (k*step <= max_len - kMatchMin)
-        auto edge = [&](uint32_t k) {
-            const uint32_t tl = max_len - k * step;
-            const uint32_t d = tab(e, hdr, tl);
-            const uint32_t mm = match_min(d);
-            if (tl < mm) return;
-            const uint32_t lv = tl - mm, lc = umin(lv, 3), np = p + tl;
-            uint32_t nx, ex;
-            const uint32_t slot = dist_slot(d - 1, nx, ex);
-            const uint32_t plen = W::lds()->seg_len_price[lv];
-            const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + slot];
-            uint32_t best = W::lds()->node_cost[np], sel = 0;
-            const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
-            const uint32_t ca = cost_p + pc_dict + plen + pdist, cb = cost_p + pc_rep + plen + (2u << 5);
-            if (ca < best) { best = ca; sel = 1; }
-            if (ri < 4 && cb < best) { best = cb; sel = 2; }
-            if (sel) {
-                W::lds()->node_cost[np] = best;
-                W::lds()->node_delta[np] = sel == 1 ? d : ri;
-                W::lds()->node_link[np] = pack_link(p, tl, sel);
-                uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
-                // selects on scalars (an array indexed by `has` would live in scratch memory)
-                uint32_t w0 = d, w1 = r0, w2 = r1, w3 = r2;
-                if (ri < 4) { w0 = r0; w1 = r1; w2 = r2; w3 = r3; }
-                dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
-            }
-            myri = ri;
-            if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
+        return W::rec_load_fn32([=](uint32_t i) {
+            return i == 0 ? W::lds()->x_spos
+                          : (i == 1 ? W::lds()->x_err
+                                    : (i < 4 ? ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)]
+                                             : (i < 20 ? W::lds()->sq_req[slot * 16 + ((i - 4) & 15u)] : *extra)));
+        });
+    }
+    // wait until `next` is posted (lane 0 of the fetch) and, for E2, listed (lane 20); false: leave
+    NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, const uint32_t *extra, bool need_extra)
+    {
+        auto ready = [&](const typename W::Rec &r) {
+            return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next && (!need_extra || W::rec_get(r, 20) > next);
         };
-        if (W::width() == 1) { for (uint32_t k = 0; k * step <= max_len - kMatchMin; k++) edge(k); }
-        else if (W::lane() * step <= max_len - kMatchMin) edge(W::lane());
-        if (W::width() != 1) {
-            const uint32_t m = myri;
-            checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
-                      (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
+        rq = edge_fetch(next & 1u, extra);
+        if (ready(rq)) return true;
+        const unsigned long long t0 = W::clock(), c0 = W::tick();
+        uint32_t spins = 0;
+        for (;;) {
+            rq = edge_fetch(next & 1u, extra);
+            if (ready(rq)) break;
+            if (W::rec_get(rq, 0) == kNone || W::rec_get(rq, 1)) return false;
+            if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return false;
+            W::xw_pause();
         }
-        W::sync();
-        return checked;
+        rq = edge_fetch(next & 1u, extra);          // count and slot came with the same read: take the slot again
+        wait_cyc += W::tick() - c0;
+        return true;
+    }
+    NLZM_HD void edge_leave(int k)
+    {
+        if (W::lane() == 0) { G.persist->prof[k] += wait_cyc; G.persist->prof[k + 1] += W::tick() - role_t0; }
     }
 
-    // =========================== wave S: the edges that leave a node ========================
-    // The parser wave finalises node p (its cost and rep set are complete once the literal edge of p-1 and the
-    // match edges of every node <= p-2 have been relaxed) and posts it; this wave relaxes its sampled-length
-    // edges (:1558-1596) and then its explicit rep probes (:1598-1628), all of which end at nodes >= p+2.
-    // The parser meanwhile relaxes the literal edge of p (after the edges of p-1 are in: the reference's order
-    // at node p+1) and finalises node p+1, so the two waves work on neighbouring nodes at the same time.
-    NLZM_HD void run_sampler(uint32_t a_first)
+    // E1a: sampled lengths tl_k = max_len - k*step while >= 2 (:1558-1562), one lane per length
+    NLZM_HD void run_edge_list(uint32_t a_first)
     {
         err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
-#ifdef NLZM_PROFILE
-        for (int k = 0; k < 16; k++) prof[k] = 0;
-#endif
-        uint32_t next = a_first, end_p = 1;
-        typename W::RepPf rpf_next{};
-        bool have_pf = false;
-        uint32_t pf_a = 0, pf_r0 = 0, pf_r1 = 0, pf_r2 = 0, pf_r3 = 0;      // what rpf_next was requested for
+        uint32_t next = a_first;
         for (;;) {
-            // post count, error word, the two command prices and the request slot with ONE LDS read; the count sits in
-            // the lowest lane (a host emulation reads the lanes in ascending order: count before data)
+            typename W::Rec rq;
+            if (!edge_wait(rq, next, &W::lds()->x_spos, false)) { edge_leave(24); return; }
             const uint32_t slot = next & 1u;
-            auto fetch = [=]() {
-                return W::rec_load_fn32([=](uint32_t i) {
-                    return i == 0 ? W::lds()->x_spos : (i == 1 ? W::lds()->x_err : (i < 4 ? ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)]
-                                                                                      : W::lds()->sq_req[slot * 16 + ((i - 4) & 15u)]));
-                });
-            };
-            typename W::Rec rq = fetch();
-            // (posted: the count has passed this position; the slot then holds it -- word 0 -- and not the node two back)
-            if (W::rec_get(rq, 0) <= next || W::rec_get(rq, 4) != next) {
-                const unsigned long long t0 = W::clock(), c0 = W::tick();
-                uint32_t spins = 0;
-                for (;;) {
-                    rq = fetch();
-                    if (W::rec_get(rq, 0) > next && (W::rec_get(rq, 4) == next || W::rec_get(rq, 0) == kNone)) break;
-                    if (W::rec_get(rq, 1)) return;
-                    if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return;
-                    W::xw_pause();
-                }
-                rq = fetch();                           // count and slot came with the same read: take the slot again
-                wait_cyc += W::tick() - c0;
-            }
-            if (W::rec_get(rq, 0) == kNone) {
-                if (W::lane() == 0) {
-                    G.persist->prof[22] += wait_cyc; G.persist->prof[23] += W::tick() - role_t0;
-#ifdef NLZM_PROFILE
-                    for (int k = 0; k < 6; k++) G.persist->prof[24 + k] += prof[k];
-#endif
-                }
-                return;
-            }
-            prof_start();
-            const uint32_t a = W::rec_get(rq, 4), p = W::rec_get(rq, 5), cost_p = W::rec_get(rq, 6);
-            const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
-            const uint32_t max_len = W::rec_get(rq, 11), hdr = W::rec_get(rq, 13), q = W::rec_get(rq, 14), rep_cap = W::rec_get(rq, 15);
+            const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
+            const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
+            const uint32_t max_len = W::rec_get(rq, 11), hdr = W::rec_get(rq, 13);
             const uint32_t pc_dict = W::rec_get(rq, 2) >> 16, pc_rep = W::rec_get(rq, 3) & 0xFFFFu;     // price(kCtxCmd, 1), (kCtxCmd, 2)
-            // the bytes the rep probes compare (kRepPf in front of each rep distance and at the position) were
-            // requested from HBM while the previous node was worked on, if this node had been posted by then
-            const bool pf_ok = have_pf && pf_a == a && pf_r0 == rp0 && pf_r1 == rp1 && pf_r2 == rp2 && pf_r3 == rp3;
-            const typename W::RepPf rpf = pf_ok ? rpf_next : W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
-            have_pf = false;
-            if (p == 0) end_p = 1;
-            prof_mark(0);
             uint32_t checked = 0;
             if (max_len) {
-                open_nodes(end_p, max_len + p);                     // :1550-1554
-                checked = sampled_relax(p, cost_p, rp0, rp1, rp2, rp3, W::lds()->er_tab + (a & (kEr - 1)) * 64, hdr, max_len, pc_dict, pc_rep);
-            }
-            prof_mark(1);
-            uint32_t rep_len[4];
-            W::rep_lengths(rpf, rep_len);
-            prof_mark(2);
-            auto look_ahead = [&]() {
-                if (have_pf) return;
-                const uint32_t s2 = slot ^ 1u;
-                const typename W::Rec r2 = W::rec_load_fn32([=](uint32_t i) { return i == 0 ? W::lds()->x_spos : W::lds()->sq_req[s2 * 16 + ((i - 1) & 7u)]; });
-                const uint32_t v = W::rec_get(r2, 0);
-                if (v == kNone || v <= next + 1 || W::rec_get(r2, 1) != next + 1) return;
-                pf_a = W::rec_get(r2, 1); pf_r0 = W::rec_get(r2, 4); pf_r1 = W::rec_get(r2, 5); pf_r2 = W::rec_get(r2, 6); pf_r3 = W::rec_get(r2, 7);
-                rpf_next = W::rep_prefetch(G.in, g.n, pf_a, pf_r0, pf_r1, pf_r2, pf_r3);
-                have_pf = true;
-            };
-            look_ahead();
-            prof_mark(3);
-            if (checked != 15) {
-                // explicit rep probes (:1598-1628): all four decided on the scalar unit; the usual case (no probe long
-                // enough to relax) costs one counter update
-                uint32_t l0 = rep_len[0], l1 = rep_len[1], l2 = rep_len[2], l3 = rep_len[3];
-                uint32_t rm = 0, csum = 0;
-                auto probe = [&](uint32_t k, uint32_t d, uint32_t &l) {
-                    if (((checked >> k) & 1u) || d >= q) return;
-                    if (l >= rep_cap) l = rep_cap;                  // min(len, 264)
-                    else if (l == kRepPf) l = wave_cmp<false>(G.in + a - d, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
-                    csum += l + 1;
-                    if (l >= match_min(d)) rm |= 1u << k;
+                const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
+                uint32_t step = (max_len - kMatchMin) >> 4;
+                step += step == 0;
+                uint32_t myri = 4;
+                auto edge = [&](uint32_t k) {
+                    uint32_t *o = W::lds()->ea + (slot * 64 + k) * 4;
+                    if (k * step > max_len - kMatchMin) { o[3] = 0; return; }
+                    const uint32_t tl = max_len - k * step;
+                    const uint32_t d = tab(e, hdr, tl);
+                    const uint32_t mm = match_min(d);
+                    if (tl < mm) { o[3] = 0; return; }
+                    const uint32_t lv = tl - mm, lc = umin(lv, 3);
+                    uint32_t nx, ex;
+                    const uint32_t ds = dist_slot(d - 1, nx, ex);
+                    const uint32_t plen = W::lds()->seg_len_price[lv];
+                    const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + ds];
+                    const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
+                    o[0] = cost_p + pc_dict + plen + pdist;
+                    o[1] = ri < 4 ? cost_p + pc_rep + plen + (2u << 5) : kNone;
+                    o[2] = d;
+                    o[3] = tl | (ri << 9) | (1u << 12);
+                    myri = ri;
+                    if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
                 };
-                probe(0, rp0, l0); probe(1, rp1, l1); probe(2, rp2, l2); probe(3, rp3, l3);
-                if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
-#ifdef NLZM_SIM_COUNT
-                g_dbg[1] += __builtin_popcount(rm); g_dbg[2]++;
-#endif
-                while (rm) {
-                    const uint32_t ri = (uint32_t)__builtin_ctz(rm);
-                    rm &= rm - 1;
-                    const uint32_t d = ri == 0 ? rp0 : (ri == 1 ? rp1 : (ri == 2 ? rp2 : rp3));
-                    const uint32_t l = ri == 0 ? l0 : (ri == 1 ? l1 : (ri == 2 ? l2 : l3));
-                    open_nodes(end_p, l + p);
-                    W::sync();
-                    relax(p, p + l, cost_p, W::uni(pc_rep + price_len(l - match_min(d)) + (2u << 5)), 2, l, ri, rp0, rp1, rp2, rp3, d);   // wave-uniform
-                    W::sync();
+                // k*step <= max_len - 2 leaves at most 32 lengths (step is 1 up to max_len 33)
+                if (W::width() == 1) { for (uint32_t k = 0; k < 64; k++) edge(k); }
+                else edge(W::lane());
+                if (W::width() != 1) {
+                    const uint32_t m = myri;
+                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
+                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
                 }
             }
-            prof_mark(4);
-            look_ahead();
+            W::lds()->ea_checked[slot] = checked;
+            W::sync();
+            next++;
+            W::xw_store(&W::lds()->x_eadone, next);
+        }
+    }
+
+    // E1b: explicit rep probes (:1598-1628): match length at each rep distance and the node cost through it.
+    // The bytes come from HBM (a rep distance reaches anywhere in the window) and a node's rep set is known only
+    // when the node is posted, so one probe list costs a full memory round trip: two waves take the even and the
+    // odd positions, each with its own request/list slot.
+    NLZM_HD void run_rep_list(uint32_t a_first, uint32_t parity)
+    {
+        err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
+        uint32_t next = a_first + ((a_first ^ parity) & 1u);
+        for (;;) {
+            typename W::Rec rq;
+            if (!edge_wait(rq, next, &W::lds()->x_spos, false)) { edge_leave(parity ? 28 : 26); return; }
+            const uint32_t slot = parity;
+            const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
+            const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
+            const uint32_t q = W::rec_get(rq, 14), rep_cap = W::rec_get(rq, 15);
+            const uint32_t pc_rep = W::rec_get(rq, 3) & 0xFFFFu;
+            // kRepPf bytes in front of each rep distance and at the position
+            const typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
+            uint32_t rep_len[4];
+            W::rep_lengths(rpf, rep_len);
+            auto probe = [&](uint32_t k, uint32_t d, uint32_t l) {
+                uint32_t w = 0, c = 0;
+                if (d < q) {
+                    if (l >= rep_cap) l = rep_cap;                  // min(len, 264)
+                    else if (l == kRepPf) l = wave_cmp<false>(G.in + a - d, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                    w = l | (1u << 31);
+                    if (l >= match_min(d)) { w |= 1u << 30; c = cost_p + W::uni(pc_rep + price_len(l - match_min(d)) + (2u << 5)); }
+                }
+                W::lds()->eb[slot * 8 + 2 * k] = w; W::lds()->eb[slot * 8 + 2 * k + 1] = c;
+            };
+            probe(0, rp0, rep_len[0]); probe(1, rp1, rep_len[1]); probe(2, rp2, rep_len[2]); probe(3, rp3, rep_len[3]);
+            W::sync();
+            next += 2;
+            W::xw_store(&W::lds()->x_ebdone[parity], next - 1);      // positions of this parity < next - 1 are listed
+        }
+    }
+
+    // E2: relaxes the listed edges of each node in the reference's order
+    NLZM_HD void run_edge_apply(uint32_t a_first)
+    {
+        err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
+        uint32_t next = a_first, end_p = 1;
+        for (;;) {
+            typename W::Rec rq;
+            if (!edge_wait(rq, next, &W::lds()->x_eadone, true)) { edge_leave(22); return; }
+            const uint32_t slot = next & 1u;
+            const uint32_t p = W::rec_get(rq, 5);
+            const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
+            const uint32_t max_len = W::rec_get(rq, 11);
+            if (p == 0) end_p = 1;
+            if (max_len) {
+                open_nodes(end_p, max_len + p);                     // :1550-1554
+                // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into one
+                // compare-and-store; the targets of different lanes are distinct nodes
+                auto apply = [&](uint32_t k) {
+                    const uint32_t *o = W::lds()->ea + (slot * 64 + k) * 4;
+                    const uint32_t ca = o[0], cb = o[1], d = o[2], w = o[3];
+                    if (!(w >> 12)) return;
+                    const uint32_t tl = w & 0x1FFu, ri = (w >> 9) & 7u, np = p + tl;
+                    uint32_t best = W::lds()->node_cost[np], sel = 0;
+                    if (ca < best) { best = ca; sel = 1; }
+                    if (cb < best) { best = cb; sel = 2; }          // cb is kNone when the distance is no rep
+                    if (sel) {
+                        W::lds()->node_cost[np] = best;
+                        W::lds()->node_delta[np] = sel == 1 ? d : ri;
+                        W::lds()->node_link[np] = pack_link(p, tl, sel);
+                        uint32_t *dst = W::lds()->reps + (np & 511) * 4;        // RepModel::Add (:1160-1171)
+                        uint32_t w0 = d, w1 = r0, w2 = r1, w3 = r2;
+                        if (ri < 4) { w0 = r0; w1 = r1; w2 = r2; w3 = r3; }
+                        dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+                    }
+                };
+                if (W::width() == 1) { for (uint32_t k = 0; k < 64; k++) apply(k); }
+                else apply(W::lane());
+                W::sync();
+            }
+            // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
+            if (!wait_ge(&W::lds()->x_ebdone[next & 1u], next + 1)) { edge_leave(22); return; }
+            const uint32_t checked = W::uni(W::lds()->ea_checked[slot]);
+            if (checked != 15) {
+                const typename W::Rec rb = W::rec_load_fn([=](uint32_t i) { return W::lds()->eb[slot * 8 + i]; });
+                uint32_t csum = 0;
+                auto probe = [&](uint32_t k, uint32_t d) {
+                    const uint32_t w = W::rec_get(rb, 2 * k);
+                    if (((checked >> k) & 1u) || !(w >> 31)) return;
+                    const uint32_t l = w & 0xFFFFu;
+                    csum += l + 1;
+                    if ((w >> 30) & 1u) {
+                        open_nodes(end_p, l + p);
+                        W::sync();
+                        relax(p, p + l, W::rec_get(rb, 2 * k + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
+                        W::sync();
+                    }
+                };
+                probe(0, r0); probe(1, r1); probe(2, r2); probe(3, r3);
+                if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
+            }
             W::lds()->sq_res[slot] = end_p;
             W::sync();
             next++;
             W::xw_store(&W::lds()->x_sdone, next);
-            prof_mark(5);
         }
     }
 
@@ -1671,7 +1712,7 @@ struct Master {
         if (W::lane() == 0) {
             W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0; W::lds()->x_bcover = a0 + 1;
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
-            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = a0; W::lds()->x_sdone = a0;
+            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = a0; W::lds()->x_sdone = a0; W::lds()->x_eadone = a0; W::lds()->x_ebdone[0] = a0; W::lds()->x_ebdone[1] = a0;
         }
         (void)G;
     }

@@ -371,8 +371,8 @@ int refresh_stats()
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
     if (getenv("NLZM_WAIT_PRINT")) {
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
-        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f | edges: total %.0f wait %.0f\n",
-                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[22] / n);
+        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f | edge list: wait %.0f | rep lists: wait %.0f %.0f | edge apply: wait %.0f\n",
+                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[24] / n, P.prof[26] / n, P.prof[28] / n, P.prof[22] / n);
         fprintf(stderr, "HW_ID of the finder/table/parser/edge waves: %04llx %04llx %04llx %04llx (SIMD = bits 5:4)\n", P.prof[30] & 0xFFFF,
                 (P.prof[30] >> 16) & 0xFFFF, (P.prof[30] >> 32) & 0xFFFF, (P.prof[30] >> 48) & 0xFFFF);
         fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
@@ -383,8 +383,6 @@ int refresh_stats()
                 (double)P.prof[13] / (P.cnt.positions ? P.cnt.positions : 1), (double)P.prof[14] / (P.cnt.positions ? P.cnt.positions : 1));
         static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
                                          "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
-        static const char *snames[6] = { "S: pickup", "S: sampled edges", "S: rep lengths", "S: look-ahead", "S: rep relax", "S: result" };
-        for (int k = 0; k < 6; k++) fprintf(stderr, "prof %-18s %7.1f cyc/pos\n", snames[k], (double)P.prof[24 + k] / (P.cnt.positions ? P.cnt.positions : 1));
         unsigned long long tot = 0;
         for (int k = 0; k < 13; k++) tot += P.prof[k];
         for (int k = 0; k < 13; k++) fprintf(stderr, "prof %-18s %12llu cyc  %5.1f%%  %7.1f cyc/pos\n", names[k], P.prof[k],

@@ -419,7 +419,7 @@ struct LaneIO {
     static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-__device__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
+__device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
 {
     const uint32_t nl = (gridDim.x - 1) * blockDim.x;
     const uint32_t gl = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
@@ -514,18 +514,24 @@ __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32
         // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
         // wave 1: the match table (carry / extend / update), published per position
         // wave 2: forward-graph parse, model, symbol emit
-        // wave 3: relaxes the sampled-length edges of each node for the parser; waves 4..7 leave
+        // waves 3 / 4, 6: list the sampled-length edges / the rep probes (even, odd positions) of each node; wave 5 relaxes them
         if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         __syncthreads();
-        if (threadIdx.x >= 256) return;
-        if ((threadIdx.x & 63u) == 0)       // diagnostics: which SIMD each role's wave landed on (HW_ID bits 5:4)
+        if (threadIdx.x >= 448) return;
+        if ((threadIdx.x & 63u) == 0 && threadIdx.x < 256)   // diagnostics: which SIMD each role's wave landed on (HW_ID bits 5:4)
             atomicOr(&G.persist->prof[30], (unsigned long long)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFFu) << (16 * (threadIdx.x >> 6)));
         Master<DevWave> m;
         m.g = g; m.G = G;
-        if (threadIdx.x < 64) m.run_finder(c0, c1);
-        else if (threadIdx.x < 128) m.run_table(c0, c1);
-        else if (threadIdx.x < 192) m.run_parser(c0, c1);
-        else m.run_sampler((uint32_t)((unsigned long long)c0 * g.chunk_size));
+        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        switch (threadIdx.x >> 6) {
+        case 0: m.run_finder(c0, c1); break;
+        case 1: m.run_table(c0, c1); break;
+        case 2: m.run_parser(c0, c1); break;
+        case 3: m.run_edge_list(a_first); break;
+        case 4: m.run_rep_list(a_first, 0); break;
+        case 5: m.run_edge_apply(a_first); break;
+        default: m.run_rep_list(a_first, 1); break;
+        }
     } else {
         worker_role(g, G, c0, c1);
     }

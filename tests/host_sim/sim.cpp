@@ -387,14 +387,18 @@ int main(int argc, char **argv)
         }
         // the two master waves as two threads
         Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
-        Master<HostWave> mb = m, mt = m, ms = m;
-        std::thread ts([&] { ms.run_sampler((uint32_t)((unsigned long long)c0 * g.chunk_size)); });
+        Master<HostWave> mb = m, mt = m, ms = m, ms2 = m, ms3 = m, ms4 = m;
+        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        std::thread ts([&] { ms.run_edge_list(a_first); });
+        std::thread ts2([&] { ms2.run_rep_list(a_first, 0); });
+        std::thread ts4([&] { ms4.run_rep_list(a_first, 1); });
+        std::thread ts3([&] { ms3.run_edge_apply(a_first); });
         std::thread tb([&] { mb.run_parser(c0, c1); });
         std::thread tt([&] { mt.run_table(c0, c1); });
         m.run_finder(c0, c1);
         tt.join();
         tb.join();
-        ts.join();
+        ts.join(); ts2.join(); ts3.join(); ts4.join();
         if (use_workers) wk.finish();
 #ifdef NLZM_SIM_COUNT
         fprintf(stderr, "dbg: long rep compares %llu (of %llu checks), relaxed rep probes %llu (of %llu nodes)\n", g_dbg[0], g_dbg[3], g_dbg[1], g_dbg[2]);
