@@ -97,7 +97,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[32];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
+    unsigned long long prof[40];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -194,17 +194,21 @@ struct MasterLds {
     uint32_t x_long_free;                   // B: long slots given back (monotonic)
     uint32_t x_err;                         // either: error code, both waves leave their loops
     uint32_t x_adone;                       // A, T: finished the launch (count)
-    // parser -> edge wave: relax the match and rep edges that leave one node (request, slot a & 1), and back
-    uint32_t sq_req[2 * 16];                // a, p, cost_p, rep set (4), max_len, -, hand-off header, q, rep cap
+    // parser -> edge waves: the node whose match and rep edges are to be relaxed (slot a & 1), and back.
+    // One 32-word, 128-byte aligned block per slot, read whole by ONE LDS instruction (lane i takes word i: 32
+    // distinct banks, a single pass, so a reader that sees the count sees the request it covers):
+    //   0      positions < this are posted in this slot (0xFFFFFFFF: leave)
+    //   2, 3   price words of the command context (symbols 0|1, 2|3) for this segment
+    //   4..19  request: a, p, cost_p, rep set (4), max_len, (stamp), hand-off header, q, rep cap
+    //   20..22 (block 0 only) list counts: x_eadone, x_ebdone[0], x_ebdone[1]
+    alignas(128) uint32_t post[2][32];
     uint32_t sq_res[2];                     // per slot: end_p after the node's edges
-    uint32_t x_spos;                        // parser: requests for positions < x_spos are posted (0xFFFFFFFF: leave)
     uint32_t x_sdone;                       // apply wave: the edges of positions < x_sdone are relaxed
     // the two list waves -> apply wave, per request slot: candidate edges of the node
     uint32_t ea[2 * 64 * 4];                // sampled lengths, lane k: cost as dict edge, cost as rep edge (or none), distance,
                                             // length | rep index << 9 | valid << 12
-    uint32_t ea_checked[2];                 // rep indices met by a sampled edge (:1573-1584)
-    uint32_t eb[2 * 8];                     // explicit rep probes, rep k: length | relaxable << 30 | valid << 31, node cost through it
-    uint32_t x_eadone, x_ebdone[2];         // lists of positions < x are written (rep probes: per position parity)
+    uint32_t eb[2 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, node cost
+                                            // through it; word 8: rep indices met by a sampled edge (:1573-1584)
 };
 
 NLZM_HD uint32_t match_min(uint32_t d)      // :813-821
@@ -370,6 +374,7 @@ struct Master {
     uint32_t pf_buf, pf_mark0, pf_mark1;    // record buffer in use; command count when buffer 0 / 1 was last left
     typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
     uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
+    uint32_t th_a, th_hdr, th_lit;  // parser wave: hand-off header and input byte of position th_a (read ahead)
     bool seg_tab_dirty;             // parser wave: a length/distance context changed since the price tables were built
     uint32_t cq_n, cq_seen;         // finder wave: commands written / consumed count last seen
     uint32_t seg_s, seg_cut;        // finder wave, inside a nice region: segment start and its forced cut
@@ -399,7 +404,7 @@ struct Master {
     unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
 #ifdef NLZM_PROFILE
     unsigned long long prof[16];
-    unsigned long long prof_t;
+    unsigned long long prof_t, lat_sum = 0, lat_sum2 = 0;
     NLZM_HD void prof_start() { prof_t = W::tick(); }
     NLZM_HD void prof_mark(int k) { const unsigned long long t = W::tick(); prof[k] += t - prof_t; prof_t = t; }
 #else
@@ -1293,41 +1298,45 @@ struct Master {
     // The parser meanwhile relaxes the literal edge of p (after E2 is done with p-1: the reference's order at
     // node p+1) and posts node p+1, so the lists of p+1 are made while the edges of p are applied.
     //
-    // One LDS read: lane 0 post count, 1 error word, 2/3 the command prices, 4..19 the request slot, 20 `extra`.
-    // The count sits in the lowest lane (a host emulation reads the lanes in ascending order: count before data).
-    NLZM_HD typename W::Rec edge_fetch(uint32_t slot, const uint32_t *extra)
+    // The post block of a slot and the list counts with one LDS read (see MasterLds::post)
+    NLZM_HD typename W::Rec edge_fetch(uint32_t slot)
     {
-        return W::rec_load_fn32([=](uint32_t i) {
-            return i == 0 ? W::lds()->x_spos
-                          : (i == 1 ? W::lds()->x_err
-                                    : (i < 4 ? ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)]
-                                             : (i < 20 ? W::lds()->sq_req[slot * 16 + ((i - 4) & 15u)] : *extra)));
-        });
+        return W::rec_load_fn32([=](uint32_t i) { return W::lds()->post[i < 20 ? slot : 0][i]; });
     }
-    // wait until `next` is posted (lane 0 of the fetch) and, for E2, listed (lane 20); false: leave
-    NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, const uint32_t *extra, bool need_extra)
+    // wait until `next` is posted and, for the apply wave, listed by both list waves; false: leave
+    NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, bool need_lists)
     {
         auto ready = [&](const typename W::Rec &r) {
-            return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next && (!need_extra || W::rec_get(r, 20) > next);
+            return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next &&
+                   (!need_lists || (W::rec_get(r, 20) > next && W::rec_get(r, (next & 1u) ? 22 : 21) > next));
         };
-        rq = edge_fetch(next & 1u, extra);
+        rq = edge_fetch(next & 1u);
         if (ready(rq)) return true;
         const unsigned long long t0 = W::clock(), c0 = W::tick();
         uint32_t spins = 0;
         for (;;) {
-            rq = edge_fetch(next & 1u, extra);
+            rq = edge_fetch(next & 1u);
             if (ready(rq)) break;
-            if (W::rec_get(rq, 0) == kNone || W::rec_get(rq, 1)) return false;
-            if ((++spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return false;
+            if (W::rec_get(rq, 0) == kNone) return false;
+            if ((++spins & 63u) == 0) {
+                if (W::xw_load(&W::lds()->x_err)) return false;
+                if ((spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) return false;
+            }
             W::xw_pause();
         }
-        rq = edge_fetch(next & 1u, extra);          // count and slot came with the same read: take the slot again
         wait_cyc += W::tick() - c0;
         return true;
     }
     NLZM_HD void edge_leave(int k)
     {
-        if (W::lane() == 0) { G.persist->prof[k] += wait_cyc; G.persist->prof[k + 1] += W::tick() - role_t0; }
+        if (W::lane() == 0) {
+            G.persist->prof[k] += wait_cyc; G.persist->prof[k + 1] += W::tick() - role_t0;
+#ifdef NLZM_PROFILE
+            // latency from the parser's post of a node to: list written (24: sampled, 26/28: rep) / apply started, done (22)
+            G.persist->prof[32 + (k == 22 ? 0 : (k == 24 ? 1 : (k == 26 ? 2 : 3)))] += lat_sum;
+            if (k == 22) G.persist->prof[36] += lat_sum2;
+#endif
+        }
     }
 
     // E1a: sampled lengths tl_k = max_len - k*step while >= 2 (:1558-1562), one lane per length
@@ -1337,7 +1346,7 @@ struct Master {
         uint32_t next = a_first;
         for (;;) {
             typename W::Rec rq;
-            if (!edge_wait(rq, next, &W::lds()->x_spos, false)) { edge_leave(24); return; }
+            if (!edge_wait(rq, next, false)) { edge_leave(24); return; }
             const uint32_t slot = next & 1u;
             const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
             const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
@@ -1378,10 +1387,13 @@ struct Master {
                               (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
                 }
             }
-            W::lds()->ea_checked[slot] = checked;
+            W::lds()->eb[slot * 16 + 8] = checked;
             W::sync();
             next++;
-            W::xw_store(&W::lds()->x_eadone, next);
+            W::xw_store(&W::lds()->post[0][20], next);
+#ifdef NLZM_PROFILE
+            lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
+#endif
         }
     }
 
@@ -1395,7 +1407,7 @@ struct Master {
         uint32_t next = a_first + ((a_first ^ parity) & 1u);
         for (;;) {
             typename W::Rec rq;
-            if (!edge_wait(rq, next, &W::lds()->x_spos, false)) { edge_leave(parity ? 28 : 26); return; }
+            if (!edge_wait(rq, next, false)) { edge_leave(parity ? 28 : 26); return; }
             const uint32_t slot = parity;
             const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
             const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
@@ -1413,12 +1425,15 @@ struct Master {
                     w = l | (1u << 31);
                     if (l >= match_min(d)) { w |= 1u << 30; c = cost_p + W::uni(pc_rep + price_len(l - match_min(d)) + (2u << 5)); }
                 }
-                W::lds()->eb[slot * 8 + 2 * k] = w; W::lds()->eb[slot * 8 + 2 * k + 1] = c;
+                W::lds()->eb[slot * 16 + 2 * k] = w; W::lds()->eb[slot * 16 + 2 * k + 1] = c;
             };
             probe(0, rp0, rep_len[0]); probe(1, rp1, rep_len[1]); probe(2, rp2, rep_len[2]); probe(3, rp3, rep_len[3]);
             W::sync();
             next += 2;
-            W::xw_store(&W::lds()->x_ebdone[parity], next - 1);      // positions of this parity < next - 1 are listed
+            W::xw_store(&W::lds()->post[0][21 + parity], next - 1);      // positions of this parity < next - 1 are listed
+#ifdef NLZM_PROFILE
+            lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
+#endif
         }
     }
 
@@ -1429,12 +1444,17 @@ struct Master {
         uint32_t next = a_first, end_p = 1;
         for (;;) {
             typename W::Rec rq;
-            if (!edge_wait(rq, next, &W::lds()->x_eadone, true)) { edge_leave(22); return; }
+            if (!edge_wait(rq, next, true)) { edge_leave(22); return; }
+#ifdef NLZM_PROFILE
+            lat_sum2 += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
+#endif
             const uint32_t slot = next & 1u;
             const uint32_t p = W::rec_get(rq, 5);
             const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
             const uint32_t max_len = W::rec_get(rq, 11);
             if (p == 0) end_p = 1;
+            // both lists are written: the probe list and the `checked` mask with one read, next to the lane's own entry
+            const typename W::Rec rb = W::rec_load_fn32([=](uint32_t i) { return W::lds()->eb[slot * 16 + (i & 15u)]; });
             if (max_len) {
                 open_nodes(end_p, max_len + p);                     // :1550-1554
                 // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into one
@@ -1462,10 +1482,8 @@ struct Master {
                 W::sync();
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
-            if (!wait_ge(&W::lds()->x_ebdone[next & 1u], next + 1)) { edge_leave(22); return; }
-            const uint32_t checked = W::uni(W::lds()->ea_checked[slot]);
+            const uint32_t checked = W::rec_get(rb, 8);
             if (checked != 15) {
-                const typename W::Rec rb = W::rec_load_fn([=](uint32_t i) { return W::lds()->eb[slot * 8 + i]; });
                 uint32_t csum = 0;
                 auto probe = [&](uint32_t k, uint32_t d) {
                     const uint32_t w = W::rec_get(rb, 2 * k);
@@ -1486,6 +1504,9 @@ struct Master {
             W::sync();
             next++;
             W::xw_store(&W::lds()->x_sdone, next);
+#ifdef NLZM_PROFILE
+            lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
+#endif
         }
     }
 
@@ -1522,49 +1543,62 @@ struct Master {
                 return i == 0 ? W::lds()->node_cost[pp] : W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)];
             });
         };
+        // hand-off header and input byte of position x (kept: the position after a segment's last node is the next
+        // segment's first)
+        auto table_head = [&](uint32_t x, uint32_t &hdr, uint32_t &lit) -> bool {
+            if (th_a != x) {
+                if (!wait_ge(&W::lds()->x_apos, x + 1)) return false;
+                const typename W::Rec hrec = W::rec_load(W::lds()->er_tab + (x & (kEr - 1)) * 64);
+                th_a = x; th_hdr = W::rec_get(hrec, 0); th_lit = W::rec_get(hrec, 1);
+            }
+            hdr = th_hdr; lit = th_lit;
+            return true;
+        };
+        // the command prices of this segment, for the list waves
+        for (uint32_t i = W::lane(); i < 4; i += W::width()) W::lds()->post[i >> 1][2 + (i & 1u)] = ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)];
         W::sync();
         W::xw_store(&W::lds()->x_bcover, seg_a + 1);
         typename W::Rec nrec = node_read(0);
-        for (;;) {                                                  // p < end_p
+        uint32_t hdr = 0, lit = 0, cst_lit = 0;
+        if (table_head(seg_a, hdr, lit)) cst_lit = price_literal(lit);
+        while (!err) {                                              // p < end_p
             const uint32_t q = seg_q + p, a = seg_a + p;
             n_pos++;
             const uint32_t cost_p = W::rec_get(nrec, 0);
             uint32_t rp[4];
             for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
-
-            // the table wave's result for this position
-            if (!wait_ge(&W::lds()->x_apos, a + 1)) break;
-            const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
-            const typename W::Rec hrec = W::rec_load(e);
-            const uint32_t hdr = W::rec_get(hrec, 0), tmax = hdr & 0xFFFFu;
-
-            uint32_t max_len = umin(tmax, max_parse - p);           // :1545-1548
+            uint32_t max_len = umin(hdr & 0xFFFFu, max_parse - p);  // :1545-1548
             if (max_len < kMatchMin) max_len = 0;
             if (max_len) seg_tables();
-            {   // node p is final: its match and rep edges go to the edge wave (slot a & 1 is free: node p-2 is settled)
-                uint32_t *r = W::lds()->sq_req + (a & 1u) * 16;
+            {   // node p is final: its match and rep edges go to the edge waves (slot a & 1 is free: node p-2 is settled)
+                uint32_t *r = W::lds()->post[a & 1u] + 4;
                 r[0] = a; r[1] = p; r[2] = cost_p; r[3] = rp[0]; r[4] = rp[1]; r[5] = rp[2]; r[6] = rp[3];
                 r[7] = max_len; r[9] = hdr; r[10] = q; r[11] = umin(max_parse - p, kMatchMax);
+#ifdef NLZM_PROFILE
+                r[8] = (uint32_t)W::tick();
+#endif
                 W::sync();
-                W::xw_store(&W::lds()->x_spos, a + 1);
+                W::xw_store(&W::lds()->post[a & 1u][0], a + 1);
             }
             if (max_len && p + max_len > end_p) { end_p = p + max_len; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
             const uint32_t pend_long_next = (hdr >> 16) ? 1u : 0u;
+            // while the edge waves work on this node: the table header and the literal price of the next position
+            uint32_t hdr_n = 0, lit_n = 0, cst_n = 0;
+            if (p + 1 < max_parse) {
+                if (!table_head(a + 1, hdr_n, lit_n)) break;
+                cst_n = price_literal(lit_n);
+            }
             prof_mark(7);
             // node p+1 takes the edges of p-1 before the literal edge of p (the reference's order, strict '<')
             if (!settle(p, true)) break;
             pend_long += pend_long_next;
             prof_mark(8);
             // literal edge (:1490-1499)
-            {
-                const uint32_t lit = W::rec_get(hrec, 1);
-                const uint32_t cst = price_literal(lit);
-                if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst) {
-                    W::lds()->node_cost[p + 1] = cost_p + cst;
-                    W::lds()->node_delta[p + 1] = lit;              // the byte itself, for the emitter
-                    W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
-                    for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
-                }
+            if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst_lit) {
+                W::lds()->node_cost[p + 1] = cost_p + cst_lit;
+                W::lds()->node_delta[p + 1] = lit;                  // the byte itself, for the emitter
+                W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
+                for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
             }
             ++p;
             W::sync();
@@ -1574,7 +1608,8 @@ struct Master {
                 if (p >= end_p) break;
                 W::xw_store(&W::lds()->x_bpos, seg_a + p);
             }
-            nrec = node_read(p);                                    // p < end_p <= 4096
+            nrec = node_read(p);                                    // p < end_p <= max_parse <= 4096
+            hdr = hdr_n; lit = lit_n; cst_lit = cst_n;
             prof_mark(9);
         }
         if (!err) settle(p, false);
@@ -1671,7 +1706,7 @@ struct Master {
         for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
-        b_long = 0; seg_tab_dirty = true;
+        b_long = 0; seg_tab_dirty = true; th_a = kNone; th_hdr = 0; th_lit = 0;
         wait_cyc = 0; role_t0 = W::tick();
         counts_zero();
 #ifdef NLZM_PROFILE
@@ -1681,7 +1716,7 @@ struct Master {
         W::sync();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk_parser(ci);
-        W::xw_store(&W::lds()->x_spos, kNone);                      // the sampler wave may leave
+        W::xw_store(&W::lds()->post[0][0], kNone); W::xw_store(&W::lds()->post[1][0], kNone);    // the edge waves may leave
         const unsigned long long role_t1 = W::tick();
         // the finder wave has stored its part of the state and its counters
         for (uint32_t spins = 0; W::xw_load(&W::lds()->x_adone) < 2 && spins < (1u << 28); spins++) W::xw_pause();
@@ -1712,7 +1747,8 @@ struct Master {
         if (W::lane() == 0) {
             W::lds()->x_apos = a0; W::lds()->x_bpos = a0; W::lds()->x_bseg = a0; W::lds()->x_bcover = a0 + 1;
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
-            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->x_spos = a0; W::lds()->x_sdone = a0; W::lds()->x_eadone = a0; W::lds()->x_ebdone[0] = a0; W::lds()->x_ebdone[1] = a0;
+            W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->post[0][0] = a0; W::lds()->post[1][0] = a0; W::lds()->x_sdone = a0;
+            W::lds()->post[0][20] = a0; W::lds()->post[0][21] = a0; W::lds()->post[0][22] = a0;
         }
         (void)G;
     }

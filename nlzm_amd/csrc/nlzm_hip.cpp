@@ -379,8 +379,11 @@ int refresh_stats()
                 1e3 * P.cnt.stale_ht / n, 1e3 * P.cnt.stale_rk / n, 1e3 * P.cnt.bt_slow / n);
     }
     if (getenv("NLZM_PROFILE_PRINT")) {
+        const double n0 = (double)(P.cnt.positions ? P.cnt.positions : 1);
         fprintf(stderr, "waits: B on A %.1f cyc/pos, A on B (nice phase, ring space excluded) %.1f cyc/pos\n",
                 (double)P.prof[13] / (P.cnt.positions ? P.cnt.positions : 1), (double)P.prof[14] / (P.cnt.positions ? P.cnt.positions : 1));
+        fprintf(stderr, "latency from a node's post (cycles): sampled list %.0f, rep list %.0f / %.0f (per own node), apply starts %.0f, apply done %.0f\n",
+                P.prof[33] / n0, 2 * P.prof[34] / n0, 2 * P.prof[35] / n0, P.prof[36] / n0, P.prof[32] / n0);
         static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
                                          "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
         unsigned long long tot = 0;
