@@ -83,6 +83,7 @@ struct Counters {
     unsigned long long n_literal, n_dict, n_rep, rans_syms, bit_ops, frames, shifts;
     unsigned long long uncertain_positions;
     unsigned long long stale_ht, stale_rk, bt_slow;     // look-ahead slots that had to take the direct path (diagnostics)
+    unsigned long long guess_used, guess_late, guess_wrong;   // rep-list waves: guessed rep set right / not seen in time / wrong
 };
 
 // State that survives between launches (one per stream), in HBM.
@@ -201,6 +202,7 @@ struct MasterLds {
     //   2, 3   price words of the command context (symbols 0|1, 2|3) for this segment
     //   4..19  request: a, p, cost_p, rep set (4), max_len, (stamp), hand-off header, q, rep cap
     //   20..22 (block 0 only) list counts: x_eadone, x_ebdone[0], x_ebdone[1]
+    //   23     positions < this have a guessed rep set in words 24..28 (position, rep set): the node is not final yet
     alignas(128) uint32_t post[2][32];
     uint32_t sq_res[2];                     // per slot: end_p after the node's edges
     uint32_t x_sdone;                       // apply wave: the edges of positions < x_sdone are relaxed
@@ -1301,14 +1303,14 @@ struct Master {
     // The post block of a slot and the list counts with one LDS read (see MasterLds::post)
     NLZM_HD typename W::Rec edge_fetch(uint32_t slot)
     {
-        return W::rec_load_fn32([=](uint32_t i) { return W::lds()->post[i < 20 ? slot : 0][i]; });
+        return W::rec_load_fn32([=](uint32_t i) { return W::lds()->post[(i < 20 || i >= 23) ? slot : 0][i]; });   // 20..22: shared counts
     }
-    // wait until `next` is posted and, for the apply wave, listed by both list waves; false: leave
+    // wait until `next` is posted and, for the apply wave, its sampled edges are listed; false: leave
     NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, bool need_lists)
     {
         auto ready = [&](const typename W::Rec &r) {
             return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next &&
-                   (!need_lists || (W::rec_get(r, 20) > next && W::rec_get(r, (next & 1u) ? 22 : 21) > next));
+                   (!need_lists || W::rec_get(r, 20) > next);
         };
         rq = edge_fetch(next & 1u);
         if (ready(rq)) return true;
@@ -1405,18 +1407,62 @@ struct Master {
     {
         err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
         uint32_t next = a_first + ((a_first ^ parity) & 1u);
+        const uint32_t slot = parity;
+        // lengths measured for a guessed rep set of `next` (the parser's guess while the node was not final)
+        bool have_g = false;
+        uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, gl0 = 0, gl1 = 0, gl2 = 0, gl3 = 0;
         for (;;) {
-            typename W::Rec rq;
-            if (!edge_wait(rq, next, false)) { edge_leave(parity ? 28 : 26); return; }
-            const uint32_t slot = parity;
+            typename W::Rec rq = edge_fetch(slot);
+            bool posted = W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next;
+            if (!posted) {
+                const unsigned long long t0 = W::clock(), c0 = W::tick();
+                uint32_t spins = 0;
+                for (;;) {
+                    if (W::rec_get(rq, 0) == kNone) { edge_leave(parity ? 28 : 26); return; }
+                    if (!have_g && W::rec_get(rq, 23) > next && W::rec_get(rq, 24) == next) {
+                        // measure for the guess now: the memory round trip is over when the node is posted
+                        wait_cyc += W::tick() - c0;
+                        g0 = W::rec_get(rq, 25); g1 = W::rec_get(rq, 26); g2 = W::rec_get(rq, 27); g3 = W::rec_get(rq, 28);
+                        const typename W::RepPf gpf = W::rep_prefetch(G.in, g.n, next, g0, g1, g2, g3);
+                        uint32_t gl[4];
+                        W::rep_lengths(gpf, gl);
+                        gl0 = gl[0]; gl1 = gl[1]; gl2 = gl[2]; gl3 = gl[3];
+                        have_g = true;
+                    } else {
+                        if ((++spins & 63u) == 0) {
+                            if (W::xw_load(&W::lds()->x_err)) { edge_leave(parity ? 28 : 26); return; }
+                            if ((spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) { edge_leave(parity ? 28 : 26); return; }
+                        }
+                        W::xw_pause();
+                    }
+                    rq = edge_fetch(slot);
+                    if (W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next) break;
+                }
+                if (!have_g) wait_cyc += W::tick() - c0;
+            }
             const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
             const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
             const uint32_t q = W::rec_get(rq, 14), rep_cap = W::rec_get(rq, 15);
             const uint32_t pc_rep = W::rec_get(rq, 3) & 0xFFFFu;
-            // kRepPf bytes in front of each rep distance and at the position
-            const typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
-            uint32_t rep_len[4];
-            W::rep_lengths(rpf, rep_len);
+            uint32_t l0, l1, l2, l3;
+            if (have_g && g0 == rp0 && g1 == rp1 && g2 == rp2 && g3 == rp3) {
+                l0 = gl0; l1 = gl1; l2 = gl2; l3 = gl3;
+                W::cnt_add(&W::lds()->cnt.guess_used, 1);
+            } else {
+                W::cnt_add(have_g ? &W::lds()->cnt.guess_wrong : &W::lds()->cnt.guess_late, 1);
+                // kRepPf bytes in front of each rep distance and at the position
+                const typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
+                uint32_t rep_len[4];
+                W::rep_lengths(rpf, rep_len);
+                l0 = rep_len[0]; l1 = rep_len[1]; l2 = rep_len[2]; l3 = rep_len[3];
+#ifdef NLZM_SIM_COUNT
+                __atomic_fetch_add(&g_dbg[6], 1, __ATOMIC_RELAXED);
+#endif
+            }
+#ifdef NLZM_SIM_COUNT
+            __atomic_fetch_add(&g_dbg[7], 1, __ATOMIC_RELAXED);
+#endif
+            have_g = false;
             auto probe = [&](uint32_t k, uint32_t d, uint32_t l) {
                 uint32_t w = 0, c = 0;
                 if (d < q) {
@@ -1427,7 +1473,7 @@ struct Master {
                 }
                 W::lds()->eb[slot * 16 + 2 * k] = w; W::lds()->eb[slot * 16 + 2 * k + 1] = c;
             };
-            probe(0, rp0, rep_len[0]); probe(1, rp1, rep_len[1]); probe(2, rp2, rep_len[2]); probe(3, rp3, rep_len[3]);
+            probe(0, rp0, l0); probe(1, rp1, l1); probe(2, rp2, l2); probe(3, rp3, l3);
             W::sync();
             next += 2;
             W::xw_store(&W::lds()->post[0][21 + parity], next - 1);      // positions of this parity < next - 1 are listed
@@ -1453,8 +1499,6 @@ struct Master {
             const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
             const uint32_t max_len = W::rec_get(rq, 11);
             if (p == 0) end_p = 1;
-            // both lists are written: the probe list and the `checked` mask with one read, next to the lane's own entry
-            const typename W::Rec rb = W::rec_load_fn32([=](uint32_t i) { return W::lds()->eb[slot * 16 + (i & 15u)]; });
             if (max_len) {
                 open_nodes(end_p, max_len + p);                     // :1550-1554
                 // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into one
@@ -1482,6 +1526,8 @@ struct Master {
                 W::sync();
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
+            if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
+            const typename W::Rec rb = W::rec_load_fn32([=](uint32_t i) { return W::lds()->eb[slot * 16 + (i & 15u)]; });
             const uint32_t checked = W::rec_get(rb, 8);
             if (checked != 15) {
                 uint32_t csum = 0;
@@ -1538,9 +1584,11 @@ struct Master {
             return true;
         };
         // node p: cost and rep set with one LDS instruction
+        // (lanes 5..9: the same of node p+1 as it stands, for the guess below)
         auto node_read = [&](uint32_t pp) {
-            return W::rec_load_fn([=](uint32_t i) {
-                return i == 0 ? W::lds()->node_cost[pp] : W::lds()->reps[(pp & 511) * 4 + ((i - 1) & 3)];
+            return W::rec_load_fn32([=](uint32_t i) {
+                const uint32_t n = pp + (i >= 5 ? 1u : 0u), j = i >= 5 ? i - 5 : i;
+                return j == 0 ? W::lds()->node_cost[n] : W::lds()->reps[(n & 511) * 4 + ((j - 1) & 3)];
             });
         };
         // hand-off header and input byte of position x (kept: the position after a segment's last node is the next
@@ -1585,6 +1633,16 @@ struct Master {
             // while the edge waves work on this node: the table header and the literal price of the next position
             uint32_t hdr_n = 0, lit_n = 0, cst_n = 0;
             if (p + 1 < max_parse) {
+                // A guess of node p+1's rep set for its rep-list wave, so that the bytes are in when the node is
+                // final: the literal edge of p would win it (then the set is p's), or it keeps what it has.  Only
+                // a length-2 edge of p-1 can still prove the guess wrong (then the wave measures again).
+                const bool lit_wins = cost_p + cst_lit < W::rec_get(nrec, 5);
+                uint32_t *sp = W::lds()->post[(a + 1) & 1u] + 24;
+                sp[0] = a + 1;
+                sp[1] = lit_wins ? rp[0] : W::rec_get(nrec, 6); sp[2] = lit_wins ? rp[1] : W::rec_get(nrec, 7);
+                sp[3] = lit_wins ? rp[2] : W::rec_get(nrec, 8); sp[4] = lit_wins ? rp[3] : W::rec_get(nrec, 9);
+                W::sync();
+                W::xw_store(&W::lds()->post[(a + 1) & 1u][23], a + 2);
                 if (!table_head(a + 1, hdr_n, lit_n)) break;
                 cst_n = price_literal(lit_n);
             }
@@ -1749,6 +1807,7 @@ struct Master {
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
             W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->post[0][0] = a0; W::lds()->post[1][0] = a0; W::lds()->x_sdone = a0;
             W::lds()->post[0][20] = a0; W::lds()->post[0][21] = a0; W::lds()->post[0][22] = a0;
+            W::lds()->post[0][23] = a0; W::lds()->post[1][23] = a0;
         }
         (void)G;
     }

@@ -375,6 +375,8 @@ int refresh_stats()
                 P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[24] / n, P.prof[26] / n, P.prof[28] / n, P.prof[22] / n);
         fprintf(stderr, "HW_ID of the finder/table/parser/edge waves: %04llx %04llx %04llx %04llx (SIMD = bits 5:4)\n", P.prof[30] & 0xFFFF,
                 (P.prof[30] >> 16) & 0xFFFF, (P.prof[30] >> 32) & 0xFFFF, (P.prof[30] >> 48) & 0xFFFF);
+        fprintf(stderr, "rep-set guesses per 1000 nodes: used %.1f, late %.1f, wrong %.1f\n", 1e3 * P.cnt.guess_used / n, 1e3 * P.cnt.guess_late / n,
+                1e3 * P.cnt.guess_wrong / n);
         fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
                 1e3 * P.cnt.stale_ht / n, 1e3 * P.cnt.stale_rk / n, 1e3 * P.cnt.bt_slow / n);
     }

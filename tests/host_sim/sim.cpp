@@ -402,7 +402,7 @@ int main(int argc, char **argv)
         if (use_workers) wk.finish();
 #ifdef NLZM_SIM_COUNT
         fprintf(stderr, "dbg: long rep compares %llu (of %llu checks), relaxed rep probes %llu (of %llu nodes)\n", g_dbg[0], g_dbg[3], g_dbg[1], g_dbg[2]);
-        fprintf(stderr, "dbg: %llu positions in %llu runs\n", g_dbg[4], g_dbg[5]);
+        fprintf(stderr, "dbg: %llu positions in %llu runs; rep-set guesses missed %llu of %llu nodes\n", g_dbg[4], g_dbg[5], g_dbg[6], g_dbg[7]);
 #endif
         if (P.error) { printf("sim error %u (info %u)\n", P.error, P.error_info[0]); return 1; }
     }
