@@ -583,22 +583,12 @@ struct Master {
     // ---- symbol output (WriteRange/WriteBits + cdf_update) -------------------
     NLZM_HD void put_sym(uint32_t ctx, uint32_t y)
     {
-        // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279)
-        const uint32_t nsy = ctx_nsyms(ctx);
-        uint16_t *cell = W::lds()->cdf + ctx * kCdfStride;
-        const uint32_t start = W::uni(cell[y]), freq = W::uni(cell[y + 1]) - start;
+        // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279), then cdf_update (:348-382) and the
+        // price row of the context (:435-438); W::cdf_step does the three with two LDS round trips
+        uint32_t start, freq;
+        W::cdf_step(W::lds()->cdf + ctx * kCdfStride, W::lds()->price + ctx * 16, W::lds()->lut, ctx_nsyms(ctx), y, start, freq);
         fsyms[nsyms] = (freq << 16) + start;            // wave-uniform store: same address, same value in every lane
         nsyms++; num_ops++;
-        // cdf_update (:348-382): cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsyms;
-        // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsyms)   (:284-298)
-        W::sync();
-        for (uint32_t i = W::lane(); i < nsy; i += W::width()) {
-            const int mix = (i <= y) ? (int)i : (int)(16384 + i + (127 - nsy));
-            cell[i] = (uint16_t)(cell[i] + ((mix - (int)cell[i]) >> 7));
-        }
-        W::sync();
-        for (uint32_t i = W::lane(); i < nsy; i += W::width())
-            W::lds()->price[ctx * 16 + i] = W::lds()->lut[((uint32_t)cell[i + 1] - (uint32_t)cell[i]) >> 6];
         W::sync();
     }
     NLZM_HD void put_bits(uint32_t v, uint32_t nb)                  // :574-588
@@ -1575,8 +1565,24 @@ struct Master {
         // edges of every node < upto are relaxed: take over end_p, give the hand-off slots back
         auto settle = [&](uint32_t upto, bool publish) -> bool {
             if (settled >= upto) return true;
-            if (!wait_ge(&W::lds()->x_sdone, seg_a + upto)) return false;
-            const uint32_t se = W::xw_load(&W::lds()->sq_res[(seg_a + upto - 1) & 1u]);
+            // count and end_p words with one read (adjacent words: one pass, the count in the lowest lane)
+            auto fetch = [=]() { return W::rec_load_fn([=](uint32_t i) { return i == 0 ? W::lds()->x_sdone : W::lds()->sq_res[(i - 1) & 1u]; }); };
+            typename W::Rec sr = fetch();
+            if (W::rec_get(sr, 0) < seg_a + upto) {
+                const unsigned long long t0 = W::clock(), c0 = W::tick();
+                uint32_t spins = 0;
+                for (;;) {
+                    sr = fetch();
+                    if (W::rec_get(sr, 0) >= seg_a + upto) break;
+                    if ((++spins & 63u) == 0) {
+                        if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
+                        if ((spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, seg_a + upto); return false; }
+                    }
+                    W::xw_pause();
+                }
+                wait_cyc += W::tick() - c0;
+            }
+            const uint32_t se = W::rec_get(sr, 1 + ((seg_a + upto - 1) & 1u));
             if (se > end_p) { end_p = se; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
             settled = upto;
             if (pend_long) { b_long += pend_long; pend_long = 0; W::xw_store(&W::lds()->x_long_free, kErLong + b_long); }

@@ -37,6 +37,24 @@ struct DevWave {
         const uint32_t v = f(lane());
         if (lane() < n && v) (void)__hip_atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // One symbol through a nibble CDF (NLZM.cpp:348-382, 435-438): lane i holds cell[i] and cell[i+1]; the (start, freq)
+    // snapshot of symbol y is picked out of the registers, cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsy with
+    // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298), and the price row follows from the new cells.
+    static __device__ __forceinline__ void cdf_step(uint16_t *cell, uint16_t *price_row, const uint16_t *lut, uint32_t nsy, uint32_t y,
+                                                    uint32_t &start, uint32_t &freq)
+    {
+        const uint32_t i = lane();
+        uint32_t c0 = 0, c1 = 0;
+        if (i <= 16) { c0 = cell[i]; c1 = cell[i + 1]; }
+        start = (uint32_t)__builtin_amdgcn_readlane((int)c0, (int)y);
+        freq = (uint32_t)__builtin_amdgcn_readlane((int)c1, (int)y) - start;
+        auto upd = [=](uint32_t j, uint32_t c) {
+            const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
+            return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
+        };
+        const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
+        if (i < nsy) { cell[i] = (uint16_t)n0; price_row[i] = lut[(n1 - n0) >> 6]; }
+    }
     // value of lane l (wave-uniform l)
     static __device__ __forceinline__ uint32_t pick(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }

@@ -39,6 +39,15 @@ struct HostWave {
     template <class F>
     static void cnt_add_fn(unsigned long long *p, uint32_t n, F f) { for (uint32_t i = 0; i < n; i++) cnt_add(p, f(i)); }
     static uint32_t pick(uint32_t v, uint32_t) { return v; }
+    static void cdf_step(uint16_t *cell, uint16_t *price_row, const uint16_t *lut, uint32_t nsy, uint32_t y, uint32_t &start, uint32_t &freq)
+    {
+        start = cell[y]; freq = (uint32_t)cell[y + 1] - start;
+        for (uint32_t i = 0; i < nsy; i++) {
+            const int mix = (i <= y) ? (int)i : (int)(16384 + i + (127 - nsy));
+            cell[i] = (uint16_t)(cell[i] + ((mix - (int)cell[i]) >> 7));
+        }
+        for (uint32_t i = 0; i < nsy; i++) price_row[i] = lut[((uint32_t)cell[i + 1] - (uint32_t)cell[i]) >> 6];
+    }
     static void xw_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
     static uint32_t xw_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
     static void xw_add(uint32_t *p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
