@@ -45,6 +45,12 @@ def test_library_has_gfx950_code_object():
     assert b"pipeline_kernel" in blob and b"rans_frames_kernel" in blob and b"prefilter_hash_kernel" in blob
 
 
+def test_persistent_kernel_has_no_scratch_flat_or_calls():
+    """Any of them puts HBM latency into the serial half: checked in the gfx950 ISA."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "nlzm_amd", "csrc"), "asmcheck"], capture_output=True, text=True)
+    assert r.returncode == 0 and "asmcheck: ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_geometry_needs_no_device(lib):
     g = nlzm_amd.geometry(1_000_000_000, 28)
     assert g == {"hist_bits": 28, "frame_bits": 17, "chunk_size": 122368, "feed_size": 122633}
