@@ -130,6 +130,26 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
                         uint32_t frame_idx, uint32_t *syms, uint32_t cap_syms,
                         uint8_t *bits, uint32_t cap_bits, uint32_t *sizes_out);
 
+/* ---- independent blocks (the path's only shard axis) ---- */
+/* The reference has no block mode: k blocks = k runs of encode_file (NLZM.cpp:1711) on the byte ranges
+ * [i*ceil(n/k), min(n, (i+1)*ceil(n/k))), each with its own header, window, model and terminator; the streams are
+ * self-delimiting (frame headers carry sizes, :645-663; terminator :646-648) and are written back to back in block
+ * order.  On one GPU all k streams are in flight at once: a stream needs one CU for its serial half and ~15 CUs of
+ * BT4 worker lanes, so an MI355X holds up to 16.  d_src needs 128 readable bytes behind it.
+ * begin binds the input and allocates every stream's state, each step advances every stream by max_chunks chunks
+ * (0: to its end), finish appends the terminators and concatenates into d_dst. */
+int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req);
+int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms);
+int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
+void nlzm_hip_blocks_abandon(void);
+/* one-shot form */
+int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req,
+                                 void *d_dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
+
+/* same, host buffers */
+int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req,
+                             uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
+
 /* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
 /* key: "workers" (0 = BT4 inside the master workgroup, 1 = per-head worker
  * lanes, default 1), "batch_chunks" (chunks per persistent launch). */

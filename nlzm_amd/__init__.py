@@ -23,6 +23,8 @@ ABI_SYMBOLS = [
     "nlzm_hip_geometry", "nlzm_hip_compress", "nlzm_hip_compress_dev", "nlzm_hip_stream_begin",
     "nlzm_hip_stream_step", "nlzm_hip_stream_finish", "nlzm_hip_get_stats", "nlzm_hip_get_timing",
     "nlzm_hip_rans_frames", "nlzm_hip_find_matches", "nlzm_hip_parse_emit", "nlzm_hip_set_option",
+    "nlzm_hip_blocks_begin", "nlzm_hip_blocks_step", "nlzm_hip_blocks_finish", "nlzm_hip_blocks_abandon",
+    "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks",
 ]
 
 
@@ -91,6 +93,12 @@ def load_library() -> C.CDLL:
     lib.nlzm_hip_parse_emit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_uint32, C.c_void_p]
     lib.nlzm_hip_set_option.argtypes = [C.c_char_p, C.c_int64]
+    lib.nlzm_hip_blocks_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.nlzm_hip_blocks_step.argtypes = [C.c_uint32, u64p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    lib.nlzm_hip_blocks_finish.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p]
+    lib.nlzm_hip_blocks_abandon.restype = None
+    lib.nlzm_hip_compress_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
+    lib.nlzm_hip_compress_blocks_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
     _lib = lib
     return lib
 
@@ -129,6 +137,25 @@ def compress(data, hist_bits: int = 22) -> bytes:
     out_len = C.c_uint64(0)
     _chk(lib.nlzm_hip_compress(src.ctypes.data if n else None, n, hist_bits, dst.ctypes.data, cap, C.byref(out_len)))
     return dst[: out_len.value].tobytes()
+
+
+def compress_blocks(data, nblocks: int, hist_bits: int = 22) -> list[bytes]:
+    """k independent streams, all in flight on the one GPU (shard.block_range gives the byte ranges); the reference
+    equivalent is encode_file (NLZM.cpp:1711) run on each range."""
+    lib = load_library()
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    n = int(src.size)
+    cap = int(lib.nlzm_hip_compress_bound(n)) + nblocks * (16 + 131072)
+    dst = np.empty(cap, dtype=np.uint8)
+    lens = (C.c_uint64 * nblocks)()
+    out_len = C.c_uint64(0)
+    _chk(lib.nlzm_hip_compress_blocks(src.ctypes.data if n else None, n, nblocks, hist_bits, dst.ctypes.data, cap, lens, C.byref(out_len)))
+    out, pos = [], 0
+    for i in range(nblocks):
+        out.append(dst[pos: pos + int(lens[i])].tobytes())
+        pos += int(lens[i])
+    assert pos == out_len.value
+    return out
 
 
 def stats() -> dict:

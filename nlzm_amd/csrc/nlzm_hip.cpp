@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/nlzm_hip.h"
@@ -38,8 +40,10 @@ using namespace nlzm;
 namespace {
 
 char g_err[512] = "";
+std::mutex g_err_mu;            // block streams run on host threads
 int set_err(int code, const char *fmt, ...)
 {
+    std::lock_guard<std::mutex> lk(g_err_mu);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
@@ -55,6 +59,8 @@ int set_err(int code, const char *fmt, ...)
                            "%s failed: %s", #expr, hipGetErrorString(e_));                        \
     } while (0)
 
+void blocks_close();         // defined with the block-set entry points
+
 inline uint32_t clampu(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct Ctx {
@@ -67,6 +73,7 @@ struct Ctx {
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
     int64_t opt_worker_blocks = 240;        // + the master block: below the 256 CUs, one 512-thread block per CU
+
 
     // stream state
     bool open = false;
@@ -108,9 +115,9 @@ struct Ctx {
     unsigned long long last_dry_runs = 0, last_flag_waits = 0;
 };
 
-Ctx C;
+Ctx g_ctx;                  // the context behind the single-stream entry points
 
-void free_stream_buffers()
+void free_stream_buffers(Ctx &C)
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
@@ -142,7 +149,7 @@ void make_geom(uint64_t n, uint32_t hist_bits_req, Geom &g)
     g.bt_tmask = g.wmask;       // widened by stream_begin once the launch size is known
 }
 
-int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
+int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
 {
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if (n >= 0xFFFF0000ull) return set_err(NLZM_HIP_E_TOOBIG, "input of %llu bytes needs >32-bit positions", (unsigned long long)n);
@@ -151,7 +158,7 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
     {   // keep caller-visible buffers of a host-entry call alive across the reset
         uint8_t *oi = C.own_in, *od = C.own_dst;
         C.own_in = C.own_dst = nullptr;
-        free_stream_buffers();
+        free_stream_buffers(C);
         C.own_in = oi; C.own_dst = od;
     }
     make_geom(n, hist_bits_req, C.g);
@@ -247,7 +254,7 @@ int stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_
     return 0;
 }
 
-int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
+int stream_step(Ctx &C, uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
 {
     if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
     const Geom &g = C.g;
@@ -358,7 +365,7 @@ int stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int 
     return 0;
 }
 
-int refresh_stats()
+int refresh_stats(Ctx &C)
 {
     Persist P;
     HIPCHK(hipMemcpy(&P, C.persist, sizeof P, hipMemcpyDeviceToHost));
@@ -402,7 +409,7 @@ int refresh_stats()
     return 0;
 }
 
-int stream_finish(uint64_t *dst_len)
+int stream_finish(Ctx &C, uint64_t *dst_len)
 {
     if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
     if (C.next_chunk < C.g.nchunks) return set_err(NLZM_HIP_E_ARG, "stream not finished (%u of %u chunks)", C.next_chunk, C.g.nchunks);
@@ -410,7 +417,7 @@ int stream_finish(uint64_t *dst_len)
     HIPCHK(hipMemsetAsync(C.d_dst + C.out_pos, 0, 4, C.st));        // terminator (:1891-1895)
     C.out_pos += 4;
     HIPCHK(hipStreamSynchronize(C.st));
-    const int rc = refresh_stats();
+    const int rc = refresh_stats(C);
     if (rc) return rc;
     if (dst_len) *dst_len = C.out_pos;
     return 0;
@@ -422,6 +429,7 @@ extern "C" {
 
 int nlzm_hip_init(int device)
 {
+    Ctx &C = g_ctx;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return set_err(NLZM_HIP_E_NODEVICE, "no HIP device (%s)", hipGetErrorString(e));
@@ -442,8 +450,10 @@ int nlzm_hip_init(int device)
 
 void nlzm_hip_shutdown(void)
 {
+    Ctx &C = g_ctx;
     if (!C.inited) return;
-    free_stream_buffers();
+    blocks_close();
+    free_stream_buffers(C);
     if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
     if (C.cap_used) { (void)hipFree(C.cap_used); C.cap_used = nullptr; }
     for (auto &ev : C.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
@@ -472,29 +482,31 @@ void nlzm_hip_geometry(uint64_t flen, uint32_t hist_bits_req, uint32_t *hist_bit
 
 int nlzm_hip_stream_begin(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap)
 {
+    Ctx &C = g_ctx;
     if (C.own_in) { (void)hipFree(C.own_in); C.own_in = nullptr; }
     if (C.own_dst) { (void)hipFree(C.own_dst); C.own_dst = nullptr; }
-    return stream_begin(d_src, n, hist_bits_req, d_dst, dst_cap);
+    return stream_begin(C, d_src, n, hist_bits_req, d_dst, dst_cap);
 }
 int nlzm_hip_stream_step(uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
 {
-    return stream_step(max_chunks, in_done, out_done, finished);
+    return stream_step(g_ctx, max_chunks, in_done, out_done, finished);
 }
-int nlzm_hip_stream_finish(uint64_t *dst_len) { return stream_finish(dst_len); }
+int nlzm_hip_stream_finish(uint64_t *dst_len) { return stream_finish(g_ctx, dst_len); }
 
 int nlzm_hip_compress_dev(const void *d_src, uint64_t n, uint32_t hist_bits_req, void *d_dst, uint64_t dst_cap,
                           uint64_t *dst_len)
 {
     int rc = nlzm_hip_stream_begin(d_src, n, hist_bits_req, d_dst, dst_cap);
     if (rc) return rc;
-    rc = stream_step(0, nullptr, nullptr, nullptr);
+    rc = stream_step(g_ctx, 0, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    return stream_finish(dst_len);
+    return stream_finish(g_ctx, dst_len);
 }
 
 int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint8_t *dst, uint64_t dst_cap,
                       uint64_t *dst_len)
 {
+    Ctx &C = g_ctx;
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if ((!src && n) || !dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
     if (n >= 0xFFFF0000ull) return set_err(NLZM_HIP_E_TOOBIG, "input too large");
@@ -510,12 +522,12 @@ int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, ui
     HIPCHK(hipStreamSynchronize(C.st));
     float h2d = 0;
     HIPCHK(hipEventElapsedTime(&h2d, C.ev[5], C.ev[6]));
-    int rc = stream_begin(C.own_in, n, hist_bits_req, C.own_dst, bound);
+    int rc = stream_begin(C, C.own_in, n, hist_bits_req, C.own_dst, bound);
     if (rc) return rc;
-    rc = stream_step(0, nullptr, nullptr, nullptr);
+    rc = stream_step(C, 0, nullptr, nullptr, nullptr);
     if (rc) return rc;
     uint64_t len = 0;
-    rc = stream_finish(&len);
+    rc = stream_finish(C, &len);
     if (rc) return rc;
     if (len > dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "stream is %llu bytes, dst_cap %llu", (unsigned long long)len, (unsigned long long)dst_cap);
     HIPCHK(hipEventRecord(C.ev[5], C.st));
@@ -531,14 +543,16 @@ int nlzm_hip_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, ui
 
 int nlzm_hip_get_stats(nlzm_hip_stats *out)
 {
+    Ctx &C = g_ctx;
     if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
-    if (C.open) { const int rc = refresh_stats(); if (rc) return rc; }
+    if (C.open) { const int rc = refresh_stats(C); if (rc) return rc; }
     *out = C.stats;
     return 0;
 }
 
 int nlzm_hip_get_timing(nlzm_hip_timing *out)
 {
+    Ctx &C = g_ctx;
     if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
     *out = C.tm;
     return 0;
@@ -546,6 +560,7 @@ int nlzm_hip_get_timing(nlzm_hip_timing *out)
 
 int nlzm_hip_set_option(const char *key, int64_t value)
 {
+    Ctx &C = g_ctx;
     if (!key) return set_err(NLZM_HIP_E_ARG, "null key");
     if (!strcmp(key, "workers")) { C.opt_workers = value; return 0; }
     if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
@@ -556,6 +571,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
 int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off, const uint8_t *bits, const uint64_t *bits_off,
                          const uint32_t *num_ops, uint32_t nframes, uint8_t *out, uint64_t out_stride, uint32_t *out_len)
 {
+    Ctx &C = g_ctx;
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if (!nframes) return 0;
     if (!syms || !sym_off || !bits || !bits_off || !num_ops || !out || !out_len) return set_err(NLZM_HIP_E_ARG, "null argument");
@@ -596,6 +612,7 @@ int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off, const ui
 int nlzm_hip_find_matches(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint64_t pos_lo, uint64_t pos_hi,
                           uint32_t *out_words, uint64_t cap_words, uint64_t *used_words)
 {
+    Ctx &C = g_ctx;
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if (!out_words || !used_words) return set_err(NLZM_HIP_E_ARG, "null argument");
     if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
@@ -622,6 +639,7 @@ int nlzm_hip_find_matches(const uint8_t *src, uint64_t n, uint32_t hist_bits_req
 int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, uint32_t frame_idx, uint32_t *syms,
                         uint32_t cap_syms, uint8_t *bits, uint32_t cap_bits, uint32_t *sizes_out)
 {
+    Ctx &C = g_ctx;
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if (!syms || !bits || !sizes_out) return set_err(NLZM_HIP_E_ARG, "null argument");
     C.want_frame = frame_idx; C.got = false;
@@ -637,6 +655,189 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, 
     memcpy(bits, C.got_bits.data(), C.got_meta.nbits_bytes);
     sizes_out[0] = C.got_meta.nsyms; sizes_out[1] = C.got_meta.nbits_bytes; sizes_out[2] = C.got_meta.num_ops;
     return 0;
+}
+
+}  // extern "C"
+
+// ---- independent blocks --------------------------------------------------------------
+namespace {
+
+struct BlockJob {
+    Ctx c;
+    uint64_t lo = 0, n = 0, len = 0, bound = 0;
+    uint8_t *d_out = nullptr;
+    int rc = 0;
+};
+
+int block_ctx_init(Ctx &c, int device, int64_t worker_blocks, int64_t batch)
+{
+    c.device = device;
+    c.opt_workers = 1; c.opt_worker_blocks = worker_blocks; c.opt_batch = batch;
+    HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+    for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
+    c.inited = true;
+    return 0;
+}
+void block_ctx_destroy(Ctx &c)
+{
+    free_stream_buffers(c);
+    for (auto &ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (c.st) { (void)hipStreamDestroy(c.st); c.st = nullptr; }
+    c.inited = false;
+}
+
+}  // namespace
+
+namespace {
+std::vector<BlockJob> g_jobs;       // the open block set (nlzm_hip_blocks_begin .. _end)
+uint64_t g_blocks_n = 0;
+const uint8_t *g_blocks_src = nullptr;
+uint32_t g_blocks_hist = 0;
+int64_t g_blocks_wb = 0;
+
+void blocks_close()
+{
+    for (auto &j : g_jobs) { if (j.d_out) (void)hipFree(j.d_out); j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
+    g_jobs.clear();
+}
+
+// run f(block) for every open block, `conc` at a time, each on a host thread of its own
+template <class F>
+void for_blocks(uint32_t conc, F f)
+{
+    const int device = g_ctx.device;
+    std::mutex mu;
+    uint32_t next_block = 0;
+    auto worker = [&]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            uint32_t i;
+            { std::lock_guard<std::mutex> lk(mu); if (next_block >= g_jobs.size()) return; i = next_block++; }
+            f(i, g_jobs[i]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < conc; t++) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
+extern "C" {
+
+int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req)
+{
+    Ctx &C = g_ctx;
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (!nblocks || nblocks > 64) return set_err(NLZM_HIP_E_ARG, "nblocks out of range");
+    blocks_close();
+    // every block is in flight at once: one master CU + its worker CUs per stream, all resident together
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, C.device));
+    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - 1 - (nblocks > 1 ? 1 : 0);
+    if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;
+    if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs", nblocks, prop.multiProcessorCount);
+    g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
+    const uint64_t per = (n + nblocks - 1) / nblocks;              // block i = [i*per, min(n, (i+1)*per))
+    g_jobs.resize(nblocks);
+    for (uint32_t i = 0; i < nblocks; i++) {
+        g_jobs[i].lo = (uint64_t)i * per < n ? (uint64_t)i * per : n;
+        const uint64_t hi = (uint64_t)(i + 1) * per < n ? (uint64_t)(i + 1) * per : n;
+        g_jobs[i].n = hi - g_jobs[i].lo;
+        g_jobs[i].bound = nlzm_hip_compress_bound(g_jobs[i].n);
+    }
+    const int device = C.device;
+    const int64_t batch = C.opt_batch;
+    for_blocks(nblocks, [&](uint32_t i, BlockJob &j) {
+        j.rc = block_ctx_init(j.c, device, wb, batch);
+        if (!j.rc && hipMalloc(&j.d_out, j.bound) != hipSuccess) j.rc = set_err(NLZM_HIP_E_NOMEM, "block %u: output buffer", i);
+        if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
+    });
+    for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
+    return 0;
+}
+
+int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms)
+{
+    Ctx &C = g_ctx;
+    if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
+    hipEvent_t e0 = C.ev[5], e1 = C.ev[6];
+    HIPCHK(hipEventRecord(e0, C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    std::vector<uint64_t> done(g_jobs.size(), 0);
+    std::vector<int> fin(g_jobs.size(), 0);
+    for_blocks((uint32_t)g_jobs.size(), [&](uint32_t i, BlockJob &j) {
+        if (j.c.next_chunk >= j.c.g.nchunks) { fin[i] = 1; done[i] = j.n; return; }
+        j.rc = stream_step(j.c, max_chunks_per_block, &done[i], nullptr, &fin[i]);
+    });
+    HIPCHK(hipEventRecord(e1, C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (device_ms) *device_ms = ms;
+    uint64_t tot = 0; int all = 1;
+    for (size_t i = 0; i < g_jobs.size(); i++) { if (g_jobs[i].rc) return g_jobs[i].rc; tot += done[i]; all &= fin[i]; }
+    if (in_done_total) *in_done_total = tot;
+    if (finished) *finished = all;
+    return 0;
+}
+
+int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len)
+{
+    Ctx &C = g_ctx;
+    if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
+    if (!d_dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
+    for_blocks((uint32_t)g_jobs.size(), [&](uint32_t, BlockJob &j) { j.rc = stream_finish(j.c, &j.len); });
+    int rc = 0;
+    uint64_t pos = 0;
+    memset(&C.stats, 0, sizeof C.stats);
+    for (size_t i = 0; i < g_jobs.size() && !rc; i++) {
+        BlockJob &j = g_jobs[i];
+        if (j.rc) { rc = j.rc; break; }
+        if (pos + j.len > dst_cap) { rc = set_err(NLZM_HIP_E_CAPACITY, "dst_cap %llu too small", (unsigned long long)dst_cap); break; }
+        if (hipMemcpyAsync((uint8_t *)d_dst + pos, j.d_out, j.len, hipMemcpyDeviceToDevice, C.st) != hipSuccess)
+            rc = set_err(NLZM_HIP_E_NODEVICE, "gathering block %zu failed", i);
+        if (block_len) block_len[i] = j.len;
+        pos += j.len;
+        uint64_t *dst = (uint64_t *)&C.stats; const uint64_t *src = (const uint64_t *)&j.c.stats;   // counters of the whole job
+        for (size_t k = 0; k < sizeof(C.stats) / 8; k++) dst[k] += src[k];
+    }
+    (void)hipStreamSynchronize(C.st);
+    blocks_close();
+    if (!rc) *dst_len = pos;
+    return rc;
+}
+
+void nlzm_hip_blocks_abandon(void) { blocks_close(); }
+
+int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req, void *d_dst,
+                                 uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len)
+{
+    int rc = nlzm_hip_blocks_begin(d_src, n, nblocks, hist_bits_req);
+    if (rc) return rc;
+    rc = nlzm_hip_blocks_step(0, nullptr, nullptr, nullptr);
+    if (rc) { blocks_close(); return rc; }
+    return nlzm_hip_blocks_finish(d_dst, dst_cap, block_len, dst_len);
+}
+
+int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req, uint8_t *dst,
+                             uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len)
+{
+    Ctx &C = g_ctx;
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if ((!src && n) || !dst || !dst_len || !nblocks) return set_err(NLZM_HIP_E_ARG, "null argument");
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    const uint64_t bound = nlzm_hip_compress_bound(n) + (uint64_t)nblocks * (16 + 131072);
+    HIPCHK(hipMalloc(&d_in, n + 512));
+    if (hipMalloc(&d_out, bound) != hipSuccess) { (void)hipFree(d_in); return set_err(NLZM_HIP_E_NOMEM, "output buffer"); }
+    (void)hipMemset(d_in + n, 0, 512);
+    if (n) (void)hipMemcpy(d_in, src, n, hipMemcpyHostToDevice);
+    uint64_t len = 0;
+    int rc = nlzm_hip_compress_blocks_dev(d_in, n, nblocks, hist_bits_req, d_out, bound, block_len, &len);
+    if (!rc && len > dst_cap) rc = set_err(NLZM_HIP_E_CAPACITY, "streams are %llu bytes, dst_cap %llu", (unsigned long long)len, (unsigned long long)dst_cap);
+    if (!rc && hipMemcpy(dst, d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = set_err(NLZM_HIP_E_NODEVICE, "copy back failed");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (!rc) *dst_len = len;
+    return rc;
 }
 
 }  // extern "C"

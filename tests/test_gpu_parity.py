@@ -115,6 +115,20 @@ def test_large_window_properties(gpu):
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(oracle_py.compress(data, 28)).hexdigest()
 
 
+@pytest.mark.parametrize("nblocks,hb", [(4, 20), (8, 16), (16, 22)])
+def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
+    """Block mode on ONE GPU: every block's stream is compressed at the same time (one master CU + worker CUs each)
+    and equals what the oracle gives for that byte range alone (the reference: encode_file per block)."""
+    from nlzm_amd import shard
+    data = corpus.mixed(1_500_000, corpus.SEED + 5)
+    got = gpu.compress_blocks(data, nblocks, hb)
+    assert len(got) == nblocks
+    for i, stream in enumerate(got):
+        lo, hi = shard.block_range(data.size, nblocks, i)
+        assert stream == oracle_py.compress(data[lo:hi], hb), f"block {i}"
+    assert shard.split_streams(b"".join(got)) == got
+
+
 def test_blocks_of_a_sharded_run(gpu):
     """k-way split: each block is an independent stream identical to the oracle's."""
     from nlzm_amd import shard
