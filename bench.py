@@ -22,6 +22,9 @@ The JSON line also carries:
                 with HIP events on the library's stream
   cpu_baseline  the reference itself (oracle/_ref/nlzm_ref, built from /root/reference at build time) or, if
                 that binary is absent, the oracle port, timed on a bounded sample of the same workload
+  blocks        (N = 1) the same stream split into --block-streams independent blocks, all in flight on the one
+                GPU: the path's only shard axis used inside a GPU.  A second measurement next to
+                `value`, never part of it (the streams differ from the single-stream output).
 """
 from __future__ import annotations
 
@@ -34,7 +37,11 @@ import sys
 import tempfile
 import time
 
-import numpy as np
+# Block mode runs more than one persistent launch at a time; the HIP runtime maps streams onto 4 hardware queues by
+# default, which would serialise them (must be set before the runtime starts, i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -76,6 +83,44 @@ def cpu_baseline(sample: np.ndarray) -> dict:
             "seconds": round(dt, 2), "host_cores_present": os.cpu_count()}
 
 
+def blocks_leg(lib, torch, dev, k: int, B: int, steps: int, warmup: int) -> dict:
+    """The path's shard axis on ONE GPU: the stream split into k independent blocks, every block's
+    NLZM stream in flight at once (one master CU + its worker CUs each, shared persistent launches).  Reported next
+    to the headline value, never instead of it: the bytes differ from the single-stream output (each block equals
+    the reference run on that block, tests/test_gpu_parity.py::test_blocks_in_flight_on_one_gpu)."""
+    per = -(-STREAM_BYTES // k)
+    need = min(per, (steps + warmup) * B * CHUNK + (1 << 20))
+    d_in = torch.zeros(STREAM_BYTES + 4096, dtype=torch.uint8, device=dev)
+    for i in range(k):      # only the prefix of each block is read by the timed rounds
+        lo = min(STREAM_BYTES, i * per)
+        m = min(need, STREAM_BYTES - lo)
+        d_in[lo:lo + m].copy_(torch.from_numpy(corpus.syn_text(m, corpus.SEED + 100 + i)))
+    torch.cuda.synchronize()
+    rc = lib.nlzm_hip_blocks_begin(d_in.data_ptr(), STREAM_BYTES, k, WINDOW)
+    if rc:
+        return {"streams": k, "error": lib.nlzm_hip_last_error().decode()}
+    done, fin, ms = C.c_uint64(0), C.c_int(0), C.c_double(0)
+    try:
+        for _ in range(warmup):
+            if lib.nlzm_hip_blocks_step(B, C.byref(done), C.byref(fin), C.byref(ms)):
+                return {"streams": k, "error": lib.nlzm_hip_last_error().decode()}
+        d0 = done.value
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if lib.nlzm_hip_blocks_step(B, C.byref(done), C.byref(fin), C.byref(ms)):
+                return {"streams": k, "error": lib.nlzm_hip_last_error().decode()}
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        lib.nlzm_hip_blocks_abandon()
+    geo = nlzm_amd.geometry(per, WINDOW)
+    return {"streams": k, "value": round((done.value - d0) / 1e6 / dt, 4), "unit": "MB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / max(1, steps), 2), "bytes_timed": int(done.value - d0),
+            "workload": f"{STREAM_BYTES} B stand-in split into {k} independent blocks of {per} B (-window:{WINDOW} auto-shrinks to "
+                        f"{geo['hist_bits']}), all in flight on one GPU; step = {B} chunks of every block"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +130,8 @@ def main():
     ap.add_argument("--full", action="store_true", help="compress the whole stream (steps = all batches, warmup 0)")
     ap.add_argument("--cpu-sample-mb", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--block-streams", type=int, default=16,
+                    help="N=1 only: also time the independent-block mode with this many streams in flight on the GPU (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -221,6 +268,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline(host[:sample_n])
         else:
             res["cpu_baseline"] = None
+        if world == 1 and args.block_streams > 0 and not args.full:
+            del d_in, d_out
+            torch.cuda.empty_cache()
+            res["blocks"] = blocks_leg(lib, torch, dev, args.block_streams, B, args.steps, args.warmup)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -13,6 +13,10 @@ import subprocess
 
 import numpy as np
 
+# block mode keeps several persistent launches in flight; the HIP runtime's default of 4 hardware queues would serialise
+# them (only effective if the runtime has not started yet)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NLZM_LIB", os.path.join(_HERE, "libnlzm_hip.so"))     # override: diagnostic builds only
 CLI_PATH = os.path.join(_HERE, "nlzm")

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -24,6 +25,10 @@ namespace nlzm {
 void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long pos0, unsigned long long pos1,
                     uint32_t *out, hipStream_t st);
 void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
+unsigned long long stream_pack_size();
+uint32_t stream_pack_capacity();
+void fill_stream_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, uint32_t c0, uint32_t c1);
+void launch_pipeline_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
@@ -254,107 +259,129 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     return 0;
 }
 
+// One launch's worth of a stream, in three parts so that several streams can share ONE persistent launch:
+//   step_pre   pre-pass kernels and the hand-off arrays of chunks [c0, c1) on the stream's own HIP stream
+//   (launch)   pipeline_kernel for this stream alone, or pipeline_multi_kernel for a group of streams
+//   step_post  frame coder, frame lengths back to the host, checks, gather into the output
+struct StepPlan { uint32_t c0 = 0, c1 = 0, nb = 0; Globals G; };
+
+int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
+{
+    const Geom &g = C.g;
+    const uint32_t c0 = C.next_chunk, nb = todo < C.batch ? todo : C.batch, c1 = c0 + nb;
+    P.c0 = c0; P.c1 = c1; P.nb = nb;
+    Globals &G = P.G;
+    memset(&G, 0, sizeof G);
+    G.in = C.d_in; G.rkhash = C.rkhash; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
+    G.bt_heads = C.bt_heads; G.bt_tree = C.bt_tree; G.persist = C.persist;
+    G.syms = C.syms; G.syms_stride = C.syms_stride; G.bits = C.bits; G.bits_stride = C.bits_stride;
+    G.fmeta = C.fmeta; G.chunk0 = c0;
+    G.cap_words = C.cap_words; G.cap_cap = C.cap_cap; G.cap_lo = C.cap_lo; G.cap_hi = C.cap_hi; G.cap_used = C.cap_used;
+    G.workers = C.workers ? 1 : 0;
+    const unsigned long long a0 = (unsigned long long)c0 * g.chunk_size;
+    unsigned long long a1 = (unsigned long long)c1 * g.chunk_size;
+    if (a1 > g.n) a1 = g.n;
+    G.batch_a0 = (uint32_t)a0;
+    {   // pre-pass: RK256 hash of every window the launch can touch (catch-up inserts reach back < 512 bytes)
+        const unsigned long long lo = a0 > 1024 ? a0 - 1024 : 0;
+        unsigned long long hi = a1 + g.feed + 256;
+        if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
+        HIPCHK(hipEventRecord(C.ev[7], C.st));
+        if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash, C.st);
+    }
+    HIPCHK(hipEventRecord(C.ev[5], C.st));
+    if (C.workers) {
+        const unsigned long long cnt = a1 - a0;
+        G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
+        G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads;
+        G.abort_word = C.abort_word; G.wcnt = C.wcnt;
+        HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4, C.st));
+        HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
+        HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
+        HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
+        launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
+                         C.pf_c1, C.unc, C.st);
+        launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
+    }
+    HIPCHK(hipEventRecord(C.ev[6], C.st));
+    return 0;
+}
+
+// pipe_ms: time of the persistent launch when it was not this stream's own (group launch), else < 0
+int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
+{
+    const Geom &g = C.g;
+    const uint32_t c0 = P.c0, c1 = P.c1, nb = P.nb;
+    std::vector<FrameMeta> hm(nb);
+    std::vector<unsigned long long> hoff(nb);
+    HIPCHK(hipEventRecord(C.ev[1], C.st));
+    launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
+                C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
+    HIPCHK(hipEventRecord(C.ev[2], C.st));
+    HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
+    Persist Pst;
+    HIPCHK(hipMemcpyAsync(&Pst, C.persist, sizeof Pst, hipMemcpyDeviceToHost, C.st));
+    uint32_t aborted = 0;
+    if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    HIPCHK(hipGetLastError());
+    float rk_ms = 0, pre_ms = 0;
+    HIPCHK(hipEventElapsedTime(&rk_ms, C.ev[7], C.ev[5]));
+    HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
+    C.tm.prep_ms += rk_ms + pre_ms; C.tm.prep_launches += C.workers ? 5 : 1; C.tm.total_ms += rk_ms + pre_ms;
+    if (Pst.error) return set_err(NLZM_HIP_E_KERNEL, "device error %u at chunk %u (info %u %u %u)", Pst.error, Pst.next_chunk,
+                                  Pst.error_info[0], Pst.error_info[1], Pst.error_info[2]);
+    if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
+    if (Pst.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", Pst.next_chunk, c1);
+    unsigned long long pos = C.out_pos;
+    for (uint32_t f = 0; f < nb; f++) {
+        // the reference asserts that the frame fits its buffer (:592, :610); the first one is 4 bytes shorter (:1784)
+        const uint32_t room = g.frame_size - ((c0 + f) == 0 ? 4 : 0);
+        if (hm[f].out_len > room)
+            return set_err(NLZM_HIP_E_KERNEL, "frame %u is %u bytes: the reference would assert (:610)", c0 + f, hm[f].out_len);
+        hoff[f] = pos; pos += hm[f].out_len;
+    }
+    if (pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap %llu too small", (unsigned long long)C.dst_cap);
+    if (C.want_frame >= (int64_t)c0 && C.want_frame < (int64_t)c1) {
+        const uint32_t f = (uint32_t)(C.want_frame - c0);
+        C.got_meta = hm[f];
+        C.got_syms.resize(hm[f].nsyms); C.got_bits.resize(hm[f].nbits_bytes);
+        HIPCHK(hipMemcpy(C.got_syms.data(), C.syms + f * C.syms_stride, hm[f].nsyms * 4ull, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(C.got_bits.data(), C.bits + f * C.bits_stride, hm[f].nbits_bytes, hipMemcpyDeviceToHost));
+        C.got = true;
+    }
+    HIPCHK(hipMemcpyAsync(C.dst_off, hoff.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, C.st));
+    HIPCHK(hipEventRecord(C.ev[3], C.st));
+    launch_gather(C.frames, C.frame_stride, C.dst_off, C.fmeta, C.d_dst, nb, C.st);
+    HIPCHK(hipEventRecord(C.ev[4], C.st));
+    HIPCHK(hipStreamSynchronize(C.st));
+    float a = pipe_ms, b = 0, c = 0;
+    if (pipe_ms < 0) HIPCHK(hipEventElapsedTime(&a, C.ev[0], C.ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, C.ev[1], C.ev[2]));
+    HIPCHK(hipEventElapsedTime(&c, C.ev[3], C.ev[4]));
+    C.tm.match_parse_ms += a; C.tm.match_parse_launches++;
+    C.tm.rans_ms += b + c; C.tm.rans_launches++;
+    C.tm.total_ms += a + b + c;
+    C.out_pos = pos;
+    C.next_chunk = c1;
+    return 0;
+}
+
 int stream_step(Ctx &C, uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
 {
     if (!C.open) return set_err(NLZM_HIP_E_ARG, "no open stream");
     const Geom &g = C.g;
     uint32_t todo = g.nchunks - C.next_chunk;
     if (max_chunks && todo > max_chunks) todo = max_chunks;
-    std::vector<FrameMeta> hm(C.batch);
-    std::vector<unsigned long long> hoff(C.batch);
     while (todo) {
-        const uint32_t c0 = C.next_chunk, nb = todo < C.batch ? todo : C.batch, c1 = c0 + nb;
-        Globals G;
-        memset(&G, 0, sizeof G);
-        G.in = C.d_in; G.rkhash = C.rkhash; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
-        G.bt_heads = C.bt_heads; G.bt_tree = C.bt_tree; G.persist = C.persist;
-        G.syms = C.syms; G.syms_stride = C.syms_stride; G.bits = C.bits; G.bits_stride = C.bits_stride;
-        G.fmeta = C.fmeta; G.chunk0 = c0;
-        G.cap_words = C.cap_words; G.cap_cap = C.cap_cap; G.cap_lo = C.cap_lo; G.cap_hi = C.cap_hi; G.cap_used = C.cap_used;
-        G.workers = C.workers ? 1 : 0;
-        const unsigned long long a0 = (unsigned long long)c0 * g.chunk_size;
-        unsigned long long a1 = (unsigned long long)c1 * g.chunk_size;
-        if (a1 > g.n) a1 = g.n;
-        G.batch_a0 = (uint32_t)a0;
-        float pre_ms = 0, rk_ms = 0;
-        {   // pre-pass: RK256 hash of every window the launch can touch (catch-up inserts reach back < 512 bytes)
-            const unsigned long long lo = a0 > 1024 ? a0 - 1024 : 0;
-            unsigned long long hi = a1 + g.feed + 256;
-            if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
-            HIPCHK(hipEventRecord(C.ev[7], C.st));
-            if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash, C.st);
-        }
-        if (C.workers) {
-            const unsigned long long cnt = a1 - a0;
-            G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
-            G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads;
-            G.abort_word = C.abort_word; G.wcnt = C.wcnt;
-            HIPCHK(hipEventRecord(C.ev[5], C.st));
-            HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4, C.st));
-            HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
-            HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
-            HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
-            launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
-                             C.pf_c1, C.unc, C.st);
-            launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
-            HIPCHK(hipEventRecord(C.ev[6], C.st));
-        }
-
+        StepPlan P;
+        int rc = step_pre(C, todo, P);
+        if (rc) return rc;
         HIPCHK(hipEventRecord(C.ev[0], C.st));
-        launch_pipeline(g, G, c0, c1, (uint32_t)C.opt_worker_blocks, C.st);
-        HIPCHK(hipEventRecord(C.ev[1], C.st));
-        launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
-                    C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
-        HIPCHK(hipEventRecord(C.ev[2], C.st));
-        HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
-        Persist P;
-        HIPCHK(hipMemcpyAsync(&P, C.persist, sizeof P, hipMemcpyDeviceToHost, C.st));
-        uint32_t aborted = 0;
-        if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
-        HIPCHK(hipStreamSynchronize(C.st));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventElapsedTime(&rk_ms, C.ev[7], C.workers ? C.ev[5] : C.ev[0]));
-        C.tm.prep_ms += rk_ms; C.tm.prep_launches += 1; C.tm.total_ms += rk_ms;
-        if (C.workers) {
-            HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
-            C.tm.prep_ms += pre_ms; C.tm.prep_launches += 4; C.tm.total_ms += pre_ms;
-        }
-        if (P.error) return set_err(NLZM_HIP_E_KERNEL, "device error %u at chunk %u (info %u %u %u)", P.error, P.next_chunk,
-                                    P.error_info[0], P.error_info[1], P.error_info[2]);
-        if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
-        if (P.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", P.next_chunk, c1);
-        unsigned long long pos = C.out_pos;
-        for (uint32_t f = 0; f < nb; f++) {
-            // the reference asserts that the frame fits its buffer (:592, :610); the first one is 4 bytes shorter (:1784)
-            const uint32_t room = g.frame_size - ((c0 + f) == 0 ? 4 : 0);
-            if (hm[f].out_len > room)
-                return set_err(NLZM_HIP_E_KERNEL, "frame %u is %u bytes: the reference would assert (:610)", c0 + f, hm[f].out_len);
-            hoff[f] = pos; pos += hm[f].out_len;
-        }
-        if (pos + 4 > C.dst_cap) return set_err(NLZM_HIP_E_CAPACITY, "dst_cap %llu too small", (unsigned long long)C.dst_cap);
-        if (C.want_frame >= (int64_t)c0 && C.want_frame < (int64_t)c1) {
-            const uint32_t f = (uint32_t)(C.want_frame - c0);
-            C.got_meta = hm[f];
-            C.got_syms.resize(hm[f].nsyms); C.got_bits.resize(hm[f].nbits_bytes);
-            HIPCHK(hipMemcpy(C.got_syms.data(), C.syms + f * C.syms_stride, hm[f].nsyms * 4ull, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(C.got_bits.data(), C.bits + f * C.bits_stride, hm[f].nbits_bytes, hipMemcpyDeviceToHost));
-            C.got = true;
-        }
-        HIPCHK(hipMemcpyAsync(C.dst_off, hoff.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, C.st));
-        HIPCHK(hipEventRecord(C.ev[3], C.st));
-        launch_gather(C.frames, C.frame_stride, C.dst_off, C.fmeta, C.d_dst, nb, C.st);
-        HIPCHK(hipEventRecord(C.ev[4], C.st));
-        HIPCHK(hipStreamSynchronize(C.st));
-        float a = 0, b = 0, c = 0;
-        HIPCHK(hipEventElapsedTime(&a, C.ev[0], C.ev[1]));
-        HIPCHK(hipEventElapsedTime(&b, C.ev[1], C.ev[2]));
-        HIPCHK(hipEventElapsedTime(&c, C.ev[3], C.ev[4]));
-        C.tm.match_parse_ms += a; C.tm.match_parse_launches++;
-        C.tm.rans_ms += b + c; C.tm.rans_launches++;
-        C.tm.total_ms += a + b + c;
-        C.out_pos = pos;
-        C.next_chunk = c1;
-        todo -= nb;
+        launch_pipeline(g, P.G, P.c0, P.c1, (uint32_t)C.opt_worker_blocks, C.st);
+        rc = step_post(C, P, -1.0f);
+        if (rc) return rc;
+        todo -= P.nb;
     }
     if (in_done) {
         const unsigned long long d = (unsigned long long)C.next_chunk * g.chunk_size;
@@ -690,6 +717,8 @@ void block_ctx_destroy(Ctx &c)
 
 namespace {
 std::vector<BlockJob> g_jobs;       // the open block set (nlzm_hip_blocks_begin .. _end)
+std::vector<hipStream_t> g_group_st;             // one HIP stream and an event pair per shared launch of a round
+std::vector<std::array<hipEvent_t, 2>> g_group_ev;
 uint64_t g_blocks_n = 0;
 const uint8_t *g_blocks_src = nullptr;
 uint32_t g_blocks_hist = 0;
@@ -699,6 +728,9 @@ void blocks_close()
 {
     for (auto &j : g_jobs) { if (j.d_out) (void)hipFree(j.d_out); j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
     g_jobs.clear();
+    for (auto &st : g_group_st) (void)hipStreamDestroy(st);
+    for (auto &ev : g_group_ev) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+    g_group_st.clear(); g_group_ev.clear();
 }
 
 // run f(block) for every open block, `conc` at a time, each on a host thread of its own
@@ -753,6 +785,13 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
+    const uint32_t ngroups = (nblocks + stream_pack_capacity() - 1) / stream_pack_capacity();
+    for (uint32_t gi = 0; gi < ngroups; gi++) {
+        hipStream_t st; std::array<hipEvent_t, 2> ev;
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&ev[0])); HIPCHK(hipEventCreate(&ev[1]));
+        g_group_st.push_back(st); g_group_ev.push_back(ev);
+    }
     return 0;
 }
 
@@ -760,22 +799,62 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
 {
     Ctx &C = g_ctx;
     if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
+    const size_t nj = g_jobs.size();
     hipEvent_t e0 = C.ev[5], e1 = C.ev[6];
     HIPCHK(hipEventRecord(e0, C.st));
     HIPCHK(hipStreamSynchronize(C.st));
-    std::vector<uint64_t> done(g_jobs.size(), 0);
-    std::vector<int> fin(g_jobs.size(), 0);
-    for_blocks((uint32_t)g_jobs.size(), [&](uint32_t i, BlockJob &j) {
-        if (j.c.next_chunk >= j.c.g.nchunks) { fin[i] = 1; done[i] = j.n; return; }
-        j.rc = stream_step(j.c, max_chunks_per_block, &done[i], nullptr, &fin[i]);
-    });
+    std::vector<uint32_t> left(nj);
+    for (size_t i = 0; i < nj; i++) {
+        left[i] = g_jobs[i].c.g.nchunks - g_jobs[i].c.next_chunk;
+        if (max_chunks_per_block && left[i] > max_chunks_per_block) left[i] = max_chunks_per_block;
+    }
+    // Rounds in lockstep: every unfinished stream advances by one batch, and the streams of a round share persistent
+    // launches (groups of up to stream_pack_capacity() streams per launch, all launches of a round in flight together)
+    const uint32_t cap = stream_pack_capacity();
+    std::vector<uint8_t> pack(stream_pack_size());
+    std::vector<StepPlan> plan(nj);
+    for (;;) {
+        std::vector<uint32_t> act;
+        for (size_t i = 0; i < nj; i++) if (left[i]) act.push_back((uint32_t)i);
+        if (act.empty()) break;
+        for (uint32_t i : act) { const int rc = step_pre(g_jobs[i].c, left[i], plan[i]); if (rc) return rc; }
+        const uint32_t ngroups = ((uint32_t)act.size() + cap - 1) / cap;
+        const uint32_t per_group = ((uint32_t)act.size() + ngroups - 1) / ngroups;
+        if (ngroups > g_group_st.size()) return set_err(NLZM_HIP_E_ARG, "too many stream groups");
+        for (uint32_t gi = 0; gi < ngroups; gi++) {
+            const uint32_t lo = gi * per_group, hi = lo + per_group < act.size() ? lo + per_group : (uint32_t)act.size();
+            hipStream_t gs = g_group_st[gi];
+            for (uint32_t k = lo; k < hi; k++) {
+                Ctx &c = g_jobs[act[k]].c;
+                HIPCHK(hipStreamWaitEvent(gs, c.ev[6], 0));            // its pre-pass is done
+                fill_stream_args(pack.data(), k - lo, c.g, plan[act[k]].G, plan[act[k]].c0, plan[act[k]].c1);
+            }
+            HIPCHK(hipEventRecord(g_group_ev[gi][0], gs));
+            launch_pipeline_multi(pack.data(), hi - lo, (uint32_t)g_blocks_wb, gs);
+            HIPCHK(hipEventRecord(g_group_ev[gi][1], gs));
+            for (uint32_t k = lo; k < hi; k++) HIPCHK(hipStreamWaitEvent(g_jobs[act[k]].c.st, g_group_ev[gi][1], 0));
+        }
+        for (uint32_t i : act) { const int rc = step_post(g_jobs[i].c, plan[i], 0.0f); if (rc) return rc; }
+        for (uint32_t gi = 0; gi < ngroups; gi++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, g_group_ev[gi][0], g_group_ev[gi][1]));
+            const uint32_t lo = gi * per_group, hi = lo + per_group < act.size() ? lo + per_group : (uint32_t)act.size();
+            for (uint32_t k = lo; k < hi; k++) { Ctx &c = g_jobs[act[k]].c; c.tm.match_parse_ms += ms; c.tm.total_ms += ms; }
+        }
+        for (uint32_t i : act) left[i] -= plan[i].nb;
+    }
     HIPCHK(hipEventRecord(e1, C.st));
     HIPCHK(hipStreamSynchronize(C.st));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     if (device_ms) *device_ms = ms;
     uint64_t tot = 0; int all = 1;
-    for (size_t i = 0; i < g_jobs.size(); i++) { if (g_jobs[i].rc) return g_jobs[i].rc; tot += done[i]; all &= fin[i]; }
+    for (size_t i = 0; i < nj; i++) {
+        const Ctx &c = g_jobs[i].c;
+        const unsigned long long d = (unsigned long long)c.next_chunk * c.g.chunk_size;
+        tot += d < c.g.n ? d : c.g.n;
+        all &= c.next_chunk >= c.g.nchunks;
+    }
     if (in_done_total) *in_done_total = tot;
     if (finished) *finished = all;
     return 0;

@@ -437,10 +437,10 @@ struct LaneIO {
     static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-__device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
+__device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
-    const uint32_t nl = (gridDim.x - 1) * blockDim.x;
-    const uint32_t gl = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    const uint32_t nl = wblocks * blockDim.x;
+    const uint32_t gl = wblock * blockDim.x + threadIdx.x;
     // Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it,
     // so the position a lane may block on is always its smallest unprocessed one.
     bool active = gl < G.nheads;
@@ -521,14 +521,11 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     }
 }
 
-// ---------------------------------------------------------------------------
-// the persistent launch: block 0 = master (one wave), blocks 1.. = worker lanes.
-// 512-thread blocks with ~81 KB of LDS: exactly one block per CU, and the grid is kept
-// below the CU count, so every block is resident at once (the roles wait on each other).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
+// the roles of one stream's blocks: block 0 of the stream is its serial half, the others its worker lanes
+__device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t local_block,
+                                               uint32_t wblocks)
 {
-    if (blockIdx.x == 0) {
+    if (local_block == 0) {
         // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
         // wave 1: the match table (carry / extend / update), published per position
         // wave 2: forward-graph parse, model, symbol emit
@@ -551,8 +548,30 @@ __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32
         default: m.run_rep_list(a_first, 1); break;
         }
     } else {
-        worker_role(g, G, c0, c1);
+        worker_role(g, G, c0, c1, wblocks, local_block - 1);
     }
+}
+
+// ---------------------------------------------------------------------------
+// the persistent launch: block 0 = the serial half (seven waves), blocks 1.. = worker lanes.
+// 512-thread blocks with ~117 KB of LDS: exactly one block per CU, and the grid is kept
+// below the CU count, so every block is resident at once (the roles wait on each other).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
+{
+    pipeline_roles(g, G, c0, c1, blockIdx.x, gridDim.x - 1);
+}
+
+// Several independent streams in ONE launch (block mode): stream s owns blocks [s*bps, (s+1)*bps).  One launch
+// keeps them all resident by construction (separate launches run at most 8 at a time on this device).
+struct StreamArgs { Geom g; Globals G; uint32_t c0, c1; };
+constexpr uint32_t kMaxStreamsPerLaunch = 12;           // the pack travels in the kernel-argument segment (4 KB)
+struct StreamPack { StreamArgs s[kMaxStreamsPerLaunch]; };
+static_assert(sizeof(StreamPack) <= 4000, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(512) void pipeline_multi_kernel(StreamPack pack, uint32_t bps)
+{
+    const uint32_t s = blockIdx.x / bps, local = blockIdx.x % bps;
+    pipeline_roles(pack.s[s].g, pack.s[s].G, pack.s[s].c0, pack.s[s].c1, local, bps - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -665,6 +684,20 @@ void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long 
 void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(512), 0, st, g, G, c0, c1);
+}
+
+// several streams in one launch: fill slot i of a host-side pack, then launch
+unsigned long long stream_pack_size() { return sizeof(StreamPack); }
+uint32_t stream_pack_capacity() { return kMaxStreamsPerLaunch; }
+void fill_stream_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
+{
+    StreamArgs &a = ((StreamPack *)host_pack)->s[i];
+    a.g = g; a.G = G; a.c0 = c0; a.c1 = c1;
+}
+void launch_pipeline_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(pipeline_multi_kernel, dim3(nstreams * (1 + worker_blocks)), dim3(512), 0, st, *(const StreamPack *)host_pack,
+                       1 + worker_blocks);
 }
 
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,

@@ -7,7 +7,7 @@ os.makedirs("profiles", exist_ok=True)
 newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)[-1]
 ks = newest(f"{src}/trace/**/*_kernel_stats.csv")
 shutil.copy(ks, f"profiles/{R}_kernel_stats.csv")
-out = {"round": R, "command": "python3 bench.py --no-cpu", "kernel": "pipeline_kernel"}
+out = {"round": R, "command": "python3 bench.py --no-cpu --block-streams 0", "kernel": "pipeline_kernel"}
 for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
     f = newest(f"{src}/{name}/**/*_counter_collection.csv")
     agg, n = {}, {}
