@@ -15,6 +15,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/nlzm_hip.h"
@@ -72,6 +73,8 @@ inline void cdf_adapt(Cdf &d, int ns, int y)
         d.c[i] = (uint16_t)(d.c[i] + ((mix - (int)d.c[i]) >> 7));                 // :348-382
     }
 }
+inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
 struct Frame {
     const uint8_t *bits, *rans, *end;
     uint32_t word = 0, word_bits = 0, num_ops = 0, st[4], idx = 0;
@@ -107,7 +110,6 @@ struct Frame {
         return y;
     }
 };
-inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 inline uint32_t match_min(uint32_t d) { return 2u + (d >= 256u) + (d >= 4096u) + (d >= (1u << 20)); }   // :813-821
 inline void rep_add(uint32_t r[4], uint32_t d)
 {
@@ -125,8 +127,32 @@ uint32_t dec_len(Frame &f, Model &m)                                            
     return lv;
 }
 
+// A byte range of the file as the decoder sees it
+struct Span {
+    const uint8_t *p; size_t n;
+    size_t size() const { return n; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+    const uint8_t *data() const { return p; }
+};
+
+// Length of the stream that starts at in[0]: header, frames hopped over by the sizes their headers carry (:645-663),
+// terminator (:646-648).  0: malformed.  Block mode (k independent streams back to back) is split with this.
+size_t stream_length(const Span &in)
+{
+    if (in.size() < 8) return 0;
+    size_t pos = 4;
+    for (;;) {
+        if (pos + 4 > in.size()) return 0;
+        if (!be32(&in[pos])) return pos + 4;
+        if (pos + 12 > in.size()) return 0;
+        const uint32_t nb = be32(&in[pos + 4]), nr = be32(&in[pos + 8]);
+        if (nb < 12 || nr < 16 || pos + (size_t)nb + nr > in.size()) return 0;
+        pos += (size_t)nb + nr;
+    }
+}
+
 // returns 0 or a negative code; out receives the decoded bytes
-int decode_stream(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, uint32_t *hist_bits, uint32_t *frame_bits)
+int decode_stream(const Span &in, std::vector<uint8_t> &out, uint32_t *hist_bits, uint32_t *frame_bits)
 {
     if (in.size() < 8) return -1;
     const uint32_t hb = ((uint32_t)in[0] << 8) + in[1], fb = ((uint32_t)in[2] << 8) + in[3];
@@ -198,6 +224,7 @@ int main(int argc, char **argv)
     printf("NLZM 1.03 - Written by Nauful (MI355X/gfx950 build)\n");
     crc_init();
     uint32_t hist_bits = 22;                                                      // :2071
+    uint32_t nblocks = 1;                           // -blocks:k (not in the reference): k independent streams, back to back
     while (argc >= 2 && *argv[1] == '-') {
         char *arg = argv[1];
         argv++; argc--;
@@ -207,6 +234,10 @@ int main(int argc, char **argv)
             const int v = atoi(arg + 7);
             hist_bits = (uint32_t)(v < 15 ? 15 : (v > 28 ? 28 : v));
             printf("Window bits: %d\n", hist_bits);
+        } else if (!strncmp(arg, "blocks:", 7)) {
+            const int v = atoi(arg + 7);
+            nblocks = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+            printf("Blocks: %d\n", nblocks);
         } else {
             printf("Unrecognized flag %s\n", arg);
             return -1;
@@ -225,12 +256,14 @@ int main(int argc, char **argv)
         printf("Dictionary: %d KB\n", (int)(((1ull << hb) + 1023) >> 10));
         printf("Frame: %d KB\n", (int)(((1u << fb) + 1023) >> 10));
         printf("Working...\r");
-        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()));
+        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nblocks * (16 + 131072));
         uint64_t out_n = 0;
         const clock_t t0 = clock();
         struct timespec w0, w1;
         clock_gettime(CLOCK_MONOTONIC, &w0);
-        const int rc = nlzm_hip_compress(in.data(), in.size(), hist_bits, out.data(), out.size(), &out_n);
+        std::vector<uint64_t> blen(nblocks);
+        const int rc = nblocks > 1 ? nlzm_hip_compress_blocks(in.data(), in.size(), nblocks, hist_bits, out.data(), out.size(), blen.data(), &out_n)
+                                   : nlzm_hip_compress(in.data(), in.size(), hist_bits, out.data(), out.size(), &out_n);
         clock_gettime(CLOCK_MONOTONIC, &w1);
         (void)t0;
         if (rc) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
@@ -253,7 +286,30 @@ int main(int argc, char **argv)
         }
         uint32_t hb = 0, fb = 0;
         const clock_t t0 = clock();
-        const int rc = decode_stream(in, out, &hb, &fb);
+        // one stream (the reference's format), or several back to back (block mode): found by hopping over the frames,
+        // decoded on a host thread each, written in order
+        std::vector<Span> parts;
+        for (size_t pos = 0; pos < in.size();) {
+            const Span rest{ in.data() + pos, in.size() - pos };
+            const size_t len = stream_length(rest);
+            if (!len) { parts.clear(); break; }
+            parts.push_back(Span{ rest.p, len });
+            pos += len;
+        }
+        int rc = parts.empty() ? -3 : 0;
+        if (parts.size() == 1) rc = decode_stream(parts[0], out, &hb, &fb);
+        else if (!rc) {
+            std::vector<std::vector<uint8_t>> outs(parts.size());
+            std::vector<int> rcs(parts.size(), 0);
+            std::vector<uint32_t> hbs(parts.size(), 0), fbs(parts.size(), 0);
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < parts.size(); i++)
+                th.emplace_back([&, i] { rcs[i] = decode_stream(parts[i], outs[i], &hbs[i], &fbs[i]); });
+            for (auto &t : th) t.join();
+            for (size_t i = 0; i < parts.size() && !rc; i++) { rc = rcs[i]; out.insert(out.end(), outs[i].begin(), outs[i].end()); }
+            hb = hbs[0]; fb = fbs[0];
+            printf("Blocks: %d\n", (int)parts.size());
+        }
         if (rc) { printf("Assert failed: malformed stream (%d)\n", rc); if (fout) fclose(fout); return -1; }
         printf("Dictionary: %d KB\n", (int)(((1ull << hb) + 1023) >> 10));
         printf("Frame: %d KB\n", (int)(((1u << fb) + 1023) >> 10));
@@ -271,7 +327,8 @@ int main(int argc, char **argv)
                "\tt [input] - Decompress input file in memory\n"
                "\th [input] - Calculate CRC32 for input file\n"
                "Flags:\n"
-               "\t-window:bits = Maximum window size in bits, default 22 (4 MB), min 15, max 28 (32 KB to 256 MB)\n");
+               "\t-window:bits = Maximum window size in bits, default 22 (4 MB), min 15, max 28 (32 KB to 256 MB)\n"
+               "\t-blocks:k = (this build) compress k independent blocks at once; d/t read the streams back to back\n");
     }
     return 0;
 }

@@ -123,6 +123,7 @@ constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
 
 struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
+    unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
 };
 
 // Everything the master needs from HBM.

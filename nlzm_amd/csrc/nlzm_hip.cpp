@@ -432,6 +432,9 @@ int refresh_stats(Ctx &C)
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
+        if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
+            fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
+                    (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));
     }
     return 0;
 }

@@ -449,7 +449,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     uint32_t i0 = 0, e0 = 0;
     uint32_t la_end = 0;            // absolute end of the chunk's lookahead
     uint32_t stage = 0, a = 0, max_len = 0;
-    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dummy_t = 0, dummy_c = 0;
+    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dummy_t = 0, dummy_c = 0, n_cyc = 0, n_cyc_tests = 0;
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0;
     bool fail = false;
@@ -482,7 +482,9 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             n_dry++;
                             stage = 1; t_wait0 = 0; idle = 0;
                         } else {
+                            const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
                             worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
+                            n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
                             n_calls++;
                         }
                     }
@@ -514,10 +516,12 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     for (int m = 32; m >= 1; m >>= 1) {
         n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
         n_dry += __shfl_xor(n_dry, m, 64); n_wait += __shfl_xor(n_wait, m, 64);
+        n_cyc += __shfl_xor(n_cyc, m, 64); n_cyc_tests += __shfl_xor(n_cyc_tests, m, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
         atomicAdd(&G.wcnt->dry_runs, n_dry); atomicAdd(&G.wcnt->flag_waits, n_wait);
+        atomicAdd(&G.wcnt->call_cycles, n_cyc); atomicAdd(&G.wcnt->call_tests, n_cyc_tests);
     }
 }
 

@@ -93,3 +93,25 @@ def test_cli_host_side_decodes_and_refuses_to_overwrite(tmp_path, lib):
     assert r.returncode != 0 and "Unrecognized flag" in r.stdout
     r = subprocess.run([nlzm_amd.CLI_PATH], capture_output=True, text=True)
     assert "Commands:" in r.stdout
+
+
+def test_cli_decodes_streams_back_to_back(tmp_path, lib):
+    """Block mode's artifact: k independent streams, concatenated; `d`/`t` find the boundaries by
+    hopping over the frames and decode the blocks on host threads."""
+    import numpy as np
+    from nlzm_amd import corpus, shard
+    from tests import oracle_py
+    data = corpus.mixed(700_000, corpus.SEED + 9)
+    k = 5
+    streams = [oracle_py.compress(data[slice(*shard.block_range(data.size, k, i))], 18) for i in range(k)]
+    f = tmp_path / "blocks.nlzm"
+    f.write_bytes(b"".join(streams))
+    out = tmp_path / "o.bin"
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(f), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and f"Blocks: {k}" in r.stdout, r.stdout
+    assert out.read_bytes() == data.tobytes()
+    # a cut-off container is refused
+    f.write_bytes(b"".join(streams)[:-3])
+    r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(f)], capture_output=True, text=True)
+    assert r.returncode != 0 and "malformed" in r.stdout
+

@@ -129,6 +129,20 @@ def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
     assert shard.split_streams(b"".join(got)) == got
 
 
+def test_cli_block_mode_round_trip(gpu, tmp_path):
+    """`nlzm -blocks:k c` writes k streams back to back (each = the oracle on its byte range), `d` reads them."""
+    from nlzm_amd import shard
+    data = corpus.syn_text(900_000, corpus.SEED + 21)
+    src, dst, back = tmp_path / "in.bin", tmp_path / "out.nlzm", tmp_path / "back.bin"
+    data.tofile(src)
+    r = subprocess.run([nlzm_amd.CLI_PATH, "-window:19", "-blocks:6", "c", str(src), str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = b"".join(oracle_py.compress(data[slice(*shard.block_range(data.size, 6, i))], 19) for i in range(6))
+    assert dst.read_bytes() == want
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(dst), str(back)], capture_output=True, text=True)
+    assert r.returncode == 0 and back.read_bytes() == data.tobytes()
+
+
 def test_blocks_of_a_sharded_run(gpu):
     """k-way split: each block is an independent stream identical to the oracle's."""
     from nlzm_amd import shard
