@@ -7,14 +7,19 @@
 // the oracle without a GPU.  Control flow is wave-uniform: every lane carries the
 // same scalar state, lanes split only inside the `for (i = W::lane(); ...)` loops.
 //
-// Reference map (all NLZM.cpp):
-//   Master::parse_segment   parse_table                      :1464-1651
-//   Master::finders         finder block of parse_table      :1501-1543
-//   Master::ht_*            MatchFinderHT::FindAndUpdate     :910-938
-//   Master::rk_*            MatchFinderRK256::FindAndUpdate  :1055-1113
-//   bt_find_and_update      MatchFinderBT::FindAndUpdate     :978-1022
-//   Master::emit_*          model_encode_*                   :1274-1367, 1428-1439
-//   Master::run_chunk       encode_file chunk loop           :1782-1886
+// The serial half is seven roles, one wave each, that hand work to each other through LDS (MasterLds):
+//   run_finder      finder block of parse_table: HT2/HT3/RK256, nice decision, worker decisions   :1501-1543
+//   run_table       MatchTable as mt_carry holds it: carry / extend / update, published per position :823-852, 1543
+//   run_parser      parse_table's node loop: literal edge, node finality, segment end, backtrack, emit :1464-1651
+//   run_edge_list   the sampled-length edges of a node, listed                                       :1558-1596
+//   run_rep_list    the explicit rep probes of a node, listed (two waves: even / odd positions)      :1598-1628
+//   run_edge_apply  relaxes both lists in the reference's order (only writer of nodes >= p+2)
+//
+// Reference map of the pieces (all NLZM.cpp):
+//   Master::finders, pf_fill, fast_run   MatchFinderHT::FindAndUpdate :910-938, MatchFinderRK256::FindAndUpdate :1055-1113
+//   bt_find_and_update                   MatchFinderBT::FindAndUpdate :978-1022 (worker lanes, nlzm_kernels.hip)
+//   Master::emit_*, put_sym              model_encode_* :1274-1367, 1428-1439, cdf_update :348-382
+//   Master::run_chunk_*                  encode_file chunk loop :1782-1886
 #pragma once
 
 #include <stdint.h>
@@ -179,11 +184,11 @@ struct MasterLds {
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
-    // ---- hand-off between the three waves of the master (run_finder -> run_table -> run_parser) ----
+    // ---- hand-off run_finder -> run_table -> run_parser ----
     // Wave A (finders) keeps only the table's length and top entry in registers and sends what happens to
     // the table as commands (cq); wave T owns the table ring, applies them and publishes, per position a,
     // slot a % kEr: word 0 = table length | (long slot + 1) << 16, word 1 = the input byte,
-    // words 2..63 = table entries 2..63 (longer tables go to er_long whole); wave B parses.
+    // words 2..63 = table entries 2..63 (longer tables go to er_long whole); the parser and edge waves read it.
     uint32_t cq[kCq * 2];                   // op | arg << 8, value
     uint32_t x_cpos;                        // A: commands < x_cpos are written
     uint32_t x_tpos;                        // T: commands < x_tpos are consumed
@@ -1089,7 +1094,7 @@ struct Master {
         W::xw_store(&W::lds()->x_err, code);
     }
 
-    // =========================== wave A: finders ===========================================
+    // =========================== table wave: publishing =====================================
     // publish position a: table length, input byte, table entries (MatchTable as mt_carry holds it, :1543)
     NLZM_HD void t_publish(uint32_t a, uint32_t lit)
     {
@@ -1547,7 +1552,7 @@ struct Master {
         }
     }
 
-    // =========================== wave B: parse + emit ======================================
+    // =========================== parser wave: parse + emit ==================================
     // table entry `tl` of the position whose hand-off header is `hdr`
     NLZM_HD uint32_t tab(const uint32_t *e, uint32_t hdr, uint32_t tl) const
     {
@@ -1805,7 +1810,7 @@ struct Master {
         }
     }
 
-    // shared start-up, run by ONE of the two waves before either role starts
+    // shared start-up, run by ONE wave before any role starts
     NLZM_HD static void init_shared(const Globals &G, uint32_t a0)
     {
         for (uint32_t i = W::lane(); i < sizeof(Counters) / 8; i += W::width()) ((unsigned long long *)&W::lds()->cnt)[i] = 0;

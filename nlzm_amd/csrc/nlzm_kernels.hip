@@ -5,8 +5,9 @@
 //                       1071-1083): pure, position-parallel, input tile staged in LDS.
 //   prefilter_*_kernel  marks the positions whose BT4 call cannot be decided from the input alone
 //   bin_kernel          groups each chunk's positions by BT4 hash head
-//   pipeline_kernel     block 0: the serial half (nlzm_core.h): HT2/HT3/RK256 state, match-table
+//   pipeline_kernel     block 0: the serial half (nlzm_core.h, seven waves): HT2/HT3/RK256 state, match-table
 //                       chain, forward-graph parse, model, symbol emit; blocks 1..: BT4 worker lanes
+//   pipeline_multi_kernel  the same for several independent streams in one launch (block mode)
 //   rans_frames_kernel  CodeFrame::Flush (NLZM.cpp:590-640): 4 interleaved rANS states
 //                       per frame, renormalisation words placed by a prefix scan.
 //   gather_frames_kernel concatenates the frames into the output stream.
@@ -176,7 +177,7 @@ struct DevWave {
     }
     template <class F>
     static __device__ __forceinline__ unsigned long long mask64(F f) { return __ballot(f(lane())); }
-    // words shared by the two master waves (same CU, LDS)
+    // words shared by the waves of the serial half (same CU, LDS)
     static __device__ __forceinline__ void xw_store(uint32_t *p, uint32_t v)
     {
         asm volatile("" ::: "memory");

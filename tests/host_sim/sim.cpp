@@ -394,7 +394,7 @@ int main(int argc, char **argv)
             wk.eager_mode = use_workers == 2;
             if (use_workers == 2) wk.eager();
         }
-        // the two master waves as two threads
+        // the roles of the serial half, one host thread each
         Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         Master<HostWave> mb = m, mt = m, ms = m, ms2 = m, ms3 = m, ms4 = m;
         const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
