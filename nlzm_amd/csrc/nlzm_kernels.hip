@@ -477,11 +477,19 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                         a = pos[i0++];
                         max_len = umin(la_end - a, kMatchMax);
                         if (G.unc[a - G.batch_a0]) {
-                            // whether this call happens is decided by the master; its MATCHES do not depend
-                            // on that: report them now from a dry run, insert once the decision is in
-                            worker_bt_call<LaneIO, false>(g, G, a, max_len, true, dummy_t, dummy_c);
-                            n_dry++;
-                            stage = 1; t_wait0 = 0; idle = 0;
+                            // whether this call happens is decided by the master.  If the decision is in already (the
+                            // master is ahead of this lane, as it is inside nice regions where 7 of 8 calls are
+                            // skipped, :1529), act on it; otherwise its MATCHES do not depend on the decision: report
+                            // them now from a dry run, insert once the decision is in
+                            const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
+                            if (f == kFlagCall) {
+                                worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
+                                n_calls++;
+                            } else if (f != kFlagSkip) {
+                                worker_bt_call<LaneIO, false>(g, G, a, max_len, true, dummy_t, dummy_c);
+                                n_dry++;
+                                stage = 1; t_wait0 = 0; idle = 0;
+                            }
                         } else {
                             const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
                             worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
