@@ -276,15 +276,27 @@ NLZM_HD void rep_add(uint32_t r[4], uint32_t d)     // :1160-1171
 // ---------------------------------------------------------------------------
 // `kWrite` = false is a dry run: the same descent (the links a call rewrites are
 // never read again by that call), all matches reported, nothing stored.
-template <bool kWrite, class Cmp, class Sink>
-NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask, uint32_t tmask,
-                                const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
-                                Cmp &cmp, Sink &sink, uint32_t &n_tests)
+// What a call does to the tree: written at once (kWrite), dropped (a dry run), or noted down by a dry run so that the
+// commit after the master's decision is a replay of stores instead of a second descent (the descent only reads what
+// earlier calls of the same head wrote, and the head's lane makes no other call in between).
+struct StoreNow {
+    NLZM_HD void head(uint32_t *heads, uint32_t i, uint32_t v) const { heads[i] = v; }
+    NLZM_HD void link(uint32_t *tree, uint32_t i, uint32_t v) const { tree[i] = v; }
+};
+struct StoreDrop {
+    NLZM_HD void head(uint32_t *, uint32_t, uint32_t) const {}
+    NLZM_HD void link(uint32_t *, uint32_t, uint32_t) const {}
+};
+
+template <class St, class Cmp, class Sink>
+NLZM_HD void bt_find_and_update_st(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask, uint32_t tmask,
+                                   const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
+                                   Cmp &cmp, Sink &sink, uint32_t &n_tests, St &st)
 {
     uint32_t pend_l = (a & tmask) << 1, pend_r = pend_l + 1;     // indices into tree[]
     uint32_t len_l = 0, len_r = 0;
     uint32_t sp = heads[h4 >> bt_shift];
-    if (kWrite) heads[h4 >> bt_shift] = a;
+    st.head(heads, h4 >> bt_shift, a);
     uint32_t tests = 256;                                       // :777, :988 (uint16 there; never wraps)
     while (sp != kNone && a > sp && a - sp <= wmask && tests-- > 0) {
         n_tests++;
@@ -294,13 +306,22 @@ NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shi
         const uint32_t l = r & 0x7FFFFFFFu;
         if (l >= match_min(a - sp)) sink(a - sp, l);
         if (l == max_len) {                                     // :1000-1004
-            if (kWrite) { tree[pend_l] = pl; tree[pend_r] = pr; }
+            st.link(tree, pend_l, pl); st.link(tree, pend_r, pr);
             return;
         }
-        if (r >> 31) { if (kWrite) tree[pend_l] = sp; pend_l = pair + 1; sp = pr; len_r = l; }
-        else         { if (kWrite) tree[pend_r] = sp; pend_r = pair;     sp = pl; len_l = l; }
+        if (r >> 31) { st.link(tree, pend_l, sp); pend_l = pair + 1; sp = pr; len_r = l; }
+        else         { st.link(tree, pend_r, sp); pend_r = pair;     sp = pl; len_l = l; }
     }
-    if (kWrite) { tree[pend_r] = kNone; tree[pend_l] = kNone; } // :1020-1021
+    st.link(tree, pend_r, kNone); st.link(tree, pend_l, kNone);    // :1020-1021
+}
+
+template <bool kWrite, class Cmp, class Sink>
+NLZM_HD void bt_find_and_update(uint32_t *heads, uint32_t *tree, uint32_t bt_shift, uint32_t wmask, uint32_t tmask,
+                                const uint8_t *in, uint32_t a /*abs pos*/, uint32_t h4, uint32_t max_len,
+                                Cmp &cmp, Sink &sink, uint32_t &n_tests)
+{
+    if (kWrite) { StoreNow st; bt_find_and_update_st(heads, tree, bt_shift, wmask, tmask, in, a, h4, max_len, cmp, sink, n_tests, st); }
+    else { StoreDrop st; bt_find_and_update_st(heads, tree, bt_shift, wmask, tmask, in, a, h4, max_len, cmp, sink, n_tests, st); }
 }
 
 // ---------------------------------------------------------------------------
@@ -343,6 +364,22 @@ struct ResultSink {
         count++;
     }
 };
+
+// the dry run of an `unc` position with its stores noted down by `st`
+template <class IO, class St>
+NLZM_HD void worker_bt_dry(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, unsigned long long &n_tests,
+                           unsigned long long &cmp_bytes, St &st)
+{
+    LaneCmp cmp{ &cmp_bytes };
+    const unsigned long long bi = a - G.batch_a0;
+    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    uint32_t tests = 0;
+    const uint32_t h4 = hash4(load32u(G.in + a));
+    bt_find_and_update_st(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests, st);
+    n_tests += tests;
+    IO::drain();                            // every pair has been written through before the ready word
+    IO::st_agent(G.bt_ready + bi, kBtReady | (tests << 9) | sink.count);
+}
 
 template <class IO, bool kWrite>
 NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, bool publish,

@@ -438,6 +438,32 @@ struct LaneIO {
     static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
+// The stores of a dry run, noted in LDS (a worker block does not use the master's LDS image): kLogCap (address, value)
+// pairs per lane, interleaved by lane so that a wave's k-th entries sit in different banks.
+constexpr uint32_t kLogCap = 24;
+static_assert(sizeof(MasterLds) >= 512 * kLogCap * 8, "store log does not fit the block's LDS");
+struct StoreLog {
+    uint32_t n;
+    bool full;
+    // entry k of this lane: target (index into tree[], or 0x80000000 | index into heads[]) and value
+    __device__ __forceinline__ static uint32_t *slot(uint32_t k) { return (uint32_t *)&g_master_lds + 2 * (k * 512 + threadIdx.x); }
+    __device__ __forceinline__ void put(uint32_t t, uint32_t v)
+    {
+        if (n < kLogCap) { uint32_t *e = slot(n); e[0] = t; e[1] = v; n++; }
+        else full = true;
+    }
+    __device__ __forceinline__ void head(uint32_t *, uint32_t i, uint32_t v) { put(0x80000000u | i, v); }
+    __device__ __forceinline__ void link(uint32_t *, uint32_t i, uint32_t v) { put(i, v); }
+    __device__ __forceinline__ void replay(uint32_t *heads, uint32_t *tree) const
+    {
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t *e = slot(k);
+            const uint32_t t = e[0];
+            if (t >> 31) heads[t & 0x7FFFFFFFu] = e[1]; else tree[t] = e[1];
+        }
+    }
+};
+
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
     const uint32_t nl = wblocks * blockDim.x;
@@ -450,7 +476,8 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     uint32_t i0 = 0, e0 = 0;
     uint32_t la_end = 0;            // absolute end of the chunk's lookahead
     uint32_t stage = 0, a = 0, max_len = 0;
-    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dummy_t = 0, dummy_c = 0, n_cyc = 0, n_cyc_tests = 0;
+    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dry_t = 0, dry_c = 0, n_cyc = 0, n_cyc_tests = 0;
+    StoreLog slog{ 0, false };
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0;
     bool fail = false;
@@ -486,7 +513,8 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                                 worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
                                 n_calls++;
                             } else if (f != kFlagSkip) {
-                                worker_bt_call<LaneIO, false>(g, G, a, max_len, true, dummy_t, dummy_c);
+                                slog.n = 0; slog.full = false; dry_t = 0; dry_c = 0;
+                                worker_bt_dry<LaneIO>(g, G, a, max_len, dry_t, dry_c, slog);
                                 n_dry++;
                                 stage = 1; t_wait0 = 0; idle = 0;
                             }
@@ -501,7 +529,9 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
             } else {
                 const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
                 if (f == kFlagCall) {
-                    worker_bt_call<LaneIO, true>(g, G, a, max_len, false, n_tests, n_cmp);
+                    // the call happens: what the dry run noted is exactly what it writes
+                    if (!slog.full) { slog.replay(G.bt_heads, G.bt_tree); n_tests += dry_t; n_cmp += dry_c; }
+                    else worker_bt_call<LaneIO, true>(g, G, a, max_len, false, n_tests, n_cmp);
                     n_calls++;
                     stage = 0;
                 } else if (f == kFlagSkip) {
