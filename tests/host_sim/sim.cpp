@@ -65,7 +65,12 @@ struct HostWave {
     struct Rec { uint32_t w[32]; };
     static Rec rec_load(const uint32_t *base) { Rec r; for (int i = 0; i < 32; i++) r.w[i] = base[i]; return r; }
     template <class F>
-    static Rec rec_load_fn(F f) { Rec r; for (uint32_t i = 0; i < 8; i++) r.w[i] = f(i); return r; }
+    static Rec rec_load_fn(F f)         // ascending, one load at a time (see rec_load_fn32)
+    {
+        Rec r;
+        for (uint32_t i = 0; i < 8; i++) { r.w[i] = f(i); __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+        return r;
+    }
     template <class F>
     static Rec rec_load_fn32(F f)       // ascending lane order, one load at a time: a count in lane 0 is read before the data it covers
     {
