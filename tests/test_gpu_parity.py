@@ -129,6 +129,19 @@ def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
     assert shard.split_streams(b"".join(got)) == got
 
 
+def test_blocks_ragged_and_empty(gpu):
+    """Fewer bytes than blocks: trailing blocks are empty streams (header + terminator), as the reference writes for an
+    empty file; a last block shorter than the others; one block = the plain stream."""
+    from nlzm_amd import shard
+    for n, k in ((5, 4), (3, 8), (300_001, 7), (70_000, 1)):
+        data = corpus.syn_text(n, corpus.SEED + n)
+        got = gpu.compress_blocks(data, k, 17)
+        for i, stream in enumerate(got):
+            lo, hi = shard.block_range(n, k, i)
+            assert stream == oracle_py.compress(data[lo:hi], 17), (n, k, i)
+    assert got[0] == gpu.compress(data, 17)
+
+
 def test_cli_block_mode_round_trip(gpu, tmp_path):
     """`nlzm -blocks:k c` writes k streams back to back (each = the oracle on its byte range), `d` reads them."""
     from nlzm_amd import shard
