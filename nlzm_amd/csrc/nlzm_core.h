@@ -116,7 +116,8 @@ struct FrameMeta {
 };
 
 // BT4 result of one position, written by a worker lane and read by the master:
-//   bt_ready[i] = 0 (not yet) | 0x80000000 | tests<<9 | count
+//   bt_ready[i * kBtRec] = 0 (not yet) | 0x80000000 | tests<<9 | count, words 1..8 of the record: the first four pairs
+//   (one 64-byte record per position: a waiting master reads word and pairs with ONE load instruction)
 //   bt_pairs[i * 2*kBtMaxPairs ...] = `count` (distance, length) pairs -- the
 // record-setters of the descent (a descent visits candidates by increasing distance,
 // so only a longer match changes the table: :835-852).  The stride is the worst case
@@ -125,6 +126,7 @@ struct FrameMeta {
 constexpr uint32_t kBtMaxPairs = 256;
 constexpr uint32_t kBtReady = 0x80000000u;
 constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
+constexpr uint32_t kBtRec = 16;         // words per bt_ready record
 
 struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
@@ -148,7 +150,7 @@ struct Globals {
     // ---- worker mode: BT4 on per-head worker lanes ------------------------------
     uint32_t workers;           // 0: BT4 runs inside the master workgroup
     uint32_t batch_a0;          // absolute position of the first byte of this launch
-    uint32_t *bt_ready;         // [a - batch_a0]
+    uint32_t *bt_ready;         // [(a - batch_a0) * kBtRec]
     uint32_t *bt_pairs;         // [(a - batch_a0) * 2 * kBtMaxPairs]
     uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
     const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
@@ -174,6 +176,7 @@ struct MasterLds {
     uint16_t seg_len_price[kMatchMax + 8];  // price of the length symbols by length value (:1214-1225), current model
     uint16_t seg_slot_price[4 * 64];        // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t btpairs[2 * kBtMaxPairs];      // worker result being consumed
+    uint32_t sq_sym[2 * 8];                 // symbols of the command being emitted: context, symbol (distinct contexts)
     Counters cnt;                           // operation counters of this launch (LDS adds, nothing to wait for)
     // look-ahead: kPf positions are evaluated by the lanes in parallel against the finder
     // tables as they stand, then consumed in order (Master::pf_fill / finders_fast)
@@ -181,6 +184,7 @@ struct MasterLds {
     //   0 input bytes (4)   1 HT2 bucket | HT3 bucket << 16   2 HT3 row 0 as read   3 flags
     //   4 number of HT updates | bytes compared << 8          5..10 HT updates: distance, length | open << 31
     //   11 RK hash   12 RK slot as read   13 RK candidate length   14 bt_ready as read   15..22 first 4 BT4 pairs
+    //   23..26 summaries of the updates (HT only / HT + BT4)   27, 28 HT2 row and HT3 row 1 as read
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
@@ -354,6 +358,7 @@ struct LaneCmp {
 template <class IO>
 struct ResultSink {
     uint32_t *pairs;        // nullptr: do not publish
+    uint32_t *rec;          // the position's bt_ready record (first four pairs go there too)
     uint32_t count, best;
     NLZM_HD void operator()(uint32_t d, uint32_t l)
     {
@@ -361,6 +366,7 @@ struct ResultSink {
         best = l;
         IO::st_agent(pairs + 2 * count, d);
         IO::st_agent(pairs + 2 * count + 1, l);
+        if (count < 4) { IO::st_agent(rec + 1 + 2 * count, d); IO::st_agent(rec + 2 + 2 * count, l); }
         count++;
     }
 };
@@ -372,13 +378,13 @@ NLZM_HD void worker_bt_dry(const Geom &g, const Globals &G, uint32_t a, uint32_t
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), G.bt_ready + bi * kBtRec, 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update_st(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests, st);
     n_tests += tests;
     IO::drain();                            // every pair has been written through before the ready word
-    IO::st_agent(G.bt_ready + bi, kBtReady | (tests << 9) | sink.count);
+    IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
 }
 
 template <class IO, bool kWrite>
@@ -387,14 +393,14 @@ NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
+    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, G.bt_ready + bi * kBtRec, 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
     if (publish) {
         IO::drain();                        // every pair has been written through before the ready word
-        IO::st_agent(G.bt_ready + bi, kBtReady | (tests << 9) | sink.count);
+        IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
     }
 }
 
@@ -419,6 +425,7 @@ struct Master {
     uint32_t pf_buf, pf_mark0, pf_mark1;    // record buffer in use; command count when buffer 0 / 1 was last left
     typename W::PfLane pfl;         // per slot (= per lane): HT buckets, RK slot, stale bits (1: HT rows, 4: RK slot)
     uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
+    uint32_t bpos_seen;             // table wave: x_bpos as last read
     uint32_t th_a, th_hdr, th_lit;  // parser wave: hand-off header and input byte of position th_a (read ahead)
     bool seg_tab_dirty;             // parser wave: a length/distance context changed since the price tables were built
     uint32_t cq_n, cq_seen;         // finder wave: commands written / consumed count last seen
@@ -443,7 +450,7 @@ struct Master {
 
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
-    uint32_t nsyms, nbits, word, word_bits, num_ops;
+    uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
 
     uint32_t err, err_info0;
     unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
@@ -624,14 +631,20 @@ struct Master {
     }
 
     // ---- symbol output (WriteRange/WriteBits + cdf_update) -------------------
+    // The symbols of ONE command go through their nibble CDFs together: their contexts are distinct (command, length
+    // direct / ext hi / ext lo[hi], slot hi[lc] / slot lo[lc][hi], literal hi / lo[hi]), so the (start, freq) snapshots
+    // (WriteCDF :559-572, :1278-1279), the adaptations (cdf_update :348-382) and the price rows (:435-438) are
+    // independent; W::cdf_multi takes four symbols per pass, sixteen lanes each.
     NLZM_HD void put_sym(uint32_t ctx, uint32_t y)
     {
-        // WriteCDF snapshots (start,freq) before the update (:559-572, :1278-1279), then cdf_update (:348-382) and the
-        // price row of the context (:435-438); W::cdf_step does the three with two LDS round trips
-        uint32_t start, freq;
-        W::cdf_step(W::lds()->cdf + ctx * kCdfStride, W::lds()->price + ctx * 16, W::lds()->lut, ctx_nsyms(ctx), y, start, freq);
-        fsyms[nsyms] = (freq << 16) + start;            // wave-uniform store: same address, same value in every lane
-        nsyms++; num_ops++;
+        W::lds()->sq_sym[2 * nq] = ctx; W::lds()->sq_sym[2 * nq + 1] = y;
+        nq++;
+    }
+    NLZM_HD void flush_syms()
+    {
+        W::sync();
+        W::cdf_multi(W::lds()->cdf, W::lds()->price, W::lds()->lut, W::lds()->sq_sym, nq, fsyms + nsyms);
+        nsyms += nq; num_ops += nq; nq = 0;
         W::sync();
     }
     NLZM_HD void put_bits(uint32_t v, uint32_t nb)                  // :574-588
@@ -663,6 +676,7 @@ struct Master {
         put_sym(kCtxCmd, 0);
         put_sym(kCtxLitHi, y >> 4);
         put_sym(kCtxLitLo + (y >> 4), y & 15);
+        flush_syms();
         W::cnt_add(&W::lds()->cnt.n_literal, 1);
     }
     NLZM_HD void emit_match(uint32_t d, uint32_t len)               // :1274-1342
@@ -673,6 +687,7 @@ struct Master {
         const uint32_t slot = dist_slot(d - 1, nx, ex);
         put_sym(kCtxSlotHi + lc, slot >> 3);
         put_sym(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+        flush_syms();
         if (d - 1 >= 4) {
             if (nx < 4) put_bits(ex, nx);
             else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
@@ -684,6 +699,7 @@ struct Master {
     {
         put_sym(kCtxCmd, 2);
         emit_len(len - match_min(idx == 0 ? rep[0] : (idx == 1 ? rep[1] : (idx == 2 ? rep[2] : rep[3]))));
+        flush_syms();
         put_bits(idx, 2);
         W::cnt_add(&W::lds()->cnt.n_rep, 1);                                                  // rep4.Add(present delta) is a no-op (:1834)
     }
@@ -811,7 +827,7 @@ struct Master {
                 const unsigned long long bi = x - G.batch_a0;
                 if (G.unc[bi]) flags |= 32u;
                 W::wait_hook(G.hook_user, x);
-                ready = W::ld_agent(G.bt_ready + bi);
+                ready = W::ld_agent(G.bt_ready + bi * kBtRec);
                 if ((ready & kBtReady) && avail >= 4) {
                     const uint32_t nb = umin(ready & 0x1FFu, 4u), max_len = umin(avail, kMatchMax);
                     const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
@@ -823,7 +839,7 @@ struct Master {
                 }
             }
             rec[25] = sl; rec[26] = sd;
-            rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags;
+            rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags; rec[27] = row[0]; rec[28] = row[2];
             rec[11] = rkh; rec[12] = rkv; rec[13] = rkl; rec[14] = ready;
             // a slot is `simple` when the look-ahead has settled everything about it: the BT4 call happens (not
             // `unc`), its result is here (<= 4 pairs), no RK candidate, no RK insert falls on it, none of its table
@@ -911,10 +927,12 @@ struct Master {
                 row[1] = W::rec_get(rec, 2);                        // HT3 row 0 moves down one row
             } else {
                 // an earlier position rewrote a row this slot had read: read them again, compare now
+                // The rows as they stand now: what the look-ahead read, overwritten by what the earlier slots of this
+                // batch have stored since (each lane knows what its own slot wrote) -- no trip to memory
                 n_sht++;
-                W::sync_global();
-                row[0] = W::uni(G.ht2[i2]); row[1] = W::uni(G.ht3[i3]); row[2] = W::uni(G.ht3[i3 + 1]);
-                uint32_t job_sp[8], job_cap[8], job_len[8];
+                row[0] = W::rec_get(rec, 27); row[1] = W::rec_get(rec, 2); row[2] = W::rec_get(rec, 28);
+                W::pfl_rows_now(pfl, s, i2, i3, q - s, g.wbits, g.tag_mask, g.ht3_shift, row);
+                uint32_t job_sp[8] = { 0, 0, 0 }, job_cap[8] = { 0, 0, 0 }, job_len[8];
                 for (int k = 0; k < 3; k++) {
                     const uint32_t sp = row[k] & g.wmask;
                     if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) {   // :922-925
@@ -928,6 +946,7 @@ struct Master {
             G.ht2[i2] = q | (tag2 << g.wbits);                  // wave-uniform stores
             G.ht3[i3] = q | (tag3 << g.wbits);
             G.ht3[i3 + 1] = row[1];
+            W::pfl_wrote(pfl, s, row[1]);
             n_ht++;
             prof_mark(2);
             bool bt_done = false;
@@ -960,7 +979,7 @@ struct Master {
                 if (G.workers) {
                     const uint32_t ready = W::rec_get(rec, 14), cnt = ready & 0x1FFu;
 #ifdef NLZM_SIM_DEBUG
-                    if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[a - G.batch_a0]);
+                    if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[(a - G.batch_a0) * kBtRec]);
 #endif
                     if ((ready & kBtReady) && cnt <= 4) {
                         for (uint32_t k = 0; k < cnt; k++) {
@@ -1032,14 +1051,24 @@ struct Master {
         const unsigned long long t0 = W::clock();
         uint32_t spins = 0, v;
         const unsigned long long c0 = W::tick();
-        while (!((v = W::uni(W::ld_agent(G.bt_ready + bi))) & kBtReady)) {
+        // the whole record with one load instruction (one 64-byte line, one request): the ready word was stored after
+        // every pair had been written through (sc1) and drained, so a record that shows it also shows the pairs
+        typename W::Rec br = W::rec_load_agent(G.bt_ready + bi * kBtRec);
+        while (!((v = W::rec_get(br, 0)) & kBtReady)) {
             if ((++spins & 255u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return; }
             if ((spins & 255u) == 0 && W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return; }
             W::sleep();
+            br = W::rec_load_agent(G.bt_ready + bi * kBtRec);
         }
         wait_cyc += W::tick() - c0;
-        // the ready word was stored after every pair had been written through (sc1) and drained
         const uint32_t count = v & 0x1FFu;
+        if (count <= 4) {
+            for (uint32_t k = 0; k < count; k++) {
+                const uint32_t l = W::rec_get(br, 2 + 2 * k);
+                mt_update(W::rec_get(br, 1 + 2 * k), l, l >= max_len);
+            }
+            return;
+        }
         const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
         W::sync();
         for (uint32_t i = W::lane(); i < 2 * count; i += W::width()) W::lds()->btpairs[i] = W::ld_agent(pairs + i);
@@ -1113,11 +1142,12 @@ struct Master {
     }
     NLZM_HD bool wait_space(uint32_t a)                             // until position a - kEr has been parsed
     {
-        if (a - W::xw_load(&W::lds()->x_bpos) < kEr) return true;
+        if (a - bpos_seen < kEr) return true;                       // x_bpos only grows: the last value seen is a safe bound
+        if (a - (bpos_seen = W::xw_load(&W::lds()->x_bpos)) < kEr) return true;
         const unsigned long long t0 = W::clock();
         const unsigned long long c0 = W::tick();
         uint32_t spins = 0;
-        while (a - W::xw_load(&W::lds()->x_bpos) >= kEr) {
+        while (a - (bpos_seen = W::xw_load(&W::lds()->x_bpos)) >= kEr) {
             if (W::xw_load(&W::lds()->x_err)) { err = kErrInternal + 100; return false; }
             if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, a); return false; }
             W::xw_pause();
@@ -1258,7 +1288,7 @@ struct Master {
         mt_base = 0; mt_max = W::uni(P->mt_max);
         for (uint32_t i = W::lane(); i < 512; i += W::width()) W::lds()->mt[i] = (i <= mt_max && i <= kMatchMax) ? P->mt_delta[i] : kNone;
         err = W::uni(P->error); err_info0 = 0;
-        a_long = 0; pf_base = 0;
+        a_long = 0; pf_base = 0; bpos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
         wait_cyc = 0; role_t0 = W::tick();
         W::sync();
         unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
@@ -1290,8 +1320,10 @@ struct Master {
                 else if (op == kOpExt) t_extend(v, arg);
                 else if (op == kOpRun) {                    // slots [s0, s0+n) of a look-ahead batch, first position v
                     const uint32_t s0 = arg & 63u, n = ((arg >> 6) & 63u) + 1, buf = (arg >> 12) & 1u;
+                    typename W::Rec r = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * s0);
                     for (uint32_t i = 0; i < n && !err; i++) {
-                        const typename W::Rec r = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + i));
+                        // the next slot's record is requested before this one is worked on
+                        const typename W::Rec rn = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + (i + 1 < n ? i + 1 : i)));
                         t_carry();
                         const uint32_t nh = W::rec_get(r, 4) & 0xFFu, nb = W::rec_get(r, 14) & 0x1FFu;
                         for (uint32_t j = 0; j < nh; j++) t_update(W::rec_get(r, 5 + 2 * j), W::rec_get(r, 6 + 2 * j) & 0x1FFu);
@@ -1300,6 +1332,7 @@ struct Master {
                         capture(v + i);
                         t_publish(v + i, W::rec_get(r, 0) & 0xFFu);
                         ended = v + i + 1;
+                        r = rn;
                     }
                 }
                 else {                                      // kOpEnd: publish position v, input byte arg
@@ -1765,7 +1798,7 @@ struct Master {
         // frame.Init (:534-550)
         fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
         fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
-        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0;
+        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0;
         if (chunk_abs - base >= W2) base += g.wmask + 1;            // same rebase schedule as the finder wave (:1786)
         const uint32_t chunk_q = (uint32_t)(chunk_abs - base);
         counts_zero();

@@ -238,7 +238,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMalloc(&C.pf_h, bpos * 4));
         HIPCHK(hipMalloc(&C.pf_c1, bpos));
         HIPCHK(hipMalloc(&C.unc, bpos + 16));
-        HIPCHK(hipMalloc(&C.bt_ready, bpos * 4));
+        HIPCHK(hipMalloc(&C.bt_ready, bpos * 4 * kBtRec));
         HIPCHK(hipMalloc(&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4)));      // worst case, 2 KiB per position
         HIPCHK(hipMalloc(&C.bt_flag, bpos * 4));
         HIPCHK(hipMalloc(&C.abort_word, 4));
@@ -295,7 +295,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
         G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads;
         G.abort_word = C.abort_word; G.wcnt = C.wcnt;
-        HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4, C.st));
+        HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4 * kBtRec, C.st));
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
         HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
         HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));

@@ -56,18 +56,42 @@ struct DevWave {
         const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
         if (i < nsy) { cell[i] = (uint16_t)n0; price_row[i] = lut[(n1 - n0) >> 6]; }
     }
+    // Up to 8 symbols of distinct contexts (list in LDS: context, symbol), four per pass on sixteen lanes each: see
+    // cdf_step for one symbol.  The lane that holds the symbol's cell writes its (freq << 16) + start word.
+    static __device__ __forceinline__ void cdf_multi(uint16_t *cdf, uint16_t *price, const uint16_t *lut, const uint32_t *list, uint32_t n,
+                                                     uint32_t *out)
+    {
+        const uint32_t grp = lane() >> 4, i = lane() & 15u;
+        for (uint32_t base = 0; base < n; base += 4) {
+            const uint32_t k = base + grp;
+            if (k < n) {
+                const uint32_t ctx = list[2 * k], y = list[2 * k + 1];
+                const uint32_t nsy = ctx == kCtxCmd ? 4u : ((ctx == kCtxLenDirect || ctx >= kCtxSlotHi) ? 8u : 16u);
+                uint16_t *cell = cdf + ctx * kCdfStride;
+                const uint32_t c0 = cell[i], c1 = cell[i + 1];
+                if (i == y) out[k] = ((c1 - c0) << 16) + c0;
+                auto upd = [=](uint32_t j, uint32_t c) {
+                    const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
+                    return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
+                };
+                const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
+                if (i < nsy) { cell[i] = (uint16_t)n0; price[ctx * 16 + i] = lut[(n1 - n0) >> 6]; }
+            }
+        }
+    }
     // value of lane l (wave-uniform l)
     static __device__ __forceinline__ uint32_t pick(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
     static __device__ __forceinline__ uint32_t width() { return 64u; }
     // per look-ahead slot state kept in the lane that evaluated the slot (slot j = lane j, kPf == 64)
-    struct PfLane { uint32_t idx, rkslot, stale, v4, row1, sl, sd, cmpb, simple; };
+    struct PfLane { uint32_t idx, rkslot, stale, v4, row1, sl, sd, cmpb, simple, wrote; };
     // idx: HT2 bucket | HT3 bucket << 16 (0xFFFFFFFF: the slot touches no HT row); sl/sd: summary of its table updates;
     // simple: everything about the slot was settled by the look-ahead (see Master::pf_fill)
     static __device__ __forceinline__ void pfl_set(PfLane &p, uint32_t, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1,
                                                    uint32_t sl, uint32_t sd, uint32_t cmpb, bool simple)
     {
         p.idx = idx; p.rkslot = rkslot; p.stale = 0; p.v4 = v4; p.row1 = row1; p.sl = sl; p.sd = sd; p.cmpb = cmpb; p.simple = simple;
+        p.wrote = 0;
     }
     // stale bit 1: an earlier slot of the batch writes an HT row this slot has read (bucket b owns rows b and b+1, :912)
     static __device__ __forceinline__ void pfl_conflicts(PfLane &p, uint32_t n)
@@ -87,7 +111,7 @@ struct DevWave {
         return __ballot(lane() < n && p.simple && !(p.stale & 5u));
     }
     // HT2/HT3 rows of slots [s0, s0+cnt) rotate (:935-936); no two of them, nor an earlier slot of the batch, share a row
-    static __device__ __forceinline__ void pfl_run_store(const PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3,
+    static __device__ __forceinline__ void pfl_run_store(PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3,
                                                          uint32_t q0, uint32_t wbits, uint32_t tag_mask, uint32_t ht3_shift)
     {
         if (lane() >= s0 && lane() < s0 + cnt) {
@@ -97,7 +121,28 @@ struct DevWave {
             ht2[i2] = q | ((h2 & tag_mask) << wbits);
             ht3[i3] = q | ((h3 & tag_mask) << wbits);
             ht3[i3 + 1] = p.row1;
+            p.wrote = 1;
         }
+    }
+    // slot s has rotated its HT rows; v1 is what it moved into HT3 row bucket+1
+    static __device__ __forceinline__ void pfl_wrote(PfLane &p, uint32_t s, uint32_t v1)
+    {
+        if (lane() == s) { p.wrote = 1; p.row1 = v1; }
+    }
+    // HT2 row i2 and HT3 rows i3, i3+1 as the slots before j of this batch have left them (row[] comes in as the
+    // look-ahead read them).  Slot k stored: HT2[i2_k] = E2_k, HT3[i3_k] = E3_k, HT3[i3_k + 1] = row1_k (:935-936).
+    static __device__ __forceinline__ void pfl_rows_now(const PfLane &p, uint32_t j, uint32_t i2, uint32_t i3, uint32_t q0, uint32_t wbits,
+                                                        uint32_t tag_mask, uint32_t ht3_shift, uint32_t row[3])
+    {
+        const bool act = p.wrote && lane() < j;
+        const uint32_t o2 = p.idx & 0xFFFFu, o3 = p.idx >> 16, qk = q0 + lane();
+        const uint32_t e2 = qk | ((hash4(p.v4 & 0xFFFFu) & tag_mask) << wbits), e3 = qk | ((hash4(p.v4 & 0xFFFFFFu) & tag_mask) << wbits);
+        const bool mA = act && o3 == i3, mB = act && o3 + 1 == i3, mC = act && o3 == i3 + 1;
+        const unsigned long long b0 = __ballot(act && o2 == i2), b1 = __ballot(mA || mB), b2 = __ballot(mC || mA);
+        (void)ht3_shift;
+        if (b0) row[0] = (uint32_t)__builtin_amdgcn_readlane((int)e2, 63 - __builtin_clzll(b0));
+        if (b1) row[1] = (uint32_t)__builtin_amdgcn_readlane((int)(mA ? e3 : p.row1), 63 - __builtin_clzll(b1));
+        if (b2) row[2] = (uint32_t)__builtin_amdgcn_readlane((int)(mC ? e3 : p.row1), 63 - __builtin_clzll(b2));
     }
     static __device__ __forceinline__ uint32_t pfl_sl(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sl, (int)s); }
     static __device__ __forceinline__ uint32_t pfl_sd(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sd, (int)s); }
@@ -138,6 +183,11 @@ struct DevWave {
     // a small record read with ONE LDS instruction (lane k holds word k), its words picked by v_readlane
     struct Rec { uint32_t v; };
     static __device__ __forceinline__ Rec rec_load(const uint32_t *base) { return Rec{ base[lane() & 31u] }; }
+    // 16 words of HBM shared with the worker lanes (agent scope), lane k takes word k
+    static __device__ __forceinline__ Rec rec_load_agent(const uint32_t *base)
+    {
+        return Rec{ __hip_atomic_load(base + (lane() & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
+    }
     template <class F>
     static __device__ __forceinline__ Rec rec_load_fn(F f) { return Rec{ f(lane() & 7u) }; }
     template <class F>
@@ -214,35 +264,35 @@ struct DevWave {
     }
     // Up to 8 byte compares at once: group k (8 lanes x 8 bytes) compares
     // in[sp[k] ..] with in[a ..] up to cap[k] bytes; len[k] = common prefix.
+    // Up to three byte compares against the bytes at `a` at once (HT2 row, two HT3 rows): job k on lanes 8k..8k+7, eight
+    // bytes per lane and round; the first mismatch of a job is the lowest set bit of its byte of one ballot.
     static __device__ __forceinline__ void cmp_multi(const uint8_t *in, const uint32_t sp[8], uint32_t a,
                                                      const uint32_t cap[8], uint32_t valid, uint32_t len[8])
     {
         const uint32_t l = lane(), grp = l >> 3, j = l & 7;
-        uint32_t mysp = 0, mycap = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (grp == (uint32_t)k) { mysp = sp[k]; mycap = cap[k]; }
-        bool active = (valid >> grp) & 1u;
-        if (!active) mycap = 0;
-        uint32_t res = mycap;          // no mismatch below cap => cap
-        uint32_t off = 0;
-        while (__any(active && off < mycap)) {
-            uint32_t m = kNone;
+        const uint32_t mysp = grp == 0 ? sp[0] : (grp == 1 ? sp[1] : sp[2]);
+        const uint32_t mycap = grp == 0 ? cap[0] : (grp == 1 ? cap[1] : cap[2]);
+        uint32_t todo = valid & 7u;                     // jobs without a result yet (wave-uniform)
+        len[0] = 0; len[1] = 0; len[2] = 0;
+        for (uint32_t off = 0; todo; off += 64) {
             const uint32_t my = off + j * 8;
-            if (active && my < mycap) {
+            uint32_t pos = kNone;
+            if (grp < 3 && ((todo >> grp) & 1u) && my < mycap) {
                 const unsigned long long d = load64u(in + mysp + my) ^ load64u(in + a + my);
                 if (d) {
-                    const uint32_t pos = my + ((uint32_t)__builtin_ctzll(d) >> 3);
-                    if (pos < mycap) m = pos;
+                    const uint32_t p = my + ((uint32_t)__builtin_ctzll(d) >> 3);
+                    if (p < mycap) pos = p;
                 }
             }
-            m = umin(m, (uint32_t)__shfl_xor((int)m, 1, 64));
-            m = umin(m, (uint32_t)__shfl_xor((int)m, 2, 64));
-            m = umin(m, (uint32_t)__shfl_xor((int)m, 4, 64));
-            if (active && m != kNone) { res = m; active = false; }
-            off += 64;
-        }
+            const uint32_t bal = (uint32_t)__ballot(pos != kNone);
 #pragma unroll
-        for (int k = 0; k < 8; k++) len[k] = (uint32_t)__shfl((int)res, k * 8, 64);
+            for (int k = 0; k < 3; k++) {
+                if (!((todo >> k) & 1u)) continue;
+                const uint32_t byte = (bal >> (8 * k)) & 0xFFu;
+                if (byte) { len[k] = (uint32_t)__builtin_amdgcn_readlane((int)pos, 8 * k + (int)__builtin_ctz(byte)); todo &= ~(1u << k); }
+                else if (off + 64 >= cap[k]) { len[k] = cap[k]; todo &= ~(1u << k); }       // no mismatch below the cap
+            }
+        }
     }
 };
 

@@ -39,6 +39,15 @@ struct HostWave {
     template <class F>
     static void cnt_add_fn(unsigned long long *p, uint32_t n, F f) { for (uint32_t i = 0; i < n; i++) cnt_add(p, f(i)); }
     static uint32_t pick(uint32_t v, uint32_t) { return v; }
+    static void cdf_multi(uint16_t *cdf, uint16_t *price, const uint16_t *lut, const uint32_t *list, uint32_t n, uint32_t *out)
+    {
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t ctx = list[2 * k], y = list[2 * k + 1];
+            uint32_t start, freq;
+            cdf_step(cdf + ctx * kCdfStride, price + ctx * 16, lut, ctx_nsyms(ctx), y, start, freq);
+            out[k] = (freq << 16) + start;
+        }
+    }
     static void cdf_step(uint16_t *cell, uint16_t *price_row, const uint16_t *lut, uint32_t nsy, uint32_t y, uint32_t &start, uint32_t &freq)
     {
         start = cell[y]; freq = (uint32_t)cell[y + 1] - start;
@@ -64,6 +73,7 @@ struct HostWave {
     static unsigned long long mask64(F f) { unsigned long long m = 0; for (uint32_t i = 0; i < 64; i++) if (f(i)) m |= 1ull << i; return m; }
     struct Rec { uint32_t w[32]; };
     static Rec rec_load(const uint32_t *base) { Rec r; for (int i = 0; i < 32; i++) r.w[i] = base[i]; return r; }
+    static Rec rec_load_agent(const uint32_t *base) { Rec r; for (int i = 0; i < 16; i++) r.w[i] = base[i]; for (int i = 16; i < 32; i++) r.w[i] = 0; return r; }
     template <class F>
     static Rec rec_load_fn(F f)         // ascending, one load at a time (see rec_load_fn32)
     {
@@ -79,12 +89,12 @@ struct HostWave {
         return r;
     }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
-    struct PfLane { uint32_t idx[64], rkslot[64], stale[64], v4[64], row1[64], sl[64], sd[64], cmpb[64], simple[64]; };
+    struct PfLane { uint32_t idx[64], rkslot[64], stale[64], v4[64], row1[64], sl[64], sd[64], cmpb[64], simple[64], wrote[64]; };
     static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1, uint32_t sl, uint32_t sd,
                         uint32_t cmpb, bool simple)
     {
         p.idx[j] = idx; p.rkslot[j] = rkslot; p.stale[j] = 0; p.v4[j] = v4; p.row1[j] = row1; p.sl[j] = sl; p.sd[j] = sd; p.cmpb[j] = cmpb;
-        p.simple[j] = simple;
+        p.simple[j] = simple; p.wrote[j] = 0;
     }
     static void pfl_conflicts(PfLane &p, uint32_t n)
     {
@@ -103,7 +113,7 @@ struct HostWave {
         for (uint32_t j = 0; j < n; j++) if (p.simple[j] && !(p.stale[j] & 5u)) m |= 1ull << j;
         return m;
     }
-    static void pfl_run_store(const PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3, uint32_t q0, uint32_t wbits,
+    static void pfl_run_store(PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3, uint32_t q0, uint32_t wbits,
                               uint32_t tag_mask, uint32_t ht3_shift)
     {
         for (uint32_t j = s0; j < s0 + cnt; j++) {
@@ -113,6 +123,21 @@ struct HostWave {
             ht2[i2] = q | ((h2 & tag_mask) << wbits);
             ht3[i3] = q | ((h3 & tag_mask) << wbits);
             ht3[i3 + 1] = p.row1[j];
+            p.wrote[j] = 1;
+        }
+    }
+    static void pfl_wrote(PfLane &p, uint32_t s, uint32_t v1) { p.wrote[s] = 1; p.row1[s] = v1; }
+    static void pfl_rows_now(const PfLane &p, uint32_t j, uint32_t i2, uint32_t i3, uint32_t q0, uint32_t wbits, uint32_t tag_mask,
+                             uint32_t, uint32_t row[3])
+    {
+        for (uint32_t k = 0; k < j; k++) {          // in order: the last writer of a row wins
+            if (!p.wrote[k]) continue;
+            const uint32_t o2 = p.idx[k] & 0xFFFFu, o3 = p.idx[k] >> 16, qk = q0 + k;
+            const uint32_t e2 = qk | ((hash4(p.v4[k] & 0xFFFFu) & tag_mask) << wbits), e3 = qk | ((hash4(p.v4[k] & 0xFFFFFFu) & tag_mask) << wbits);
+            if (o2 == i2) row[0] = e2;
+            if (o3 == i3) { row[1] = e3; row[2] = p.row1[k]; }
+            if (o3 + 1 == i3) row[1] = p.row1[k];
+            if (o3 == i3 + 1) row[2] = e3;
         }
     }
     static uint32_t pfl_sl(const PfLane &p, uint32_t s) { return p.sl[s]; }
@@ -391,7 +416,7 @@ int main(int argc, char **argv)
             unsigned long long a1 = (unsigned long long)c1 * g.chunk_size; if (a1 > (unsigned long long)n) a1 = n;
             pf.run(in.data(), (unsigned long long)n, (uint32_t)a0, (uint32_t)a1, g.wmask, unc);
             for (unsigned long long i = 0; i < a1 - a0; i++) unc_total += unc[i];
-            ready.assign(a1 - a0 + 1, 0); pairs.resize((size_t)(a1 - a0 + 1) * 2 * kBtMaxPairs); flag.assign(a1 - a0 + 1, 0);
+            ready.assign((a1 - a0 + 1) * (size_t)kBtRec, 0); pairs.resize((size_t)(a1 - a0 + 1) * 2 * kBtMaxPairs); flag.assign(a1 - a0 + 1, 0);
             m.G.workers = 1; m.G.batch_a0 = (uint32_t)a0; m.G.bt_ready = ready.data(); m.G.bt_pairs = pairs.data(); m.G.bt_flag = flag.data(); m.G.unc = unc.data();
             m.G.nheads = 1u << (32 - g.bt_shift);
             m.G.abort_word = &abort_word; m.G.wcnt = &wc;
