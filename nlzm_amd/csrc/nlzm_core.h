@@ -772,23 +772,68 @@ struct Master {
             uint32_t row[3] = { 0, 0, 0 };
             unsigned long long dummy = 0;
             LaneCmp lcmp{ &dummy };
-            if (avail >= 4) {
-                v4 = load32u(cur);
-                const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu);
-                const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;
-                idx = i2 | (i3 << 16);
-                row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1];
+            // Loads in rounds of independent requests (a dependent HBM access is ~2,000 cycles):
+            // round 1: what the position alone addresses -- its bytes, its RK256 hash, `unc`, the BT4 result word
+            const bool h4 = avail >= 4, h256 = avail >= 256;
+            const unsigned long long bi = x - G.batch_a0;
+            if (h4) v4 = load32u(cur);
+            uint32_t rkh = h256 ? G.rkhash[x] : 0u, rkv = 0, rkl = 0, ready = 0;
+            if (G.workers) {
+                if (G.unc[bi]) flags |= 32u;
+                W::wait_hook(G.hook_user, x);
+                ready = W::ld_agent(G.bt_ready + bi * kBtRec);
+            }
+            // round 2: the HT rows, the RK slot, the pairs of a BT4 result that is in
+            const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu);
+            const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;
+            if (h4) { idx = i2 | (i3 << 16); row[0] = G.ht2[i2]; row[1] = G.ht3[i3]; row[2] = G.ht3[i3 + 1]; }
+            if (h256) rkv = G.rk_table[rkh >> g.rk_shift];
+            uint32_t nb = 0, bd[4] = { 0, 0, 0, 0 }, bl[4] = { 0, 0, 0, 0 };
+            if ((ready & kBtReady) && h4) {
+                nb = umin(ready & 0x1FFu, 4u);
+                const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if ((uint32_t)k < nb) { bd[k] = W::ld_agent(pairs + 2 * k); bl[k] = W::ld_agent(pairs + 2 * k + 1); }
+            }
+            // round 3: the first eight bytes of every candidate (most compares end there); longer ones go on alone
+            const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
+            uint32_t csp[4] = { 0, 0, 0, 0 };           // q - sp of the valid candidates: HT2, HT3 row 0, HT3 row 1, RK
+            unsigned long long c8[4] = { 0, 0, 0, 0 }, own8 = 0;
+            if (h4) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t sp = row[k] & g.wmask;
+                    if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) { flags |= 1u << k; csp[k] = q - sp; }
+                }
+            }
+            if (h256) {
+                const uint32_t sp = rkv & g.wmask;
+                if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) { flags |= 8u; csp[3] = q - sp; }
+            }
+            if (flags & 15u) own8 = load64u(cur);
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((flags >> k) & 1u) c8[k] = load64u(cur - csp[k]);
+            // MatchLengthSigned (:854-877) with the first eight bytes in hand
+            auto cmp8 = [&](int k, uint32_t cap) -> uint32_t {
+                const unsigned long long d = c8[k] ^ own8;
+                if (d) {
+                    const uint32_t nbm = (uint32_t)__builtin_ctzll(d) >> 3;
+                    if (nbm < cap) return nbm;
+                    return cap;
+                }
+                if (cap <= 8) return cap;
+                return lcmp(cur - csp[k], cur, 8, cap) & 0x7FFFFFFFu;
+            };
+            if (h4) {
                 const uint32_t max_len = umin(avail, kMatchMax);
-                const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
                 // MatchFinderHT::FindAndUpdate (:917-933) for HT2 then HT3, as a list of table updates
                 uint32_t np = 0, cmpb = 0, best = 1;
+#pragma unroll
                 for (int k = 0; k < 3; k++) {
                     if (k == 1) best = 1;                           // HT3 is its own call
-                    const uint32_t sp = row[k] & g.wmask;
-                    if ((row[k] >> g.wbits) == (k ? tag3 : tag2) && sp < q && q - sp <= g.wmask) {
-                        flags |= 1u << k;
+                    if ((flags >> k) & 1u) {
                         if (best < max_len) {
-                            const uint32_t l = lcmp(cur - (q - sp), cur, 0, max_len) & 0x1FFu, d = q - sp;
+                            const uint32_t l = cmp8(k, max_len) & 0x1FFu, d = csp[k];
                             lens |= l << (9 * k);
                             cmpb += l + (l < max_len);
                             if (l > best && l >= match_min(d)) {
@@ -801,19 +846,11 @@ struct Master {
                 }
                 rec[4] = np | (cmpb << 8);
             } else rec[4] = 0;
-            uint32_t rkh = 0, rkv = 0, rkl = 0;
-            if (avail >= 256) {
-                rkh = G.rkhash[x];
-                rkv = G.rk_table[rkh >> g.rk_shift];
-                const uint32_t sp = rkv & g.wmask;
-                if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) {
-                    flags |= 8u;
-                    const uint32_t cap = avail & 0xFFFFu, lim = umin(cap, kMatchMax + 8);
-                    rkl = lcmp(cur - (q - sp), cur, 0, lim) & 0x7FFFFFFFu;
-                    if (rkl == lim && lim < cap) flags |= 16u;      // longer than we looked: exact length on demand
-                }
+            if (flags & 8u) {
+                const uint32_t cap = avail & 0xFFFFu, lim = umin(cap, kMatchMax + 8);
+                rkl = cmp8(3, lim);
+                if (rkl == lim && lim < cap) flags |= 16u;          // longer than we looked: exact length on demand
             }
-            uint32_t ready = 0;
             // summary of a set of table updates: longest length | open << 31, smallest distance among the longest
             uint32_t sl = 0, sd = kNone;
             auto summarise = [&](uint32_t d, uint32_t lo) {
@@ -821,21 +858,15 @@ struct Master {
                 if (l > (sl & 0x1FFu)) { sl = lo; sd = d; }
                 else if (l == (sl & 0x1FFu)) { sl |= lo & 0x80000000u; sd = umin(sd, d); }
             };
-            if (avail >= 4) for (uint32_t k = 0; k < (rec[4] & 0xFFu); k++) summarise(rec[5 + 2 * k], rec[6 + 2 * k]);
+            if (h4) for (uint32_t k = 0; k < (rec[4] & 0xFFu); k++) summarise(rec[5 + 2 * k], rec[6 + 2 * k]);
             rec[23] = sl; rec[24] = sd;
-            if (G.workers) {
-                const unsigned long long bi = x - G.batch_a0;
-                if (G.unc[bi]) flags |= 32u;
-                W::wait_hook(G.hook_user, x);
-                ready = W::ld_agent(G.bt_ready + bi * kBtRec);
-                if ((ready & kBtReady) && avail >= 4) {
-                    const uint32_t nb = umin(ready & 0x1FFu, 4u), max_len = umin(avail, kMatchMax);
-                    const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-                    for (uint32_t k = 0; k < nb; k++) {
-                        const uint32_t d = W::ld_agent(pairs + 2 * k), l = W::ld_agent(pairs + 2 * k + 1);
-                        rec[15 + 2 * k] = d; rec[16 + 2 * k] = l | ((uint32_t)(l >= max_len) << 31);
-                        summarise(d, rec[16 + 2 * k]);
-                    }
+            {
+                const uint32_t max_len = umin(avail, kMatchMax);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((uint32_t)k >= nb) continue;
+                    rec[15 + 2 * k] = bd[k]; rec[16 + 2 * k] = bl[k] | ((uint32_t)(bl[k] >= max_len) << 31);
+                    summarise(bd[k], rec[16 + 2 * k]);
                 }
             }
             rec[25] = sl; rec[26] = sd;
