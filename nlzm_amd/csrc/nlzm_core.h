@@ -184,7 +184,7 @@ struct MasterLds {
     //   0 input bytes (4)   1 HT2 bucket | HT3 bucket << 16   2 HT3 row 0 as read   3 flags
     //   4 number of HT updates | bytes compared << 8          5..10 HT updates: distance, length | open << 31
     //   11 RK hash   12 RK slot as read   13 RK candidate length   14 bt_ready as read   15..22 first 4 BT4 pairs
-    //   23..26 summaries of the updates (HT only / HT + BT4)   27, 28 HT2 row and HT3 row 1 as read
+    //   23..26 summaries of the updates (HT only / HT + BT4)   27, 28 HT2 row and HT3 row 1 as read   29 simple but for BT4
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
@@ -780,6 +780,9 @@ struct Master {
             uint32_t rkh = h256 ? G.rkhash[x] : 0u, rkv = 0, rkl = 0, ready = 0;
             if (G.workers) {
                 if (G.unc[bi]) flags |= 32u;
+#ifdef NLZM_SIM_LATE
+                if ((x * 2654435761u) >> 29)            // host simulation: every 8th result is "not in yet" at this point
+#endif
                 W::wait_hook(G.hook_user, x);
                 ready = W::ld_agent(G.bt_ready + bi * kBtRec);
             }
@@ -875,8 +878,9 @@ struct Master {
             // a slot is `simple` when the look-ahead has settled everything about it: the BT4 call happens (not
             // `unc`), its result is here (<= 4 pairs), no RK candidate, no RK insert falls on it, none of its table
             // updates can extend at the next position.  Whether an earlier slot rewrites its HT rows is added below.
-            const bool simple = G.workers && avail >= 256 && !(flags & (32u | 8u)) && (q & 255u) != 0 && (ready & kBtReady) &&
-                                (ready & 0x1FFu) <= 4 && !(sl >> 31);
+            const bool pre = G.workers && avail >= 256 && !(flags & (32u | 8u)) && (q & 255u) != 0;
+            rec[29] = pre ? 1u : 0u;                                // (for bt_refresh)
+            const bool simple = pre && (ready & kBtReady) && (ready & 0x1FFu) <= 4 && !(sl >> 31);
             W::pfl_set(pfl, j, idx, rkh >> g.rk_shift, v4, row[1], sl, sd, rec[4] >> 8, simple);
         }
         W::pfl_conflicts(pfl, pf_n);
@@ -896,7 +900,7 @@ struct Master {
         const uint32_t avail = la_end - q;
         prof_mark(0);
         const uint32_t s = a - pf_base;
-        const typename W::Rec rec = W::rec_load(W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * s);
+        typename W::Rec rec = W::rec_load(W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * s);
         const uint32_t pflags = W::rec_get(rec, 3), pstale = W::pfl_stale(pfl, s);
 
         // carry by one (:1501-1502, CarryFrom :823-833)
@@ -946,6 +950,10 @@ struct Master {
         prev_nice = nice;
         const bool have4 = call && avail >= 4, have256 = call && avail >= 256;
         const uint32_t max_len = umin(avail, kMatchMax);            // :915, :987
+        if (G.workers && !nice && have4 && !(W::rec_get(rec, 14) & kBtReady)) {
+            bt_refresh(s, q);
+            rec = W::rec_load(W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * s);
+        }
 
         if (have4) {
             const uint32_t v4 = W::rec_get(rec, 0);
@@ -1072,6 +1080,39 @@ struct Master {
             }
         }
         prof_mark(6);
+    }
+
+    // The BT4 result of slot s was not in when the look-ahead read it.  Before waiting for it, every later slot
+    // of the batch that was not in either looks again (one load round for all of them): the worker lanes have had
+    // the time the finder wave spent on the slots in between.
+    NLZM_HD void bt_refresh(uint32_t s, uint32_t q_s)
+    {
+        W::sync();
+        for (uint32_t j = W::lane(); j < pf_n; j += W::width()) {
+            if (j < s) continue;
+            uint32_t *rec = W::lds()->pf_rec + pf_buf * (32 * kPf) + 32 * j;
+            if (rec[14] & kBtReady) continue;
+            const uint32_t x = pf_base + j, avail = la_end - (q_s + (j - s));
+            if (avail < 4) continue;
+            const unsigned long long bi = x - G.batch_a0;
+            W::wait_hook(G.hook_user, x);
+            const uint32_t *br = G.bt_ready + bi * kBtRec;
+            const uint32_t ready = W::ld_agent(br);
+            if (!(ready & kBtReady)) continue;
+            // (the record's pairs were written through before its ready word)
+            const uint32_t nb = umin(ready & 0x1FFu, 4u), max_len = umin(avail, kMatchMax);
+            uint32_t sl = rec[23], sd = rec[24];
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t d = W::ld_agent(br + 1 + 2 * k), l = W::ld_agent(br + 2 + 2 * k);
+                const uint32_t lo = l | ((uint32_t)(l >= max_len) << 31);
+                rec[15 + 2 * k] = d; rec[16 + 2 * k] = lo;
+                if (l > (sl & 0x1FFu)) { sl = lo; sd = d; }
+                else if (l == (sl & 0x1FFu)) { sl |= lo & 0x80000000u; sd = umin(sd, d); }
+            }
+            rec[25] = sl; rec[26] = sd; rec[14] = ready;
+            W::pfl_update(pfl, j, sl, sd, rec[29] && (ready & 0x1FFu) <= 4 && !(sl >> 31));
+        }
+        W::sync();
     }
 
     // BT4 result of a worker lane: wait for it, then merge its pairs (MatchTable::Update, :996-998).

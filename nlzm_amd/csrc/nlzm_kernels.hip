@@ -124,6 +124,11 @@ struct DevWave {
             p.wrote = 1;
         }
     }
+    // (called by the lane of slot j itself) the BT4 result of the slot has arrived after the look-ahead
+    static __device__ __forceinline__ void pfl_update(PfLane &p, uint32_t, uint32_t sl, uint32_t sd, bool simple)
+    {
+        p.sl = sl; p.sd = sd; p.simple = simple;
+    }
     // slot s has rotated its HT rows; v1 is what it moved into HT3 row bucket+1
     static __device__ __forceinline__ void pfl_wrote(PfLane &p, uint32_t s, uint32_t v1)
     {

@@ -126,6 +126,7 @@ struct HostWave {
             p.wrote[j] = 1;
         }
     }
+    static void pfl_update(PfLane &p, uint32_t j, uint32_t sl, uint32_t sd, bool simple) { p.sl[j] = sl; p.sd[j] = sd; p.simple[j] = simple; }
     static void pfl_wrote(PfLane &p, uint32_t s, uint32_t v1) { p.wrote[s] = 1; p.row1[s] = v1; }
     static void pfl_rows_now(const PfLane &p, uint32_t j, uint32_t i2, uint32_t i3, uint32_t q0, uint32_t wbits, uint32_t tag_mask,
                              uint32_t, uint32_t row[3])

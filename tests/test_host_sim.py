@@ -29,3 +29,14 @@ def test_master_logic_matches_oracle(sim, name, workers, tmp_path):
     cases.make_case(case).tofile(p)
     r = subprocess.run([sim, str(p), str(case[4]), "1", str(workers)], capture_output=True, text=True)
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["text_200k_w15", "dups_400k_w16", "runs_300k_w18"])
+def test_master_logic_with_late_worker_results(sim, name, tmp_path):
+    """Same, with every 8th BT4 result not in when the look-ahead reads it: the refresh and wait paths."""
+    case = next(c for c in cases.CASES if c[0] == name)
+    p = tmp_path / "in.bin"
+    cases.make_case(case).tofile(p)
+    r = subprocess.run([SIM + "_late", str(p), str(case[4]), "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and ": OK" in r.stdout, r.stdout + r.stderr
+
