@@ -127,10 +127,12 @@ constexpr uint32_t kBtMaxPairs = 256;
 constexpr uint32_t kBtReady = 0x80000000u;
 constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
 constexpr uint32_t kBtRec = 16;         // words per bt_ready record
+constexpr uint32_t kBtxPairs = 16;      // longest BT4 result the look-ahead keeps in LDS
 
 struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
     unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
+    unsigned long long lead[6];                     // NLZM_LEAD_DIAG: calls by how far ahead of the master they ended
 };
 
 // Everything the master needs from HBM.
@@ -187,6 +189,7 @@ struct MasterLds {
     //   23..26 summaries of the updates (HT only / HT + BT4)   27, 28 HT2 row and HT3 row 1 as read   29 simple but for BT4
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
+    uint32_t pf_btx[kPf * 2 * kBtxPairs];   // BT4 results of 5..kBtxPairs pairs (8 % of text positions), fetched by the look-ahead
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
     // ---- hand-off run_finder -> run_table -> run_parser ----
     // Wave A (finders) keeps only the table's length and top entry in registers and sends what happens to
@@ -454,6 +457,7 @@ struct Master {
 
     uint32_t err, err_info0;
     unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
+    unsigned long long wait_cq = 0, wait_guard = 0;     // finder wave: of them for queue space / for the record buffer
 #ifdef NLZM_PROFILE
     unsigned long long prof[16];
     unsigned long long prof_t, lat_sum = 0, lat_sum2 = 0;
@@ -524,7 +528,7 @@ struct Master {
                 if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, cq_n); return; }
                 W::xw_pause();
             }
-            wait_cyc += W::tick() - c0;
+            { const unsigned long long w = W::tick() - c0; wait_cyc += w; wait_cq += w; }
         }
         uint32_t *c = W::lds()->cq + (cq_n & (kCq - 1)) * 2;
         c[0] = op | (arg << 8); c[1] = val;
@@ -757,9 +761,12 @@ struct Master {
                     if ((++spins & 1023u) == 0 && W::clock() - t0 > W::timeout_ticks()) { fail(kErrTimeout, need); return; }
                     W::xw_pause();
                 }
-                wait_cyc += W::tick() - c0;
+                { const unsigned long long w = W::tick() - c0; wait_cyc += w; wait_guard += w; }
             }
         }
+#ifdef NLZM_LEAD_DIAG
+        if (W::lane() == 0) W::st_agent((uint32_t *)&G.persist->prof[31], a_start);
+#endif
         pf_base = a_start;
         pf_n = umin(kPf, pos_end_abs - a_start);
         for (uint32_t i = W::lane(); i < kPf + kWinTail; i += W::width())
@@ -797,6 +804,12 @@ struct Master {
                 const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
 #pragma unroll
                 for (int k = 0; k < 4; k++) if ((uint32_t)k < nb) { bd[k] = W::ld_agent(pairs + 2 * k); bl[k] = W::ld_agent(pairs + 2 * k + 1); }
+                // a longer list (every record-setter of the descent, :996-998) comes along whole, into LDS
+                const uint32_t cnt = ready & 0x1FFu;
+                if (cnt > 4 && cnt <= kBtxPairs) {
+                    uint32_t *bx = W::lds()->pf_btx + j * (2 * kBtxPairs);
+                    for (uint32_t k = 0; k < 2 * cnt; k++) bx[k] = W::ld_agent(pairs + k);
+                }
             }
             // round 3: the first eight bytes of every candidate (most compares end there); longer ones go on alone
             const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
@@ -1025,6 +1038,12 @@ struct Master {
                             const uint32_t l = W::rec_get(rec, 16 + 2 * k) & 0x1FFu;
                             mt_update(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
                         }
+                    } else if ((ready & kBtReady) && cnt <= kBtxPairs) {
+                        const typename W::Rec xr = W::rec_load(W::lds()->pf_btx + s * (2 * kBtxPairs));
+                        for (uint32_t k = 0; k < cnt; k++) {
+                            const uint32_t l = W::rec_get(xr, 2 * k + 1);
+                            mt_update(W::rec_get(xr, 2 * k), l, l >= max_len);
+                        }
                     } else { n_sbt++; bt_consume(a, max_len); }
                 } else bt_step(a, h4, max_len);
             }
@@ -1109,8 +1128,14 @@ struct Master {
                 if (l > (sl & 0x1FFu)) { sl = lo; sd = d; }
                 else if (l == (sl & 0x1FFu)) { sl |= lo & 0x80000000u; sd = umin(sd, d); }
             }
+            const uint32_t cnt = ready & 0x1FFu;
+            if (cnt > 4 && cnt <= kBtxPairs) {                      // the longer list whole, as the look-ahead would have taken it
+                const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+                uint32_t *bx = W::lds()->pf_btx + j * (2 * kBtxPairs);
+                for (uint32_t k = 0; k < 2 * cnt; k++) bx[k] = W::ld_agent(pairs + k);
+            }
             rec[25] = sl; rec[26] = sd; rec[14] = ready;
-            W::pfl_update(pfl, j, sl, sd, rec[29] && (ready & 0x1FFu) <= 4 && !(sl >> 31));
+            W::pfl_update(pfl, j, sl, sd, rec[29] && cnt <= 4 && !(sl >> 31));
         }
         W::sync();
     }
@@ -1342,7 +1367,7 @@ struct Master {
         if (W::lane() == 0) {
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
             P->reb_base = base;
-            P->prof[16] += wait_cyc; P->prof[17] += W::tick() - role_t0;
+            P->prof[16] += wait_cyc; P->prof[17] += W::tick() - role_t0; P->prof[37] += wait_cq; P->prof[38] += wait_guard;
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 1; }
 #ifdef NLZM_PROFILE
             for (int k = 0; k < 7; k++) P->prof[k] += prof[k];

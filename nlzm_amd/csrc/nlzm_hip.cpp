@@ -238,9 +238,19 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMalloc(&C.pf_h, bpos * 4));
         HIPCHK(hipMalloc(&C.pf_c1, bpos));
         HIPCHK(hipMalloc(&C.unc, bpos + 16));
-        HIPCHK(hipMalloc(&C.bt_ready, bpos * 4 * kBtRec));
-        HIPCHK(hipMalloc(&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4)));      // worst case, 2 KiB per position
-        HIPCHK(hipMalloc(&C.bt_flag, bpos * 4));
+        {   // hand-off arrays between workgroups on different XCDs (each XCD has its own L2)
+            const char *hm = getenv("NLZM_HANDOFF_MEM");
+            const unsigned fl = hm && !strcmp(hm, "uncached") ? hipDeviceMallocUncached : (hm && !strcmp(hm, "fine") ? hipDeviceMallocFinegrained : 0u);
+            if (fl) {
+                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_ready, bpos * 4 * kBtRec, fl));
+                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4), fl));
+                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_flag, bpos * 4, fl));
+            } else {
+                HIPCHK(hipMalloc(&C.bt_ready, bpos * 4 * kBtRec));
+                HIPCHK(hipMalloc(&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4)));      // worst case, 2 KiB per position
+                HIPCHK(hipMalloc(&C.bt_flag, bpos * 4));
+            }
+        }
         HIPCHK(hipMalloc(&C.abort_word, 4));
         HIPCHK(hipMalloc(&C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4));
         HIPCHK(hipMalloc(&C.bin_cur, (size_t)C.batch * C.nheads * 4));
@@ -409,6 +419,8 @@ int refresh_stats(Ctx &C)
                 P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[24] / n, P.prof[26] / n, P.prof[28] / n, P.prof[22] / n);
         fprintf(stderr, "HW_ID of the finder/table/parser/edge waves: %04llx %04llx %04llx %04llx (SIMD = bits 5:4)\n", P.prof[30] & 0xFFFF,
                 (P.prof[30] >> 16) & 0xFFFF, (P.prof[30] >> 32) & 0xFFFF, (P.prof[30] >> 48) & 0xFFFF);
+        fprintf(stderr, "finder wait: queue space %.0f, record buffer (table wave two batches behind) %.0f, rest (BT4 results, nice phase) %.0f\n",
+                P.prof[37] / n, P.prof[38] / n, (P.prof[16] - P.prof[37] - P.prof[38]) / n);
         fprintf(stderr, "rep-set guesses per 1000 nodes: used %.1f, late %.1f, wrong %.1f\n", 1e3 * P.cnt.guess_used / n, 1e3 * P.cnt.guess_late / n,
                 1e3 * P.cnt.guess_wrong / n);
         fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
@@ -432,6 +444,9 @@ int refresh_stats(Ctx &C)
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
+        if (getenv("NLZM_WAIT_PRINT") && wc.lead[0] + wc.lead[1] + wc.lead[2] + wc.lead[3] + wc.lead[4] + wc.lead[5])
+            fprintf(stderr, "non-unc calls by lead over the master's batch start when done: behind %llu, <64 %llu, <256 %llu, <4096 %llu, <65536 %llu, more %llu\n",
+                    wc.lead[0], wc.lead[1], wc.lead[2], wc.lead[3], wc.lead[4], wc.lead[5]);
         if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));

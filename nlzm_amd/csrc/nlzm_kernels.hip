@@ -578,6 +578,14 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
                             n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
                             n_calls++;
+#ifdef NLZM_LEAD_DIAG
+                            {   // where is the master (start of its look-ahead batch) now that this call is done?
+                                const uint32_t mp = LaneIO::ld_agent((const uint32_t *)&G.persist->prof[31]);
+                                const int lead = (int)(a - mp);
+                                const int k = lead < 0 ? 0 : (lead < 64 ? 1 : (lead < 256 ? 2 : (lead < 4096 ? 3 : (lead < 65536 ? 4 : 5))));
+                                atomicAdd(&G.wcnt->lead[k], 1ull);
+                            }
+#endif
                         }
                     }
                 }
