@@ -1666,12 +1666,18 @@ struct Master {
                 open_nodes(end_p, max_len + p);                     // :1550-1554
                 // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into one
                 // compare-and-store; the targets of different lanes are distinct nodes
+                uint32_t step = (max_len - kMatchMin) >> 4;
+                step += step == 0;
                 auto apply = [&](uint32_t k) {
+                    // the lane's target node follows from max_len alone (tl_k = max_len - k*step): its cost is read
+                    // together with the listed entry
+                    if (k * step > max_len - kMatchMin) return;
                     const uint32_t *o = W::lds()->ea + (slot * 64 + k) * 4;
+                    const uint32_t tl = max_len - k * step, np = p + tl;
+                    uint32_t best = W::lds()->node_cost[np], sel = 0;
                     const uint32_t ca = o[0], cb = o[1], d = o[2], w = o[3];
                     if (!(w >> 12)) return;
-                    const uint32_t tl = w & 0x1FFu, ri = (w >> 9) & 7u, np = p + tl;
-                    uint32_t best = W::lds()->node_cost[np], sel = 0;
+                    const uint32_t ri = (w >> 9) & 7u;
                     if (ca < best) { best = ca; sel = 1; }
                     if (cb < best) { best = cb; sel = 2; }          // cb is kNone when the distance is no rep
                     if (sel) {
@@ -1689,20 +1695,25 @@ struct Master {
                 W::sync();
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
-            if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
-            const typename W::Rec rb = W::rec_load_fn32([=](uint32_t i) { return W::lds()->eb[slot * 16 + (i & 15u)]; });
-            const uint32_t checked = W::rec_get(rb, 8);
+            // (count and list with one read; if the count was not there yet, the list is read again after the wait)
+            auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return i == 0 ? W::lds()->post[0][21 + slot] : W::lds()->eb[slot * 16 + ((i - 1) & 15u)]; }); };
+            typename W::Rec rb0 = rb_fetch();
+            if (W::rec_get(rb0, 0) < next + 1) {
+                if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
+                rb0 = rb_fetch();
+            }
+            const uint32_t checked = W::rec_get(rb0, 1 + 8);        // (word k of the list is in lane k + 1)
             if (checked != 15) {
                 uint32_t csum = 0;
                 auto probe = [&](uint32_t k, uint32_t d) {
-                    const uint32_t w = W::rec_get(rb, 2 * k);
+                    const uint32_t w = W::rec_get(rb0, 1 + 2 * k);
                     if (((checked >> k) & 1u) || !(w >> 31)) return;
                     const uint32_t l = w & 0xFFFFu;
                     csum += l + 1;
                     if ((w >> 30) & 1u) {
                         open_nodes(end_p, l + p);
                         W::sync();
-                        relax(p, p + l, W::rec_get(rb, 2 * k + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
+                        relax(p, p + l, W::rec_get(rb0, 2 + 2 * k), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
                         W::sync();
                     }
                 };
