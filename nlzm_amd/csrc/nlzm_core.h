@@ -103,7 +103,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[40];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
+    unsigned long long prof[48];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -214,14 +214,17 @@ struct MasterLds {
     //   0      positions < this are posted in this slot (0xFFFFFFFF: leave)
     //   2, 3   price words of the command context (symbols 0|1, 2|3) for this segment
     //   4..19  request: a, p, cost_p, rep set (4), max_len, (stamp), hand-off header, q, rep cap
-    //   20..22 (block 0 only) list counts: x_eadone, x_ebdone[0], x_ebdone[1]
+    //   21, 22 (block 0 only) rep-list counts of the even / odd positions
     //   23     positions < this have a guessed rep set in words 24..28 (position, rep set): the node is not final yet
     alignas(128) uint32_t post[2][32];
     uint32_t sq_res[2];                     // per slot: end_p after the node's edges
     uint32_t x_sdone;                       // apply wave: the edges of positions < x_sdone are relaxed
-    // the two list waves -> apply wave, per request slot: candidate edges of the node
-    uint32_t ea[2 * 64 * 4];                // sampled lengths, lane k: cost as dict edge, cost as rep edge (or none), distance,
-                                            // length | rep index << 9 | valid << 12
+    // edge-list wave -> apply wave: the sampled-length edges of position a in slot a & 3, listed AHEAD of the node's
+    // finality (they depend on the position's table, the segment's prices and its place in the segment only).
+    // lane k: cost of the edge as dict edge and as rep edge (without the node's cost), distance, length | valid << 12
+    uint32_t ea[4 * 64 * 4];
+    uint32_t ea_tag[4 * 2];                 // per slot: a + 1, segment sequence number (written after the entries)
+    alignas(32) uint32_t seginfo[8];        // parser -> edge-list wave: sequence number (written last), seg_a, max_parse
     uint32_t eb[2 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, node cost
                                             // through it; word 8: rep indices met by a sampled edge (:1573-1584)
 };
@@ -430,6 +433,7 @@ struct Master {
     uint32_t a_long, b_long;        // long hand-off slots taken (table wave) / given back (parser wave)
     uint32_t bpos_seen;             // table wave: x_bpos as last read
     uint32_t th_a, th_hdr, th_lit;  // parser wave: hand-off header and input byte of position th_a (read ahead)
+    uint32_t seg_seq;               // parser wave: segments started in this launch
     bool seg_tab_dirty;             // parser wave: a length/distance context changed since the price tables were built
     uint32_t cq_n, cq_seen;         // finder wave: commands written / consumed count last seen
     uint32_t seg_s, seg_cut;        // finder wave, inside a nice region: segment start and its forced cut
@@ -1463,24 +1467,26 @@ struct Master {
     // The parser meanwhile relaxes the literal edge of p (after E2 is done with p-1: the reference's order at
     // node p+1) and posts node p+1, so the lists of p+1 are made while the edges of p are applied.
     //
-    // The post block of a slot and the list counts with one LDS read (see MasterLds::post)
-    NLZM_HD typename W::Rec edge_fetch(uint32_t slot)
+    // The post block of a slot (lanes 0..19, 23..28) and the tag of the position's edge list (20, 21) with one LDS read
+    NLZM_HD typename W::Rec edge_fetch(uint32_t slot, uint32_t lslot)
     {
-        return W::rec_load_fn32([=](uint32_t i) { return W::lds()->post[(i < 20 || i >= 23) ? slot : 0][i]; });   // 20..22: shared counts
+        return W::rec_load_fn32([=](uint32_t i) {
+            return (i == 20 || i == 21) ? W::lds()->ea_tag[lslot * 2 + (i - 20)] : W::lds()->post[(i < 20 || i >= 23) ? slot : 0][i];
+        });
     }
-    // wait until `next` is posted and, for the apply wave, its sampled edges are listed; false: leave
+    // wait until `next` is posted and, for the apply wave, its sampled edges are listed for this segment; false: leave
     NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, bool need_lists)
     {
         auto ready = [&](const typename W::Rec &r) {
             return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next &&
-                   (!need_lists || W::rec_get(r, 20) > next);
+                   (!need_lists || (W::rec_get(r, 20) == next + 1 && W::rec_get(r, 21) == W::rec_get(r, 16)));
         };
-        rq = edge_fetch(next & 1u);
+        rq = edge_fetch(next & 1u, next & 3u);
         if (ready(rq)) return true;
         const unsigned long long t0 = W::clock(), c0 = W::tick();
         uint32_t spins = 0;
         for (;;) {
-            rq = edge_fetch(next & 1u);
+            rq = edge_fetch(next & 1u, next & 3u);
             if (ready(rq)) break;
             if (W::rec_get(rq, 0) == kNone) return false;
             if ((++spins & 63u) == 0) {
@@ -1499,30 +1505,47 @@ struct Master {
 #ifdef NLZM_PROFILE
             // latency from the parser's post of a node to: list written (24: sampled, 26/28: rep) / apply started, done (22)
             G.persist->prof[32 + (k == 22 ? 0 : (k == 24 ? 1 : (k == 26 ? 2 : 3)))] += lat_sum;
-            if (k == 22) G.persist->prof[36] += lat_sum2;
+            if (k == 22) { G.persist->prof[36] += lat_sum2; for (int i = 0; i < 6; i++) G.persist->prof[40 + i] += prof[i]; }
 #endif
         }
     }
 
-    // E1a: sampled lengths tl_k = max_len - k*step while >= 2 (:1558-1562), one lane per length
+    // E1a: sampled lengths tl_k = max_len - k*step while >= 2 (:1558-1562), one lane per length.  The list of a position
+    // needs its match table, its index in the segment (for the cap max_parse - p, :1545) and the segment's prices --
+    // nothing of the node -- so this wave runs ahead of the parser inside the segment, up to the list ring's depth.
     NLZM_HD void run_edge_list(uint32_t a_first)
     {
         err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
-        uint32_t next = a_first;
+        uint32_t next = a_first, seq = 0, seg_a = 0, maxp = 0, pc_dict = 0, pc_rep = 0;
         for (;;) {
-            typename W::Rec rq;
-            if (!edge_wait(rq, next, false)) { edge_leave(24); return; }
-            const uint32_t slot = next & 1u;
-            const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
-            const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
-            const uint32_t max_len = W::rec_get(rq, 11), hdr = W::rec_get(rq, 13);
-            const uint32_t pc_dict = W::rec_get(rq, 2) >> 16, pc_rep = W::rec_get(rq, 3) & 0xFFFFu;     // price(kCtxCmd, 1), (kCtxCmd, 2)
-            uint32_t checked = 0;
+            // segment, progress of the apply wave and of the table wave, leave order: one read
+            const typename W::Rec st = W::rec_load_fn([=](uint32_t i) {
+                return i < 3 ? W::lds()->seginfo[i] : (i == 3 ? W::lds()->x_sdone : (i == 4 ? W::lds()->x_apos : (i == 5 ? W::lds()->post[0][0] : W::lds()->x_err)));
+            });
+            if (W::rec_get(st, 5) == kNone || W::rec_get(st, 6)) { edge_leave(24); return; }
+            if (W::rec_get(st, 0) != seq) {
+                // a new segment: its prices are in place (the parser rebuilds them before it announces the segment)
+                const typename W::Rec s2 = W::rec_load_fn([=](uint32_t i) { return W::lds()->seginfo[i & 3u]; });   // a consistent set
+                if (W::rec_get(s2, 0) != W::rec_get(st, 0)) continue;
+                seq = W::rec_get(s2, 0); seg_a = W::rec_get(s2, 1); maxp = W::rec_get(s2, 2);
+                next = seg_a;
+                pc_dict = W::uni(price(kCtxCmd, 1)); pc_rep = W::uni(price(kCtxCmd, 2));
+            }
+            const uint32_t sdone = W::rec_get(st, 3), apos = W::rec_get(st, 4);
+            if (!seq || next - seg_a >= maxp || (int32_t)(next - sdone) > 3 || (int32_t)(apos - next) < 1) {
+                const unsigned long long c0 = W::tick();
+                W::xw_pause();
+                wait_cyc += W::tick() - c0;
+                continue;
+            }
+            const uint32_t a = next, p = a - seg_a, slot = a & 3u;
+            const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
+            const uint32_t hdr = W::uni(e[0]);
+            uint32_t max_len = umin(hdr & 0xFFFFu, maxp - p);       // :1545-1548, as the parser computes it
+            if (max_len < kMatchMin) max_len = 0;
             if (max_len) {
-                const uint32_t *e = W::lds()->er_tab + (a & (kEr - 1)) * 64;
                 uint32_t step = (max_len - kMatchMin) >> 4;
                 step += step == 0;
-                uint32_t myri = 4;
                 auto edge = [&](uint32_t k) {
                     uint32_t *o = W::lds()->ea + (slot * 64 + k) * 4;
                     if (k * step > max_len - kMatchMin) { o[3] = 0; return; }
@@ -1534,31 +1557,19 @@ struct Master {
                     uint32_t nx, ex;
                     const uint32_t ds = dist_slot(d - 1, nx, ex);
                     const uint32_t plen = W::lds()->seg_len_price[lv];
-                    const uint32_t pdist = (nx << 5) + W::lds()->seg_slot_price[lc * 64 + ds];
-                    const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
-                    o[0] = cost_p + pc_dict + plen + pdist;
-                    o[1] = ri < 4 ? cost_p + pc_rep + plen + (2u << 5) : kNone;
+                    o[0] = pc_dict + plen + (nx << 5) + W::lds()->seg_slot_price[lc * 64 + ds];
+                    o[1] = pc_rep + plen + (2u << 5);
                     o[2] = d;
-                    o[3] = tl | (ri << 9) | (1u << 12);
-                    myri = ri;
-                    if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
+                    o[3] = tl | (1u << 12);
                 };
                 // k*step <= max_len - 2 leaves at most 32 lengths (step is 1 up to max_len 33)
                 if (W::width() == 1) { for (uint32_t k = 0; k < 64; k++) edge(k); }
                 else edge(W::lane());
-                if (W::width() != 1) {
-                    const uint32_t m = myri;
-                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
-                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
-                }
             }
-            W::lds()->eb[slot * 16 + 8] = checked;
             W::sync();
+            W::lds()->ea_tag[slot * 2 + 1] = seq;
+            W::xw_store(&W::lds()->ea_tag[slot * 2], a + 1);
             next++;
-            W::xw_store(&W::lds()->post[0][20], next);
-#ifdef NLZM_PROFILE
-            lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
-#endif
         }
     }
 
@@ -1575,7 +1586,7 @@ struct Master {
         bool have_g = false;
         uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, gl0 = 0, gl1 = 0, gl2 = 0, gl3 = 0;
         for (;;) {
-            typename W::Rec rq = edge_fetch(slot);
+            typename W::Rec rq = edge_fetch(slot, 0);
             bool posted = W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next;
             if (!posted) {
                 const unsigned long long t0 = W::clock(), c0 = W::tick();
@@ -1598,7 +1609,7 @@ struct Master {
                         }
                         W::xw_pause();
                     }
-                    rq = edge_fetch(slot);
+                    rq = edge_fetch(slot, 0);
                     if (W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next) break;
                 }
                 if (!have_g) wait_cyc += W::tick() - c0;
@@ -1650,6 +1661,9 @@ struct Master {
     NLZM_HD void run_edge_apply(uint32_t a_first)
     {
         err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 16; k++) prof[k] = 0;
+#endif
         uint32_t next = a_first, end_p = 1;
         for (;;) {
             typename W::Rec rq;
@@ -1657,13 +1671,17 @@ struct Master {
 #ifdef NLZM_PROFILE
             lat_sum2 += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
 #endif
+            prof_start();
             const uint32_t slot = next & 1u;
             const uint32_t p = W::rec_get(rq, 5);
             const uint32_t r0 = W::rec_get(rq, 7), r1 = W::rec_get(rq, 8), r2 = W::rec_get(rq, 9), r3 = W::rec_get(rq, 10);
-            const uint32_t max_len = W::rec_get(rq, 11);
+            const uint32_t max_len = W::rec_get(rq, 11), cost_p = W::rec_get(rq, 6);
             if (p == 0) end_p = 1;
+            uint32_t checked = 0, myri = 4;
+            prof_mark(0);
             if (max_len) {
                 open_nodes(end_p, max_len + p);                     // :1550-1554
+                prof_mark(1);
                 // Dict edge then Rep edge to the same node (:1568 then :1586), strict '<' both times, folded into one
                 // compare-and-store; the targets of different lanes are distinct nodes
                 uint32_t step = (max_len - kMatchMin) >> 4;
@@ -1672,12 +1690,15 @@ struct Master {
                     // the lane's target node follows from max_len alone (tl_k = max_len - k*step): its cost is read
                     // together with the listed entry
                     if (k * step > max_len - kMatchMin) return;
-                    const uint32_t *o = W::lds()->ea + (slot * 64 + k) * 4;
+                    const uint32_t *o = W::lds()->ea + ((next & 3u) * 64 + k) * 4;
                     const uint32_t tl = max_len - k * step, np = p + tl;
                     uint32_t best = W::lds()->node_cost[np], sel = 0;
-                    const uint32_t ca = o[0], cb = o[1], d = o[2], w = o[3];
+                    const uint32_t cd = o[0], cr = o[1], d = o[2], w = o[3];
                     if (!(w >> 12)) return;
-                    const uint32_t ri = (w >> 9) & 7u;
+                    const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
+                    const uint32_t ca = cost_p + cd, cb = ri < 4 ? cost_p + cr : kNone;
+                    myri = ri;
+                    if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
                     if (ca < best) { best = ca; sel = 1; }
                     if (cb < best) { best = cb; sel = 2; }          // cb is kNone when the distance is no rep
                     if (sel) {
@@ -1692,6 +1713,11 @@ struct Master {
                 };
                 if (W::width() == 1) { for (uint32_t k = 0; k < 64; k++) apply(k); }
                 else apply(W::lane());
+                if (W::width() != 1) {                              // rep indices a sampled edge has met (:1573-1584)
+                    const uint32_t m = myri;
+                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
+                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
+                }
                 W::sync();
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
@@ -1702,28 +1728,31 @@ struct Master {
                 if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
                 rb0 = rb_fetch();
             }
-            const uint32_t checked = W::rec_get(rb0, 1 + 8);        // (word k of the list is in lane k + 1)
+            // (word k of the rep list is in lane k + 1)
+            prof_mark(3);
             if (checked != 15) {
-                uint32_t csum = 0;
-                auto probe = [&](uint32_t k, uint32_t d) {
-                    const uint32_t w = W::rec_get(rb0, 1 + 2 * k);
-                    if (((checked >> k) & 1u) || !(w >> 31)) return;
-                    const uint32_t l = w & 0xFFFFu;
-                    csum += l + 1;
-                    if ((w >> 30) & 1u) {
-                        open_nodes(end_p, l + p);
-                        W::sync();
-                        relax(p, p + l, W::rec_get(rb0, 2 + 2 * k), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
-                        W::sync();
-                    }
-                };
-                probe(0, r0); probe(1, r1); probe(2, r2); probe(3, r3);
+                // rep k's word sits in lane 1 + 2k: bytes compared (:1605) summed and the probes long enough to relax
+                // found without a branch per rep; relaxing one is the rare case
+                auto live = [=](uint32_t i, uint32_t w) { return (i & 1u) && i < 8 && !((checked >> (i >> 1)) & 1u) && (w >> 31); };
+                const uint32_t csum = W::rec_sum_odd4(rb0, [=](uint32_t i, uint32_t w) { return live(i, w) ? (w & 0xFFFFu) + 1 : 0u; });
+                uint32_t rm = (uint32_t)W::rec_mask(rb0, [=](uint32_t i, uint32_t w) { return live(i, w) && ((w >> 30) & 1u); });
+                while (rm) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(rm), k = i >> 1;
+                    rm &= rm - 1;
+                    const uint32_t l = W::rec_get(rb0, i) & 0xFFFFu, d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+                    open_nodes(end_p, l + p);
+                    W::sync();
+                    relax(p, p + l, W::rec_get(rb0, i + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
+                    W::sync();
+                }
                 if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
             }
+            prof_mark(4);
             W::lds()->sq_res[slot] = end_p;
             W::sync();
             next++;
             W::xw_store(&W::lds()->x_sdone, next);
+            prof_mark(5);
 #ifdef NLZM_PROFILE
             lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
 #endif
@@ -1792,6 +1821,12 @@ struct Master {
             hdr = th_hdr; lit = th_lit;
             return true;
         };
+        // the segment for the edge-list wave, which lists ahead: prices first (:1491, :1567 use the model as it is now)
+        seg_tables();
+        seg_seq++;
+        W::lds()->seginfo[1] = seg_a; W::lds()->seginfo[2] = max_parse;
+        W::sync();
+        W::xw_store(&W::lds()->seginfo[0], seg_seq);
         // the command prices of this segment, for the list waves
         for (uint32_t i = W::lane(); i < 4; i += W::width()) W::lds()->post[i >> 1][2 + (i & 1u)] = ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)];
         W::sync();
@@ -1811,7 +1846,7 @@ struct Master {
             {   // node p is final: its match and rep edges go to the edge waves (slot a & 1 is free: node p-2 is settled)
                 uint32_t *r = W::lds()->post[a & 1u] + 4;
                 r[0] = a; r[1] = p; r[2] = cost_p; r[3] = rp[0]; r[4] = rp[1]; r[5] = rp[2]; r[6] = rp[3];
-                r[7] = max_len; r[9] = hdr; r[10] = q; r[11] = umin(max_parse - p, kMatchMax);
+                r[7] = max_len; r[9] = hdr; r[10] = q; r[11] = umin(max_parse - p, kMatchMax); r[12] = seg_seq;
 #ifdef NLZM_PROFILE
                 r[8] = (uint32_t)W::tick();
 #endif
@@ -1954,7 +1989,7 @@ struct Master {
         for (int k = 0; k < 4; k++) rep[k] = W::uni(P->rep[k]);
         base = ((unsigned long long)W::uni((uint32_t)(P->reb_base >> 32)) << 32) | W::uni((uint32_t)P->reb_base);
         err = W::uni(P->error); err_info0 = 0;
-        b_long = 0; seg_tab_dirty = true; th_a = kNone; th_hdr = 0; th_lit = 0;
+        b_long = 0; seg_tab_dirty = true; th_a = kNone; th_hdr = 0; th_lit = 0; seg_seq = 0;
         wait_cyc = 0; role_t0 = W::tick();
         counts_zero();
 #ifdef NLZM_PROFILE
@@ -1997,6 +2032,7 @@ struct Master {
             W::lds()->x_long_free = kErLong; W::lds()->x_err = 0; W::lds()->x_adone = 0;
             W::lds()->x_cpos = 0; W::lds()->x_tpos = 0; W::lds()->post[0][0] = a0; W::lds()->post[1][0] = a0; W::lds()->x_sdone = a0;
             W::lds()->post[0][20] = a0; W::lds()->post[0][21] = a0; W::lds()->post[0][22] = a0;
+            for (uint32_t i = 0; i < 8; i++) { W::lds()->ea_tag[i] = 0; W::lds()->seginfo[i] = 0; }
             W::lds()->post[0][23] = a0; W::lds()->post[1][23] = a0;
         }
         (void)G;

@@ -188,6 +188,16 @@ struct DevWave {
     // a small record read with ONE LDS instruction (lane k holds word k), its words picked by v_readlane
     struct Rec { uint32_t v; };
     static __device__ __forceinline__ Rec rec_load(const uint32_t *base) { return Rec{ base[lane() & 31u] }; }
+    // lanes of a record as a vector: ballot of a predicate / sum over lanes 1, 3, 5, 7
+    template <class F>
+    static __device__ __forceinline__ unsigned long long rec_mask(const Rec &r, F f) { return __ballot(f(lane(), r.v)); }
+    template <class F>
+    static __device__ __forceinline__ uint32_t rec_sum_odd4(const Rec &r, F f)
+    {
+        const uint32_t c = f(lane(), r.v);
+        return (uint32_t)__builtin_amdgcn_readlane((int)c, 1) + (uint32_t)__builtin_amdgcn_readlane((int)c, 3) +
+               (uint32_t)__builtin_amdgcn_readlane((int)c, 5) + (uint32_t)__builtin_amdgcn_readlane((int)c, 7);
+    }
     // 16 words of HBM shared with the worker lanes (agent scope), lane k takes word k
     static __device__ __forceinline__ Rec rec_load_agent(const uint32_t *base)
     {

@@ -89,6 +89,10 @@ struct HostWave {
         return r;
     }
     static uint32_t rec_get(const Rec &r, uint32_t k) { return r.w[k]; }
+    template <class F>
+    static unsigned long long rec_mask(const Rec &r, F f) { unsigned long long m = 0; for (uint32_t i = 0; i < 32; i++) if (f(i, r.w[i])) m |= 1ull << i; return m; }
+    template <class F>
+    static uint32_t rec_sum_odd4(const Rec &r, F f) { return f(1, r.w[1]) + f(3, r.w[3]) + f(5, r.w[5]) + f(7, r.w[7]); }
     struct PfLane { uint32_t idx[64], rkslot[64], stale[64], v4[64], row1[64], sl[64], sd[64], cmpb[64], simple[64], wrote[64]; };
     static void pfl_set(PfLane &p, uint32_t j, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1, uint32_t sl, uint32_t sd,
                         uint32_t cmpb, bool simple)
