@@ -1637,17 +1637,33 @@ struct Master {
             __atomic_fetch_add(&g_dbg[7], 1, __ATOMIC_RELAXED);
 #endif
             have_g = false;
-            auto probe = [&](uint32_t k, uint32_t d, uint32_t l) {
-                uint32_t w = 0, c = 0;
-                if (d < q) {
-                    if (l >= rep_cap) l = rep_cap;                  // min(len, 264)
-                    else if (l == kRepPf) l = wave_cmp<false>(G.in + a - d, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
-                    w = l | (1u << 31);
-                    if (l >= match_min(d)) { w |= 1u << 30; c = cost_p + W::uni(pc_rep + price_len(l - match_min(d)) + (2u << 5)); }
-                }
-                W::lds()->eb[slot * 16 + 2 * k] = w; W::lds()->eb[slot * 16 + 2 * k + 1] = c;
-            };
-            probe(0, rp0, l0); probe(1, rp1, l1); probe(2, rp2, l2); probe(3, rp3, l3);
+            // The four probes in straight-line scalar code (selects, no branch per rep); the two rare cases -- a match
+            // that runs past the prefetched bytes, a probe long enough to relax (its price needs the length tables) --
+            // are found by one test each.
+            const bool v0 = rp0 < q, v1 = rp1 < q, v2 = rp2 < q, v3 = rp3 < q;
+            if (rep_cap > kRepPf && ((v0 && l0 == kRepPf) || (v1 && l1 == kRepPf) || (v2 && l2 == kRepPf) || (v3 && l3 == kRepPf))) {
+                if (v0 && l0 == kRepPf) l0 = wave_cmp<false>(G.in + a - rp0, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                if (v1 && l1 == kRepPf) l1 = wave_cmp<false>(G.in + a - rp1, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                if (v2 && l2 == kRepPf) l2 = wave_cmp<false>(G.in + a - rp2, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+                if (v3 && l3 == kRepPf) l3 = wave_cmp<false>(G.in + a - rp3, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
+            }
+            l0 = umin(l0, rep_cap); l1 = umin(l1, rep_cap); l2 = umin(l2, rep_cap); l3 = umin(l3, rep_cap);     // min(len, 264)
+            const uint32_t m0 = match_min(rp0), m1 = match_min(rp1), m2 = match_min(rp2), m3 = match_min(rp3);
+            const bool x0 = v0 && l0 >= m0, x1 = v1 && l1 >= m1, x2 = v2 && l2 >= m2, x3 = v3 && l3 >= m3;
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (x0 || x1 || x2 || x3) {
+                if (x0) c0 = cost_p + W::uni(pc_rep + price_len(l0 - m0) + (2u << 5));
+                if (x1) c1 = cost_p + W::uni(pc_rep + price_len(l1 - m1) + (2u << 5));
+                if (x2) c2 = cost_p + W::uni(pc_rep + price_len(l2 - m2) + (2u << 5));
+                if (x3) c3 = cost_p + W::uni(pc_rep + price_len(l3 - m3) + (2u << 5));
+            }
+            {
+                uint32_t *o = W::lds()->eb + slot * 16;
+                o[0] = v0 ? (l0 | (1u << 31) | ((uint32_t)x0 << 30)) : 0u; o[1] = c0;
+                o[2] = v1 ? (l1 | (1u << 31) | ((uint32_t)x1 << 30)) : 0u; o[3] = c1;
+                o[4] = v2 ? (l2 | (1u << 31) | ((uint32_t)x2 << 30)) : 0u; o[5] = c2;
+                o[6] = v3 ? (l3 | (1u << 31) | ((uint32_t)x3 << 30)) : 0u; o[7] = c3;
+            }
             W::sync();
             next += 2;
             W::xw_store(&W::lds()->post[0][21 + parity], next - 1);      // positions of this parity < next - 1 are listed
