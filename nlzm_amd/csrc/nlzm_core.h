@@ -1426,9 +1426,19 @@ struct Master {
                         // the next slot's record is requested before this one is worked on
                         const typename W::Rec rn = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + (i + 1 < n ? i + 1 : i)));
                         t_carry();
+                        // every update of the slot (:835-852 is an element-wise min: the order does not matter) in ONE pass over
+                        // the table: lane i takes entry i, the smallest distance among the pairs that reach it
                         const uint32_t nh = W::rec_get(r, 4) & 0xFFu, nb = W::rec_get(r, 14) & 0x1FFu;
-                        for (uint32_t j = 0; j < nh; j++) t_update(W::rec_get(r, 5 + 2 * j), W::rec_get(r, 6 + 2 * j) & 0x1FFu);
-                        for (uint32_t j = 0; j < nb; j++) t_update(W::rec_get(r, 15 + 2 * j), W::rec_get(r, 16 + 2 * j) & 0x1FFu);
+                        const uint32_t maxl = W::rec_get(r, 25) & 0x1FFu;       // longest of them (HT + BT4 summary)
+                        if (nh + nb) {
+                            for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+                                uint32_t m = kNone;
+                                for (uint32_t j = 0; j < nh; j++) if (e <= (W::rec_get(r, 6 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 5 + 2 * j));
+                                for (uint32_t j = 0; j < nb; j++) if (e <= (W::rec_get(r, 16 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 15 + 2 * j));
+                                if (m != kNone) W::lds_min(&mt(e), m);
+                            }
+                            mt_max = umax(mt_max, maxl);
+                        }
                         if (!wait_space(v + i)) break;
                         capture(v + i);
                         t_publish(v + i, W::rec_get(r, 0) & 0xFFu);
