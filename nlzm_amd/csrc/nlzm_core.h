@@ -189,7 +189,7 @@ struct MasterLds {
     //   23..26 summaries of the updates (HT only / HT + BT4)   27, 28 HT2 row and HT3 row 1 as read   29 simple but for BT4
     // flags: bits 0..2 HT candidate valid, 3 RK candidate valid, 4 RK length inexact, 5 unc
     uint32_t pf_rec[2 * 32 * kPf];          // two batches: the table wave reads the records of a run after the finder wave has moved on
-    uint32_t pf_btx[kPf * 2 * kBtxPairs];   // BT4 results of 5..kBtxPairs pairs (8 % of text positions), fetched by the look-ahead
+    uint32_t pf_btx[2 * kPf * 2 * kBtxPairs];   // BT4 results of 5..kBtxPairs pairs (8 % of text positions), per record buffer
     uint8_t win[kPf + kWinTail];            // input bytes from the first look-ahead position on
     // ---- hand-off run_finder -> run_table -> run_parser ----
     // Wave A (finders) keeps only the table's length and top entry in registers and sends what happens to
@@ -520,7 +520,8 @@ struct Master {
     // ---- table commands (finder wave) ---------------------------------------------
     // The finder wave needs only the table's length and its top entry (for the nice decision :1514 and
     // the extension :1503-1512); every change is forwarded to the table wave in program order.
-    static constexpr uint32_t kOpCarry = 1, kOpExt = 2, kOpUpd = 3, kOpEnd = 4, kOpRun = 5;
+    static constexpr uint32_t kOpCarry = 1, kOpExt = 2, kOpUpd = 3, kOpEnd = 4, kOpRun = 5, kOpSet = 6;
+    static constexpr uint32_t kSetHt = 1, kSetBt = 2, kSetBtx = 4;     // kOpSet: which pairs of the slot's record
     NLZM_HD void cq_push(uint32_t op, uint32_t arg, uint32_t val)
     {
         if (cq_n - cq_seen >= kCq) {                    // queue full as far as we know: look again / wait
@@ -551,13 +552,19 @@ struct Master {
     // The HT2/HT3 (and, when they were there in time, BT4) updates of one position; pairs k < nh sit at record
     // words 5.., the next nb at words 15..; (sl, sd) is their summary as the look-ahead lane computed it
     // (longest length | open << 31, smallest distance among the longest).
-    NLZM_HD void mt_apply_set(const typename W::Rec &rec, uint32_t nh, uint32_t nb, uint32_t sl, uint32_t sd)
+    NLZM_HD void mt_apply_set(uint32_t s, const typename W::Rec &rec, uint32_t nh, uint32_t nb, uint32_t sl, uint32_t sd)
     {
         const uint32_t lm = sl & 0x1FFu;
-        for (uint32_t k = 0; k < nh; k++) cq_push(kOpUpd, W::rec_get(rec, 6 + 2 * k) & 0x1FFu, W::rec_get(rec, 5 + 2 * k));
-        for (uint32_t k = 0; k < nb; k++) cq_push(kOpUpd, W::rec_get(rec, 16 + 2 * k) & 0x1FFu, W::rec_get(rec, 15 + 2 * k));
+        (void)rec;
+        cq_push(kOpSet, s | (pf_buf << 6) | (((nh ? kSetHt : 0u) | (nb ? kSetBt : 0u)) << 7), 0);     // the table wave reads the record
         if (lm > mt_max) { mt_max = lm; top_d = sd; top_open = (sl >> 31) != 0; }
         else if (lm == mt_max) { top_d = umin(top_d, sd); top_open = top_open || (sl >> 31) != 0; }
+    }
+    // the table's length / top entry after an update that the table wave applies from a record
+    NLZM_HD void mt_note(uint32_t d, uint32_t len, bool open)
+    {
+        if (len > mt_max) { mt_max = len; top_d = d; top_open = open; }
+        else if (len == mt_max) { top_d = umin(top_d, d); top_open = top_open || open; }
     }
     // carry by one position (CarryFrom with shift 1, :823-833)
     NLZM_HD void mt_carry()
@@ -574,6 +581,19 @@ struct Master {
     {
         for (uint32_t i = W::lane(); i <= len; i += W::width()) W::lds_min(&mt(i), d);
         mt_max = umax(mt_max, len);
+    }
+    // every update of a slot (:835-852 is an element-wise min: the order does not matter) in ONE pass over the table:
+    // lane e takes entry e, the smallest distance among the record's pairs that reach it (nh HT pairs, nb BT4 pairs)
+    NLZM_HD void t_apply_set(const typename W::Rec &r, uint32_t nh, uint32_t nb, uint32_t maxl)
+    {
+        if (!(nh + nb)) return;
+        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+            uint32_t m = kNone;
+            for (uint32_t j = 0; j < nh; j++) if (e <= (W::rec_get(r, 6 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 5 + 2 * j));
+            for (uint32_t j = 0; j < nb; j++) if (e <= (W::rec_get(r, 16 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 15 + 2 * j));
+            if (m != kNone) W::lds_min(&mt(e), m);
+        }
+        mt_max = umax(mt_max, maxl);
     }
     NLZM_HD void t_carry()
     {
@@ -811,7 +831,7 @@ struct Master {
                 // a longer list (every record-setter of the descent, :996-998) comes along whole, into LDS
                 const uint32_t cnt = ready & 0x1FFu;
                 if (cnt > 4 && cnt <= kBtxPairs) {
-                    uint32_t *bx = W::lds()->pf_btx + j * (2 * kBtxPairs);
+                    uint32_t *bx = W::lds()->pf_btx + (pf_buf * kPf + j) * (2 * kBtxPairs);
                     for (uint32_t k = 0; k < 2 * cnt; k++) bx[k] = W::ld_agent(pairs + k);
                 }
             }
@@ -1013,7 +1033,7 @@ struct Master {
                 n_cmp += np >> 8;
                 bt_done = !nice && G.workers && (ready & kBtReady) && cnt <= 4;
                 const uint32_t nh = np & 0xFFu, nb = bt_done ? cnt : 0;
-                if (nh + nb) mt_apply_set(rec, nh, nb, W::rec_get(rec, bt_done ? 25 : 23), W::rec_get(rec, bt_done ? 26 : 24));
+                if (nh + nb) mt_apply_set(s, rec, nh, nb, W::rec_get(rec, bt_done ? 25 : 23), W::rec_get(rec, bt_done ? 26 : 24));
             } else {
             // HT2 (:917-933)
             if ((valid & 1) && 1 < max_len) {
@@ -1038,15 +1058,17 @@ struct Master {
                     if (a == NLZM_SIM_DEBUG) printf("dbg a=%u ready=%08x cnt=%u unc=%u nice=%d max_len=%u live_ready=%08x\n", a, ready, cnt, pflags & 32u, (int)nice, max_len, G.bt_ready[(a - G.batch_a0) * kBtRec]);
 #endif
                     if ((ready & kBtReady) && cnt <= 4) {
+                        if (cnt) cq_push(kOpSet, s | (pf_buf << 6) | (kSetBt << 7), 0);
                         for (uint32_t k = 0; k < cnt; k++) {
                             const uint32_t l = W::rec_get(rec, 16 + 2 * k) & 0x1FFu;
-                            mt_update(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
+                            mt_note(W::rec_get(rec, 15 + 2 * k), l, l >= max_len);
                         }
                     } else if ((ready & kBtReady) && cnt <= kBtxPairs) {
-                        const typename W::Rec xr = W::rec_load(W::lds()->pf_btx + s * (2 * kBtxPairs));
+                        const typename W::Rec xr = W::rec_load(W::lds()->pf_btx + (pf_buf * kPf + s) * (2 * kBtxPairs));
+                        cq_push(kOpSet, s | (pf_buf << 6) | (kSetBtx << 7), 0);
                         for (uint32_t k = 0; k < cnt; k++) {
                             const uint32_t l = W::rec_get(xr, 2 * k + 1);
-                            mt_update(W::rec_get(xr, 2 * k), l, l >= max_len);
+                            mt_note(W::rec_get(xr, 2 * k), l, l >= max_len);
                         }
                     } else { n_sbt++; bt_consume(a, max_len); }
                 } else bt_step(a, h4, max_len);
@@ -1135,7 +1157,7 @@ struct Master {
             const uint32_t cnt = ready & 0x1FFu;
             if (cnt > 4 && cnt <= kBtxPairs) {                      // the longer list whole, as the look-ahead would have taken it
                 const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-                uint32_t *bx = W::lds()->pf_btx + j * (2 * kBtxPairs);
+                uint32_t *bx = W::lds()->pf_btx + (pf_buf * kPf + j) * (2 * kBtxPairs);
                 for (uint32_t k = 0; k < 2 * cnt; k++) bx[k] = W::ld_agent(pairs + k);
             }
             rec[25] = sl; rec[26] = sd; rec[14] = ready;
@@ -1426,24 +1448,33 @@ struct Master {
                         // the next slot's record is requested before this one is worked on
                         const typename W::Rec rn = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + (i + 1 < n ? i + 1 : i)));
                         t_carry();
-                        // every update of the slot (:835-852 is an element-wise min: the order does not matter) in ONE pass over
-                        // the table: lane i takes entry i, the smallest distance among the pairs that reach it
-                        const uint32_t nh = W::rec_get(r, 4) & 0xFFu, nb = W::rec_get(r, 14) & 0x1FFu;
-                        const uint32_t maxl = W::rec_get(r, 25) & 0x1FFu;       // longest of them (HT + BT4 summary)
-                        if (nh + nb) {
-                            for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
-                                uint32_t m = kNone;
-                                for (uint32_t j = 0; j < nh; j++) if (e <= (W::rec_get(r, 6 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 5 + 2 * j));
-                                for (uint32_t j = 0; j < nb; j++) if (e <= (W::rec_get(r, 16 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 15 + 2 * j));
-                                if (m != kNone) W::lds_min(&mt(e), m);
-                            }
-                            mt_max = umax(mt_max, maxl);
-                        }
+                        t_apply_set(r, W::rec_get(r, 4) & 0xFFu, W::rec_get(r, 14) & 0x1FFu, W::rec_get(r, 25) & 0x1FFu);
                         if (!wait_space(v + i)) break;
                         capture(v + i);
                         t_publish(v + i, W::rec_get(r, 0) & 0xFFu);
                         ended = v + i + 1;
                         r = rn;
+                    }
+                }
+                else if (op == kOpSet) {                    // updates of one slot, read from its look-ahead record
+                    const uint32_t s0 = arg & 63u, buf = (arg >> 6) & 1u, mode = arg >> 7;
+                    const typename W::Rec r = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * s0);
+                    if (mode & kSetBtx) {
+                        // a BT4 list of 5..kBtxPairs record-setters: lengths grow along it, the last one is the longest
+                        const uint32_t cnt = W::rec_get(r, 14) & 0x1FFu;
+                        const typename W::Rec x = W::rec_load(W::lds()->pf_btx + (buf * kPf + s0) * (2 * kBtxPairs));
+                        const uint32_t maxl = W::rec_get(x, 2 * cnt - 1);
+                        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+                            uint32_t m = kNone;
+                            for (uint32_t j = 0; j < cnt; j++) if (e <= W::rec_get(x, 2 * j + 1)) m = umin(m, W::rec_get(x, 2 * j));
+                            if (m != kNone) W::lds_min(&mt(e), m);
+                        }
+                        mt_max = umax(mt_max, maxl);
+                    } else {
+                        const uint32_t nh = (mode & kSetHt) ? W::rec_get(r, 4) & 0xFFu : 0u, nb = (mode & kSetBt) ? W::rec_get(r, 14) & 0x1FFu : 0u;
+                        uint32_t maxl = (mode & kSetHt) ? W::rec_get(r, 23) & 0x1FFu : 0u;
+                        if (nb) maxl = umax(maxl, W::rec_get(r, 16 + 2 * (nb - 1)) & 0x1FFu);      // (record-setters: the last is the longest)
+                        t_apply_set(r, nh, nb, maxl);
                     }
                 }
                 else {                                      // kOpEnd: publish position v, input byte arg
