@@ -556,7 +556,7 @@ struct Master {
     {
         const uint32_t lm = sl & 0x1FFu;
         (void)rec;
-        cq_push(kOpSet, s | (pf_buf << 6) | (((nh ? kSetHt : 0u) | (nb ? kSetBt : 0u)) << 7), 0);     // the table wave reads the record
+        cq_push(kOpSet, s | (pf_buf << 6) | (((nh ? kSetHt : 0u) | (nb > 4 ? kSetBtx : (nb ? kSetBt : 0u))) << 7), 0);   // the table wave reads the record
         if (lm > mt_max) { mt_max = lm; top_d = sd; top_open = (sl >> 31) != 0; }
         else if (lm == mt_max) { top_d = umin(top_d, sd); top_open = top_open || (sl >> 31) != 0; }
     }
@@ -591,6 +591,18 @@ struct Master {
             uint32_t m = kNone;
             for (uint32_t j = 0; j < nh; j++) if (e <= (W::rec_get(r, 6 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 5 + 2 * j));
             for (uint32_t j = 0; j < nb; j++) if (e <= (W::rec_get(r, 16 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 15 + 2 * j));
+            if (m != kNone) W::lds_min(&mt(e), m);
+        }
+        mt_max = umax(mt_max, maxl);
+    }
+    // a BT4 list of 5..kBtxPairs record-setters (look-ahead slot s of record buffer buf): lengths grow along it
+    NLZM_HD void t_apply_btx(uint32_t buf, uint32_t s, uint32_t cnt)
+    {
+        const typename W::Rec x = W::rec_load(W::lds()->pf_btx + (buf * kPf + s) * (2 * kBtxPairs));
+        const uint32_t maxl = W::rec_get(x, 2 * cnt - 1);
+        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+            uint32_t m = kNone;
+            for (uint32_t j = 0; j < cnt; j++) if (e <= W::rec_get(x, 2 * j + 1)) m = umin(m, W::rec_get(x, 2 * j));
             if (m != kNone) W::lds_min(&mt(e), m);
         }
         mt_max = umax(mt_max, maxl);
@@ -908,6 +920,12 @@ struct Master {
                     rec[15 + 2 * k] = bd[k]; rec[16 + 2 * k] = bl[k] | ((uint32_t)(bl[k] >= max_len) << 31);
                     summarise(bd[k], rec[16 + 2 * k]);
                 }
+                // (a longer list: the rest of it from LDS, where round 2 put it)
+                const uint32_t cnt = ready & 0x1FFu;
+                if ((ready & kBtReady) && h4 && cnt > 4 && cnt <= kBtxPairs) {
+                    const uint32_t *bx = W::lds()->pf_btx + (pf_buf * kPf + j) * (2 * kBtxPairs);
+                    for (uint32_t k = 4; k < cnt; k++) summarise(bx[2 * k], bx[2 * k + 1] | ((uint32_t)(bx[2 * k + 1] >= max_len) << 31));
+                }
             }
             rec[25] = sl; rec[26] = sd;
             rec[0] = v4; rec[1] = idx; rec[2] = row[1]; rec[3] = flags; rec[27] = row[0]; rec[28] = row[2];
@@ -917,7 +935,7 @@ struct Master {
             // updates can extend at the next position.  Whether an earlier slot rewrites its HT rows is added below.
             const bool pre = G.workers && avail >= 256 && !(flags & (32u | 8u)) && (q & 255u) != 0;
             rec[29] = pre ? 1u : 0u;                                // (for bt_refresh)
-            const bool simple = pre && (ready & kBtReady) && (ready & 0x1FFu) <= 4 && !(sl >> 31);
+            const bool simple = pre && (ready & kBtReady) && (ready & 0x1FFu) <= kBtxPairs && !(sl >> 31);
             W::pfl_set(pfl, j, idx, rkh >> g.rk_shift, v4, row[1], sl, sd, rec[4] >> 8, simple);
         }
         W::pfl_conflicts(pfl, pf_n);
@@ -1031,7 +1049,7 @@ struct Master {
                 // of the worker lanes if it was there): all table updates of the position in one pass
                 const uint32_t np = W::rec_get(rec, 4), ready = W::rec_get(rec, 14), cnt = ready & 0x1FFu;
                 n_cmp += np >> 8;
-                bt_done = !nice && G.workers && (ready & kBtReady) && cnt <= 4;
+                bt_done = !nice && G.workers && (ready & kBtReady) && cnt <= kBtxPairs;
                 const uint32_t nh = np & 0xFFu, nb = bt_done ? cnt : 0;
                 if (nh + nb) mt_apply_set(s, rec, nh, nb, W::rec_get(rec, bt_done ? 25 : 23), W::rec_get(rec, bt_done ? 26 : 24));
             } else {
@@ -1159,9 +1177,14 @@ struct Master {
                 const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
                 uint32_t *bx = W::lds()->pf_btx + (pf_buf * kPf + j) * (2 * kBtxPairs);
                 for (uint32_t k = 0; k < 2 * cnt; k++) bx[k] = W::ld_agent(pairs + k);
+                for (uint32_t k = 4; k < cnt; k++) {
+                    const uint32_t d = bx[2 * k], l = bx[2 * k + 1], lo = l | ((uint32_t)(l >= max_len) << 31);
+                    if (l > (sl & 0x1FFu)) { sl = lo; sd = d; }
+                    else if (l == (sl & 0x1FFu)) { sl |= lo & 0x80000000u; sd = umin(sd, d); }
+                }
             }
             rec[25] = sl; rec[26] = sd; rec[14] = ready;
-            W::pfl_update(pfl, j, sl, sd, rec[29] && cnt <= 4 && !(sl >> 31));
+            W::pfl_update(pfl, j, sl, sd, rec[29] && cnt <= kBtxPairs && !(sl >> 31));
         }
         W::sync();
     }
@@ -1448,7 +1471,11 @@ struct Master {
                         // the next slot's record is requested before this one is worked on
                         const typename W::Rec rn = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * (s0 + (i + 1 < n ? i + 1 : i)));
                         t_carry();
-                        t_apply_set(r, W::rec_get(r, 4) & 0xFFu, W::rec_get(r, 14) & 0x1FFu, W::rec_get(r, 25) & 0x1FFu);
+                        {
+                            const uint32_t nb = W::rec_get(r, 14) & 0x1FFu;
+                            if (nb <= 4) t_apply_set(r, W::rec_get(r, 4) & 0xFFu, nb, W::rec_get(r, 25) & 0x1FFu);
+                            else { t_apply_set(r, W::rec_get(r, 4) & 0xFFu, 0, W::rec_get(r, 23) & 0x1FFu); t_apply_btx(buf, s0 + i, nb); }
+                        }
                         if (!wait_space(v + i)) break;
                         capture(v + i);
                         t_publish(v + i, W::rec_get(r, 0) & 0xFFu);
@@ -1460,16 +1487,8 @@ struct Master {
                     const uint32_t s0 = arg & 63u, buf = (arg >> 6) & 1u, mode = arg >> 7;
                     const typename W::Rec r = W::rec_load(W::lds()->pf_rec + buf * (32 * kPf) + 32 * s0);
                     if (mode & kSetBtx) {
-                        // a BT4 list of 5..kBtxPairs record-setters: lengths grow along it, the last one is the longest
-                        const uint32_t cnt = W::rec_get(r, 14) & 0x1FFu;
-                        const typename W::Rec x = W::rec_load(W::lds()->pf_btx + (buf * kPf + s0) * (2 * kBtxPairs));
-                        const uint32_t maxl = W::rec_get(x, 2 * cnt - 1);
-                        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
-                            uint32_t m = kNone;
-                            for (uint32_t j = 0; j < cnt; j++) if (e <= W::rec_get(x, 2 * j + 1)) m = umin(m, W::rec_get(x, 2 * j));
-                            if (m != kNone) W::lds_min(&mt(e), m);
-                        }
-                        mt_max = umax(mt_max, maxl);
+                        if (mode & kSetHt) t_apply_set(r, W::rec_get(r, 4) & 0xFFu, 0, W::rec_get(r, 23) & 0x1FFu);
+                        t_apply_btx(buf, s0, W::rec_get(r, 14) & 0x1FFu);
                     } else {
                         const uint32_t nh = (mode & kSetHt) ? W::rec_get(r, 4) & 0xFFu : 0u, nb = (mode & kSetBt) ? W::rec_get(r, 14) & 0x1FFu : 0u;
                         uint32_t maxl = (mode & kSetHt) ? W::rec_get(r, 23) & 0x1FFu : 0u;
