@@ -462,6 +462,7 @@ struct Master {
     uint32_t err, err_info0;
     unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
     unsigned long long wait_cq = 0, wait_guard = 0;     // finder wave: of them for queue space / for the record buffer
+    unsigned long long wait_rep = 0;                    // apply wave: of them for the rep list
 #ifdef NLZM_PROFILE
     unsigned long long prof[16];
     unsigned long long prof_t, lat_sum = 0, lat_sum2 = 0;
@@ -1562,6 +1563,7 @@ struct Master {
     {
         if (W::lane() == 0) {
             G.persist->prof[k] += wait_cyc; G.persist->prof[k + 1] += W::tick() - role_t0;
+            if (k == 22) G.persist->prof[39] += wait_rep;
 #ifdef NLZM_PROFILE
             // latency from the parser's post of a node to: list written (24: sampled, 26/28: rep) / apply started, done (22)
             G.persist->prof[32 + (k == 22 ? 0 : (k == 24 ? 1 : (k == 26 ? 2 : 3)))] += lat_sum;
@@ -1801,7 +1803,9 @@ struct Master {
             auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return i == 0 ? W::lds()->post[0][21 + slot] : W::lds()->eb[slot * 16 + ((i - 1) & 15u)]; }); };
             typename W::Rec rb0 = rb_fetch();
             if (W::rec_get(rb0, 0) < next + 1) {
+                const unsigned long long w0 = wait_cyc;
                 if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
+                wait_rep += wait_cyc - w0;
                 rb0 = rb_fetch();
             }
             // (word k of the rep list is in lane k + 1)

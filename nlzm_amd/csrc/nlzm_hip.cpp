@@ -421,6 +421,7 @@ int refresh_stats(Ctx &C)
                 (P.prof[30] >> 16) & 0xFFFF, (P.prof[30] >> 32) & 0xFFFF, (P.prof[30] >> 48) & 0xFFFF);
         fprintf(stderr, "finder wait: queue space %.0f, record buffer (table wave two batches behind) %.0f, rest (BT4 results, nice phase) %.0f\n",
                 P.prof[37] / n, P.prof[38] / n, (P.prof[16] - P.prof[37] - P.prof[38]) / n);
+        fprintf(stderr, "apply wave wait: for the rep list %.0f, for the next node's post / sampled list %.0f\n", P.prof[39] / n, (P.prof[22] - P.prof[39]) / n);
         fprintf(stderr, "rep-set guesses per 1000 nodes: used %.1f, late %.1f, wrong %.1f\n", 1e3 * P.cnt.guess_used / n, 1e3 * P.cnt.guess_late / n,
                 1e3 * P.cnt.guess_wrong / n);
         fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
