@@ -670,7 +670,7 @@ __device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, 
 
 // ---------------------------------------------------------------------------
 // the persistent launch: block 0 = the serial half (seven waves), blocks 1.. = worker lanes.
-// 512-thread blocks with ~117 KB of LDS: exactly one block per CU, and the grid is kept
+// 512-thread blocks with 136 KB of LDS: exactly one block per CU, and the grid is kept
 // below the CU count, so every block is resident at once (the roles wait on each other).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
