@@ -103,7 +103,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[48];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
+    unsigned long long prof[56];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;
@@ -1437,6 +1437,9 @@ struct Master {
         err = W::uni(P->error); err_info0 = 0;
         a_long = 0; pf_base = 0; bpos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
         wait_cyc = 0; role_t0 = W::tick();
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 16; k++) prof[k] = 0;
+#endif
         W::sync();
         unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
         if (a_end > g.n) a_end = g.n;
@@ -1460,10 +1463,12 @@ struct Master {
             const uint32_t first = done;
             const typename W::Rec r0 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->cq[((first + i) & (kCq - 1)) * 2]; });
             const typename W::Rec r1 = W::rec_load_fn32([=](uint32_t i) { return W::lds()->cq[((first + i) & (kCq - 1)) * 2 + 1]; });
+            prof_mark(0);
             for (uint32_t k = 0; k < nb && !err; k++) {
+                prof_start();
                 const uint32_t c = W::rec_get(r0, k), v = W::rec_get(r1, k), op = c & 0xFFu, arg = c >> 8;
-                if (op == kOpUpd) t_update(v, arg);
-                else if (op == kOpCarry) t_carry();
+                if (op == kOpUpd) { t_update(v, arg); prof_mark(1); }
+                else if (op == kOpCarry) { t_carry(); prof_mark(2); }
                 else if (op == kOpExt) t_extend(v, arg);
                 else if (op == kOpRun) {                    // slots [s0, s0+n) of a look-ahead batch, first position v
                     const uint32_t s0 = arg & 63u, n = ((arg >> 6) & 63u) + 1, buf = (arg >> 12) & 1u;
@@ -1483,6 +1488,7 @@ struct Master {
                         ended = v + i + 1;
                         r = rn;
                     }
+                    prof_mark(3);
                 }
                 else if (op == kOpSet) {                    // updates of one slot, read from its look-ahead record
                     const uint32_t s0 = arg & 63u, buf = (arg >> 6) & 1u, mode = arg >> 7;
@@ -1496,22 +1502,28 @@ struct Master {
                         if (nb) maxl = umax(maxl, W::rec_get(r, 16 + 2 * (nb - 1)) & 0x1FFu);      // (record-setters: the last is the longest)
                         t_apply_set(r, nh, nb, maxl);
                     }
+                    prof_mark(4);
                 }
                 else {                                      // kOpEnd: publish position v, input byte arg
                     if (!wait_space(v)) break;              // slot v % kEr is free again
                     capture(v);
                     t_publish(v, arg);
                     ended = v + 1;
+                    prof_mark(5);
                 }
             }
             done += nb;
             W::xw_store(&W::lds()->x_tpos, done);
+            prof_start();
         }
         W::sync();
         for (uint32_t i = W::lane(); i <= kMatchMax; i += W::width()) P->mt_delta[i] = i <= mt_max ? mt(i) : 0;
         if (W::lane() == 0) {
             P->mt_max = mt_max;
             P->prof[18] += wait_cyc; P->prof[19] += W::tick() - role_t0;
+#ifdef NLZM_PROFILE
+            for (int k = 0; k < 6; k++) P->prof[48 + k] += prof[k];
+#endif
             if (err && err < 100) { P->error = err; P->error_info[0] = err_info0; P->error_info[1] = 3; }
         }
         W::sync_global();
@@ -1793,8 +1805,9 @@ struct Master {
                 else apply(W::lane());
                 if (W::width() != 1) {                              // rep indices a sampled edge has met (:1573-1584)
                     const uint32_t m = myri;
-                    checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
-                              (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
+                    if (W::mask64([=](uint32_t) { return m < 4; }))     // (usually none)
+                        checked = (W::mask64([=](uint32_t) { return m == 0; }) ? 1u : 0u) | (W::mask64([=](uint32_t) { return m == 1; }) ? 2u : 0u) |
+                                  (W::mask64([=](uint32_t) { return m == 2; }) ? 4u : 0u) | (W::mask64([=](uint32_t) { return m == 3; }) ? 8u : 0u);
                 }
                 W::sync();
             }

@@ -435,6 +435,8 @@ int refresh_stats(Ctx &C)
                 P.prof[33] / n0, 2 * P.prof[34] / n0, 2 * P.prof[35] / n0, P.prof[36] / n0, P.prof[32] / n0);
         fprintf(stderr, "apply wave sections (cycles/pos): request %.0f, open nodes %.0f, sampled edges %.0f, rep list in %.0f, rep probes %.0f, done %.0f\n",
                 P.prof[40] / n0, P.prof[41] / n0, P.prof[42] / n0, P.prof[43] / n0, P.prof[44] / n0, P.prof[45] / n0);
+        fprintf(stderr, "table wave sections (cycles/pos): fetch %.0f, update %.0f, carry %.0f, run %.0f, set %.0f, end %.0f\n",
+                P.prof[48] / n0, P.prof[49] / n0, P.prof[50] / n0, P.prof[51] / n0, P.prof[52] / n0, P.prof[53] / n0);
         static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
                                          "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
         unsigned long long tot = 0;
