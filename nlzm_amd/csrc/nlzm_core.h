@@ -588,11 +588,18 @@ struct Master {
     NLZM_HD void t_apply_set(const typename W::Rec &r, uint32_t nh, uint32_t nb, uint32_t maxl)
     {
         if (!(nh + nb)) return;
-        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+        // (uniform loops and selects only: a min with 0xFFFFFFFF leaves an entry as it is, entries beyond every pair's
+        // length included, so no lane needs a branch)
+        for (uint32_t base = 0; base <= maxl; base += W::width()) {
+            const uint32_t e = base + W::lane();
             uint32_t m = kNone;
-            for (uint32_t j = 0; j < nh; j++) if (e <= (W::rec_get(r, 6 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 5 + 2 * j));
-            for (uint32_t j = 0; j < nb; j++) if (e <= (W::rec_get(r, 16 + 2 * j) & 0x1FFu)) m = umin(m, W::rec_get(r, 15 + 2 * j));
-            if (m != kNone) W::lds_min(&mt(e), m);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if ((uint32_t)j < nh) { const uint32_t l = W::rec_get(r, 6 + 2 * j) & 0x1FFu, d = W::rec_get(r, 5 + 2 * j); m = umin(m, e <= l ? d : kNone); }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)j < nb) { const uint32_t l = W::rec_get(r, 16 + 2 * j) & 0x1FFu, d = W::rec_get(r, 15 + 2 * j); m = umin(m, e <= l ? d : kNone); }
+            W::lds_min(&mt(e), m);
         }
         mt_max = umax(mt_max, maxl);
     }
@@ -601,10 +608,11 @@ struct Master {
     {
         const typename W::Rec x = W::rec_load(W::lds()->pf_btx + (buf * kPf + s) * (2 * kBtxPairs));
         const uint32_t maxl = W::rec_get(x, 2 * cnt - 1);
-        for (uint32_t e = W::lane(); e <= maxl; e += W::width()) {
+        for (uint32_t base = 0; base <= maxl; base += W::width()) {
+            const uint32_t e = base + W::lane();
             uint32_t m = kNone;
-            for (uint32_t j = 0; j < cnt; j++) if (e <= W::rec_get(x, 2 * j + 1)) m = umin(m, W::rec_get(x, 2 * j));
-            if (m != kNone) W::lds_min(&mt(e), m);
+            for (uint32_t j = 0; j < cnt; j++) { const uint32_t l = W::rec_get(x, 2 * j + 1), d = W::rec_get(x, 2 * j); m = umin(m, e <= l ? d : kNone); }
+            W::lds_min(&mt(e), m);
         }
         mt_max = umax(mt_max, maxl);
     }
