@@ -1615,8 +1615,10 @@ struct Master {
             }
             const uint32_t sdone = W::rec_get(st, 3), apos = W::rec_get(st, 4);
             if (!seq || next - seg_a >= maxp || (int32_t)(next - sdone) > 3 || (int32_t)(apos - next) < 1) {
+                // nothing to list: ahead of the apply wave by the ring's depth, at the segment's end, or the table is not
+                // out yet.  This wave shares its SIMD with the finder wave: it sleeps longer while it is ahead
                 const unsigned long long c0 = W::tick();
-                W::xw_pause();
+                if ((int32_t)(apos - next) < 1) W::xw_pause(); else W::sleep();
                 wait_cyc += W::tick() - c0;
                 continue;
             }

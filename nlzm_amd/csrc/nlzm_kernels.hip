@@ -645,7 +645,7 @@ __device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, 
         // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
         // wave 1: the match table (carry / extend / update), published per position
         // wave 2: forward-graph parse, model, symbol emit
-        // waves 3 / 4, 6: list the sampled-length edges / the rep probes (even, odd positions) of each node; wave 5 relaxes them
+        // wave 3: relaxes the listed edges of each node; waves 4 / 5, 6: list the sampled-length edges / the rep probes (even, odd positions)
         if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         __syncthreads();
         if (threadIdx.x >= 448) return;
@@ -658,9 +658,9 @@ __device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, 
         case 0: m.run_finder(c0, c1); break;
         case 1: m.run_table(c0, c1); break;
         case 2: m.run_parser(c0, c1); break;
-        case 3: m.run_edge_list(a_first); break;
-        case 4: m.run_rep_list(a_first, 0); break;
-        case 5: m.run_edge_apply(a_first); break;
+        case 3: m.run_edge_apply(a_first); break;       // the four waves of the dependency chain get a SIMD each
+        case 4: m.run_edge_list(a_first); break;        // (waves 4..6 share them: list makers, mostly waiting)
+        case 5: m.run_rep_list(a_first, 0); break;
         default: m.run_rep_list(a_first, 1); break;
         }
     } else {
