@@ -259,7 +259,7 @@ struct DevWave {
         asm volatile("" ::: "memory");
         if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    static __device__ __forceinline__ void xw_pause() { __builtin_amdgcn_s_sleep(1); }
+    static __device__ __forceinline__ void xw_pause() { __builtin_amdgcn_s_sleep(0); }      // (hand-offs between the waves are on the critical chain)
     static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
     static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }      // 100 MHz
     static __device__ __forceinline__ unsigned long long timeout_ticks() { return 2000000000ull; } // 20 s
