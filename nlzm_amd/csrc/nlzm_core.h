@@ -225,7 +225,7 @@ struct MasterLds {
     uint32_t ea[4 * 64 * 4];
     uint32_t ea_tag[4 * 2];                 // per slot: a + 1, segment sequence number (written after the entries)
     alignas(32) uint32_t seginfo[8];        // parser -> edge-list wave: sequence number (written last), seg_a, max_parse
-    uint32_t eb[2 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, node cost
+    uint32_t eb[4 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, edge price; 15: listed-for-guess count
                                             // through it; word 8: rep indices met by a sampled edge (:1573-1584)
 };
 
@@ -1666,64 +1666,16 @@ struct Master {
         err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
         uint32_t next = a_first + ((a_first ^ parity) & 1u);
         const uint32_t slot = parity;
-        // lengths measured for a guessed rep set of `next` (the parser's guess while the node was not final)
+        // The list for a guessed rep set of `next` (the parser's guess while the node was not final) is written as
+        // soon as it is measured: the apply wave checks the guess against the posted node itself and takes the list
+        // without waiting for this wave to see the post.  (Costs are listed without the node's cost for that reason.)
         bool have_g = false;
-        uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, gl0 = 0, gl1 = 0, gl2 = 0, gl3 = 0;
-        for (;;) {
-            typename W::Rec rq = edge_fetch(slot, 0);
-            bool posted = W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next;
-            if (!posted) {
-                const unsigned long long t0 = W::clock(), c0 = W::tick();
-                uint32_t spins = 0;
-                for (;;) {
-                    if (W::rec_get(rq, 0) == kNone) { edge_leave(parity ? 28 : 26); return; }
-                    if (!have_g && W::rec_get(rq, 23) > next && W::rec_get(rq, 24) == next) {
-                        // measure for the guess now: the memory round trip is over when the node is posted
-                        wait_cyc += W::tick() - c0;
-                        g0 = W::rec_get(rq, 25); g1 = W::rec_get(rq, 26); g2 = W::rec_get(rq, 27); g3 = W::rec_get(rq, 28);
-                        const typename W::RepPf gpf = W::rep_prefetch(G.in, g.n, next, g0, g1, g2, g3);
-                        uint32_t gl[4];
-                        W::rep_lengths(gpf, gl);
-                        gl0 = gl[0]; gl1 = gl[1]; gl2 = gl[2]; gl3 = gl[3];
-                        have_g = true;
-                    } else {
-                        if ((++spins & 63u) == 0) {
-                            if (W::xw_load(&W::lds()->x_err)) { edge_leave(parity ? 28 : 26); return; }
-                            if ((spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) { edge_leave(parity ? 28 : 26); return; }
-                        }
-                        W::xw_pause();
-                    }
-                    rq = edge_fetch(slot, 0);
-                    if (W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next) break;
-                }
-                if (!have_g) wait_cyc += W::tick() - c0;
-            }
-            const uint32_t a = W::rec_get(rq, 4), cost_p = W::rec_get(rq, 6);
-            const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
-            const uint32_t q = W::rec_get(rq, 14), rep_cap = W::rec_get(rq, 15);
-            const uint32_t pc_rep = W::rec_get(rq, 3) & 0xFFFFu;
-            uint32_t l0, l1, l2, l3;
-            if (have_g && g0 == rp0 && g1 == rp1 && g2 == rp2 && g3 == rp3) {
-                l0 = gl0; l1 = gl1; l2 = gl2; l3 = gl3;
-                W::cnt_add(&W::lds()->cnt.guess_used, 1);
-            } else {
-                W::cnt_add(have_g ? &W::lds()->cnt.guess_wrong : &W::lds()->cnt.guess_late, 1);
-                // kRepPf bytes in front of each rep distance and at the position
-                const typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
-                uint32_t rep_len[4];
-                W::rep_lengths(rpf, rep_len);
-                l0 = rep_len[0]; l1 = rep_len[1]; l2 = rep_len[2]; l3 = rep_len[3];
-#ifdef NLZM_SIM_COUNT
-                __atomic_fetch_add(&g_dbg[6], 1, __ATOMIC_RELAXED);
-#endif
-            }
-#ifdef NLZM_SIM_COUNT
-            __atomic_fetch_add(&g_dbg[7], 1, __ATOMIC_RELAXED);
-#endif
-            have_g = false;
-            // The four probes in straight-line scalar code (selects, no branch per rep); the two rare cases -- a match
-            // that runs past the prefetched bytes, a probe long enough to relax (its price needs the length tables) --
-            // are found by one test each.
+        uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, gseq = 0;
+        // The four probes in straight-line scalar code (selects, no branch per rep); the two rare cases -- a match
+        // that runs past the prefetched bytes, a probe long enough to relax (its price needs the length tables) --
+        // are found by one test each.
+        auto list = [&](uint32_t a, uint32_t rp0, uint32_t rp1, uint32_t rp2, uint32_t rp3, uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3,
+                        uint32_t q, uint32_t rep_cap, uint32_t pc_rep) {
             const bool v0 = rp0 < q, v1 = rp1 < q, v2 = rp2 < q, v3 = rp3 < q;
             if (rep_cap > kRepPf && ((v0 && l0 == kRepPf) || (v1 && l1 == kRepPf) || (v2 && l2 == kRepPf) || (v3 && l3 == kRepPf))) {
                 if (v0 && l0 == kRepPf) l0 = wave_cmp<false>(G.in + a - rp0, G.in + a, kRepPf, rep_cap) & 0x7FFFFFFFu;
@@ -1736,20 +1688,73 @@ struct Master {
             const bool x0 = v0 && l0 >= m0, x1 = v1 && l1 >= m1, x2 = v2 && l2 >= m2, x3 = v3 && l3 >= m3;
             uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             if (x0 || x1 || x2 || x3) {
-                if (x0) c0 = cost_p + W::uni(pc_rep + price_len(l0 - m0) + (2u << 5));
-                if (x1) c1 = cost_p + W::uni(pc_rep + price_len(l1 - m1) + (2u << 5));
-                if (x2) c2 = cost_p + W::uni(pc_rep + price_len(l2 - m2) + (2u << 5));
-                if (x3) c3 = cost_p + W::uni(pc_rep + price_len(l3 - m3) + (2u << 5));
+                if (x0) c0 = W::uni(pc_rep + price_len(l0 - m0) + (2u << 5));
+                if (x1) c1 = W::uni(pc_rep + price_len(l1 - m1) + (2u << 5));
+                if (x2) c2 = W::uni(pc_rep + price_len(l2 - m2) + (2u << 5));
+                if (x3) c3 = W::uni(pc_rep + price_len(l3 - m3) + (2u << 5));
             }
-            {
-                uint32_t *o = W::lds()->eb + slot * 16;
-                o[0] = v0 ? (l0 | (1u << 31) | ((uint32_t)x0 << 30)) : 0u; o[1] = c0;
-                o[2] = v1 ? (l1 | (1u << 31) | ((uint32_t)x1 << 30)) : 0u; o[3] = c1;
-                o[4] = v2 ? (l2 | (1u << 31) | ((uint32_t)x2 << 30)) : 0u; o[5] = c2;
-                o[6] = v3 ? (l3 | (1u << 31) | ((uint32_t)x3 << 30)) : 0u; o[7] = c3;
-            }
+            uint32_t *o = W::lds()->eb + (a & 3u) * 16;
+            o[0] = v0 ? (l0 | (1u << 31) | ((uint32_t)x0 << 30)) : 0u; o[1] = c0;
+            o[2] = v1 ? (l1 | (1u << 31) | ((uint32_t)x1 << 30)) : 0u; o[3] = c1;
+            o[4] = v2 ? (l2 | (1u << 31) | ((uint32_t)x2 << 30)) : 0u; o[5] = c2;
+            o[6] = v3 ? (l3 | (1u << 31) | ((uint32_t)x3 << 30)) : 0u; o[7] = c3;
             W::sync();
+        };
+        for (;;) {
+            typename W::Rec rq = edge_fetch(slot, 0);
+            // (a post of a later position: the apply wave took the list made for the guess and the parser went on)
+            auto later = [&](const typename W::Rec &r) { return W::rec_get(r, 0) == W::rec_get(r, 4) + 1 && (int32_t)(W::rec_get(r, 4) - next) > 0; };
+            bool posted = (W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next) || later(rq);
+            if (!posted) {
+                const unsigned long long t0 = W::clock(), c0 = W::tick();
+                uint32_t spins = 0;
+                for (;;) {
+                    if (W::rec_get(rq, 0) == kNone) { edge_leave(parity ? 28 : 26); return; }
+                    if (!have_g && W::rec_get(rq, 23) > next && W::rec_get(rq, 24) == next) {
+                        // measure for the guess now: the memory round trip is over when the node is posted
+                        wait_cyc += W::tick() - c0;
+                        g0 = W::rec_get(rq, 25); g1 = W::rec_get(rq, 26); g2 = W::rec_get(rq, 27); g3 = W::rec_get(rq, 28);
+                        gseq = W::rec_get(rq, 31);
+                        const typename W::RepPf gpf = W::rep_prefetch(G.in, g.n, next, g0, g1, g2, g3);
+                        uint32_t gl[4];
+                        W::rep_lengths(gpf, gl);
+                        list(next, g0, g1, g2, g3, gl[0], gl[1], gl[2], gl[3], W::rec_get(rq, 29), W::rec_get(rq, 30), W::rec_get(rq, 3) & 0xFFFFu);
+                        W::xw_store(&W::lds()->eb[(next & 3u) * 16 + 15], next + 1);    // listed for the guess of `next`
+                        have_g = true;
+                    } else {
+                        if ((++spins & 63u) == 0) {
+                            if (W::xw_load(&W::lds()->x_err)) { edge_leave(parity ? 28 : 26); return; }
+                            if ((spins & 1023u) == 0 && W::clock() - t0 > 4 * W::timeout_ticks()) { edge_leave(parity ? 28 : 26); return; }
+                        }
+                        W::xw_pause();
+                    }
+                    rq = edge_fetch(slot, 0);
+                    if ((W::rec_get(rq, 0) > next && W::rec_get(rq, 4) == next) || later(rq)) break;
+                }
+                if (!have_g) wait_cyc += W::tick() - c0;
+            }
+            if (W::rec_get(rq, 4) != next) { next = W::rec_get(rq, 4); have_g = false; }
+            const uint32_t a = W::rec_get(rq, 4);
+            const uint32_t rp0 = W::rec_get(rq, 7), rp1 = W::rec_get(rq, 8), rp2 = W::rec_get(rq, 9), rp3 = W::rec_get(rq, 10);
+            if (have_g && g0 == rp0 && g1 == rp1 && g2 == rp2 && g3 == rp3 && gseq == W::rec_get(rq, 16)) {
+                W::cnt_add(&W::lds()->cnt.guess_used, 1);
+            } else {
+                W::cnt_add(have_g ? &W::lds()->cnt.guess_wrong : &W::lds()->cnt.guess_late, 1);
+                // kRepPf bytes in front of each rep distance and at the position
+                const typename W::RepPf rpf = W::rep_prefetch(G.in, g.n, a, rp0, rp1, rp2, rp3);
+                uint32_t rep_len[4];
+                W::rep_lengths(rpf, rep_len);
+                list(a, rp0, rp1, rp2, rp3, rep_len[0], rep_len[1], rep_len[2], rep_len[3], W::rec_get(rq, 14), W::rec_get(rq, 15), W::rec_get(rq, 3) & 0xFFFFu);
+#ifdef NLZM_SIM_COUNT
+                __atomic_fetch_add(&g_dbg[6], 1, __ATOMIC_RELAXED);
+#endif
+            }
+#ifdef NLZM_SIM_COUNT
+            __atomic_fetch_add(&g_dbg[7], 1, __ATOMIC_RELAXED);
+#endif
+            have_g = false;
             next += 2;
+            W::lds()->eb[(a & 3u) * 16 + 15] = next - 1;
             W::xw_store(&W::lds()->post[0][21 + parity], next - 1);      // positions of this parity < next - 1 are listed
 #ifdef NLZM_PROFILE
             lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
@@ -1823,11 +1828,16 @@ struct Master {
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
             // (count and list with one read; if the count was not there yet, the list is read again after the wait)
-            auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return i == 0 ? W::lds()->post[0][21 + slot] : W::lds()->eb[slot * 16 + ((i - 1) & 15u)]; }); };
+            // If the parser's guess of this node's rep set (still in the post block) was right, the list made for the
+            // guess is this node's list: its count word is up before the rep-list wave has seen the post.
+            const bool guess_ok = W::rec_get(rq, 23) > next && W::rec_get(rq, 24) == next && W::rec_get(rq, 25) == r0 &&
+                                  W::rec_get(rq, 26) == r1 && W::rec_get(rq, 27) == r2 && W::rec_get(rq, 28) == r3 && W::rec_get(rq, 31) == W::rec_get(rq, 16);
+            const uint32_t *cw = guess_ok ? &W::lds()->eb[(next & 3u) * 16 + 15] : &W::lds()->post[0][21 + slot];
+            auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return i == 0 ? *cw : W::lds()->eb[(next & 3u) * 16 + ((i - 1) & 15u)]; }); };
             typename W::Rec rb0 = rb_fetch();
             if (W::rec_get(rb0, 0) < next + 1) {
                 const unsigned long long w0 = wait_cyc;
-                if (!wait_ge(&W::lds()->post[0][21 + slot], next + 1)) { edge_leave(22); return; }
+                if (!wait_ge(cw, next + 1)) { edge_leave(22); return; }
                 wait_rep += wait_cyc - w0;
                 rb0 = rb_fetch();
             }
@@ -1845,7 +1855,7 @@ struct Master {
                     const uint32_t l = W::rec_get(rb0, i) & 0xFFFFu, d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
                     open_nodes(end_p, l + p);
                     W::sync();
-                    relax(p, p + l, W::rec_get(rb0, i + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
+                    relax(p, p + l, cost_p + W::rec_get(rb0, i + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
                     W::sync();
                 }
                 if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
@@ -1969,6 +1979,7 @@ struct Master {
                 sp[0] = a + 1;
                 sp[1] = lit_wins ? rp[0] : W::rec_get(nrec, 6); sp[2] = lit_wins ? rp[1] : W::rec_get(nrec, 7);
                 sp[3] = lit_wins ? rp[2] : W::rec_get(nrec, 8); sp[4] = lit_wins ? rp[3] : W::rec_get(nrec, 9);
+                sp[5] = q + 1; sp[6] = umin(max_parse - p - 1, kMatchMax); sp[7] = seg_seq;    // (what the post of p+1 will say)
                 W::sync();
                 W::xw_store(&W::lds()->post[(a + 1) & 1u][23], a + 2);
                 if (!table_head(a + 1, hdr_n, lit_n)) break;
@@ -2137,6 +2148,7 @@ struct Master {
             W::lds()->post[0][20] = a0; W::lds()->post[0][21] = a0; W::lds()->post[0][22] = a0;
             for (uint32_t i = 0; i < 8; i++) { W::lds()->ea_tag[i] = 0; W::lds()->seginfo[i] = 0; }
             W::lds()->post[0][23] = a0; W::lds()->post[1][23] = a0;
+            for (uint32_t i = 0; i < 4; i++) W::lds()->eb[i * 16 + 15] = a0;
         }
         (void)G;
     }

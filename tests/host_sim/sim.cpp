@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #define NLZM_HD inline
@@ -433,6 +434,17 @@ int main(int argc, char **argv)
         Master<HostWave>::init_shared(m.G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
         Master<HostWave> mb = m, mt = m, ms = m, ms2 = m, ms3 = m, ms4 = m;
         const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        std::thread twatch;
+        if (getenv("NLZM_SIM_WATCH")) twatch = std::thread([&] {
+            std::this_thread::sleep_for(std::chrono::seconds(atoi(getenv("NLZM_SIM_WATCH"))));
+            MasterLds *L = g_lds;
+            fprintf(stderr, "watch: sdone %u apos %u bpos %u post0 %u post1 %u cnt %u %u early %u %u\n", L->x_sdone, L->x_apos, L->x_bpos,
+                    L->post[0][0], L->post[1][0], L->post[0][21], L->post[0][22], L->eb[15], L->eb[31]);
+            for (int b = 0; b < 2; b++) { fprintf(stderr, "post[%d]:", b); for (int i = 0; i < 32; i++) fprintf(stderr, " %u", L->post[b][i]); fprintf(stderr, "\n"); }
+            fprintf(stderr, "ea_tag:"); for (int i = 0; i < 8; i++) fprintf(stderr, " %u", L->ea_tag[i]); fprintf(stderr, "\n");
+            _Exit(3);
+        });
+        if (twatch.joinable()) twatch.detach();
         std::thread ts([&] { ms.run_edge_list(a_first); });
         std::thread ts2([&] { ms2.run_rep_list(a_first, 0); });
         std::thread ts4([&] { ms4.run_rep_list(a_first, 1); });
