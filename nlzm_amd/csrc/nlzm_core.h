@@ -225,7 +225,7 @@ struct MasterLds {
     uint32_t ea[4 * 64 * 4];
     uint32_t ea_tag[4 * 2];                 // per slot: a + 1, segment sequence number (written after the entries)
     alignas(32) uint32_t seginfo[8];        // parser -> edge-list wave: sequence number (written last), seg_a, max_parse
-    uint32_t eb[4 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, edge price; 15: listed-for-guess count
+    uint32_t eb[4 * 16];                    // explicit rep probes, words 2k, 2k+1: length | relaxable << 30 | valid << 31, edge price; 14, 15: listed / listed for the guess at least (position + 1)
                                             // through it; word 8: rep indices met by a sampled edge (:1573-1584)
 };
 
@@ -463,6 +463,7 @@ struct Master {
     unsigned long long wait_cyc, role_t0;   // cycles spent waiting for another wave / role start (diagnostics)
     unsigned long long wait_cq = 0, wait_guard = 0;     // finder wave: of them for queue space / for the record buffer
     unsigned long long wait_rep = 0;                    // apply wave: of them for the rep list
+    unsigned long long cmp_acc = 0;                     // apply wave: bytes compared by the rep probes it took (Persist::prof[46])
 #ifdef NLZM_PROFILE
     unsigned long long prof[16];
     unsigned long long prof_t, lat_sum = 0, lat_sum2 = 0;
@@ -674,9 +675,12 @@ struct Master {
         W::sync();
         seg_tab_dirty = false;
     }
+    static NLZM_HD typename W::Rec nrec_none() { return W::rec_load_fn([](uint32_t) { return 0u; }); }
     NLZM_HD uint32_t price_literal(uint32_t y) const               // :1418-1426
     {
-        return W::uni(price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15));
+        uint32_t c0 = price(kCtxCmd, 0), c1 = price(kCtxLitHi, y >> 4), c2 = price(kCtxLitLo + (y >> 4), y & 15);
+        W::join3(c0, c1, c2);                                       // three loads in flight, one wait
+        return W::uni(c0 + c1 + c2);
     }
 
     // ---- symbol output (WriteRange/WriteBits + cdf_update) -------------------
@@ -1558,9 +1562,9 @@ struct Master {
     // wait until `next` is posted and, for the apply wave, its sampled edges are listed for this segment; false: leave
     NLZM_HD bool edge_wait(typename W::Rec &rq, uint32_t next, bool need_lists)
     {
-        auto ready = [&](const typename W::Rec &r) {
-            return W::rec_get(r, 0) > next && W::rec_get(r, 4) == next &&
-                   (!need_lists || (W::rec_get(r, 20) == next + 1 && W::rec_get(r, 21) == W::rec_get(r, 16)));
+        auto ready = [&](const typename W::Rec &r) {      // (no branch per term)
+            const uint32_t miss = (W::rec_get(r, 4) ^ next) | (need_lists ? (W::rec_get(r, 20) ^ (next + 1)) | (W::rec_get(r, 21) ^ W::rec_get(r, 16)) : 0u);
+            return (uint32_t)(W::rec_get(r, 0) > next) & (uint32_t)(miss == 0);
         };
         rq = edge_fetch(next & 1u, next & 3u);
         if (ready(rq)) return true;
@@ -1583,7 +1587,7 @@ struct Master {
     {
         if (W::lane() == 0) {
             G.persist->prof[k] += wait_cyc; G.persist->prof[k + 1] += W::tick() - role_t0;
-            if (k == 22) G.persist->prof[39] += wait_rep;
+            if (k == 22) { G.persist->prof[39] += wait_rep; G.persist->prof[46] += cmp_acc; }
 #ifdef NLZM_PROFILE
             // latency from the parser's post of a node to: list written (24: sampled, 26/28: rep) / apply started, done (22)
             G.persist->prof[32 + (k == 22 ? 0 : (k == 24 ? 1 : (k == 26 ? 2 : 3)))] += lat_sum;
@@ -1755,7 +1759,7 @@ struct Master {
             have_g = false;
             next += 2;
             W::lds()->eb[(a & 3u) * 16 + 15] = next - 1;
-            W::xw_store(&W::lds()->post[0][21 + parity], next - 1);      // positions of this parity < next - 1 are listed
+            W::xw_store(&W::lds()->eb[(a & 3u) * 16 + 14], next - 1);    // a is listed (word 15: for the guess at least)
 #ifdef NLZM_PROFILE
             lat_sum += (uint32_t)((uint32_t)W::tick() - W::rec_get(rq, 12));
 #endif
@@ -1765,7 +1769,7 @@ struct Master {
     // E2: relaxes the listed edges of each node in the reference's order
     NLZM_HD void run_edge_apply(uint32_t a_first)
     {
-        err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick();
+        err = 0; err_info0 = 0; wait_cyc = 0; role_t0 = W::tick(); cmp_acc = 0; wait_rep = 0;
 #ifdef NLZM_PROFILE
         for (int k = 0; k < 16; k++) prof[k] = 0;
 #endif
@@ -1797,11 +1801,12 @@ struct Master {
                     if (k * step > max_len - kMatchMin) return;
                     const uint32_t *o = W::lds()->ea + ((next & 3u) * 64 + k) * 4;
                     const uint32_t tl = max_len - k * step, np = p + tl;
+                    // (all five words are read before the first use: one LDS round trip, not two)
                     uint32_t best = W::lds()->node_cost[np], sel = 0;
                     const uint32_t cd = o[0], cr = o[1], d = o[2], w = o[3];
-                    if (!(w >> 12)) return;
-                    const uint32_t ri = r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u)));
-                    const uint32_t ca = cost_p + cd, cb = ri < 4 ? cost_p + cr : kNone;
+                    const bool listed = (w >> 12) != 0;
+                    const uint32_t ri = !listed ? 4u : (r0 == d ? 0u : (r1 == d ? 1u : (r2 == d ? 2u : (r3 == d ? 3u : 4u))));
+                    const uint32_t ca = listed ? cost_p + cd : kNone, cb = ri < 4 ? cost_p + cr : kNone;
                     myri = ri;
                     if (W::width() == 1) checked |= ri < 4 ? 1u << ri : 0u;
                     if (ca < best) { best = ca; sel = 1; }
@@ -1828,12 +1833,11 @@ struct Master {
             }
             // the rep probes come after the sampled edges (:1598); rep indices a sampled edge has met are skipped
             // (count and list with one read; if the count was not there yet, the list is read again after the wait)
-            // If the parser's guess of this node's rep set (still in the post block) was right, the list made for the
-            // guess is this node's list: its count word is up before the rep-list wave has seen the post.
-            const bool guess_ok = W::rec_get(rq, 23) > next && W::rec_get(rq, 24) == next && W::rec_get(rq, 25) == r0 &&
-                                  W::rec_get(rq, 26) == r1 && W::rec_get(rq, 27) == r2 && W::rec_get(rq, 28) == r3 && W::rec_get(rq, 31) == W::rec_get(rq, 16);
-            const uint32_t *cw = guess_ok ? &W::lds()->eb[(next & 3u) * 16 + 15] : &W::lds()->post[0][21 + slot];
-            auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return i == 0 ? *cw : W::lds()->eb[(next & 3u) * 16 + ((i - 1) & 15u)]; }); };
+            prof_mark(2);
+            // If the parser's guess of this node's rep set was right (the post says so), the list made for the guess is
+            // this node's list: its count word is up before the rep-list wave has seen the post.
+            const uint32_t *cw = &W::lds()->eb[(next & 3u) * 16 + 14 + (W::rec_get(rq, 17) & 1u)];
+            auto rb_fetch = [=]() { return W::rec_load_fn32([=](uint32_t i) { return cw[i == 0 ? 0 : (int)((i - 1) & 15u) - 14 - (int)(W::rec_get(rq, 17) & 1u)]; }); };
             typename W::Rec rb0 = rb_fetch();
             if (W::rec_get(rb0, 0) < next + 1) {
                 const unsigned long long w0 = wait_cyc;
@@ -1858,7 +1862,7 @@ struct Master {
                     relax(p, p + l, cost_p + W::rec_get(rb0, i + 1), 0, 2, l, k, r0, r1, r2, r3, d);   // wave-uniform
                     W::sync();
                 }
-                if (csum) W::cnt_add(&W::lds()->cnt.cmp_bytes, csum);
+                cmp_acc += csum;                                    // (to the counters when the wave leaves)
             }
             prof_mark(4);
             W::lds()->sq_res[slot] = end_p;
@@ -1889,11 +1893,20 @@ struct Master {
         uint32_t p = 0, end_p = 1;
         uint32_t settled = 0, pend_long = 0;            // nodes whose edges are in / long hand-off slots they still hold
         // edges of every node < upto are relaxed: take over end_p, give the hand-off slots back
-        auto settle = [&](uint32_t upto, bool publish) -> bool {
-            if (settled >= upto) return true;
-            // count and end_p words with one read (adjacent words: one pass, the count in the lowest lane)
-            auto fetch = [=]() { return W::rec_load_fn([=](uint32_t i) { return i == 0 ? W::lds()->x_sdone : W::lds()->sq_res[(i - 1) & 1u]; }); };
-            typename W::Rec sr = fetch();
+        // (with nodes: the same read brings nodes upto+1 and upto+2 as they stand then -- cost and rep set in lanes 3..7
+        //  and 8..12 -- which is all the parser needs of them for its next step)
+        typename W::Rec sr = nrec_none();
+        auto settle = [&](uint32_t upto, bool publish, bool nodes = false) -> bool {
+            if (!nodes && settled >= upto) return true;
+            // count and end_p words with one read (the count in the lowest lane)
+            auto fetch = [=]() {
+                return W::rec_load_fn32([=](uint32_t i) {
+                    const uint32_t n = upto + (i >= 8 ? 2u : 1u), j = i >= 8 ? i - 8 : i - 3;
+                    return i == 0 ? W::lds()->x_sdone : (i < 3 ? W::lds()->sq_res[(i - 1) & 1u] :
+                           (j == 0 ? W::lds()->node_cost[n] : W::lds()->reps[(n & 511) * 4 + ((j - 1) & 3)]));
+                });
+            };
+            sr = fetch();
             if (W::rec_get(sr, 0) < seg_a + upto) {
                 const unsigned long long t0 = W::clock(), c0 = W::tick();
                 uint32_t spins = 0;
@@ -1908,6 +1921,7 @@ struct Master {
                 }
                 wait_cyc += W::tick() - c0;
             }
+            if (settled >= upto) return true;                       // (read for the nodes only)
             const uint32_t se = W::rec_get(sr, 1 + ((seg_a + upto - 1) & 1u));
             if (se > end_p) { end_p = se; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
             settled = upto;
@@ -1916,20 +1930,24 @@ struct Master {
             return true;
         };
         // node p: cost and rep set with one LDS instruction
-        // (lanes 5..9: the same of node p+1 as it stands, for the guess below)
-        auto node_read = [&](uint32_t pp) {
-            return W::rec_load_fn32([=](uint32_t i) {
-                const uint32_t n = pp + (i >= 5 ? 1u : 0u), j = i >= 5 ? i - 5 : i;
-                return j == 0 ? W::lds()->node_cost[n] : W::lds()->reps[(n & 511) * 4 + ((j - 1) & 3)];
-            });
+        // (read for p and, as it stands, for p+1: the guess below)
+        auto node_read = [&](uint32_t n) {
+            return W::rec_load_fn([=](uint32_t i) { return i == 0 ? W::lds()->node_cost[n] : W::lds()->reps[(n & 511) * 4 + ((i - 1) & 3)]; });
         };
         // hand-off header and input byte of position x (kept: the position after a segment's last node is the next
         // segment's first)
         auto table_head = [&](uint32_t x, uint32_t &hdr, uint32_t &lit) -> bool {
             if (th_a != x) {
-                if (!wait_ge(&W::lds()->x_apos, x + 1)) return false;
-                const typename W::Rec hrec = W::rec_load(W::lds()->er_tab + (x & (kEr - 1)) * 64);
-                th_a = x; th_hdr = W::rec_get(hrec, 0); th_lit = W::rec_get(hrec, 1);
+                // the table wave's position (lane 0, read first) and the two header words with one read
+                auto fetch = [=]() {
+                    return W::rec_load_fn([=](uint32_t i) { return i == 0 ? W::lds()->x_apos : W::lds()->er_tab[(x & (kEr - 1)) * 64 + ((i - 1) & 1u)]; });
+                };
+                typename W::Rec hrec = fetch();
+                if (W::rec_get(hrec, 0) < x + 1) {
+                    if (!wait_ge(&W::lds()->x_apos, x + 1)) return false;
+                    hrec = fetch();
+                }
+                th_a = x; th_hdr = W::rec_get(hrec, 1); th_lit = W::rec_get(hrec, 2);
             }
             hdr = th_hdr; lit = th_lit;
             return true;
@@ -1944,9 +1962,13 @@ struct Master {
         for (uint32_t i = W::lane(); i < 4; i += W::width()) W::lds()->post[i >> 1][2 + (i & 1u)] = ((const uint32_t *)W::lds()->price)[kCtxCmd * 8 + (i & 1u)];
         W::sync();
         W::xw_store(&W::lds()->x_bcover, seg_a + 1);
-        typename W::Rec nrec = node_read(0);
+        typename W::Rec nrec = node_read(0), nrec1 = node_read(1);
         uint32_t hdr = 0, lit = 0, cst_lit = 0;
+        // the rep set guessed for the node about to be posted (lanes 1..4, as in a node record)
+        typename W::Rec gs = nrec;
+        uint32_t gs_valid = 0;
         if (table_head(seg_a, hdr, lit)) cst_lit = price_literal(lit);
+        prof_mark(0);                                               // (segment set-up)
         while (!err) {                                              // p < end_p
             const uint32_t q = seg_q + p, a = seg_a + p;
             n_pos++;
@@ -1957,46 +1979,62 @@ struct Master {
             if (max_len < kMatchMin) max_len = 0;
             if (max_len) seg_tables();
             {   // node p is final: its match and rep edges go to the edge waves (slot a & 1 is free: node p-2 is settled)
-                uint32_t *r = W::lds()->post[a & 1u] + 4;
-                r[0] = a; r[1] = p; r[2] = cost_p; r[3] = rp[0]; r[4] = rp[1]; r[5] = rp[2]; r[6] = rp[3];
-                r[7] = max_len; r[9] = hdr; r[10] = q; r[11] = umin(max_parse - p, kMatchMax); r[12] = seg_seq;
+                // (the request is put together in one register, word k in lane k, and stored with one instruction;
+                //  words 2..6 are the node record's lanes 0..4 as they are)
+                typename W::Rec r = W::rec_shift2(nrec);
+                r = W::rec_set(r, 0, a); r = W::rec_set(r, 1, p);
+                r = W::rec_set(r, 7, max_len); r = W::rec_set(r, 9, hdr); r = W::rec_set(r, 10, q);
+                r = W::rec_set(r, 11, umin(max_parse - p, kMatchMax)); r = W::rec_set(r, 12, seg_seq);
+                // the guess posted for this node was right: the rep list made for it is this node's list
+                r = W::rec_set(r, 13, gs_valid & W::rec_eq4(gs, nrec));
 #ifdef NLZM_PROFILE
-                r[8] = (uint32_t)W::tick();
+                r = W::rec_set(r, 8, (uint32_t)W::tick());
 #endif
+                W::rec_store_n(W::lds()->post[a & 1u] + 4, r, 14);
                 W::sync();
                 W::xw_store(&W::lds()->post[a & 1u][0], a + 1);
             }
             if (max_len && p + max_len > end_p) { end_p = p + max_len; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
+            prof_mark(1);                                           // (post)
             const uint32_t pend_long_next = (hdr >> 16) ? 1u : 0u;
             // while the edge waves work on this node: the table header and the literal price of the next position
             uint32_t hdr_n = 0, lit_n = 0, cst_n = 0;
+            gs_valid = 0;
             if (p + 1 < max_parse) {
                 // A guess of node p+1's rep set for its rep-list wave, so that the bytes are in when the node is
                 // final: the literal edge of p would win it (then the set is p's), or it keeps what it has.  Only
                 // a length-2 edge of p-1 can still prove the guess wrong (then the wave measures again).
-                const bool lit_wins = cost_p + cst_lit < W::rec_get(nrec, 5);
+                const bool lit_wins = cost_p + cst_lit < W::rec_get(nrec1, 0);
                 uint32_t *sp = W::lds()->post[(a + 1) & 1u] + 24;
-                sp[0] = a + 1;
-                sp[1] = lit_wins ? rp[0] : W::rec_get(nrec, 6); sp[2] = lit_wins ? rp[1] : W::rec_get(nrec, 7);
-                sp[3] = lit_wins ? rp[2] : W::rec_get(nrec, 8); sp[4] = lit_wins ? rp[3] : W::rec_get(nrec, 9);
-                sp[5] = q + 1; sp[6] = umin(max_parse - p - 1, kMatchMax); sp[7] = seg_seq;    // (what the post of p+1 will say)
+                gs = W::rec_sel(lit_wins, nrec, nrec1);             // lanes 1..4: the set
+                gs_valid = 1;
+                gs = W::rec_set(gs, 0, a + 1);
+                gs = W::rec_set(gs, 5, q + 1); gs = W::rec_set(gs, 6, umin(max_parse - p - 1, kMatchMax));    // (what the post of p+1 will say)
+                gs = W::rec_set(gs, 7, seg_seq);
+                W::rec_store_n(sp, gs, 8);
                 W::sync();
                 W::xw_store(&W::lds()->post[(a + 1) & 1u][23], a + 2);
+                prof_mark(2);                                       // (guess)
                 if (!table_head(a + 1, hdr_n, lit_n)) break;
                 cst_n = price_literal(lit_n);
             }
             prof_mark(7);
             // node p+1 takes the edges of p-1 before the literal edge of p (the reference's order, strict '<')
-            if (!settle(p, true)) break;
+            if (!settle(p, true, true)) break;
             pend_long += pend_long_next;
             prof_mark(8);
             // literal edge (:1490-1499)
-            if (W::uni(W::lds()->node_cost[p + 1]) > cost_p + cst_lit) {
+            const bool lit_edge = W::rec_get(sr, 3) > cost_p + cst_lit;
+            if (lit_edge) {
                 W::lds()->node_cost[p + 1] = cost_p + cst_lit;
                 W::lds()->node_delta[p + 1] = lit;                  // the byte itself, for the emitter
                 W::lds()->node_link[p + 1] = pack_link(p, 0, 0);
-                for (int k = 0; k < 4; k++) W::lds()->reps[((p + 1) & 511) * 4 + k] = rp[k];
+                W::rec_store4(W::lds()->reps + ((p + 1) & 511) * 4 - 1, nrec);     // lanes 1..4: node p's set
             }
+            // the next node: what the literal edge made of it, or what it was when the edges of its last predecessor
+            // were in; the one after it as it stood then (for the guess)
+            nrec = W::rec_sel(lit_edge, W::rec_set(nrec, 0, cost_p + cst_lit), W::rec_shl3(sr));
+            nrec1 = W::rec_shl8(sr);
             ++p;
             W::sync();
             if (p >= end_p) {
@@ -2005,7 +2043,6 @@ struct Master {
                 if (p >= end_p) break;
                 W::xw_store(&W::lds()->x_bpos, seg_a + p);
             }
-            nrec = node_read(p);                                    // p < end_p <= max_parse <= 4096
             hdr = hdr_n; lit = lit_n; cst_lit = cst_n;
             prof_mark(9);
         }
@@ -2130,6 +2167,7 @@ struct Master {
 #ifdef NLZM_PROFILE
             for (int k = 7; k < 12; k++) P->prof[k] += prof[k];
             P->prof[13] += prof[13];
+            P->prof[47] += prof[0]; P->prof[54] += prof[1]; P->prof[55] += prof[2];
 #endif
             unsigned long long *dst = (unsigned long long *)&P->cnt;
             const unsigned long long *src = (const unsigned long long *)&W::lds()->cnt;
@@ -2148,7 +2186,7 @@ struct Master {
             W::lds()->post[0][20] = a0; W::lds()->post[0][21] = a0; W::lds()->post[0][22] = a0;
             for (uint32_t i = 0; i < 8; i++) { W::lds()->ea_tag[i] = 0; W::lds()->seginfo[i] = 0; }
             W::lds()->post[0][23] = a0; W::lds()->post[1][23] = a0;
-            for (uint32_t i = 0; i < 4; i++) W::lds()->eb[i * 16 + 15] = a0;
+            for (uint32_t i = 0; i < 4; i++) { W::lds()->eb[i * 16 + 14] = a0; W::lds()->eb[i * 16 + 15] = a0; }
         }
         (void)G;
     }

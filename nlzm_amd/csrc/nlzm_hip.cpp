@@ -408,7 +408,7 @@ int refresh_stats(Ctx &C)
     HIPCHK(hipMemcpy(&P, C.persist, sizeof P, hipMemcpyDeviceToHost));
     nlzm_hip_stats &s = C.stats;
     s.out_bytes = C.out_pos;
-    s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes; s.ht_rows = P.cnt.ht_rows;
+    s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes + P.prof[46]; s.ht_rows = P.cnt.ht_rows;
     s.rk_probes = P.cnt.rk_probes; s.rk_inserts = P.cnt.rk_inserts; s.positions = P.cnt.positions;
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
@@ -437,6 +437,9 @@ int refresh_stats(Ctx &C)
                 P.prof[40] / n0, P.prof[41] / n0, P.prof[42] / n0, P.prof[43] / n0, P.prof[44] / n0, P.prof[45] / n0);
         fprintf(stderr, "table wave sections (cycles/pos): fetch %.0f, update %.0f, carry %.0f, run %.0f, set %.0f, end %.0f\n",
                 P.prof[48] / n0, P.prof[49] / n0, P.prof[50] / n0, P.prof[51] / n0, P.prof[52] / n0, P.prof[53] / n0);
+        fprintf(stderr, "parser wave sections (cycles/pos): segment set-up %.0f, post %.0f, guess %.0f, next table head + literal price %.0f, settle %.0f, "
+                        "literal edge + node %.0f, backtrack %.0f, emit %.0f\n", P.prof[47] / n0, P.prof[54] / n0, P.prof[55] / n0, P.prof[7] / n0,
+                P.prof[8] / n0, P.prof[9] / n0, P.prof[10] / n0, P.prof[11] / n0);
         static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
                                          "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
         unsigned long long tot = 0;

@@ -207,6 +207,27 @@ struct DevWave {
     static __device__ __forceinline__ Rec rec_load_fn(F f) { return Rec{ f(lane() & 7u) }; }
     template <class F>
     static __device__ __forceinline__ Rec rec_load_fn32(F f) { return Rec{ f(lane() & 31u) }; }
+    // records as vectors: a or b whole / lanes 1..4 stored to dst[1..4] / lanes 1..4 equal
+    static __device__ __forceinline__ Rec rec_sel(bool c, Rec a, Rec b) { return Rec{ c ? a.v : b.v }; }
+    static __device__ __forceinline__ void rec_store4(uint32_t *dst, Rec r) { if (lane() - 1u < 4u) dst[lane()] = r.v; }
+    static __device__ __forceinline__ uint32_t rec_eq4(Rec a, Rec b) { return ((uint32_t)__ballot(a.v == b.v) & 0x1Eu) == 0x1Eu ? 1u : 0u; }
+    // the three values are all loaded before any of them is used (the loads overlap)
+    static __device__ __forceinline__ void join3(uint32_t &a, uint32_t &b, uint32_t &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+    // word k set (v_writelane) / lanes 0..n-1 stored to dst[0..n-1] / lane k moved to lane k + 2 (lanes 0, 1 undefined)
+    static __device__ __forceinline__ Rec rec_set(Rec r, uint32_t k, uint32_t v)
+    {
+        const uint32_t sv = uni(v);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(r.v) : "s"(sv), "n"(k));      // (no builtin for it in this compiler)
+        return r;
+    }
+    static __device__ __forceinline__ void rec_store_n(uint32_t *dst, Rec r, uint32_t n) { if (lane() < n) dst[lane()] = r.v; }
+    // lane k + 3 / k + 8 moved to lane k (within the 16 lanes a record uses)
+    static __device__ __forceinline__ Rec rec_shl3(Rec r) { return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x103 /* row_shl:3 */, 0xF, 0xF, false) }; }
+    static __device__ __forceinline__ Rec rec_shl8(Rec r) { return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x108 /* row_shl:8 */, 0xF, 0xF, false) }; }
+    static __device__ __forceinline__ Rec rec_shift2(Rec r)
+    {
+        return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x112 /* row_shr:2 */, 0xF, 0xF, false) };
+    }
     static __device__ __forceinline__ uint32_t rec_get(Rec r, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)r.v, (int)k); }
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
