@@ -30,6 +30,7 @@
 #ifndef NLZM_HDN
 #define NLZM_HDN __host__ __device__
 #endif
+#define NLZM_RARE(x) __builtin_expect(!!(x), 0)     // block placement: the common path falls through
 
 namespace nlzm {
 
@@ -1907,7 +1908,7 @@ struct Master {
                 });
             };
             sr = fetch();
-            if (W::rec_get(sr, 0) < seg_a + upto) {
+            if (NLZM_RARE(W::rec_get(sr, 0) < seg_a + upto)) {
                 const unsigned long long t0 = W::clock(), c0 = W::tick();
                 uint32_t spins = 0;
                 for (;;) {
@@ -1925,7 +1926,7 @@ struct Master {
             const uint32_t se = W::rec_get(sr, 1 + ((seg_a + upto - 1) & 1u));
             if (se > end_p) { end_p = se; W::xw_store(&W::lds()->x_bcover, seg_a + end_p); }
             settled = upto;
-            if (pend_long) { b_long += pend_long; pend_long = 0; W::xw_store(&W::lds()->x_long_free, kErLong + b_long); }
+            if (NLZM_RARE(pend_long != 0)) { b_long += pend_long; pend_long = 0; W::xw_store(&W::lds()->x_long_free, kErLong + b_long); }
             if (publish) W::xw_store(&W::lds()->x_bpos, seg_a + upto);
             return true;
         };
@@ -1943,7 +1944,7 @@ struct Master {
                     return W::rec_load_fn([=](uint32_t i) { return i == 0 ? W::lds()->x_apos : W::lds()->er_tab[(x & (kEr - 1)) * 64 + ((i - 1) & 1u)]; });
                 };
                 typename W::Rec hrec = fetch();
-                if (W::rec_get(hrec, 0) < x + 1) {
+                if (NLZM_RARE(W::rec_get(hrec, 0) < x + 1)) {
                     if (!wait_ge(&W::lds()->x_apos, x + 1)) return false;
                     hrec = fetch();
                 }
@@ -2000,7 +2001,7 @@ struct Master {
             // while the edge waves work on this node: the table header and the literal price of the next position
             uint32_t hdr_n = 0, lit_n = 0, cst_n = 0;
             gs_valid = 0;
-            if (p + 1 < max_parse) {
+            if (!NLZM_RARE(p + 1 >= max_parse)) {
                 // A guess of node p+1's rep set for its rep-list wave, so that the bytes are in when the node is
                 // final: the literal edge of p would win it (then the set is p's), or it keeps what it has.  Only
                 // a length-2 edge of p-1 can still prove the guess wrong (then the wave measures again).
@@ -2015,12 +2016,12 @@ struct Master {
                 W::sync();
                 W::xw_store(&W::lds()->post[(a + 1) & 1u][23], a + 2);
                 prof_mark(2);                                       // (guess)
-                if (!table_head(a + 1, hdr_n, lit_n)) break;
+                if (NLZM_RARE(!table_head(a + 1, hdr_n, lit_n))) break;
                 cst_n = price_literal(lit_n);
             }
             prof_mark(7);
             // node p+1 takes the edges of p-1 before the literal edge of p (the reference's order, strict '<')
-            if (!settle(p, true, true)) break;
+            if (NLZM_RARE(!settle(p, true, true))) break;
             pend_long += pend_long_next;
             prof_mark(8);
             // literal edge (:1490-1499)
@@ -2037,7 +2038,7 @@ struct Master {
             nrec1 = W::rec_shl8(sr);
             ++p;
             W::sync();
-            if (p >= end_p) {
+            if (NLZM_RARE(p >= end_p)) {
                 // only a rep probe of the node just posted can still extend the segment
                 if (!settle(p, false)) break;
                 if (p >= end_p) break;
