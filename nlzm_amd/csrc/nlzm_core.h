@@ -1978,7 +1978,6 @@ struct Master {
             for (int k = 0; k < 4; k++) rp[k] = W::rec_get(nrec, 1 + k);
             uint32_t max_len = umin(hdr & 0xFFFFu, max_parse - p);  // :1545-1548
             if (max_len < kMatchMin) max_len = 0;
-            if (max_len) seg_tables();
             {   // node p is final: its match and rep edges go to the edge waves (slot a & 1 is free: node p-2 is settled)
                 // (the request is put together in one register, word k in lane k, and stored with one instruction;
                 //  words 2..6 are the node record's lanes 0..4 as they are)
