@@ -27,7 +27,9 @@ def test_master_logic_matches_oracle(sim, name, workers, tmp_path):
     case = next(c for c in cases.CASES if c[0] == name)
     p = tmp_path / "in.bin"
     cases.make_case(case).tofile(p)
-    r = subprocess.run([sim, str(p), str(case[4]), "1", str(workers)], capture_output=True, text=True)
+    # (the simulator's waits have no timeout of their own: NLZM_SIM_WATCH dumps the hand-off words and exits)
+    r = subprocess.run([sim, str(p), str(case[4]), "1", str(workers)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, NLZM_SIM_WATCH="300"))
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -37,6 +39,7 @@ def test_master_logic_with_late_worker_results(sim, name, tmp_path):
     case = next(c for c in cases.CASES if c[0] == name)
     p = tmp_path / "in.bin"
     cases.make_case(case).tofile(p)
-    r = subprocess.run([SIM + "_late", str(p), str(case[4]), "1", "1"], capture_output=True, text=True)
+    r = subprocess.run([SIM + "_late", str(p), str(case[4]), "1", "1"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, NLZM_SIM_WATCH="300"))
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout + r.stderr
 
