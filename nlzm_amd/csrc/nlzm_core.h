@@ -367,10 +367,11 @@ struct ResultSink {
     uint32_t *pairs;        // nullptr: do not publish
     uint32_t *rec;          // the position's bt_ready record (first four pairs go there too)
     uint32_t count, best;
+    uint32_t best_d = 0;
     NLZM_HD void operator()(uint32_t d, uint32_t l)
     {
         if (!pairs || l <= best) return;    // only record-setters change the table
-        best = l;
+        best = l; best_d = d;
         IO::st_agent(pairs + 2 * count, d);
         IO::st_agent(pairs + 2 * count + 1, l);
         if (count < 4) { IO::st_agent(rec + 1 + 2 * count, d); IO::st_agent(rec + 2 + 2 * count, l); }
@@ -390,6 +391,8 @@ NLZM_HD void worker_bt_dry(const Geom &g, const Globals &G, uint32_t a, uint32_t
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update_st(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests, st);
     n_tests += tests;
+    IO::st_agent(G.bt_ready + bi * kBtRec + 9, sink.best_d);       // the longest record-setter (the last one), for the finder stage
+    IO::st_agent(G.bt_ready + bi * kBtRec + 10, sink.count ? sink.best : 0u);
     IO::drain();                            // every pair has been written through before the ready word
     IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
 }
@@ -406,6 +409,8 @@ NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_
     bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
     if (publish) {
+        IO::st_agent(G.bt_ready + bi * kBtRec + 9, sink.best_d);
+        IO::st_agent(G.bt_ready + bi * kBtRec + 10, sink.count ? sink.best : 0u);
         IO::drain();                        // every pair has been written through before the ready word
         IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
     }

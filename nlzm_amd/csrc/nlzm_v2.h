@@ -1,0 +1,1460 @@
+// nlzm_v2.h -- the serial half of the compress path as three pipelined stages whose lanes are POSITIONS (finder,
+// table) or EDGES (parser), one workgroup (CU) per stage, hand-off through small rings in HBM/L2:
+//
+//   role_finder  HT2/HT3 (tables in LDS), RK256, the nice decision and the decisions for the BT4 worker lanes
+//                (:1501-1543 minus BT4).  A block of up to 64 consecutive positions is evaluated by the lanes in
+//                parallel under a PREDICTED set of finder calls; a cross-lane scan verifies the prediction and the
+//                block is cut at the first position that the reference would have treated differently.
+//   role_table   the match table as mt_carry holds it (:746-752, :823-852, :1543), kept as its Pareto front
+//                (distance falls as length falls); the front of every position of a block comes out of ONE
+//                parallel prefix scan over the lanes; then the sampled lengths of :1558-1562 are listed.
+//   role_parser  parse_table's graph (:1464-1651) as a wavefront: two nodes per step, lanes = their out-edges,
+//                relaxation by 64-bit LDS atomic min on (cost, source, rank) -- the lexicographic order IS the
+//                reference's "first candidate wins" under strict '>' (:1492, :1568, :1586, :1616); backtrack,
+//                model_encode_* (:1274-1367, :1428-1439), frame symbol/bit streams.
+//
+// Written against xw.h: the same source is the gfx950 kernel and, under -DNLZM_SIM, the CPU simulation
+// that tests/host_sim/sim2.cpp checks against the oracle.  All file:line cites are NLZM.cpp.
+#pragma once
+
+#include "nlzm_core.h"
+#include "xw.h"
+
+namespace nlzm {
+namespace v2 {
+
+// ------------------------------------------------------------------------------------------------
+// hand-off between the stages (HBM; payload stored sc1 and drained before the progress word, R1 form)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFtRing = 1u << 14;          // finder -> table: positions in flight
+constexpr uint32_t kFtStride = 16;              // words per position
+constexpr uint32_t kTpRing = 1u << 13;          // table -> parser
+constexpr uint32_t kMaxEdges = 32;              // sampled lengths per position (:1558-1560: at most 32, at max_len 33)
+constexpr uint32_t kTpStride = 2 + 2 * kMaxEdges + 2;   // header (2), edges (distance, attributes), pad to 16 bytes
+constexpr uint32_t kFrontMax = 264;             // entries of a front (one per length at most)
+constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the front ring (end, distance)
+
+// finder -> table record:
+//   w0        number of pairs in w2.. (bits 0..2) | BT4 ran: take the worker record's list (bit 3) | top pair present (bit 4)
+//             | input byte << 8
+//   w2..w13   up to six (distance, length) pairs: HT2, HT3 x2, RK256 carried / new, a former top entry that has stopped growing
+//   w14, w15  the top entry (distance, length) while it is still growing with the position (:1503-1512)
+constexpr uint32_t kFtBt = 8u, kFtTop = 16u;
+// table -> parser record:
+//   w0        edges (bits 0..5) | input byte << 8 | table length (mt.max_len) << 16
+//   w1        entries of the front in the front ring
+//   w2..      per sampled length: distance, length | length value << 9 | distance slot << 18 | extra bits << 24 | valid << 31
+struct Hx {                                     // progress words, one 128-byte line each
+    alignas(128) uint32_t f_pos;                // finder: records of positions < f_pos are written
+    alignas(128) uint32_t t_pos;                // table: records of positions < t_pos are consumed
+    alignas(128) uint32_t t_out;                // table: parser records of positions < t_out are written
+    alignas(128) uint32_t p_pos;                // parser: records of positions < p_pos are consumed
+    alignas(128) unsigned long long p_seg;      // parser: segment start << 32 | positions below this lie in that segment
+    alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves
+    alignas(128) uint32_t pad;
+};
+
+struct GlobalsV2 {
+    uint32_t *ft;                               // [kFtRing][kFtStride]
+    uint32_t *tp;                               // [kTpRing][kTpStride]
+    uint32_t *tf;                               // [kTpRing][kTfStride]
+    Hx *hx;
+    uint32_t *state;                            // StateV2 (survives between launches)
+};
+
+// stage state that survives between launches (HBM)
+struct StateV2 {
+    // finder
+    uint32_t reach;                             // largest end (absolute) of any closed table entry so far
+    uint32_t s_active, s_d, s_end, s_seen;      // growing top entry: distance, first mismatch (kNone: not found yet), verified up to
+    uint32_t prev_nice, seg_s;
+    // table: the front after the last position of the launch
+    uint32_t front_n;
+    uint32_t front[2 * kFrontMax];
+};
+
+constexpr uint32_t kErrV2Front = 40;            // front overflow on the slow path (cannot happen: one entry per length)
+constexpr uint32_t kErrV2Promise = 41;          // a position the pre-filter promised not to be nice is
+constexpr uint32_t kErrV2Edges = 42;
+
+NLZM_HD uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return umin(a, umin(b, c)); }
+
+// wave-wide byte compare (MatchLengthSigned without the sign, :854-877): common prefix of in[s..] and in[t..] from `init`,
+// at most cap; lanes look at 8 bytes each, 512 per round.  Uniform arguments, uniform result.
+XW_FN uint32_t wave_cmp(const uint8_t *in, uint32_t s, uint32_t t, uint32_t init, uint32_t cap)
+{
+    uint32_t off = init;
+    while (off < cap) {
+        const uint32_t my = off + xw::lane() * 8;
+        uint32_t m = kNone;
+        if (my < cap) {
+            const unsigned long long d = load64u(in + s + my) ^ load64u(in + t + my);
+            if (d) {
+                const uint32_t p = my + ((uint32_t)__builtin_ctzll(d) >> 3);
+                if (p < cap) m = p;
+            }
+        }
+        const unsigned long long bal = xw::ballot(m != kNone);
+        if (bal) return xw::readlane(m, (uint32_t)__builtin_ctzll(bal));
+        off += 512;
+    }
+    return cap;
+}
+
+// bounded wait for a progress word to reach v; false: another stage failed or the wait timed out (err set)
+XW_FN bool wait_word_ge(const uint32_t *w, uint32_t v, Hx *hx, uint32_t code)
+{
+    if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) return true;
+    const unsigned long long t0 = xw::clock100();
+    uint32_t spins = 0;
+    for (;;) {
+        if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) return true;
+        if ((++spins & 63u) == 0) {
+            if (xw::readfirst(xw::ld_agent(&hx->err))) return false;
+#ifndef NLZM_SIM
+            if (xw::clock100() - t0 > 3000000000ull) {            // 30 s
+                if (xw::lane() == 0) xw::st_agent(&hx->err, kErrTimeout * 100 + code);
+                return false;
+            }
+#else
+            (void)t0; (void)code;
+#endif
+        }
+        xw::pause();
+    }
+}
+
+// =================================================================================================
+// finder stage
+// =================================================================================================
+struct FLds {
+    uint32_t ht2[4096];                         // :1750
+    uint32_t ht3[16384 + 8];                    // :1751 (bucket b uses rows b and b+1, :912: 2^14 + 1 rows are ever touched)
+    uint32_t stage[64 * kFtStride];             // the block's records, one per lane
+    uint32_t job[64 * 3 * 4];                   // byte compares longer than the lanes' own first look: lane | cand << 8, distance, cap
+    uint32_t job_len[64 * 4];
+    uint32_t njobs;
+    Counters cnt;
+};
+
+struct Finder {
+    Geom g;
+    Globals G;
+    GlobalsV2 V;
+    // wave-uniform state
+    uint32_t base;              // absolute offset of rebased 0 (:888-891)
+    uint32_t reach;             // largest absolute end of a closed table entry
+    uint32_t s_active, s_d, s_end, s_seen;
+    uint32_t rk_from, rk_to, rk_len, rk_end;
+    uint32_t prev_nice, seg_s;
+    uint32_t t_pos_seen;
+    uint32_t err;
+    unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut[6];
+    unsigned long long t_wait, t_total;
+
+    XW_FN void fail(uint32_t code, uint32_t info)
+    {
+        err = code;
+        if (xw::lane() == 0) {
+            G.persist->error = code; G.persist->error_info[0] = info; G.persist->error_info[1] = 11;
+            xw::st_agent(&V.hx->err, code);
+        }
+    }
+
+    // The growing top entry (distance s_d): find where it stops matching, as far as `limit` (:1507-1509).
+    XW_FN void slider_look(uint32_t limit)
+    {
+        while (s_end == kNone && s_seen < limit) {
+            const uint32_t cap = umin(limit - s_seen, 512u);
+            const uint32_t l = wave_cmp(G.in, s_seen - s_d, s_seen, 0, cap);
+            if (l < cap) s_end = s_seen + l; else s_seen += cap;
+        }
+        if (s_end == kNone && (unsigned long long)s_seen >= g.n) s_end = (uint32_t)g.n;
+    }
+
+    // One block: positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end (all
+    // absolute).  Returns how many of them are final (>= 1); the records of those are in the ring.
+    XW_FN uint32_t block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    {
+        FLds *L = xw::lds<FLds>();
+        const uint32_t i = xw::lane();
+        const bool in_blk = i < n;
+        const uint32_t a = a0 + i, q = a - base;
+        const uint32_t avail = in_blk ? la_end - a : 0u;
+        const uint32_t cap = umin(avail, kMatchMax);                 // :915, :987
+        const uint8_t *cur = G.in + a;
+        const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
+
+        // ---- the growing top entry: its end must be known as far as this block can see it
+        if (s_active) slider_look(umin(a0 + n + kMatchMax, la_end));
+        const bool s_known = s_active && s_end != kNone;
+        // end of the top entry at this position after carry + extension (:1501-1512)
+        const uint32_t s_e = s_active ? (s_known ? umin(s_end, a + cap) : a + cap) : 0u;
+        const bool s_sliding = s_active && (!s_known || s_end >= a + cap);   // still growing here (it is the top entry)
+        // lanes from jc on see it as an ordinary closed entry that ends at s_end
+        const unsigned long long closed_mask = xw::ballot(in_blk && s_active && !s_sliding);
+        const uint32_t jc = closed_mask ? (uint32_t)__builtin_ctzll(closed_mask) : 64u;
+
+        // ---- predicted finder calls (:1514, :1529) from the state the block starts with
+        const uint32_t reach_pred = umax(reach, s_e);
+        const bool nice_pred = in_blk && reach_pred >= a + kNice && reach_pred > a;
+        if (xw::readlane(nice_pred ? 1u : 0u, 0) && !prev_nice) {
+            // a nice region starts here: which segment is a0 in?  The parser knows once it has seen an edge that
+            // spans a0 (the table of a0 - 1 reaches 64 further) or has ended a segment exactly there.
+            if (a0 == (uint32_t)((unsigned long long)(a0 / g.chunk_size) * g.chunk_size)) seg_s = a0;   // a chunk starts a segment (:1802)
+            else {
+                const unsigned long long tw = xw::tick();
+                const unsigned long long t0 = xw::clock100();
+                uint32_t spins = 0;
+                for (;;) {
+                    const unsigned long long ps = xw::readfirst64(xw::ld_agent64(&V.hx->p_seg));
+                    if ((int32_t)((uint32_t)ps - (a0 + 1)) >= 0) { seg_s = (uint32_t)(ps >> 32); break; }
+                    if ((++spins & 63u) == 0) {
+                        if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
+#ifndef NLZM_SIM
+                        if (xw::clock100() - t0 > 3000000000ull) { fail(kErrTimeout, a0); return 1; }
+#else
+                        (void)t0;
+#endif
+                    }
+                    xw::pause();
+                }
+                t_wait += xw::tick() - tw;
+            }
+        }
+        const bool call_full = in_blk && !nice_pred;
+        const bool call_some = call_full || (nice_pred && ((a - seg_s) & 7u) == 0);
+        const bool ht_call = call_some && avail >= 4;                // :1515, :1530
+        const bool rk_call = call_some && avail >= 256;              // :1525, :1538
+
+        // ---- RK256: window ends passed since the last call are inserted with the CALLING position (:1084-1087).
+        // Lane 0 does its own now; a later lane that has any becomes lane 0 of the next block.
+        uint32_t cut_rk = 64;
+        {
+            const unsigned long long rkm = xw::ballot(rk_call);
+            if (rkm & 1ull) {
+                const uint32_t q0 = a0 - base;
+                for (uint32_t e = (rk_end | 255u) + 1; e < q0 + 256; e += 256) {
+                    const uint32_t hh = xw::readfirst(G.rkhash[base + e - 256]);
+                    if (i == 0) G.rk_table[hh >> g.rk_shift] = q0 | (hh << g.wbits);
+                    n_rki++;
+                }
+                xw::drain();
+            }
+            // rk_end as lane i finds it: the previous calling lane's q + 256
+            const unsigned long long below = rkm & ((1ull << i) - 1);
+            const uint32_t prev_end = below ? (a0 + (63u - (uint32_t)__builtin_clzll(below))) - base + 256 : rk_end;
+            const bool catch_up = rk_call && i > 0 && ((prev_end | 255u) + 1) < q + 256;
+            const unsigned long long cm = xw::ballot(catch_up);
+            if (cm) cut_rk = (uint32_t)__builtin_ctzll(cm);
+        }
+
+        // ---- loads that the position alone addresses
+        uint32_t v4 = 0;
+        unsigned long long own0 = 0, own1 = 0;
+        if (in_blk) { own0 = load64u(cur); own1 = load64u(cur + 8); v4 = (uint32_t)own0; }
+        const uint32_t rkh = rk_call ? G.rkhash[a] : 0u;
+        uint32_t rkv = rk_call ? G.rk_table[rkh >> g.rk_shift] : 0u;
+        const bool unc = in_blk && G.workers && G.unc[bi] != 0;
+        const bool bt_call = call_full && avail >= 4 && G.workers;
+
+        // ---- HT2 / HT3 rows as each calling lane finds them (:910-938): the tables in LDS, overwritten by what the
+        // earlier calling lanes of the block store (bucket b: HT2[b] = E2; HT3[b+1] = HT3[b], HT3[b] = E3)
+        const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu);     // :1516-1517
+        const uint32_t i2 = h2 >> 20, i3 = h3 >> g.ht3_shift;
+        const uint32_t tag2 = h2 & g.tag_mask, tag3 = h3 & g.tag_mask;
+        const uint32_t e2 = q | (tag2 << g.wbits), e3 = q | (tag3 << g.wbits);   // q un-masked (:913)
+        uint32_t row2 = 0, r0 = 0, r1 = 0;
+        if (ht_call) { row2 = L->ht2[i2]; r0 = L->ht3[i3]; r1 = L->ht3[i3 + 1]; }
+        const unsigned long long htm = xw::ballot(ht_call);
+        for (unsigned long long mm = htm; mm; mm &= mm - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+            if (!(htm >> j >> 1)) break;                                        // no calling lane after j
+            const uint32_t b2 = xw::readlane(i2, j), b3 = xw::readlane(i3, j);
+            const uint32_t x2 = xw::readlane(e2, j), x3 = xw::readlane(e3, j), y0 = xw::readlane(r0, j);
+            if (ht_call && i > j) {
+                if (i2 == b2) row2 = x2;
+                if (i3 == b3) { r0 = x3; r1 = y0; }
+                else if (i3 == b3 + 1) r0 = y0;
+                else if (i3 + 1 == b3) r1 = x3;
+            }
+        }
+
+        // ---- candidates (:922-925) and their first 16 bytes; what is longer goes to the job list
+        uint32_t cd[4] = { 0, 0, 0, 0 };            // distance of candidate k: HT2, HT3 row 0, HT3 row 1, RK256; 0: none
+        if (ht_call) {
+            const uint32_t s0 = row2 & g.wmask, s1 = r0 & g.wmask, s2 = r1 & g.wmask;
+            if ((row2 >> g.wbits) == tag2 && s0 < q && q - s0 <= g.wmask) cd[0] = q - s0;
+            if ((r0 >> g.wbits) == tag3 && s1 < q && q - s1 <= g.wmask) cd[1] = q - s1;
+            if ((r1 >> g.wbits) == tag3 && s2 < q && q - s2 <= g.wmask) cd[2] = q - s2;
+        }
+        uint32_t cl[3] = { 0, 0, 0 };
+        L->njobs = 0;
+        xw::wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (!cd[k]) continue;
+            const unsigned long long x0 = load64u(cur - cd[k]) ^ own0;
+            uint32_t l;
+            if (x0) l = (uint32_t)__builtin_ctzll(x0) >> 3;
+            else {
+                const unsigned long long x1 = load64u(cur - cd[k] + 8) ^ own1;
+                l = x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
+            }
+            if (l >= cap) l = cap;
+            else if (l == 16) {                                                 // longer than 16 bytes: a job
+                const uint32_t at = xw::lds_inc(&L->njobs);
+                L->job[at * 4] = i | ((uint32_t)k << 8); L->job[at * 4 + 1] = cd[k]; L->job[at * 4 + 2] = cap;
+                l = kNone;
+            }
+            cl[k] = l;
+        }
+        xw::wave_sync();
+        {   // jobs, eight at a time: job j on lanes 8j..8j+7, eight bytes per lane and round
+            const uint32_t nj = xw::readfirst(L->njobs);
+            for (uint32_t jb = 0; jb < nj; jb += 8) {
+                const uint32_t j = jb + (i >> 3), sub = i & 7u;
+                const bool have = j < nj;
+                const uint32_t jl = have ? L->job[j * 4] : 0u, jd = have ? L->job[j * 4 + 1] : 1u, jcap = have ? L->job[j * 4 + 2] : 0u;
+                const uint32_t ja = a0 + (jl & 63u);
+                uint32_t res = kNone;                // first mismatch found by this lane
+                bool open = have;
+                uint32_t off = 16;
+                while (xw::any(open)) {
+                    uint32_t pos = kNone;
+                    const uint32_t my = off + sub * 8;
+                    if (open && my < jcap) {
+                        const unsigned long long d = load64u(G.in + ja - jd + my) ^ load64u(G.in + ja + my);
+                        if (d) { const uint32_t p = my + ((uint32_t)__builtin_ctzll(d) >> 3); if (p < jcap) pos = p; }
+                    }
+                    const unsigned long long bal = xw::ballot(pos != kNone);
+                    const uint32_t mine = (uint32_t)(bal >> (i & ~7u)) & 0xFFu;
+                    const uint32_t got = xw::shfl(pos, (i & ~7u) + (mine ? (uint32_t)__builtin_ctz(mine) : 0u));
+                    if (open && mine) { res = got; open = false; }
+                    else if (open && off + 64 >= jcap) { res = jcap; open = false; }
+                    off += 64;
+                }
+                if (have && sub == 0) L->job_len[(jl & 63u) * 4 + (jl >> 8)] = res;
+            }
+            xw::wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; k++) if (cd[k] && cl[k] == kNone) cl[k] = L->job_len[i * 4 + k];
+        }
+
+        // ---- the record of this position: pairs of HT2 and HT3 (:917-933)
+        uint32_t *st = L->stage + i * kFtStride;
+        uint32_t np = 0, ec = 0, od = kNone, cmpb = 0;      // pairs, largest closed end, smallest open distance, bytes compared
+        auto add_pair = [&](uint32_t d, uint32_t l) {
+            if (l >= cap) { od = umin(od, d); return; }     // as long as the lookahead allows: may grow at the next position
+            st[2 + 2 * np] = d; st[3 + 2 * np] = l; np++;
+            ec = umax(ec, a + l);
+        };
+        if (ht_call) {
+            if (cd[0] && 1 < cap) {
+                cmpb += cl[0] + (cl[0] < cap);
+                if (cl[0] > 1 && cl[0] >= match_min(cd[0])) add_pair(cd[0], cl[0]);
+            }
+            uint32_t best = 1;
+#pragma unroll
+            for (int k = 1; k < 3; k++) {
+                if (!cd[k] || !(best < cap)) continue;
+                cmpb += cl[k] + (cl[k] < cap);
+                if (cl[k] > best && cl[k] >= match_min(cd[k])) { add_pair(cd[k], cl[k]); best = cl[k]; }
+            }
+        }
+
+        // ---- RK256 (:1055-1113)
+        const bool rk_act = rk_len > 0 && q - rk_to < rk_len;       // the carried match still covers this position (:1056-1069)
+        if (rk_call && rk_act) {
+            const uint32_t d = rk_to - rk_from, l = rk_len - (q - rk_to);
+            if (l >= match_min(d)) add_pair(d, umin(l, kMatchMax));
+        }
+        const uint32_t rk_eff = rk_act ? rk_len : 0u;
+        const bool rk_probe = rk_call && rk_eff < 256;              // :1090
+        // an aligned insert (:1109-1112) of an earlier lane rewrites the slot this lane read: cut there
+        uint32_t cut_slot = 64;
+        {
+            const unsigned long long im = xw::ballot(rk_call && (q & 255u) == 0);
+            for (unsigned long long mm = im; mm; mm &= mm - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+                const uint32_t sj = xw::readlane(rkh >> g.rk_shift, j);
+                const unsigned long long hit = xw::ballot(rk_probe && i > j && (rkh >> g.rk_shift) == sj);
+                if (hit) cut_slot = umin(cut_slot, (uint32_t)__builtin_ctzll(hit));
+            }
+        }
+        bool rk_cand = false;
+        uint32_t rk_d = 0;
+        if (rk_probe) {
+            const uint32_t sp = rkv & g.wmask;
+            if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) { rk_cand = true; rk_d = q - sp; }
+        }
+        uint32_t cut_ev = 64, ev_d = 0, ev_l = 0;
+        bool ev_ok = false;
+        {   // the first candidate is measured by the whole wave (up to 65,535 bytes: uint16 parameter, :760, :1096)
+            const unsigned long long evm = xw::ballot(rk_cand);
+            if (evm) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(evm);
+                const uint32_t kd = xw::readlane(rk_d, k), kav = xw::readlane(avail, k) & 0xFFFFu, keff = xw::readlane(rk_eff, k);
+                const uint32_t ka = a0 + k;
+                const uint32_t l = wave_cmp(G.in, ka - kd, ka, 0, kav);
+                cut_ev = k + 1;
+                ev_ok = l >= keff && l >= match_min(kd);                        // :1099-1105 (state taken over below if lane k is final)
+                ev_d = kd; ev_l = l;
+                if (i == k) {
+                    cmpb += l + (l < kav);
+                    if (ev_ok) add_pair(kd, umin(l, kMatchMax));
+                }
+            }
+        }
+
+        // ---- BT4: the worker lanes' result (longest record-setter in the record's words 9, 10).
+        // A worker lane walks its bin in position order and, at an `unc` position, waits for this stage's decision before
+        // it goes on: the result of a later position of the same bin cannot arrive before this block is committed.
+        // Such a position becomes lane 0 of the next block.
+        uint32_t cut_bin = 64;
+        if (G.workers) {
+            const uint32_t bin = (hash4(v4) >> g.bt_shift) % G.nheads;
+            for (unsigned long long um = xw::ballot(unc && avail >= 4); um; um &= um - 1) {
+                const uint32_t x = (uint32_t)__builtin_ctzll(um);
+                const uint32_t bx = xw::readlane(bin, x);
+                const unsigned long long later = xw::ballot(bt_call && i > x && bin == bx);
+                if (later) cut_bin = umin(cut_bin, (uint32_t)__builtin_ctzll(later));
+            }
+        }
+        const bool bt_wait = bt_call && i < cut_bin;
+        uint32_t bt_n = 0;
+        if (xw::any(bt_wait)) {
+            const unsigned long long tw = xw::tick();
+            const unsigned long long t0 = xw::clock100();
+            uint32_t spins = 0;
+            if (bt_wait) xw::need_bt(G.hook_user, a);
+            for (;;) {
+                uint32_t w0 = bt_wait ? xw::ld_agent(G.bt_ready + bi * kBtRec) : kBtReady;
+                if (!xw::any(!(w0 & kBtReady))) {
+                    if (bt_wait) {
+                        bt_n = w0 & 0x1FFu;
+                        if (bt_n) {
+                            const uint32_t d = xw::ld_agent(G.bt_ready + bi * kBtRec + 9), l = xw::ld_agent(G.bt_ready + bi * kBtRec + 10);
+                            if (l >= cap) od = umin(od, d); else ec = umax(ec, a + l);
+                        }
+                    }
+                    break;
+                }
+                if ((++spins & 63u) == 0) {
+                    if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
+#ifndef NLZM_SIM
+                    if (xw::clock100() - t0 > 3000000000ull) { fail(kErrTimeout, a0); return 1; }
+#else
+                    (void)t0;
+#endif
+                }
+                xw::pause();
+            }
+            t_wait += xw::tick() - tw;
+        }
+
+        // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
+        uint32_t pm = in_blk ? ec : 0u;                                         // inclusive prefix max of the closed ends
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(pm, d); if (i >= d) pm = umax(pm, o); }
+        uint32_t before = xw::shfl_up(pm, 1);
+        if (i == 0) before = 0;
+        before = umax(before, reach);
+        if (i >= jc && s_active) before = umax(before, s_end);                  // the former top entry, closed
+        const bool nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
+        const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
+        const uint32_t cut_nice = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+        // a match as long as the lookahead allows becomes the growing top entry, unless one with a smaller
+        // distance is growing already (:835-852 keeps the smaller distance at the table's end)
+        const bool s_here = s_sliding;                                          // the old one still grows at this lane
+        const unsigned long long om = xw::ballot(in_blk && od != kNone && (!s_here || od < s_d));
+        const uint32_t jo = om ? (uint32_t)__builtin_ctzll(om) : 64u;
+        uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
+        if (m == 0) { fail(kErrInternal, a0); return 1; }
+        n_blocks++;
+        if (m < n) n_cut[m == cut_nice ? 0 : (m == jo + 1 ? 1 : (m == cut_ev ? 2 : (m == cut_rk ? 3 : (m == cut_bin ? 5 : 4))))]++;
+        const bool fin = i < m;
+
+        // a position that the pre-filter promised to be a BT4 position must not be nice
+        if (xw::any(fin && nice_real && !unc && avail >= 4 && G.workers)) { fail(kErrV2Promise, a0); return 1; }
+
+        // ---- commit
+        // HT rows in position order (the last writer of a row wins)
+        for (unsigned long long mm = htm & ((m < 64 ? (1ull << m) : 0ull) - 1ull); mm; mm &= mm - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+            if (i == j) { L->ht2[i2] = e2; L->ht3[i3] = e3; L->ht3[i3 + 1] = r0; }
+            xw::wave_sync();
+        }
+        if (fin && unc && avail >= 4) xw::st_agent(G.bt_flag + bi, nice_real ? kFlagSkip : kFlagCall);
+        if (fin && rk_call && (q & 255u) == 0) G.rk_table[rkh >> g.rk_shift] = q | (rkh << g.wbits);
+        // the record
+        if (fin) {
+            uint32_t w0 = np | (bt_call && bt_n ? kFtBt : 0u) | ((uint32_t)(uint8_t)own0 << 8);
+            // the former top entry stops growing here: from now on an ordinary entry
+            if (i == jc && s_active && s_end > a + 1) { st[2 + 2 * np] = s_d; st[3 + 2 * np] = s_end - a; np++; w0++; }
+            if (s_sliding && i <= jo) { st[14] = s_d; st[15] = cap; w0 |= kFtTop; }
+            if (i == jo) { st[14] = od; st[15] = cap; w0 |= kFtTop; }
+            st[0] = w0; st[1] = a;
+            uint32_t *dst = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
+#pragma unroll
+            for (int k = 0; k < 8; k++) xw::st_agent64((unsigned long long *)(dst + 2 * k), (unsigned long long)st[2 * k] | ((unsigned long long)st[2 * k + 1] << 32));
+        }
+        xw::drain();
+        // ---- state after lane m - 1
+        {
+            const uint32_t last = m - 1;
+            const uint32_t pm_last = xw::readlane(pm, last);
+            reach = umax(reach, pm_last);
+            if (s_active && jc <= last) { reach = umax(reach, s_end); s_active = 0; }
+            if (jo == last) { s_active = 1; s_d = xw::readlane(od, last); s_end = kNone; s_seen = a0 + last + xw::readlane(cap, last); }
+            prev_nice = xw::readlane(nice_real ? 1u : 0u, last);
+            const unsigned long long rkf = xw::ballot(fin && rk_call);
+            if (rkf) rk_end = (a0 + (63u - (uint32_t)__builtin_clzll(rkf))) - base + 256;
+            if (ev_ok && cut_ev == m) {                                         // the RK candidate of lane m-1 was taken (:1102-1104)
+                rk_from = (a0 + last - base) - ev_d; rk_to = a0 + last - base; rk_len = ev_l;
+            }
+        }
+        // counters
+        n_pos += m;
+        n_nice += (unsigned long long)__builtin_popcountll(xw::ballot(fin && nice_real));
+        n_unc += (unsigned long long)__builtin_popcountll(xw::ballot(fin && unc && avail >= 4));
+        n_ht += (unsigned long long)__builtin_popcountll(xw::ballot(fin && ht_call));
+        n_rkp += (unsigned long long)__builtin_popcountll(xw::ballot(fin && rk_probe));
+        n_rki += (unsigned long long)__builtin_popcountll(xw::ballot(fin && rk_call && (q & 255u) == 0));
+        {
+            uint32_t c = fin ? cmpb : 0u;
+            for (uint32_t d = 32; d; d >>= 1) c += xw::shfl(c, i ^ d);
+            n_cmp += xw::readfirst(c);
+        }
+        if (i == 0) xw::st_agent(&V.hx->f_pos, a0 + m);
+#ifdef NLZM_SIM
+        if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "F block a0 %u n %u m %u reach %u slider %u d %u end %u\n", a0, n, m, reach, s_active, s_d, s_end);
+#endif
+        return m;
+    }
+
+    XW_FN void run(uint32_t c0, uint32_t c1)
+    {
+        FLds *L = xw::lds<FLds>();
+        Persist *P = G.persist;
+        StateV2 *S = (StateV2 *)V.state;
+        const uint32_t i = xw::lane();
+        const uint32_t ht3_rows = (1u << (32 - g.ht3_shift)) + 1;
+        for (uint32_t k = i; k < 4096; k += 64) L->ht2[k] = G.ht2[k];
+        for (uint32_t k = i; k < ht3_rows; k += 64) L->ht3[k] = G.ht3[k];
+        base = xw::readfirst((uint32_t)P->reb_base);
+        reach = xw::readfirst(S->reach); s_active = xw::readfirst(S->s_active); s_d = xw::readfirst(S->s_d);
+        s_end = xw::readfirst(S->s_end); s_seen = xw::readfirst(S->s_seen);
+        prev_nice = xw::readfirst(S->prev_nice); seg_s = xw::readfirst(S->seg_s);
+        rk_from = xw::readfirst(P->rk_from); rk_to = xw::readfirst(P->rk_to); rk_len = xw::readfirst(P->rk_len); rk_end = xw::readfirst(P->rk_end);
+        err = xw::readfirst(P->error);
+        n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = n_blocks = 0;
+        for (int k = 0; k < 6; k++) n_cut[k] = 0;
+        t_wait = 0;
+        const unsigned long long t_start = xw::tick();
+        t_pos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        unsigned long long shifts = 0;
+        xw::wave_sync();
+        for (uint32_t ci = c0; ci < c1 && !err; ci++) {
+            const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+            const unsigned long long remain = g.n - chunk_abs;
+            const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+            const uint32_t p_end = umin(g.chunk_size, chunk_read);
+            if (chunk_abs - base >= 2ull * (g.wmask + 1)) {                     // :1786-1792
+                base += g.wmask + 1;
+                shifts++;
+                if (i == 0) { L->ht2[0] = kNone; L->ht3[0] = kNone; }           // MatchFinderHT::Shift (:940-957)
+                if (rk_end >= g.wmask + 1) rk_end -= g.wmask + 1; else rk_end = 0;   // :1115-1123
+                xw::wave_sync();
+            }
+            if (prev_nice) seg_s = (uint32_t)chunk_abs;                          // a chunk starts a segment (:1802)
+            const uint32_t a1 = (uint32_t)chunk_abs + p_end, la_end = (uint32_t)chunk_abs + chunk_read;
+            uint32_t a = (uint32_t)chunk_abs;
+            while (a < a1 && !err) {
+                const uint32_t n = umin(64u, a1 - a);
+                // ring space: the table stage must have consumed position a + n - kFtRing
+                if ((int32_t)(a + n - t_pos_seen - kFtRing) > 0) {
+                    const unsigned long long tw = xw::tick();
+                    if (!wait_word_ge(&V.hx->t_pos, a + n - kFtRing, V.hx, 1)) { err = kErrInternal + 100; break; }
+                    t_pos_seen = xw::readfirst(xw::ld_agent(&V.hx->t_pos));
+                    t_wait += xw::tick() - tw;
+                }
+                a += block(a, n, a1, la_end);
+            }
+        }
+        xw::wave_sync();
+        for (uint32_t k = i; k < 4096; k += 64) G.ht2[k] = L->ht2[k];
+        for (uint32_t k = i; k < ht3_rows; k += 64) G.ht3[k] = L->ht3[k];
+        if (i == 0) {
+            P->reb_base = base;
+            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
+            S->reach = reach; S->s_active = s_active; S->s_d = s_d; S->s_end = s_end; S->s_seen = s_seen;
+            S->prev_nice = prev_nice; S->seg_s = seg_s;
+            Counters &c = P->cnt;
+            c.positions += n_pos; c.nice_positions += n_nice; c.uncertain_positions += n_unc;
+            c.ht_rows += 3 * n_ht; c.rk_probes += n_rkp; c.rk_inserts += n_rki; c.cmp_bytes += n_cmp; c.shifts += shifts;
+            P->prof[0] += n_blocks; for (int k = 0; k < 5; k++) P->prof[1 + k] += n_cut[k];
+            P->prof[12] += n_cut[5];
+            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start;
+        }
+    }
+};
+
+
+// =================================================================================================
+// table stage
+// =================================================================================================
+// The match table of a position (mt_carry as :1543 leaves it) is delta[l] = smallest distance of any match found at a
+// position q <= p that still has >= l bytes left at p (Update is an element-wise min, :835-852; CarryFrom shifts by
+// one, :823-833).  With e = q + length (the match's absolute end), delta[l] at p is the smallest distance among the
+// entries with e >= p + l: only the Pareto front over (e larger, distance smaller) matters, and dominance between two
+// entries does not depend on p.  So the front at p is the Pareto front of ALL pairs found at positions <= p, cut to
+// e >= p + 2 -- an associative merge, computed for the 64 positions of a block by a parallel prefix scan.
+// (The one entry whose end moves with p, the top entry while it keeps extending :1503-1512, arrives from the finder
+// stage as a fresh pair per position.)
+constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
+
+struct TLds {
+    unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
+    uint32_t recs[64 * kFtStride];              // the block's finder records
+    unsigned long long carry[kFrontMax + 8];    // front after the last finished position
+    unsigned long long tmp[2 * kFrontMax + 300];
+    uint32_t carry_n;
+    uint32_t overflow;
+};
+
+NLZM_HD unsigned long long fr_key(uint32_t e, uint32_t d) { return ((unsigned long long)e << 32) | (0xFFFFFFFFu - d); }
+NLZM_HD uint32_t fr_end(unsigned long long k) { return (uint32_t)(k >> 32); }
+NLZM_HD uint32_t fr_dist(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
+
+struct Table {
+    Geom g;
+    Globals G;
+    GlobalsV2 V;
+    uint32_t err;
+    uint32_t p_pos_seen;
+    unsigned long long n_blocks, n_slow, t_wait;
+
+    // merge two fronts (each sorted by descending key, at most na / nb entries at pa / pb with stride 1) into out;
+    // entries of b that end before `low` are left out.  Returns the count, or kNone if it exceeds cap.
+    static XW_FN uint32_t merge(const unsigned long long *pa, uint32_t na, const unsigned long long *pb, uint32_t nb, uint32_t low,
+                                unsigned long long *out, uint32_t cap)
+    {
+        while (nb && fr_end(pb[nb - 1]) < low) nb--;            // (ends fall along the list: the expired ones are at its tail)
+        while (na && fr_end(pa[na - 1]) < low) na--;
+        uint32_t ia = 0, ib = 0, no = 0, dmin = kNone;
+        unsigned long long ka = na ? pa[0] : 0, kb = nb ? pb[0] : 0;
+        while (ia < na || ib < nb) {
+            const bool ta = ib >= nb || (ia < na && ka >= kb);
+            const unsigned long long k = ta ? ka : kb;
+            if (ta) { ia++; ka = ia < na ? pa[ia] : 0; } else { ib++; kb = ib < nb ? pb[ib] : 0; }
+            const uint32_t d = fr_dist(k);
+            if (d < dmin) {                                     // not dominated by an entry that ends at least as late
+                if (no >= cap) return kNone;
+                out[no++] = k; dmin = d;
+            }
+        }
+        return no;
+    }
+
+    // pairs of position a into a list (unsorted); returns the count or kNone (more than cap)
+    XW_FN uint32_t gather(uint32_t a, uint32_t cap_len, const uint32_t *rec, unsigned long long *out, uint32_t cap)
+    {
+        uint32_t n = 0;
+        const uint32_t w0 = rec[0], np = w0 & 7u;
+        for (uint32_t k = 0; k < np; k++) {
+            if (n >= cap) return kNone;
+            out[n++] = fr_key(a + rec[3 + 2 * k], rec[2 + 2 * k]);
+        }
+        if (w0 & kFtTop) { if (n >= cap) return kNone; out[n++] = fr_key(a + rec[15], rec[14]); }
+        if (w0 & kFtBt) {
+            // the worker lane's record: the record-setters of the descent, lengths and distances growing along the list
+            const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
+            const uint32_t *br = G.bt_ready + bi * kBtRec;
+            const uint32_t cnt = xw::ld_agent(br) & 0x1FFu;
+            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t d = k < 4 ? xw::ld_agent(br + 1 + 2 * k) : xw::ld_agent(pairs + 2 * k);
+                const uint32_t l = k < 4 ? xw::ld_agent(br + 2 + 2 * k) : xw::ld_agent(pairs + 2 * k + 1);
+                if (l >= cap_len) continue;                     // as long as the lookahead allows: the finder stage's top entry covers it
+                if (n >= cap) return kNone;
+                out[n++] = fr_key(a + l, d);
+            }
+        }
+        return n;
+    }
+
+    // sort a short list by descending key and drop dominated entries, in place; returns the count
+    static XW_FN uint32_t sort_filter(unsigned long long *v, uint32_t n)
+    {
+        for (uint32_t x = 1; x < n; x++) {
+            const unsigned long long k = v[x];
+            uint32_t y = x;
+            while (y > 0 && v[y - 1] < k) { v[y] = v[y - 1]; y--; }
+            v[y] = k;
+        }
+        uint32_t no = 0, dmin = kNone;
+        for (uint32_t x = 0; x < n; x++) {
+            const uint32_t d = fr_dist(v[x]);
+            if (d < dmin) { v[no++] = v[x]; dmin = d; }
+        }
+        return no;
+    }
+
+    // write the parser's record of position a from its front (fn entries at f, descending)
+    XW_FN void emit(uint32_t a, uint32_t a1, uint32_t lit, const unsigned long long *f, uint32_t fn)
+    {
+        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+        const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
+        uint32_t max_len = umin(mt_max, a1 - a);                // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
+        if (max_len < kMatchMin) max_len = 0;
+        uint32_t ne = 0;
+        if (max_len) {
+            uint32_t step = (max_len - kMatchMin) >> 4;         // :1558-1560
+            step += step == 0;
+            uint32_t j = 0;
+            unsigned long long kj = f[0], kn = fn > 1 ? f[1] : 0;
+            for (uint32_t tl = max_len; tl >= kMatchMin; tl -= umin(tl, step)) {
+                while (j + 1 < fn && fr_end(kn) >= a + tl) { j++; kj = kn; kn = j + 1 < fn ? f[j + 1] : 0; }   // the entry with the smallest end >= a + tl
+                const uint32_t d = fr_dist(kj), mm = match_min(d);
+                uint32_t nx, ex;
+                const uint32_t slot = dist_slot(d - 1, nx, ex);
+                const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
+                xw::st_agent64((unsigned long long *)(rec + 2 + 2 * ne),
+                               (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32));
+                ne++;
+            }
+        }
+        xw::st_agent64((unsigned long long *)rec, (unsigned long long)(ne | (lit << 8) | (mt_max << 16)) | ((unsigned long long)fn << 32));
+        for (uint32_t k = 0; k < fn; k++)
+            xw::st_agent64((unsigned long long *)(fo + 2 * k), (unsigned long long)(fr_end(f[k]) - a) | ((unsigned long long)fr_dist(f[k]) << 32));
+    }
+
+    XW_FN void capture(uint32_t a, const unsigned long long *f, uint32_t fn);
+
+    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end
+    XW_FN void block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    {
+        TLds *L = xw::lds<TLds>();
+        const uint32_t i = xw::lane();
+        const bool in_blk = i < n;
+        const uint32_t a = a0 + i;
+        const uint32_t cap_len = in_blk ? umin(la_end - a, kMatchMax) : 0u;
+        const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
+        uint32_t *r = L->recs + i * kFtStride;
+        if (in_blk) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * k));
+                r[2 * k] = (uint32_t)w; r[2 * k + 1] = (uint32_t)(w >> 32);
+            }
+        } else r[0] = 0;
+        const uint32_t lit = (r[0] >> 8) & 0xFFu;
+        L->overflow = 0;
+        xw::wave_sync();
+        // the position's own pairs as a front
+        unsigned long long *mine = L->fr[0] + i * kFrCap;
+        uint32_t cnt = 0;
+        if (in_blk) {
+            cnt = gather(a, cap_len, r, mine, kFrCap);
+            if (cnt == kNone) { L->overflow = 1; cnt = 0; }
+            else cnt = sort_filter(mine, cnt);
+        }
+        // prefix scan: after the step with offset D lane i holds the front of the pairs of lanes (i - 2D, i]
+        uint32_t cur = 0;
+        for (uint32_t D = 1; D < 64; D <<= 1) {
+            xw::wave_sync();
+            const uint32_t ocnt = xw::shfl_up(cnt, D);
+            unsigned long long *dst = L->fr[cur ^ 1] + i * kFrCap;
+            const unsigned long long *own = L->fr[cur] + i * kFrCap;
+            uint32_t nn;
+            if (i >= D && in_blk) nn = merge(own, cnt, L->fr[cur] + (i - D) * kFrCap, ocnt, a + kMatchMin, dst, kFrCap);
+            else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
+            if (nn == kNone) { L->overflow = 1; nn = 0; }
+            cnt = nn;
+            cur ^= 1;
+        }
+        xw::wave_sync();
+        // the front carried into the block
+        const uint32_t cn = xw::readfirst(L->carry_n);
+        unsigned long long *fin_f = L->fr[cur ^ 1] + i * kFrCap;
+        uint32_t fn = 0;
+        if (in_blk) {
+            fn = merge(L->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + kMatchMin, fin_f, kFrCap);
+            if (fn == kNone) { L->overflow = 1; fn = 0; }
+        }
+        xw::wave_sync();
+        n_blocks++;
+        if (xw::readfirst(L->overflow)) { slow_block(a0, n, a1, la_end); return; }
+        if (in_blk) emit(a, a1, lit, fin_f, fn);
+        if (G.cap_words) {
+            for (uint32_t j = 0; j < n; j++) capture(a0 + j, L->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
+        }
+#ifdef NLZM_SIM
+        if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
+#endif
+        // carry out: the last position's front
+        const uint32_t last_n = xw::readlane(fn, n - 1);
+        for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = L->fr[cur ^ 1][(n - 1) * kFrCap + k];
+        if (i == 0) L->carry_n = last_n;
+        xw::wave_sync();
+    }
+
+    // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
+    XW_FN void slow_block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    {
+        TLds *L = xw::lds<TLds>();
+        n_slow++;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t a = a0 + j;
+            const uint32_t cap_len = umin(la_end - a, kMatchMax);
+            const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
+            uint32_t *r = L->recs;
+            if (xw::lane() < 8) {
+                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * xw::lane()));
+                r[2 * xw::lane()] = (uint32_t)w; r[2 * xw::lane() + 1] = (uint32_t)(w >> 32);
+            }
+            xw::wave_sync();
+            unsigned long long *t0 = L->tmp, *t1 = L->tmp + 300;
+            if (xw::lane() == 0) {
+                uint32_t c = gather(a, cap_len, r, t0, 300);    // <= 7 + 256 pairs
+                c = sort_filter(t0, c);
+                const uint32_t fn = merge(t0, c, L->carry, L->carry_n, a + kMatchMin, t1, kFrontMax + 8);
+                for (uint32_t k = 0; k < fn; k++) L->carry[k] = t1[k];
+                L->carry_n = fn;
+                emit(a, a1, (r[0] >> 8) & 0xFFu, L->carry, fn);
+#ifdef NLZM_SIM
+                sim_on_front(G.hook_user, a, L->carry, fn);
+#endif
+            }
+            xw::wave_sync();
+            if (G.cap_words) capture(a, L->carry, xw::readfirst(L->carry_n));
+        }
+    }
+
+#ifdef NLZM_SIM
+    static void sim_on_front(void *user, uint32_t a, const unsigned long long *f, uint32_t fn);
+#endif
+
+    XW_FN void run(uint32_t c0, uint32_t c1)
+    {
+        TLds *L = xw::lds<TLds>();
+        StateV2 *S = (StateV2 *)V.state;
+        const uint32_t i = xw::lane();
+        const uint32_t cn = xw::readfirst(S->front_n);
+        for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
+        if (i == 0) L->carry_n = cn;
+        err = 0; n_blocks = n_slow = 0; t_wait = 0;
+        const unsigned long long t_start = xw::tick();
+        p_pos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        xw::wave_sync();
+        uint32_t f_seen = p_pos_seen;
+        for (uint32_t ci = c0; ci < c1 && !err; ci++) {
+            const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+            const unsigned long long remain = g.n - chunk_abs;
+            const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+            const uint32_t p_end = umin(g.chunk_size, chunk_read);
+            const uint32_t a1 = (uint32_t)chunk_abs + p_end, la_end = (uint32_t)chunk_abs + chunk_read;
+            uint32_t a = (uint32_t)chunk_abs;
+            while (a < a1 && !err) {
+                if ((int32_t)(f_seen - a) <= 0) {
+                    const unsigned long long tw = xw::tick();
+                    if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
+                    f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
+                    t_wait += xw::tick() - tw;
+                }
+                const uint32_t n = umin(64u, umin(a1, f_seen) - a);
+                if ((int32_t)(a + n - p_pos_seen - kTpRing) > 0) {
+                    const unsigned long long tw = xw::tick();
+                    if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
+                    p_pos_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
+                    t_wait += xw::tick() - tw;
+                }
+                block(a, n, a1, la_end);
+                xw::drain();
+#ifdef NLZM_SIM
+                if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "T block a %u n %u\n", a, n);
+#endif
+                a += n;
+                if (i == 0) { xw::st_agent(&V.hx->t_out, a); xw::st_agent(&V.hx->t_pos, a); }
+            }
+        }
+        xw::wave_sync();
+        const uint32_t on = xw::readfirst(L->carry_n);
+        for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
+        if (i == 0) {
+            S->front_n = on;
+            G.persist->prof[6] += n_blocks; G.persist->prof[7] += n_slow;
+            G.persist->prof[18] += t_wait; G.persist->prof[19] += xw::tick() - t_start;
+        }
+    }
+};
+
+// stage test tap: {position, max_len, delta[2..max_len]} (what the reference copies into mt_carry, :1543)
+XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
+{
+    if (a < G.cap_lo || a >= G.cap_hi) return;
+    const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
+    const unsigned long long used = xw::readfirst64(*G.cap_used);
+    const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
+    if (used + need > G.cap_cap) { err = kErrCapture; if (xw::lane() == 0) xw::st_agent(&V.hx->err, kErrCapture); return; }
+    if (xw::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
+    for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < fn; k++) if (fr_end(f[k]) >= a + l) d = fr_dist(f[k]);    // the last entry that still reaches
+        G.cap_words[used + l] = d;
+    }
+    xw::drain();
+    if (xw::lane() == 0) *G.cap_used = used + need;
+    xw::drain();
+    xw::wave_sync();
+}
+
+
+// =================================================================================================
+// parser stage
+// =================================================================================================
+// parse_table (:1464-1651) visits the nodes of a segment in order; node p takes, in this order, the literal edge of
+// p-1 and then relaxes its own sampled-length edges (dict, then rep where the distance is in the node's rep set) and
+// its explicit rep probes, all with strict '>'.  For a target node the candidates therefore arrive ordered by
+// (source, rank inside the source) and the first of the cheapest wins: the winner is the minimum of
+// key = cost << 32 | source << 8 | rank.  Every edge of a node ends >= 2 further on, so when nodes < f are done the
+// nodes f and f+1 are complete up to the literal edge between them: a step finalises BOTH (their keys out of LDS,
+// the literal edges in registers), then lanes 0..31 relax the edges of f and lanes 32..63 those of f+1 with one
+// 64-bit LDS atomic min each.
+constexpr unsigned long long kKeyNone = ~0ull;
+constexpr uint32_t kRankLit = 255, kRankProbe = 64;
+constexpr uint32_t kEqSlots = 256;
+
+struct PLds {
+    unsigned long long mkey[512];               // best key of node n at [n & 511]
+    unsigned long long eq_mask[kEqSlots];       // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
+    uint32_t eq_r[kEqSlots], eq_b[kEqSlots];
+    uint32_t nrep[512 * 4];                     // rep set of node n (CarriedState ring, :1460-1467)
+    uint32_t ncost[512];
+    uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
+    uint32_t attr[128 * kMaxEdges];             // their attribute words, positions fetched ahead (a & 127)
+    uint32_t hdr[128];                          // header word of the fetched positions
+    uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22
+    uint32_t node_delta[kParseMax + 2];         // distance (dict), rep index (rep), the byte (literal)
+    uint16_t cmdlist[kParseMax + 2];
+    uint16_t cdf[kNumCtx * kCdfStride];
+    uint16_t price[kNumCtx * 16];               // log2_lut[freq >> 6] per (context, symbol) (:435-438)
+    uint16_t lut[256];
+    uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
+    uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
+    uint32_t sq_sym[2 * 8];
+    Counters cnt;
+};
+
+struct Parser {
+    Geom g;
+    Globals G;
+    GlobalsV2 V;
+    uint32_t base;                  // absolute offset of rebased 0
+    uint32_t rep[4];                // live model rep set
+    uint32_t fetched;               // parser records of positions < fetched are in LDS
+    uint32_t t_out_seen;
+    bool tab_dirty;
+    // frame writer (CodeFrame, :490-513)
+    uint32_t *fsyms; uint8_t *fbits;
+    uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
+    uint32_t err;
+    unsigned long long n_steps, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_fetch;
+
+    XW_FN PLds *L() const { return xw::lds<PLds>(); }
+    XW_FN void fail(uint32_t code, uint32_t info)
+    {
+        err = code;
+        if (xw::lane() == 0) {
+            G.persist->error = code; G.persist->error_info[0] = info; G.persist->error_info[1] = 13;
+            xw::st_agent(&V.hx->err, code);
+        }
+    }
+    XW_FN void cnt_add(unsigned long long *p, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(p, v); }
+    XW_FN uint32_t price(uint32_t ctx, uint32_t y) const { return L()->price[ctx * 16 + y]; }
+    XW_FN uint32_t price_len(uint32_t lv) const                     // :1214-1225
+    {
+        uint32_t c = price(kCtxLenDirect, umin(lv, 7));
+        if (lv >= 7) { const uint32_t e = lv - 7; c += price(kCtxLenExtHi, e >> 4) + price(kCtxLenExtLo + (e >> 4), e & 15); }
+        return c;
+    }
+    XW_FN uint32_t price_literal(uint32_t y) const                  // :1418-1426
+    {
+        return xw::readfirst(price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15));
+    }
+    // per-model price tables of the match edges, rebuilt after an emit touched a length or distance context
+    XW_FN void seg_tables()
+    {
+        if (!tab_dirty) return;
+        xw::wave_sync();
+        for (uint32_t lv = xw::lane(); lv <= kMatchMax; lv += 64) L()->len_price[lv] = (uint16_t)price_len(lv);
+        for (uint32_t k = xw::lane(); k < 4 * 64; k += 64) {
+            const uint32_t lc = k >> 6, slot = k & 63;
+            L()->slot_price[k] = slot < 56 ? (uint16_t)(price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7)) : 0;
+        }
+        xw::wave_sync();
+        tab_dirty = false;
+    }
+
+    // ---- symbol output (WriteRange/WriteBits + cdf_update), as in the reference's model_encode_* ------------------
+    // Up to 8 symbols of DISTINCT contexts go through their nibble CDFs together, four per pass on sixteen lanes each:
+    // lane i of a group holds cell[i] and cell[i+1]; (start, freq) snapshot (:559-572), adaptation
+    // cell[i] += (mixin[y][i] - cell[i]) >> 7 with mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298, :348-382),
+    // and the price row of the new cells (:435-438).
+    XW_FN void put_sym(uint32_t ctx, uint32_t y) { L()->sq_sym[2 * nq] = ctx; L()->sq_sym[2 * nq + 1] = y; nq++; }
+    XW_FN void flush_syms()
+    {
+        xw::wave_sync();
+        const uint32_t grp = xw::lane() >> 4, i = xw::lane() & 15u;
+        for (uint32_t b = 0; b < nq; b += 4) {
+            const uint32_t k = b + grp;
+            if (k < nq) {
+                const uint32_t ctx = L()->sq_sym[2 * k], y = L()->sq_sym[2 * k + 1];
+                const uint32_t nsy = ctx_nsyms(ctx);
+                uint16_t *cell = L()->cdf + ctx * kCdfStride;
+                const uint32_t c0 = cell[i], c1 = cell[i + 1];
+                if (i == y) fsyms[nsyms + k] = ((c1 - c0) << 16) + c0;
+                auto upd = [=](uint32_t j, uint32_t c) {
+                    const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
+                    return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
+                };
+                const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
+                // (lane i writes cell i only, after the lanes that read it: same wave, DS operations in order)
+                if (i < nsy) { cell[i] = (uint16_t)n0; L()->price[ctx * 16 + i] = L()->lut[(n1 - n0) >> 6]; }
+            }
+        }
+        nsyms += nq; num_ops += nq; nq = 0;
+        xw::wave_sync();
+    }
+    XW_FN void put_bits(uint32_t v, uint32_t nb)                    // :574-588
+    {
+        num_ops++;
+        word |= v << (32 - word_bits - nb);
+        word_bits += nb;
+        while (word_bits >= 8) {
+            if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            nbits++; word <<= 8; word_bits -= 8;
+        }
+    }
+    XW_FN uint32_t emit_len(uint32_t lv)                            // :1281-1297
+    {
+        tab_dirty = true;
+        put_sym(kCtxLenDirect, umin(lv, 7));
+        if (lv >= 7) { const uint32_t e = lv - 7; put_sym(kCtxLenExtHi, e >> 4); put_sym(kCtxLenExtLo + (e >> 4), e & 15); }
+        return umin(lv, 3);
+    }
+    XW_FN void emit_literal(uint32_t y)                             // :1428-1439
+    {
+        put_sym(kCtxCmd, 0); put_sym(kCtxLitHi, y >> 4); put_sym(kCtxLitLo + (y >> 4), y & 15);
+        flush_syms();
+    }
+    XW_FN void emit_match(uint32_t d, uint32_t len)                 // :1274-1342
+    {
+        put_sym(kCtxCmd, 1);
+        const uint32_t lc = emit_len(len - match_min(d));
+        uint32_t nx, ex;
+        const uint32_t slot = dist_slot(d - 1, nx, ex);
+        put_sym(kCtxSlotHi + lc, slot >> 3);
+        put_sym(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
+        flush_syms();
+        if (d - 1 >= 4) {
+            if (nx < 4) put_bits(ex, nx);
+            else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
+        }
+        rep_add(rep, d);                                            // :1819
+    }
+    XW_FN void emit_rep(uint32_t idx, uint32_t len)                 // :1344-1367; rep4.Add of a distance that is present is a no-op (:1834)
+    {
+        put_sym(kCtxCmd, 2);
+        emit_len(len - match_min(idx == 0 ? rep[0] : (idx == 1 ? rep[1] : (idx == 2 ? rep[2] : rep[3]))));
+        flush_syms();
+        put_bits(idx, 2);
+    }
+
+    // ---- records of the table stage into LDS: positions [fetched, upto) ------------------------------------------
+    XW_FN bool fetch(uint32_t need, uint32_t limit, uint32_t cur)
+    {
+        // need: records of positions < need must be there; limit: fetch no further (ring of 128 positions in LDS)
+        while ((int32_t)(fetched - need) < 0) {
+            if ((int32_t)(t_out_seen - fetched) <= 0) {
+                const unsigned long long tw = xw::tick();
+                if (!wait_word_ge(&V.hx->t_out, fetched + 1, V.hx, 4)) { err = kErrInternal + 100; return false; }
+                t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                t_wait += xw::tick() - tw;
+            }
+            const unsigned long long tf = xw::tick();
+            uint32_t hi = fetched + 64;
+            if ((int32_t)(hi - t_out_seen) > 0) hi = t_out_seen;
+            if ((int32_t)(hi - limit) > 0) hi = limit;
+            const uint32_t a = fetched + xw::lane();
+            if ((int32_t)(a - hi) < 0) {
+                const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+                const unsigned long long h = xw::ld_agent64((const unsigned long long *)rec);
+                const uint32_t ne = (uint32_t)h & 63u;
+                L()->hdr[a & 127u] = (uint32_t)h;
+                for (uint32_t k = 0; k < ne; k++) {
+                    const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
+                    L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)e;
+                    L()->attr[(a & 127u) * kMaxEdges + k] = (uint32_t)(e >> 32);
+                }
+            }
+            fetched = hi;
+            xw::wave_sync();
+            if (xw::lane() == 0) xw::st_agent(&V.hx->p_pos, cur);     // (the ring slots of positions >= cur may still be read: resample)
+            t_fetch += xw::tick() - tf;
+        }
+        return true;
+    }
+
+    // The segment is within 264 of its forced cut (:1469): the sampled lengths of position a change with the smaller
+    // max_len (:1545, :1558-1560).  Re-list them from the position's front (lanes = samples).
+    XW_FN void resample(uint32_t a, uint32_t max_len)
+    {
+        n_redo++;
+        const uint32_t h = xw::readfirst(L()->hdr[a & 127u]);
+        const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        const uint32_t fn = xw::readfirst(xw::ld_agent(rec + 1));
+        const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+        uint32_t step = (max_len - kMatchMin) >> 4;
+        step += step == 0;
+        const uint32_t k = xw::lane();
+        uint32_t ne = 0;
+        if (max_len >= kMatchMin) ne = (max_len - kMatchMin) / step + 1;
+        if (k < ne) {
+            const uint32_t tl = max_len - k * step;
+            uint32_t d = 0;
+            for (uint32_t j = 0; j < fn; j++) {                     // the last entry (smallest end) that still has >= tl bytes
+                const unsigned long long e = xw::ld_agent64((const unsigned long long *)(fo + 2 * j));
+                if ((uint32_t)e >= tl) d = (uint32_t)(e >> 32);
+            }
+            const uint32_t mm = match_min(d);
+            uint32_t nx, ex;
+            const uint32_t slot = dist_slot(d - 1, nx, ex);
+            const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
+            L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
+            L()->attr[(a & 127u) * kMaxEdges + k] = tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31);
+        }
+        if (k == 0) L()->hdr[a & 127u] = (h & ~63u) | ne;
+        xw::wave_sync();
+    }
+
+    // ---- explicit rep probes (:1598-1628): match length of (position a, distance r), at most c bytes ----------------
+    // Lanes with `want` ask; byte equality comes from the mask cache (one 64-byte block of the input against itself r
+    // bytes earlier per entry), filled for every lane that misses by the whole wave.
+    XW_FN uint32_t probe_len(bool want, uint32_t a, uint32_t r, uint32_t c)
+    {
+        uint32_t len = 0;
+        bool open = want && c > 0;
+        uint32_t x = a;                                             // next byte to look at
+        while (xw::any(open)) {
+            n_eq_rounds++;
+            const uint32_t b = x >> 6, slot = (r * 0x9E3779B1u + b * 0x85EBCA77u) >> 24;
+            unsigned long long m = 0;
+            bool hit = false;
+            if (open) { hit = L()->eq_r[slot] == r && L()->eq_b[slot] == b; m = L()->eq_mask[slot]; }
+            unsigned long long miss = xw::ballot(open && !hit);
+            while (miss) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(miss);
+                const uint32_t rj = xw::readlane(r, j), bj = xw::readlane(b, j), sj = xw::readlane(slot, j);
+                const unsigned long long pos = (unsigned long long)bj * 64 + xw::lane();
+                const bool eq = pos >= rj && pos < g.n && G.in[pos] == G.in[pos - rj];
+                const unsigned long long mj = xw::ballot(eq);
+                n_eq_fill++;
+                if (xw::lane() == 0) { L()->eq_r[sj] = rj; L()->eq_b[sj] = bj; L()->eq_mask[sj] = mj; }
+                if (open && !hit && r == rj && b == bj) { m = mj; hit = true; }
+                miss &= ~xw::ballot(open && r == rj && b == bj);       // (lanes served by this fill are out of the list)
+            }
+            xw::wave_sync();
+            if (open) {
+                const uint32_t sh = x & 63u, room = 64 - sh;
+                const unsigned long long z = ~(m >> sh);            // zero bits = equal bytes
+                const uint32_t run = z ? (uint32_t)__builtin_ctzll(z) : 64u;
+                const uint32_t got = umin(umin(run, room), c - len);
+                len += got; x += got;
+                if (got < room || len >= c) open = false;
+            }
+        }
+        return len;
+    }
+
+    // ---- one parse segment: nodes 0.. of positions seg_a.. ; returns its length, path in cmdlist (ncmds, end first) ---
+    XW_FN uint32_t parse_segment(uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
+    {
+        max_parse = umin(max_parse, kParseMax);
+        const uint32_t i = xw::lane();
+        const uint32_t seg_q = seg_a - base;
+        seg_tables();
+        const uint32_t pc_dict = xw::readfirst(price(kCtxCmd, 1)), pc_rep = xw::readfirst(price(kCtxCmd, 2));
+        // node 0 (:1472-1482)
+        if (i == 0) { L()->mkey[0] = 0; L()->mkey[1] = kKeyNone; L()->node_link[0] = 0x1FFF; }
+        uint32_t end_p = 1, f = 0;
+        uint32_t c_prev = 0, l_prev = 0;                            // cost of node f-1 and price of its literal edge
+        uint32_t rp0 = rep[0], rp1 = rep[1], rp2 = rep[2], rp3 = rep[3];   // rep set of node f-1 (node 0: the model's, :1476)
+        uint32_t lit_prev = 0;
+        if (i == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
+        xw::wave_sync();
+        for (;;) {
+            n_steps++;
+            const uint32_t aA = seg_a + f;
+#ifdef NLZM_SIM
+            if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "P step seg %u f %u end %u\n", seg_a, f, end_p);
+#endif
+            const bool lastA = f >= end_p;                           // node f is the segment's last node: no edges leave it
+            if (!lastA && !fetch(aA + 1, aA + 128 - 2, aA)) return 0;
+            // position f+1 is taken along if it exists (a node f+1 beyond the cut has no edges) and its record is out already:
+            // the stages before this one may be waiting for what THIS node shows (the segment of a nice region, :1529)
+            bool haveB = !lastA && f + 1 < max_parse;
+            if (haveB && (int32_t)(fetched - (aA + 2)) < 0) {
+                if ((int32_t)(t_out_seen - (aA + 2)) < 0) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                if ((int32_t)(t_out_seen - (aA + 2)) >= 0) { if (!fetch(aA + 2, aA + 128 - 2, aA)) return 0; }
+                else haveB = false;
+            }
+            // ---- finalise nodes f and f+1
+            const unsigned long long kA = f ? xw::readfirst64(L()->mkey[f & 511u]) : 0ull;
+            const unsigned long long kB = xw::readfirst64(L()->mkey[(f + 1) & 511u]);
+            const uint32_t hA = lastA ? 0u : xw::readfirst(L()->hdr[aA & 127u]);
+            const uint32_t hB = haveB ? xw::readfirst(L()->hdr[(aA + 1) & 127u]) : 0u;
+            const uint32_t litA = (hA >> 8) & 0xFFu, litB = (hB >> 8) & 0xFFu;
+            const uint32_t lA = lastA ? 0u : price_literal(litA);
+            // node A
+            uint32_t cA, srcA, rankA;
+            if (f == 0) { cA = 0; srcA = 0x1FFF; rankA = 0; }
+            else {
+                const uint32_t mc = (uint32_t)(kA >> 32);
+                if (mc > c_prev + l_prev) { cA = c_prev + l_prev; srcA = f - 1; rankA = kRankLit; }     // :1492 (the literal edge comes last: strict)
+                else { cA = mc; srcA = (uint32_t)(kA >> 8) & 0xFFFFFFu; rankA = (uint32_t)kA & 0xFFu; }
+            }
+            // node B (its in-edges from f-1 and before are in; the literal edge of A in registers)
+            uint32_t cB, srcB, rankB;
+            {
+                const uint32_t mc = (uint32_t)(kB >> 32);
+                if (mc > cA + lA) { cB = cA + lA; srcB = f; rankB = kRankLit; }
+                else { cB = mc; srcB = (uint32_t)(kB >> 8) & 0xFFFFFFu; rankB = (uint32_t)kB & 0xFFu; }
+            }
+            // rep sets: of the source, plus the distance of a dict edge (RepModel::Add, :1160-1171)
+            auto node_set = [&](uint32_t node, uint32_t src, uint32_t rank, uint32_t lit_byte, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
+                                bool src_in_regs, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+                uint32_t s0 = q0, s1 = q1, s2 = q2, s3 = q3;
+                if (!src_in_regs) {
+                    const uint32_t *sr = L()->nrep + (src & 511u) * 4;
+                    s0 = xw::readfirst(sr[0]); s1 = xw::readfirst(sr[1]); s2 = xw::readfirst(sr[2]); s3 = xw::readfirst(sr[3]);
+                }
+                uint32_t cmd = 0, delta = lit_byte, len = 0;
+                o0 = s0; o1 = s1; o2 = s2; o3 = s3;
+                if (rank != kRankLit) {
+                    len = node - src;
+                    if (rank >= kRankProbe) { cmd = 2; delta = rank - kRankProbe; }
+                    else {
+                        const uint32_t d = xw::readfirst(L()->edge_d[((seg_a + src) & 511u) * kMaxEdges + (rank >> 1)]);
+                        if (rank & 1u) { cmd = 2; delta = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
+                        else {
+                            cmd = 1; delta = d;
+                            if (!(d == s0 || d == s1 || d == s2 || d == s3)) { o0 = d; o1 = s0; o2 = s1; o3 = s2; }
+                        }
+                    }
+                }
+                if (i == 0) {
+                    L()->node_link[node] = src | (len << 13) | (cmd << 22);
+                    L()->node_delta[node] = delta;
+                    uint32_t *dr = L()->nrep + (node & 511u) * 4;
+                    dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3;
+                }
+            };
+            uint32_t a0r, a1r, a2r, a3r, b0r, b1r, b2r, b3r;
+            if (f == 0) {
+                a0r = rp0; a1r = rp1; a2r = rp2; a3r = rp3;
+                if (i == 0) { uint32_t *dr = L()->nrep; dr[0] = a0r; dr[1] = a1r; dr[2] = a2r; dr[3] = a3r; }
+            } else node_set(f, srcA, rankA, lit_prev, rp0, rp1, rp2, rp3, rankA == kRankLit, a0r, a1r, a2r, a3r);
+            if (lastA) { f = end_p; break; }
+            node_set(f + 1, srcB, rankB, litA, a0r, a1r, a2r, a3r, rankB == kRankLit, b0r, b1r, b2r, b3r);
+            xw::wave_sync();
+
+            // ---- the edges: lanes 0..31 node A, lanes 32..63 node B
+            const bool isB = i >= 32;
+            const uint32_t k = i & 31u;
+            const uint32_t node = isB ? f + 1 : f, aN = seg_a + node;
+            // within 264 of the forced cut the table is cut short (:1545)
+            {
+                const uint32_t mlA = (hA & 63u) ? (xw::readfirst(L()->attr[(aA & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
+                if (mlA > max_parse - f) resample(aA, max_parse - f);
+                if (haveB) {
+                    const uint32_t mlB = (hB & 63u) ? (xw::readfirst(L()->attr[((aA + 1) & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
+                    if (mlB > max_parse - f - 1) resample(aA + 1, max_parse - f - 1);
+                }
+            }
+            const uint32_t neA = xw::readfirst(L()->hdr[aA & 127u]) & 63u, neB = haveB ? xw::readfirst(L()->hdr[(aA + 1) & 127u]) & 63u : 0u;
+            const uint32_t ne = isB ? neB : neA;
+            const bool have = k < ne;
+            const uint32_t ed = have ? L()->edge_d[(aN & 511u) * kMaxEdges + k] : 0u;
+            const uint32_t ea = have ? L()->attr[(aN & 127u) * kMaxEdges + k] : 0u;
+            const bool valid = have && (ea >> 31);
+            const uint32_t tl = ea & 0x1FFu, lv = (ea >> 9) & 0x1FFu, slot = (ea >> 18) & 63u, nx = (ea >> 24) & 31u;
+            const uint32_t r0 = isB ? b0r : a0r, r1 = isB ? b1r : a1r, r2 = isB ? b2r : a2r, r3 = isB ? b3r : a3r;
+            // GetMatch (:1173-1181): the first slot that holds the distance
+            const uint32_t ridx = !valid ? 4u : (ed == r0 ? 0u : (ed == r1 ? 1u : (ed == r2 ? 2u : (ed == r3 ? 3u : 4u))));
+            uint32_t checkedA = 0, checkedB = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const unsigned long long bm = xw::ballot(ridx == j);
+                if ((uint32_t)bm) checkedA |= 1u << j;
+                if ((uint32_t)(bm >> 32)) checkedB |= 1u << j;
+            }
+            const uint32_t max_lenA = neA ? (xw::readfirst(L()->attr[(aA & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
+            const uint32_t max_lenB = neB ? (xw::readfirst(L()->attr[((aA + 1) & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
+            // explicit probes of the rep slots no sampled edge has met (:1598-1628): lanes 0..3 (A) and 32..35 (B)
+            const uint32_t pr = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+            const uint32_t chk = isB ? checkedB : checkedA;
+            const bool pwant = k < 4 && (isB ? haveB : true) && !((chk >> k) & 1u) && pr < seg_q + node;      // :1601
+            const uint32_t pcap = umin(max_parse - node, kMatchMax);                        // :1605-1606
+            const uint32_t pl = probe_len(pwant, aN, pr, pcap);
+            const bool pok = pwant && pl >= match_min(pr);                                  // :1607
+            // end_p (:1550-1554, :1608-1612)
+            uint32_t reachA = f + max_lenA, reachB = f + 1 + max_lenB;
+            {
+                const uint32_t pe = pok ? node + pl : 0u;
+                uint32_t ra = isB ? 0u : pe, rb = isB ? pe : 0u;
+                for (uint32_t d = 1; d < 4; d <<= 1) { ra = umax(ra, xw::shfl(ra, i ^ d)); rb = umax(rb, xw::shfl(rb, i ^ d)); }
+                reachA = umax(reachA, xw::readlane(ra, 0));
+                reachB = umax(reachB, xw::readlane(rb, 32));
+            }
+            const uint32_t e1 = umax(end_p, reachA);
+            const bool liveB = haveB && f + 1 < e1;
+            if (pwant && (!isB || liveB)) n_cmp += pl + (pl < pcap);
+            const uint32_t e2 = liveB ? umax(e1, reachB) : e1;
+            for (uint32_t t = end_p + 1 + i; t <= e2; t += 64) L()->mkey[t & 511u] = kKeyNone;   // (:1552-1553)
+            if (e2 != end_p && i == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + e2));
+            end_p = e2;
+            xw::wave_sync();
+            // relax (:1566-1595, :1614-1625)
+            const uint32_t cN = isB ? cB : cA;
+            if (valid && (!isB || liveB)) {
+                const uint32_t lp = L()->len_price[lv];
+                const uint32_t wd = pc_dict + lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];
+                xw::lds_min64(&L()->mkey[(node + tl) & 511u], ((unsigned long long)(cN + wd) << 32) | (node << 8) | (2 * k));
+                if (ridx < 4) {
+                    const uint32_t wr = pc_rep + lp + (2u << 5);                           // :1253-1272
+                    xw::lds_min64(&L()->mkey[(node + tl) & 511u], ((unsigned long long)(cN + wr) << 32) | (node << 8) | (2 * k + 1));
+                }
+            }
+            if (pok && (!isB || liveB)) {
+                const uint32_t wr = pc_rep + L()->len_price[pl - match_min(pr)] + (2u << 5);
+                xw::lds_min64(&L()->mkey[(node + pl) & 511u], ((unsigned long long)(cN + wr) << 32) | (node << 8) | (kRankProbe + k));
+            }
+            xw::wave_sync();
+            if (liveB) {
+                f += 2;
+                c_prev = cB; l_prev = price_literal(litB); lit_prev = litB;
+                rp0 = b0r; rp1 = b1r; rp2 = b2r; rp3 = b3r;
+            } else {
+                // node f+1 is the last node of the segment (it is final already), or its record was not out yet
+                f += 1;
+                if (f >= end_p) break;
+                c_prev = cA; l_prev = lA; lit_prev = litA;
+                rp0 = a0r; rp1 = a1r; rp2 = a2r; rp3 = a3r;
+            }
+        }
+        // backtrack (:1633-1650): node indices of the path, end first
+        uint32_t n = 0, cur = end_p;
+        while (cur != 0) {
+            if (i == 0) L()->cmdlist[n] = (uint16_t)cur;
+            n++;
+            cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
+        }
+        xw::wave_sync();
+        ncmds = n;
+        // the rep set the model ends with is the last node's (:1819, :1834 applied along the path)
+        return end_p;
+    }
+
+    // one chunk = one frame (:1782-1886)
+    XW_FN void run_chunk(uint32_t ci)
+    {
+        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+        const unsigned long long remain = g.n - chunk_abs;
+        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+        const uint32_t p_end = umin(g.chunk_size, chunk_read);
+        fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
+        fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
+        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0;
+        if (chunk_abs - base >= 2ull * (g.wmask + 1)) base += g.wmask + 1;      // :1786
+        unsigned long long n_lit = 0, n_dict = 0, n_rep = 0, n_seg = 0;
+        uint32_t p = 0;
+        while (p < p_end && !err) {
+            uint32_t ncmds = 0;
+            const uint32_t seg_a = (uint32_t)chunk_abs + p;
+            const uint32_t len = parse_segment(seg_a, p_end - p, ncmds);
+            if (err) break;
+            n_seg++;
+            const unsigned long long te = xw::tick();
+            for (uint32_t k = ncmds; k-- > 0;) {                                // :1809-1843
+                const uint32_t node = xw::readfirst(L()->cmdlist[k]);
+                const uint32_t link = xw::readfirst(L()->node_link[node]);
+                const uint32_t delta = xw::readfirst(L()->node_delta[node]);
+                const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
+                if (cmd == 0) { emit_literal(delta); n_lit++; }
+                else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
+                else { emit_rep(delta, ln); n_rep++; }
+            }
+            t_emit += xw::tick() - te;
+            p += len;
+            if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
+        }
+        for (int k = 0; k < 4; k++) {                                           // bit pad of Flush (:591-597)
+            if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+            nbits++; word <<= 8;
+        }
+        if (xw::lane() == 0) {
+            FrameMeta &fm = G.fmeta[ci - G.chunk0];
+            fm.nsyms = nsyms; fm.nbits_bytes = nbits; fm.num_ops = num_ops; fm.out_len = 0;
+            Counters &c = L()->cnt;
+            c.n_literal += n_lit; c.n_dict += n_dict; c.n_rep += n_rep; c.segments += n_seg;
+            c.rans_syms += nsyms; c.bit_ops += num_ops - nsyms; c.frames += 1;
+        }
+    }
+
+    XW_FN void run(uint32_t c0, uint32_t c1)
+    {
+        Persist *P = G.persist;
+        const uint32_t i = xw::lane();
+        for (uint32_t k = i; k < kNumCtx * kCdfStride; k += 64) L()->cdf[k] = P->cdf[k];
+        for (uint32_t k = i; k < 256; k += 64) L()->lut[k] = log2_lut_entry(k);
+        for (uint32_t k = i; k < kEqSlots; k += 64) { L()->eq_r[k] = 0; L()->eq_b[k] = kNone; }
+        for (uint32_t k = i; k < sizeof(Counters) / 8; k += 64) ((unsigned long long *)&L()->cnt)[k] = 0;
+        xw::wave_sync();
+        for (uint32_t k = i; k < kNumCtx * 16; k += 64) {
+            const uint32_t ctx = k >> 4, y = k & 15;
+            const uint16_t *cell = L()->cdf + ctx * kCdfStride;
+            L()->price[k] = (y < ctx_nsyms(ctx)) ? L()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
+        }
+        for (int k = 0; k < 4; k++) rep[k] = xw::readfirst(P->rep[k]);
+        base = xw::readfirst((uint32_t)P->reb_base);
+        err = xw::readfirst(P->error);
+        tab_dirty = true;
+        fetched = (uint32_t)((unsigned long long)c0 * g.chunk_size); t_out_seen = fetched;
+        n_steps = n_eq_fill = n_eq_rounds = n_cmp = n_redo = 0; t_wait = t_emit = t_fetch = 0;
+        const unsigned long long t_start = xw::tick();
+        xw::wave_sync();
+        uint32_t ci = c0;
+        for (; ci < c1 && !err; ci++) run_chunk(ci);
+        xw::wave_sync();
+        for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, i ^ d);       // (kept per lane: the probe lanes)
+        for (uint32_t k = i; k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];
+        if (i == 0) {
+            for (int k = 0; k < 4; k++) P->rep[k] = rep[k];
+            P->next_chunk = ci;
+            unsigned long long *dst = (unsigned long long *)&P->cnt;
+            const unsigned long long *src = (const unsigned long long *)&L()->cnt;
+            for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
+            P->cnt.cmp_bytes += n_cmp;
+            P->prof[8] += n_steps; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo;
+            P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_fetch;
+            const uint32_t xe = xw::ld_agent(&V.hx->err);
+            if (xe && !P->error) P->error = xe;
+            if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
+        }
+    }
+};
+
+}  // namespace v2
+}  // namespace nlzm
