@@ -20,11 +20,18 @@
 
 #include "../../include/nlzm_hip.h"
 #include "nlzm_core.h"
+#include "nlzm_v2.h"
 
 namespace nlzm {
 void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long pos0, unsigned long long pos1,
                     uint32_t *out, hipStream_t st);
 void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
+void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
+unsigned long long stream2_pack_size();
+uint32_t stream2_pack_capacity();
+uint32_t pipeline2_role_blocks();
+void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1);
+void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 unsigned long long stream_pack_size();
 uint32_t stream_pack_capacity();
 void fill_stream_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, uint32_t c0, uint32_t c1);
@@ -77,7 +84,7 @@ struct Ctx {
     // options
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
-    int64_t opt_worker_blocks = 240;        // + the master block: below the 256 CUs, one 512-thread block per CU
+    int64_t opt_worker_blocks = 240;        // + the three stage blocks: below the 256 CUs, one 512-thread block per CU
 
 
     // stream state
@@ -104,6 +111,9 @@ struct Ctx {
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
     uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr;
     WorkerCounters *wcnt = nullptr;
+    // three-stage pipeline (nlzm_v2.h): hand-off rings, progress words, stage state
+    uint32_t *v2_ft = nullptr, *v2_tp = nullptr, *v2_tf = nullptr, *v2_state = nullptr;
+    v2::Hx *v2_hx = nullptr;
 
     // capture (stage tests)
     uint32_t *cap_words = nullptr; unsigned long long cap_cap = 0, cap_lo = 0, cap_hi = 0; unsigned long long *cap_used = nullptr;
@@ -126,8 +136,10 @@ void free_stream_buffers(Ctx &C)
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
-                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt };
+                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt,
+                     C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
     C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
@@ -259,6 +271,14 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
     }
 
+    // hand-off between the finder, table and parser stages
+    HIPCHK(hipMalloc(&C.v2_ft, (size_t)v2::kFtRing * v2::kFtStride * 4));
+    HIPCHK(hipMalloc(&C.v2_tp, (size_t)v2::kTpRing * v2::kTpStride * 4));
+    HIPCHK(hipMalloc(&C.v2_tf, (size_t)v2::kTpRing * v2::kTfStride * 4));
+    HIPCHK(hipMalloc(&C.v2_state, sizeof(v2::StateV2)));
+    HIPCHK(hipMalloc(&C.v2_hx, sizeof(v2::Hx)));
+    HIPCHK(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
+
     // stream header (:1762-1766)
     const uint8_t hdr[4] = { (uint8_t)(g.wbits >> 8), (uint8_t)g.wbits, (uint8_t)(g.frame_bits >> 8), (uint8_t)g.frame_bits };
     HIPCHK(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
@@ -273,7 +293,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
 //   step_pre   pre-pass kernels and the hand-off arrays of chunks [c0, c1) on the stream's own HIP stream
 //   (launch)   pipeline_kernel for this stream alone, or pipeline_multi_kernel for a group of streams
 //   step_post  frame coder, frame lengths back to the host, checks, gather into the output
-struct StepPlan { uint32_t c0 = 0, c1 = 0, nb = 0; Globals G; };
+struct StepPlan { uint32_t c0 = 0, c1 = 0, nb = 0; Globals G; v2::GlobalsV2 V; };
 
 int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
 {
@@ -312,6 +332,14 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
                          C.pf_c1, C.unc, C.st);
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
+    }
+    {   // progress words of the stages: everything before the launch's first position is done
+        v2::Hx h;
+        memset(&h, 0, sizeof h);
+        h.f_pos = h.t_pos = h.t_out = h.p_pos = (uint32_t)a0;
+        h.p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
+        HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
+        P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state;
     }
     HIPCHK(hipEventRecord(C.ev[6], C.st));
     return 0;
@@ -388,7 +416,7 @@ int stream_step(Ctx &C, uint32_t max_chunks, uint64_t *in_done, uint64_t *out_do
         int rc = step_pre(C, todo, P);
         if (rc) return rc;
         HIPCHK(hipEventRecord(C.ev[0], C.st));
-        launch_pipeline(g, P.G, P.c0, P.c1, (uint32_t)C.opt_worker_blocks, C.st);
+        launch_pipeline2(g, P.G, P.V, P.c0, P.c1, (uint32_t)C.opt_worker_blocks, C.st);
         rc = step_post(C, P, -1.0f);
         if (rc) return rc;
         todo -= P.nb;
@@ -414,38 +442,14 @@ int refresh_stats(Ctx &C)
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
     if (getenv("NLZM_WAIT_PRINT")) {
+        // per-stage accounting of the three-stage pipeline (Persist::prof, filled by nlzm_v2.h)
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
-        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f | edge list: wait %.0f | rep lists: wait %.0f %.0f | edge apply: wait %.0f\n",
-                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[24] / n, P.prof[26] / n, P.prof[28] / n, P.prof[22] / n);
-        fprintf(stderr, "HW_ID of the finder/table/parser/edge waves: %04llx %04llx %04llx %04llx (SIMD = bits 5:4)\n", P.prof[30] & 0xFFFF,
-                (P.prof[30] >> 16) & 0xFFFF, (P.prof[30] >> 32) & 0xFFFF, (P.prof[30] >> 48) & 0xFFFF);
-        fprintf(stderr, "finder wait: queue space %.0f, record buffer (table wave two batches behind) %.0f, rest (BT4 results, nice phase) %.0f\n",
-                P.prof[37] / n, P.prof[38] / n, (P.prof[16] - P.prof[37] - P.prof[38]) / n);
-        fprintf(stderr, "apply wave wait: for the rep list %.0f, for the next node's post / sampled list %.0f\n", P.prof[39] / n, (P.prof[22] - P.prof[39]) / n);
-        fprintf(stderr, "rep-set guesses per 1000 nodes: used %.1f, late %.1f, wrong %.1f\n", 1e3 * P.cnt.guess_used / n, 1e3 * P.cnt.guess_late / n,
-                1e3 * P.cnt.guess_wrong / n);
-        fprintf(stderr, "direct-path slots per 1000 positions: HT rows rewritten %.1f, RK slot rewritten %.1f, BT4 result late or long %.1f\n",
-                1e3 * P.cnt.stale_ht / n, 1e3 * P.cnt.stale_rk / n, 1e3 * P.cnt.bt_slow / n);
-    }
-    if (getenv("NLZM_PROFILE_PRINT")) {
-        const double n0 = (double)(P.cnt.positions ? P.cnt.positions : 1);
-        fprintf(stderr, "waits: B on A %.1f cyc/pos, A on B (nice phase, ring space excluded) %.1f cyc/pos\n",
-                (double)P.prof[13] / (P.cnt.positions ? P.cnt.positions : 1), (double)P.prof[14] / (P.cnt.positions ? P.cnt.positions : 1));
-        fprintf(stderr, "latency from a node's post (cycles): sampled list %.0f, rep list %.0f / %.0f (per own node), apply starts %.0f, apply done %.0f\n",
-                P.prof[33] / n0, 2 * P.prof[34] / n0, 2 * P.prof[35] / n0, P.prof[36] / n0, P.prof[32] / n0);
-        fprintf(stderr, "apply wave sections (cycles/pos): request %.0f, open nodes %.0f, sampled edges %.0f, rep list in %.0f, rep probes %.0f, done %.0f\n",
-                P.prof[40] / n0, P.prof[41] / n0, P.prof[42] / n0, P.prof[43] / n0, P.prof[44] / n0, P.prof[45] / n0);
-        fprintf(stderr, "table wave sections (cycles/pos): fetch %.0f, update %.0f, carry %.0f, run %.0f, set %.0f, end %.0f\n",
-                P.prof[48] / n0, P.prof[49] / n0, P.prof[50] / n0, P.prof[51] / n0, P.prof[52] / n0, P.prof[53] / n0);
-        fprintf(stderr, "parser wave sections (cycles/pos): segment set-up %.0f, post %.0f, guess %.0f, next table head + literal price %.0f, settle %.0f, "
-                        "literal edge + node %.0f, backtrack %.0f, emit %.0f\n", P.prof[47] / n0, P.prof[54] / n0, P.prof[55] / n0, P.prof[7] / n0,
-                P.prof[8] / n0, P.prof[9] / n0, P.prof[10] / n0, P.prof[11] / n0);
-        static const char *names[13] = { "A: look-ahead fill", "A: carry+extend", "A: HT consume", "B: rep probes", "A: HT logic", "A: BT consume",
-                                         "A: RK", "B: wait+literal", "B: sampled relax", "B: rep relax+next", "B: backtrack", "B: emit", "A: publish" };
-        unsigned long long tot = 0;
-        for (int k = 0; k < 13; k++) tot += P.prof[k];
-        for (int k = 0; k < 13; k++) fprintf(stderr, "prof %-18s %12llu cyc  %5.1f%%  %7.1f cyc/pos\n", names[k], P.prof[k],
-                                             100.0 * P.prof[k] / (tot ? tot : 1), (double)P.prof[k] / (P.cnt.positions ? P.cnt.positions : 1));
+        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (emit %.0f, record fetch %.0f)\n",
+                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[22] / n, P.prof[23] / n);
+        fprintf(stderr, "finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
+                P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
+        fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu steps (%.2f nodes each), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
+                P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11]);
     }
     if (C.workers) {
         WorkerCounters wc;
@@ -791,7 +795,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     // every block is in flight at once: one master CU + its worker CUs per stream, all resident together
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, C.device));
-    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - 1 - (nblocks > 1 ? 1 : 0);
+    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - (int64_t)pipeline2_role_blocks() - (nblocks > 1 ? 1 : 0);
     if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;
     if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs", nblocks, prop.multiProcessorCount);
     g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
@@ -811,7 +815,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
-    const uint32_t ngroups = (nblocks + stream_pack_capacity() - 1) / stream_pack_capacity();
+    const uint32_t ngroups = (nblocks + stream2_pack_capacity() - 1) / stream2_pack_capacity();
     for (uint32_t gi = 0; gi < ngroups; gi++) {
         hipStream_t st; std::array<hipEvent_t, 2> ev;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -836,8 +840,8 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
     }
     // Rounds in lockstep: every unfinished stream advances by one batch, and the streams of a round share persistent
     // launches (groups of up to stream_pack_capacity() streams per launch, all launches of a round in flight together)
-    const uint32_t cap = stream_pack_capacity();
-    std::vector<uint8_t> pack(stream_pack_size());
+    const uint32_t cap = stream2_pack_capacity();
+    std::vector<uint8_t> pack(stream2_pack_size());
     std::vector<StepPlan> plan(nj);
     for (;;) {
         std::vector<uint32_t> act;
@@ -853,10 +857,10 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
             for (uint32_t k = lo; k < hi; k++) {
                 Ctx &c = g_jobs[act[k]].c;
                 HIPCHK(hipStreamWaitEvent(gs, c.ev[6], 0));            // its pre-pass is done
-                fill_stream_args(pack.data(), k - lo, c.g, plan[act[k]].G, plan[act[k]].c0, plan[act[k]].c1);
+                fill_stream2_args(pack.data(), k - lo, c.g, plan[act[k]].G, plan[act[k]].V, plan[act[k]].c0, plan[act[k]].c1);
             }
             HIPCHK(hipEventRecord(g_group_ev[gi][0], gs));
-            launch_pipeline_multi(pack.data(), hi - lo, (uint32_t)g_blocks_wb, gs);
+            launch_pipeline2_multi(pack.data(), hi - lo, (uint32_t)g_blocks_wb, gs);
             HIPCHK(hipEventRecord(g_group_ev[gi][1], gs));
             for (uint32_t k = lo; k < hi; k++) HIPCHK(hipStreamWaitEvent(g_jobs[act[k]].c.st, g_group_ev[gi][1], 0));
         }

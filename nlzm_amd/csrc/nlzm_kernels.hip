@@ -15,7 +15,22 @@
 #include <stdint.h>
 
 #include "nlzm_core.h"
+#include "nlzm_v2.h"
 
+namespace nlzm {
+
+// LDS image of the three-stage pipeline (nlzm_v2.h): every block of pipeline2_kernel has ONE role, so the roles share
+// the bytes.  A file-scope __shared__ object: every access is a ds_* instruction.
+constexpr uint32_t kLogCap = 24;                    // stores a worker lane notes down during a dry run
+union V2Lds {
+    v2::FLds f; v2::TLds t; v2::PLds p;
+    uint32_t wlog[512 * kLogCap * 2];
+};
+__shared__ V2Lds g_v2_lds;
+}  // namespace nlzm
+namespace xw {
+template <class T> XW_FN T *lds() { return reinterpret_cast<T *>(&nlzm::g_v2_lds); }
+}
 namespace nlzm {
 
 // ---------------------------------------------------------------------------
@@ -526,13 +541,15 @@ struct LaneIO {
 
 // The stores of a dry run, noted in LDS (a worker block does not use the master's LDS image): kLogCap (address, value)
 // pairs per lane, interleaved by lane so that a wave's k-th entries sit in different banks.
-constexpr uint32_t kLogCap = 24;
 static_assert(sizeof(MasterLds) >= 512 * kLogCap * 8, "store log does not fit the block's LDS");
+struct LogInMaster { static __device__ __forceinline__ uint32_t *base() { return (uint32_t *)&g_master_lds; } };
+struct LogInV2 { static __device__ __forceinline__ uint32_t *base() { return (uint32_t *)&g_v2_lds; } };
+template <class LB>
 struct StoreLog {
     uint32_t n;
     bool full;
     // entry k of this lane: target (index into tree[], or 0x80000000 | index into heads[]) and value
-    __device__ __forceinline__ static uint32_t *slot(uint32_t k) { return (uint32_t *)&g_master_lds + 2 * (k * 512 + threadIdx.x); }
+    __device__ __forceinline__ static uint32_t *slot(uint32_t k) { return LB::base() + 2 * (k * 512 + threadIdx.x); }
     __device__ __forceinline__ void put(uint32_t t, uint32_t v)
     {
         if (n < kLogCap) { uint32_t *e = slot(n); e[0] = t; e[1] = v; n++; }
@@ -550,6 +567,7 @@ struct StoreLog {
     }
 };
 
+template <class LB>
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
     const uint32_t nl = wblocks * blockDim.x;
@@ -563,7 +581,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     uint32_t la_end = 0;            // absolute end of the chunk's lookahead
     uint32_t stage = 0, a = 0, max_len = 0;
     unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dry_t = 0, dry_c = 0, n_cyc = 0, n_cyc_tests = 0;
-    StoreLog slog{ 0, false };
+    StoreLog<LB> slog{ 0, false };
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0;
     bool fail = false;
@@ -685,7 +703,7 @@ __device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, 
         default: m.run_rep_list(a_first, 1); break;
         }
     } else {
-        worker_role(g, G, c0, c1, wblocks, local_block - 1);
+        worker_role<LogInMaster>(g, G, c0, c1, wblocks, local_block - 1);
     }
 }
 
@@ -709,6 +727,39 @@ __global__ __launch_bounds__(512) void pipeline_multi_kernel(StreamPack pack, ui
 {
     const uint32_t s = blockIdx.x / bps, local = blockIdx.x % bps;
     pipeline_roles(pack.s[s].g, pack.s[s].G, pack.s[s].c0, pack.s[s].c1, local, bps - 1);
+}
+
+// ---------------------------------------------------------------------------
+// the persistent launch of the three-stage pipeline (nlzm_v2.h): blocks 0, 1, 2 of a stream are its finder, table and
+// parser stage (one wave each: the lanes are the positions of a block / the edges of two nodes), the others its BT4
+// worker lanes.  512-thread blocks with > 80 KB of LDS: one block per CU; the grid is kept below the CU count, so every
+// block is resident at once (the stages wait on each other through progress words in HBM).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kV2Roles = 3;
+__device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1,
+                                                uint32_t local_block, uint32_t wblocks)
+{
+    if (local_block < kV2Roles) {
+        if (threadIdx.x >= 64) return;
+        if (local_block == 0) { v2::Finder r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
+        else if (local_block == 1) { v2::Table r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
+        else { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
+    } else {
+        worker_role<LogInV2>(g, G, c0, c1, wblocks, local_block - kV2Roles);
+    }
+}
+__global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::GlobalsV2 V, uint32_t c0, uint32_t c1)
+{
+    pipeline2_roles(g, G, V, c0, c1, blockIdx.x, gridDim.x - kV2Roles);
+}
+struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; };
+constexpr uint32_t kMaxStreams2PerLaunch = 10;          // the pack travels in the kernel-argument segment (4 KB)
+struct Stream2Pack { Stream2Args s[kMaxStreams2PerLaunch]; };
+static_assert(sizeof(Stream2Pack) <= 4000, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(512) void pipeline2_multi_kernel(Stream2Pack pack, uint32_t bps)
+{
+    const uint32_t s = blockIdx.x / bps, local = blockIdx.x % bps;
+    pipeline2_roles(pack.s[s].g, pack.s[s].G, pack.s[s].V, pack.s[s].c0, pack.s[s].c1, local, bps - kV2Roles);
 }
 
 // ---------------------------------------------------------------------------
@@ -821,6 +872,24 @@ void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long 
 void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(512), 0, st, g, G, c0, c1);
+}
+
+void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(pipeline2_kernel, dim3(kV2Roles + worker_blocks), dim3(512), 0, st, g, G, V, c0, c1);
+}
+unsigned long long stream2_pack_size() { return sizeof(Stream2Pack); }
+uint32_t stream2_pack_capacity() { return kMaxStreams2PerLaunch; }
+uint32_t pipeline2_role_blocks() { return kV2Roles; }
+void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1)
+{
+    Stream2Args &a = ((Stream2Pack *)host_pack)->s[i];
+    a.g = g; a.G = G; a.V = V; a.c0 = c0; a.c1 = c1;
+}
+void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(pipeline2_multi_kernel, dim3(nstreams * (kV2Roles + worker_blocks)), dim3(512), 0, st, *(const Stream2Pack *)host_pack,
+                       kV2Roles + worker_blocks);
 }
 
 // several streams in one launch: fill slot i of a host-side pack, then launch

@@ -149,7 +149,7 @@ struct Finder {
     uint32_t prev_nice, seg_s;
     uint32_t t_pos_seen;
     uint32_t err;
-    unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut[6];
+    unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long t_wait, t_total;
 
     XW_FN void fail(uint32_t code, uint32_t info)
@@ -344,7 +344,7 @@ struct Finder {
         // ---- the record of this position: pairs of HT2 and HT3 (:917-933)
         uint32_t *st = L->stage + i * kFtStride;
         uint32_t np = 0, ec = 0, od = kNone, cmpb = 0;      // pairs, largest closed end, smallest open distance, bytes compared
-        auto add_pair = [&](uint32_t d, uint32_t l) {
+        auto add_pair = [&](uint32_t d, uint32_t l) __attribute__((always_inline)) {
             if (l >= cap) { od = umin(od, d); return; }     // as long as the lookahead allows: may grow at the next position
             st[2 + 2 * np] = d; st[3 + 2 * np] = l; np++;
             ec = umax(ec, a + l);
@@ -453,6 +453,12 @@ struct Finder {
             t_wait += xw::tick() - tw;
         }
 
+#ifdef NLZM_SIM
+        if (getenv("NLZM_SIM_DEBUG_POS") && in_blk && a == (uint32_t)atoi(getenv("NLZM_SIM_DEBUG_POS")))
+            fprintf(stderr, "dbg pos %u q %u base %u: ct full %d some %d ht %d rk %d | cd %u %u %u cl %u %u %u | rkh %08x rkv %08x rk_cand %d rk_d %u rk_eff %u rk_len %u rk_to %u rk_end %u | bt_n %u ec %u od %u np %u cap %u\n",
+                    a, q, base, (int)call_full, (int)call_some, (int)ht_call, (int)rk_call, cd[0], cd[1], cd[2], cl[0], cl[1], cl[2], rkh, rkv,
+                    (int)rk_cand, rk_d, rk_eff, rk_len, rk_to, rk_end, bt_n, ec, od, np, cap);
+#endif
         // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
         uint32_t pm = in_blk ? ec : 0u;                                         // inclusive prefix max of the closed ends
         for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(pm, d); if (i >= d) pm = umax(pm, o); }
@@ -471,7 +477,11 @@ struct Finder {
         uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
         if (m == 0) { fail(kErrInternal, a0); return 1; }
         n_blocks++;
-        if (m < n) n_cut[m == cut_nice ? 0 : (m == jo + 1 ? 1 : (m == cut_ev ? 2 : (m == cut_rk ? 3 : (m == cut_bin ? 5 : 4))))]++;
+        if (m < n) {        // (why the block was cut; diagnostics)
+            // (adds, not a chain of branches: the compiler turns the chain into ONE indexed access and the stage's state goes to scratch)
+            const uint32_t w = m == cut_nice ? 0u : (m == jo + 1 ? 1u : (m == cut_ev ? 2u : (m == cut_rk ? 3u : (m == cut_bin ? 5u : 4u))));
+            n_cut0 += w == 0; n_cut1 += w == 1; n_cut2 += w == 2; n_cut3 += w == 3; n_cut4 += w == 4; n_cut5 += w == 5;
+        }
         const bool fin = i < m;
 
         // a position that the pre-filter promised to be a BT4 position must not be nice
@@ -509,6 +519,9 @@ struct Finder {
             prev_nice = xw::readlane(nice_real ? 1u : 0u, last);
             const unsigned long long rkf = xw::ballot(fin && rk_call);
             if (rkf) rk_end = (a0 + (63u - (uint32_t)__builtin_clzll(rkf))) - base + 256;
+            // a calling position beyond the carried RK match drops it for good (:1066-1068; rk_to is never rebased, so a
+            // later position of the next epoch could look covered again)
+            if (rk_len && xw::any(fin && rk_call && !rk_act)) rk_len = 0;
             if (ev_ok && cut_ev == m) {                                         // the RK candidate of lane m-1 was taken (:1102-1104)
                 rk_from = (a0 + last - base) - ev_d; rk_to = a0 + last - base; rk_len = ev_l;
             }
@@ -548,7 +561,7 @@ struct Finder {
         rk_from = xw::readfirst(P->rk_from); rk_to = xw::readfirst(P->rk_to); rk_len = xw::readfirst(P->rk_len); rk_end = xw::readfirst(P->rk_end);
         err = xw::readfirst(P->error);
         n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = n_blocks = 0;
-        for (int k = 0; k < 6; k++) n_cut[k] = 0;
+        n_cut0 = n_cut1 = n_cut2 = n_cut3 = n_cut4 = n_cut5 = 0;
         t_wait = 0;
         const unsigned long long t_start = xw::tick();
         t_pos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
@@ -592,8 +605,8 @@ struct Finder {
             Counters &c = P->cnt;
             c.positions += n_pos; c.nice_positions += n_nice; c.uncertain_positions += n_unc;
             c.ht_rows += 3 * n_ht; c.rk_probes += n_rkp; c.rk_inserts += n_rki; c.cmp_bytes += n_cmp; c.shifts += shifts;
-            P->prof[0] += n_blocks; for (int k = 0; k < 5; k++) P->prof[1 + k] += n_cut[k];
-            P->prof[12] += n_cut[5];
+            P->prof[0] += n_blocks; P->prof[1] += n_cut0; P->prof[2] += n_cut1; P->prof[3] += n_cut2; P->prof[4] += n_cut3; P->prof[5] += n_cut4;
+            P->prof[12] += n_cut5;
             P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start;
         }
     }
@@ -952,7 +965,7 @@ struct Parser {
     Globals G;
     GlobalsV2 V;
     uint32_t base;                  // absolute offset of rebased 0
-    uint32_t rep[4];                // live model rep set
+    uint32_t rep0, rep1, rep2, rep3;   // live model rep set
     uint32_t fetched;               // parser records of positions < fetched are in LDS
     uint32_t t_out_seen;
     bool tab_dirty;
@@ -1015,7 +1028,7 @@ struct Parser {
                 uint16_t *cell = L()->cdf + ctx * kCdfStride;
                 const uint32_t c0 = cell[i], c1 = cell[i + 1];
                 if (i == y) fsyms[nsyms + k] = ((c1 - c0) << 16) + c0;
-                auto upd = [=](uint32_t j, uint32_t c) {
+                auto upd = [=](uint32_t j, uint32_t c) __attribute__((always_inline)) {
                     const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
                     return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
                 };
@@ -1062,12 +1075,12 @@ struct Parser {
             if (nx < 4) put_bits(ex, nx);
             else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
         }
-        rep_add(rep, d);                                            // :1819
+        if (!(rep0 == d || rep1 == d || rep2 == d || rep3 == d)) { rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = d; }   // RepModel::Add (:1160-1171, :1819)
     }
     XW_FN void emit_rep(uint32_t idx, uint32_t len)                 // :1344-1367; rep4.Add of a distance that is present is a no-op (:1834)
     {
         put_sym(kCtxCmd, 2);
-        emit_len(len - match_min(idx == 0 ? rep[0] : (idx == 1 ? rep[1] : (idx == 2 ? rep[2] : rep[3]))));
+        emit_len(len - match_min(idx == 0 ? rep0 : (idx == 1 ? rep1 : (idx == 2 ? rep2 : rep3))));
         flush_syms();
         put_bits(idx, 2);
     }
@@ -1190,7 +1203,7 @@ struct Parser {
         if (i == 0) { L()->mkey[0] = 0; L()->mkey[1] = kKeyNone; L()->node_link[0] = 0x1FFF; }
         uint32_t end_p = 1, f = 0;
         uint32_t c_prev = 0, l_prev = 0;                            // cost of node f-1 and price of its literal edge
-        uint32_t rp0 = rep[0], rp1 = rep[1], rp2 = rep[2], rp3 = rep[3];   // rep set of node f-1 (node 0: the model's, :1476)
+        uint32_t rp0 = rep0, rp1 = rep1, rp2 = rep2, rp3 = rep3;   // rep set of node f-1 (node 0: the model's, :1476)
         uint32_t lit_prev = 0;
         if (i == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         xw::wave_sync();
@@ -1234,7 +1247,7 @@ struct Parser {
             }
             // rep sets: of the source, plus the distance of a dict edge (RepModel::Add, :1160-1171)
             auto node_set = [&](uint32_t node, uint32_t src, uint32_t rank, uint32_t lit_byte, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
-                                bool src_in_regs, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+                                bool src_in_regs, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) __attribute__((always_inline)) {
                 uint32_t s0 = q0, s1 = q1, s2 = q2, s3 = q3;
                 if (!src_in_regs) {
                     const uint32_t *sr = L()->nrep + (src & 511u) * 4;
@@ -1427,7 +1440,7 @@ struct Parser {
             const uint16_t *cell = L()->cdf + ctx * kCdfStride;
             L()->price[k] = (y < ctx_nsyms(ctx)) ? L()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
         }
-        for (int k = 0; k < 4; k++) rep[k] = xw::readfirst(P->rep[k]);
+        rep0 = xw::readfirst(P->rep[0]); rep1 = xw::readfirst(P->rep[1]); rep2 = xw::readfirst(P->rep[2]); rep3 = xw::readfirst(P->rep[3]);
         base = xw::readfirst((uint32_t)P->reb_base);
         err = xw::readfirst(P->error);
         tab_dirty = true;
@@ -1441,7 +1454,7 @@ struct Parser {
         for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, i ^ d);       // (kept per lane: the probe lanes)
         for (uint32_t k = i; k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];
         if (i == 0) {
-            for (int k = 0; k < 4; k++) P->rep[k] = rep[k];
+            P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
             P->next_chunk = ci;
             unsigned long long *dst = (unsigned long long *)&P->cnt;
             const unsigned long long *src = (const unsigned long long *)&L()->cnt;
