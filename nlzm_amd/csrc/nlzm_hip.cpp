@@ -619,7 +619,10 @@ int nlzm_hip_set_option(const char *key, int64_t value)
 {
     Ctx &C = g_ctx;
     if (!key) return set_err(NLZM_HIP_E_ARG, "null key");
-    if (!strcmp(key, "workers")) { C.opt_workers = value; return 0; }
+    if (!strcmp(key, "workers")) {      // BT4 always runs on the worker lanes (the three-stage pipeline has no other place for it)
+        if (value != 1) return set_err(NLZM_HIP_E_ARG, "workers: only 1 is supported");
+        return 0;
+    }
     if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);

@@ -42,17 +42,6 @@ def test_stream_bit_exact_big(gpu, case):
         assert st[k] == ost[k], k
 
 
-def test_worker_and_inline_modes_agree(gpu):
-    """BT4 inside the master workgroup vs. per-head worker lanes: same bytes."""
-    data = corpus.dups(300_000)
-    outs = []
-    for w in (0, 1):
-        gpu.set_option("workers", w)
-        outs.append(gpu.compress(data, 17))
-    gpu.set_option("workers", 1)
-    assert outs[0] == outs[1] == oracle_py.compress(data, 17)
-
-
 def test_batching_is_invisible(gpu):
     """State carried across persistent launches (model, finders, carry table) is exact."""
     data = corpus.syn_text(700_000, corpus.SEED + 21)
