@@ -450,6 +450,10 @@ int refresh_stats(Ctx &C)
                 P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu steps (%.2f nodes each), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11]);
+        if (P.prof[24] + P.prof[25])
+            fprintf(stderr, "parser step sections (cycles/position, profile build): fetch %.0f, finalise %.0f, edges + rep match %.0f, probes %.0f, end + open %.0f, relax %.0f, "
+                            "between steps (segment set-up, backtrack, emit) %.0f\n", P.prof[24] / n, P.prof[25] / n, P.prof[26] / n, P.prof[27] / n, P.prof[28] / n,
+                    P.prof[29] / n, P.prof[31] / n);
     }
     if (C.workers) {
         WorkerCounters wc;

@@ -208,7 +208,13 @@ struct Finder {
                 uint32_t spins = 0;
                 for (;;) {
                     const unsigned long long ps = xw::readfirst64(xw::ld_agent64(&V.hx->p_seg));
-                    if ((int32_t)((uint32_t)ps - (a0 + 1)) >= 0) { seg_s = (uint32_t)(ps >> 32); break; }
+                    if ((int32_t)((uint32_t)ps - (a0 + 1)) >= 0) {
+                        seg_s = (uint32_t)(ps >> 32);
+#ifdef NLZM_SIM
+                        if (i == 0 && getenv("NLZM_SIM_TRACE_SEG")) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a0, seg_s, (uint32_t)ps);
+#endif
+                        break;
+                    }
                     if ((++spins & 63u) == 0) {
                         if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
 #ifndef NLZM_SIM
@@ -969,11 +975,18 @@ struct Parser {
     uint32_t fetched;               // parser records of positions < fetched are in LDS
     uint32_t t_out_seen;
     bool tab_dirty;
+    bool quiet = false, quiet_abort = false;   // (simulation experiments: a parse whose progress is not published and that never waits)
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
     unsigned long long n_steps, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_fetch;
+#ifdef NLZM_PROFILE
+    unsigned long long pf[8], pf_t;
+    XW_FN void pmark(int k) { const unsigned long long t = xw::tick(); pf[k] += t - pf_t; pf_t = t; }
+#else
+    XW_FN void pmark(int) {}
+#endif
 
     XW_FN PLds *L() const { return xw::lds<PLds>(); }
     XW_FN void fail(uint32_t code, uint32_t info)
@@ -1091,6 +1104,11 @@ struct Parser {
         // need: records of positions < need must be there; limit: fetch no further (ring of 128 positions in LDS)
         while ((int32_t)(fetched - need) < 0) {
             if ((int32_t)(t_out_seen - fetched) <= 0) {
+                if (quiet) {                                        // (an experiment's parse never waits)
+                    t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                    if ((int32_t)(t_out_seen - fetched) <= 0) { quiet_abort = true; return false; }
+                    continue;
+                }
                 const unsigned long long tw = xw::tick();
                 if (!wait_word_ge(&V.hx->t_out, fetched + 1, V.hx, 4)) { err = kErrInternal + 100; return false; }
                 t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
@@ -1114,7 +1132,7 @@ struct Parser {
             }
             fetched = hi;
             xw::wave_sync();
-            if (xw::lane() == 0) xw::st_agent(&V.hx->p_pos, cur);     // (the ring slots of positions >= cur may still be read: resample)
+            if (xw::lane() == 0 && !quiet) xw::st_agent(&V.hx->p_pos, cur);     // (the ring slots of positions >= cur may still be read: resample)
             t_fetch += xw::tick() - tf;
         }
         return true;
@@ -1205,7 +1223,7 @@ struct Parser {
         uint32_t c_prev = 0, l_prev = 0;                            // cost of node f-1 and price of its literal edge
         uint32_t rp0 = rep0, rp1 = rep1, rp2 = rep2, rp3 = rep3;   // rep set of node f-1 (node 0: the model's, :1476)
         uint32_t lit_prev = 0;
-        if (i == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
+        if (i == 0 && !quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         xw::wave_sync();
         for (;;) {
             n_steps++;
@@ -1214,6 +1232,7 @@ struct Parser {
             if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "P step seg %u f %u end %u\n", seg_a, f, end_p);
 #endif
             const bool lastA = f >= end_p;                           // node f is the segment's last node: no edges leave it
+            pmark(7);
             if (!lastA && !fetch(aA + 1, aA + 128 - 2, aA)) return 0;
             // position f+1 is taken along if it exists (a node f+1 beyond the cut has no edges) and its record is out already:
             // the stages before this one may be waiting for what THIS node shows (the segment of a nice region, :1529)
@@ -1223,6 +1242,7 @@ struct Parser {
                 if ((int32_t)(t_out_seen - (aA + 2)) >= 0) { if (!fetch(aA + 2, aA + 128 - 2, aA)) return 0; }
                 else haveB = false;
             }
+            pmark(0);
             // ---- finalise nodes f and f+1
             const unsigned long long kA = f ? xw::readfirst64(L()->mkey[f & 511u]) : 0ull;
             const unsigned long long kB = xw::readfirst64(L()->mkey[(f + 1) & 511u]);
@@ -1283,6 +1303,7 @@ struct Parser {
             node_set(f + 1, srcB, rankB, litA, a0r, a1r, a2r, a3r, rankB == kRankLit, b0r, b1r, b2r, b3r);
             xw::wave_sync();
 
+            pmark(1);
             // ---- the edges: lanes 0..31 node A, lanes 32..63 node B
             const bool isB = i >= 32;
             const uint32_t k = i & 31u;
@@ -1320,7 +1341,9 @@ struct Parser {
             const uint32_t chk = isB ? checkedB : checkedA;
             const bool pwant = k < 4 && (isB ? haveB : true) && !((chk >> k) & 1u) && pr < seg_q + node;      // :1601
             const uint32_t pcap = umin(max_parse - node, kMatchMax);                        // :1605-1606
+            pmark(2);
             const uint32_t pl = probe_len(pwant, aN, pr, pcap);
+            pmark(3);
             const bool pok = pwant && pl >= match_min(pr);                                  // :1607
             // end_p (:1550-1554, :1608-1612)
             uint32_t reachA = f + max_lenA, reachB = f + 1 + max_lenB;
@@ -1336,9 +1359,10 @@ struct Parser {
             if (pwant && (!isB || liveB)) n_cmp += pl + (pl < pcap);
             const uint32_t e2 = liveB ? umax(e1, reachB) : e1;
             for (uint32_t t = end_p + 1 + i; t <= e2; t += 64) L()->mkey[t & 511u] = kKeyNone;   // (:1552-1553)
-            if (e2 != end_p && i == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + e2));
+            if (e2 != end_p && i == 0 && !quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + e2));
             end_p = e2;
             xw::wave_sync();
+            pmark(4);
             // relax (:1566-1595, :1614-1625)
             const uint32_t cN = isB ? cB : cA;
             if (valid && (!isB || liveB)) {
@@ -1355,6 +1379,7 @@ struct Parser {
                 xw::lds_min64(&L()->mkey[(node + pl) & 511u], ((unsigned long long)(cN + wr) << 32) | (node << 8) | (kRankProbe + k));
             }
             xw::wave_sync();
+            pmark(5);
             if (liveB) {
                 f += 2;
                 c_prev = cB; l_prev = price_literal(litB); lit_prev = litB;
@@ -1396,7 +1421,51 @@ struct Parser {
         while (p < p_end && !err) {
             uint32_t ncmds = 0;
             const uint32_t seg_a = (uint32_t)chunk_abs + p;
+#ifdef NLZM_SIM
+            // experiment: would this segment's command list come out the same under the model as it was k
+            // segments ago?  (true rep set, stale prices)
+            static int stale_k = getenv("NLZM_SIM_STALE") ? atoi(getenv("NLZM_SIM_STALE")) : 0;
+            static uint16_t hist[1024][kNumCtx * 16];
+            static unsigned long long seg_no = 0, same = 0, tried = 0, same_pos = 0, tried_pos = 0;
+            uint32_t s_len = 0, s_n = 0;
+            static uint32_t s_cmd[3 * (kParseMax + 2)];
+            if (stale_k) {
+                if (xw::lane() == 0) memcpy(hist[seg_no & 1023], L()->price, sizeof hist[0]);
+                xw::wave_sync();
+                if (seg_no >= (unsigned long long)stale_k) {
+                    if (xw::lane() == 0) memcpy(L()->price, hist[(seg_no - stale_k) & 1023], sizeof hist[0]);
+                    xw::wave_sync();
+                    tab_dirty = true;
+                    quiet = true; quiet_abort = false;
+                    s_len = parse_segment(seg_a, p_end - p, s_n);
+                    quiet = false;
+                    if (quiet_abort) { err = 0; s_len = 0; }
+                    fetched = seg_a; t_out_seen = seg_a;            // (the records in LDS are re-read: the experiment ran ahead in the ring)
+                    if (xw::lane() == 0) {
+                        for (uint32_t k = 0; k < s_n; k++) { const uint32_t node = L()->cmdlist[k]; s_cmd[3 * k] = node; s_cmd[3 * k + 1] = L()->node_link[node]; s_cmd[3 * k + 2] = L()->node_delta[node]; }
+                        memcpy(L()->price, hist[seg_no & 1023], sizeof hist[0]);
+                    }
+                    xw::wave_sync();
+                    tab_dirty = true;
+                }
+            }
+#endif
             const uint32_t len = parse_segment(seg_a, p_end - p, ncmds);
+#ifdef NLZM_SIM
+            if (stale_k && xw::lane() == 0) {
+                if (seg_no >= (unsigned long long)stale_k && s_len) {
+                    bool eq = s_len == len && s_n == ncmds;
+                    for (uint32_t k = 0; eq && k < ncmds; k++) {
+                        const uint32_t node = L()->cmdlist[k];
+                        eq = s_cmd[3 * k] == node && s_cmd[3 * k + 1] == L()->node_link[node] && s_cmd[3 * k + 2] == L()->node_delta[node];
+                    }
+                    tried++; same += eq; tried_pos += len; same_pos += eq ? len : 0;
+                }
+                seg_no++;
+                if ((seg_no & 4095) == 0 || p + len >= p_end)
+                    fprintf(stderr, "stale %d: %llu of %llu segments the same (%.2f%%), %.2f%% of positions\n", stale_k, same, tried, 100.0 * same / (tried ? tried : 1), 100.0 * same_pos / (tried_pos ? tried_pos : 1));
+            }
+#endif
             if (err) break;
             n_seg++;
             const unsigned long long te = xw::tick();
@@ -1447,6 +1516,10 @@ struct Parser {
         fetched = (uint32_t)((unsigned long long)c0 * g.chunk_size); t_out_seen = fetched;
         n_steps = n_eq_fill = n_eq_rounds = n_cmp = n_redo = 0; t_wait = t_emit = t_fetch = 0;
         const unsigned long long t_start = xw::tick();
+#ifdef NLZM_PROFILE
+        for (int k = 0; k < 8; k++) pf[k] = 0;
+        pf_t = t_start;
+#endif
         xw::wave_sync();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk(ci);
@@ -1462,6 +1535,9 @@ struct Parser {
             P->cnt.cmp_bytes += n_cmp;
             P->prof[8] += n_steps; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo;
             P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_fetch;
+#ifdef NLZM_PROFILE
+            for (int k = 0; k < 8; k++) P->prof[24 + k] += pf[k];
+#endif
             const uint32_t xe = xw::ld_agent(&V.hx->err);
             if (xe && !P->error) P->error = xe;
             if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
