@@ -444,16 +444,13 @@ int refresh_stats(Ctx &C)
     if (getenv("NLZM_WAIT_PRINT")) {
         // per-stage accounting of the three-stage pipeline (Persist::prof, filled by nlzm_v2.h)
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
-        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (emit %.0f, record fetch %.0f)\n",
-                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[22] / n, P.prof[23] / n);
+        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (block set-up %.0f, passes %.0f, emit %.0f)\n",
+                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[24] / n, P.prof[22] / n);
         fprintf(stderr, "finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
                 P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
-        fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu steps (%.2f nodes each), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
-                P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11]);
-        if (P.prof[24] + P.prof[25])
-            fprintf(stderr, "parser step sections (cycles/position, profile build): fetch %.0f, finalise %.0f, edges + rep match %.0f, probes %.0f, end + open %.0f, relax %.0f, "
-                            "between steps (segment set-up, backtrack, emit) %.0f\n", P.prof[24] / n, P.prof[25] / n, P.prof[26] / n, P.prof[27] / n, P.prof[28] / n,
-                    P.prof[29] / n, P.prof[31] / n);
+        fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
+                P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
+                (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
     }
     if (C.workers) {
         WorkerCounters wc;

@@ -933,27 +933,42 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 // =================================================================================================
 // parser stage
 // =================================================================================================
-// parse_table (:1464-1651) visits the nodes of a segment in order; node p takes, in this order, the literal edge of
-// p-1 and then relaxes its own sampled-length edges (dict, then rep where the distance is in the node's rep set) and
-// its explicit rep probes, all with strict '>'.  For a target node the candidates therefore arrive ordered by
-// (source, rank inside the source) and the first of the cheapest wins: the winner is the minimum of
-// key = cost << 32 | source << 8 | rank.  Every edge of a node ends >= 2 further on, so when nodes < f are done the
-// nodes f and f+1 are complete up to the literal edge between them: a step finalises BOTH (their keys out of LDS,
-// the literal edges in registers), then lanes 0..31 relax the edges of f and lanes 32..63 those of f+1 with one
-// 64-bit LDS atomic min each.
+// parse_table (:1464-1651) visits the nodes of a segment in order; node p takes the literal edge of p-1, then relaxes
+// its own sampled-length edges (dict, then rep where the distance is in the node's rep set) and its explicit rep
+// probes, all with strict '>'.  For a target node the candidates therefore arrive ordered by (source, rank inside the
+// source) and the first of the cheapest wins: the winner is the minimum of key = cost << 32 | source << 8 | rank.
+//
+// The state of node t (cost, winning edge, rep set, inside the segment or not) is a function of the states of the
+// nodes < t alone, so the segment's states are the unique fixed point of "recompute every node from the others".
+// A block of up to 64 nodes is iterated to that fixed point with the lanes as NODES (Jacobi passes):
+//   push    every node relaxes its edges from its state of the previous pass: 64-bit LDS atomic min per edge, the
+//           sampled edges split over three waves, the explicit rep probes on a fourth;
+//   update  keys -> costs through the literal edges by a (min,+) prefix scan, membership by a prefix max of the
+//           edges' reach, rep sets from the winners' sources;
+// until a pass changes nothing.  A node is right after pass k if its winner chain has at most k match edges inside
+// the block; literal runs cost no pass.  Then the block's edges that end beyond it are merged into the keys of the
+// nodes to come, and the next block starts.
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
+constexpr uint32_t kSrcNone = 0x1FFF;
 constexpr uint32_t kEqSlots = 256;
+constexpr uint32_t kPushWaves = 3;              // waves 0..2 relax the sampled edges (edge k on wave k % 3), wave 3 the rep probes
+constexpr uint32_t kEdgesPerWave = (kMaxEdges + kPushWaves - 1) / kPushWaves;
+constexpr uint32_t kParserThreads = 256;
+constexpr uint32_t kInf = 0x3FFFFFFFu;
 
 struct PLds {
-    unsigned long long mkey[512];               // best key of node n at [n & 511]
+    unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
+    unsigned long long mcur[2][512];            // ... over the edges of the block being iterated (this pass / being cleared)
+    unsigned long long nkey[512];               // winner of node n (state of the last pass; final once its block is done)
     unsigned long long eq_mask[kEqSlots];       // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
     uint32_t eq_r[kEqSlots], eq_b[kEqSlots];
     uint32_t nrep[512 * 4];                     // rep set of node n (CarriedState ring, :1460-1467)
     uint32_t ncost[512];
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
-    uint32_t attr[128 * kMaxEdges];             // their attribute words, positions fetched ahead (a & 127)
-    uint32_t hdr[128];                          // header word of the fetched positions
+    uint32_t reach[64];                         // per lane of the block: furthest node an edge of the node ends at
+    uint32_t live[64];                          // per lane: the node has edges (it lies inside the segment)
+    uint32_t sh[16];                            // wave 0 -> all: 0 block size, 1 pass changed something, 2 segment length (0: goes on), 3 records out, 4 error
     uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22
     uint32_t node_delta[kParseMax + 2];         // distance (dict), rep index (rep), the byte (literal)
     uint16_t cmdlist[kParseMax + 2];
@@ -972,7 +987,6 @@ struct Parser {
     GlobalsV2 V;
     uint32_t base;                  // absolute offset of rebased 0
     uint32_t rep0, rep1, rep2, rep3;   // live model rep set
-    uint32_t fetched;               // parser records of positions < fetched are in LDS
     uint32_t t_out_seen;
     bool tab_dirty;
     bool quiet = false, quiet_abort = false;   // (simulation experiments: a parse whose progress is not published and that never waits)
@@ -980,24 +994,17 @@ struct Parser {
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
-    unsigned long long n_steps, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_fetch;
-#ifdef NLZM_PROFILE
-    unsigned long long pf[8], pf_t;
-    XW_FN void pmark(int k) { const unsigned long long t = xw::tick(); pf[k] += t - pf_t; pf_t = t; }
-#else
-    XW_FN void pmark(int) {}
-#endif
+    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_setup, t_pass;
 
     XW_FN PLds *L() const { return xw::lds<PLds>(); }
     XW_FN void fail(uint32_t code, uint32_t info)
     {
         err = code;
-        if (xw::lane() == 0) {
+        if (xw::thread() == 0) {
             G.persist->error = code; G.persist->error_info[0] = info; G.persist->error_info[1] = 13;
             xw::st_agent(&V.hx->err, code);
         }
     }
-    XW_FN void cnt_add(unsigned long long *p, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(p, v); }
     XW_FN uint32_t price(uint32_t ctx, uint32_t y) const { return L()->price[ctx * 16 + y]; }
     XW_FN uint32_t price_len(uint32_t lv) const                     // :1214-1225
     {
@@ -1005,25 +1012,22 @@ struct Parser {
         if (lv >= 7) { const uint32_t e = lv - 7; c += price(kCtxLenExtHi, e >> 4) + price(kCtxLenExtLo + (e >> 4), e & 15); }
         return c;
     }
-    XW_FN uint32_t price_literal(uint32_t y) const                  // :1418-1426
-    {
-        return xw::readfirst(price(kCtxCmd, 0) + price(kCtxLitHi, y >> 4) + price(kCtxLitLo + (y >> 4), y & 15));
-    }
-    // per-model price tables of the match edges, rebuilt after an emit touched a length or distance context
+    // per-model price tables of the match edges, rebuilt (by every thread of the stage) after an emit touched a length or
+    // distance context.  Ends with a workgroup barrier either way.
     XW_FN void seg_tables()
     {
-        if (!tab_dirty) return;
-        xw::wave_sync();
-        for (uint32_t lv = xw::lane(); lv <= kMatchMax; lv += 64) L()->len_price[lv] = (uint16_t)price_len(lv);
-        for (uint32_t k = xw::lane(); k < 4 * 64; k += 64) {
-            const uint32_t lc = k >> 6, slot = k & 63;
-            L()->slot_price[k] = slot < 56 ? (uint16_t)(price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7)) : 0;
+        const uint32_t dirty = L()->sh[5];
+        if (dirty) {
+            for (uint32_t lv = xw::thread(); lv <= kMatchMax; lv += kParserThreads) L()->len_price[lv] = (uint16_t)price_len(lv);
+            for (uint32_t k = xw::thread(); k < 4 * 64; k += kParserThreads) {
+                const uint32_t lc = k >> 6, slot = k & 63;
+                L()->slot_price[k] = slot < 56 ? (uint16_t)(price(kCtxSlotHi + lc, slot >> 3) + price(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7)) : 0;
+            }
         }
-        xw::wave_sync();
-        tab_dirty = false;
+        xw::block_sync();
     }
 
-    // ---- symbol output (WriteRange/WriteBits + cdf_update), as in the reference's model_encode_* ------------------
+    // ---- symbol output (WriteRange/WriteBits + cdf_update), as in the reference's model_encode_* (wave 0) -----------
     // Up to 8 symbols of DISTINCT contexts go through their nibble CDFs together, four per pass on sixteen lanes each:
     // lane i of a group holds cell[i] and cell[i+1]; (start, freq) snapshot (:559-572), adaptation
     // cell[i] += (mixin[y][i] - cell[i]) >> 7 with mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298, :348-382),
@@ -1098,54 +1102,15 @@ struct Parser {
         put_bits(idx, 2);
     }
 
-    // ---- records of the table stage into LDS: positions [fetched, upto) ------------------------------------------
-    XW_FN bool fetch(uint32_t need, uint32_t limit, uint32_t cur)
-    {
-        // need: records of positions < need must be there; limit: fetch no further (ring of 128 positions in LDS)
-        while ((int32_t)(fetched - need) < 0) {
-            if ((int32_t)(t_out_seen - fetched) <= 0) {
-                if (quiet) {                                        // (an experiment's parse never waits)
-                    t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
-                    if ((int32_t)(t_out_seen - fetched) <= 0) { quiet_abort = true; return false; }
-                    continue;
-                }
-                const unsigned long long tw = xw::tick();
-                if (!wait_word_ge(&V.hx->t_out, fetched + 1, V.hx, 4)) { err = kErrInternal + 100; return false; }
-                t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
-                t_wait += xw::tick() - tw;
-            }
-            const unsigned long long tf = xw::tick();
-            uint32_t hi = fetched + 64;
-            if ((int32_t)(hi - t_out_seen) > 0) hi = t_out_seen;
-            if ((int32_t)(hi - limit) > 0) hi = limit;
-            const uint32_t a = fetched + xw::lane();
-            if ((int32_t)(a - hi) < 0) {
-                const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-                const unsigned long long h = xw::ld_agent64((const unsigned long long *)rec);
-                const uint32_t ne = (uint32_t)h & 63u;
-                L()->hdr[a & 127u] = (uint32_t)h;
-                for (uint32_t k = 0; k < ne; k++) {
-                    const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
-                    L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)e;
-                    L()->attr[(a & 127u) * kMaxEdges + k] = (uint32_t)(e >> 32);
-                }
-            }
-            fetched = hi;
-            xw::wave_sync();
-            if (xw::lane() == 0 && !quiet) xw::st_agent(&V.hx->p_pos, cur);     // (the ring slots of positions >= cur may still be read: resample)
-            t_fetch += xw::tick() - tf;
-        }
-        return true;
-    }
-
     // The segment is within 264 of its forced cut (:1469): the sampled lengths of position a change with the smaller
-    // max_len (:1545, :1558-1560).  Re-list them from the position's front (lanes = samples).
+    // max_len (:1545, :1558-1560).  Re-listed from the position's front into its ring record (lanes = samples; the
+    // record is this stage's until p_pos passes it).
     XW_FN void resample(uint32_t a, uint32_t max_len)
     {
         n_redo++;
-        const uint32_t h = xw::readfirst(L()->hdr[a & 127u]);
-        const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-        const uint32_t fn = xw::readfirst(xw::ld_agent(rec + 1));
+        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        const unsigned long long h = xw::readfirst64(xw::ld_agent64((const unsigned long long *)rec));
+        const uint32_t fn = (uint32_t)(h >> 32);
         const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
         uint32_t step = (max_len - kMatchMin) >> 4;
         step += step == 0;
@@ -1163,16 +1128,16 @@ struct Parser {
             uint32_t nx, ex;
             const uint32_t slot = dist_slot(d - 1, nx, ex);
             const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
-            L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
-            L()->attr[(a & 127u) * kMaxEdges + k] = tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31);
+            xw::st_agent64((unsigned long long *)(rec + 2 + 2 * k),
+                           (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32));
         }
-        if (k == 0) L()->hdr[a & 127u] = (h & ~63u) | ne;
-        xw::wave_sync();
+        if (k == 0) xw::st_agent64((unsigned long long *)rec, (h & ~63ull) | ne);
+        xw::drain();
     }
 
     // ---- explicit rep probes (:1598-1628): match length of (position a, distance r), at most c bytes ----------------
     // Lanes with `want` ask; byte equality comes from the mask cache (one 64-byte block of the input against itself r
-    // bytes earlier per entry), filled for every lane that misses by the whole wave.
+    // bytes earlier per entry), filled for every lane that misses by the whole wave.  (Probe wave only.)
     XW_FN uint32_t probe_len(bool want, uint32_t a, uint32_t r, uint32_t c)
     {
         uint32_t len = 0;
@@ -1209,200 +1174,345 @@ struct Parser {
         return len;
     }
 
-    // ---- one parse segment: nodes 0.. of positions seg_a.. ; returns its length, path in cmdlist (ncmds, end first) ---
+    // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171); also what the emitter needs
+    // of the winner: cmd, length, distance / rep index / byte
+    XW_FN void winner_set(uint32_t seg_a, uint32_t node, unsigned long long key, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3,
+                          uint32_t &link, uint32_t &delta) const
+    {
+        const uint32_t src = (uint32_t)(key >> 8) & 0xFFFFFFu, rank = (uint32_t)key & 0xFFu;
+        if (src == kSrcNone) { o0 = rep0; o1 = rep1; o2 = rep2; o3 = rep3; link = kSrcNone; delta = 0; return; }   // node 0 (:1476)
+        const uint32_t *sr = L()->nrep + (src & 511u) * 4;
+        const uint32_t s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+        o0 = s0; o1 = s1; o2 = s2; o3 = s3;
+        uint32_t cmd = 0, len = 0;
+        delta = 0;
+        if (rank != kRankLit) {
+            len = node - src;
+            if (rank >= kRankProbe) { cmd = 2; delta = rank - kRankProbe; }
+            else {
+                const uint32_t d = L()->edge_d[((seg_a + src) & 511u) * kMaxEdges + (rank >> 1)];
+                if (rank & 1u) { cmd = 2; delta = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
+                else {
+                    cmd = 1; delta = d;
+                    if (!(d == s0 || d == s1 || d == s2 || d == s3)) { o0 = d; o1 = s0; o2 = s1; o3 = s2; }
+                }
+            }
+        }
+        link = src | (len << 13) | (cmd << 22);
+    }
+
+    // ---- one parse segment: nodes 0.. of positions seg_a.. (every thread of the stage); returns its length, the path
+    // in cmdlist (ncmds entries, end first)
     XW_FN uint32_t parse_segment(uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
     {
         max_parse = umin(max_parse, kParseMax);
-        const uint32_t i = xw::lane();
+        const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
+        if (tid == 0) L()->sh[5] = tab_dirty ? 1u : 0u;
+        xw::block_sync();
         seg_tables();
-        const uint32_t pc_dict = xw::readfirst(price(kCtxCmd, 1)), pc_rep = xw::readfirst(price(kCtxCmd, 2));
+        tab_dirty = false;
+        const uint32_t pc_dict = price(kCtxCmd, 1), pc_rep = price(kCtxCmd, 2), pc_lit = price(kCtxCmd, 0);
         // node 0 (:1472-1482)
-        if (i == 0) { L()->mkey[0] = 0; L()->mkey[1] = kKeyNone; L()->node_link[0] = 0x1FFF; }
-        uint32_t end_p = 1, f = 0;
-        uint32_t c_prev = 0, l_prev = 0;                            // cost of node f-1 and price of its literal edge
-        uint32_t rp0 = rep0, rp1 = rep1, rp2 = rep2, rp3 = rep3;   // rep set of node f-1 (node 0: the model's, :1476)
-        uint32_t lit_prev = 0;
-        if (i == 0 && !quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
-        xw::wave_sync();
-        for (;;) {
-            n_steps++;
-            const uint32_t aA = seg_a + f;
-#ifdef NLZM_SIM
-            if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "P step seg %u f %u end %u\n", seg_a, f, end_p);
-#endif
-            const bool lastA = f >= end_p;                           // node f is the segment's last node: no edges leave it
-            pmark(7);
-            if (!lastA && !fetch(aA + 1, aA + 128 - 2, aA)) return 0;
-            // position f+1 is taken along if it exists (a node f+1 beyond the cut has no edges) and its record is out already:
-            // the stages before this one may be waiting for what THIS node shows (the segment of a nice region, :1529)
-            bool haveB = !lastA && f + 1 < max_parse;
-            if (haveB && (int32_t)(fetched - (aA + 2)) < 0) {
-                if ((int32_t)(t_out_seen - (aA + 2)) < 0) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
-                if ((int32_t)(t_out_seen - (aA + 2)) >= 0) { if (!fetch(aA + 2, aA + 128 - 2, aA)) return 0; }
-                else haveB = false;
-            }
-            pmark(0);
-            // ---- finalise nodes f and f+1
-            const unsigned long long kA = f ? xw::readfirst64(L()->mkey[f & 511u]) : 0ull;
-            const unsigned long long kB = xw::readfirst64(L()->mkey[(f + 1) & 511u]);
-            const uint32_t hA = lastA ? 0u : xw::readfirst(L()->hdr[aA & 127u]);
-            const uint32_t hB = haveB ? xw::readfirst(L()->hdr[(aA + 1) & 127u]) : 0u;
-            const uint32_t litA = (hA >> 8) & 0xFFu, litB = (hB >> 8) & 0xFFu;
-            const uint32_t lA = lastA ? 0u : price_literal(litA);
-            // node A
-            uint32_t cA, srcA, rankA;
-            if (f == 0) { cA = 0; srcA = 0x1FFF; rankA = 0; }
-            else {
-                const uint32_t mc = (uint32_t)(kA >> 32);
-                if (mc > c_prev + l_prev) { cA = c_prev + l_prev; srcA = f - 1; rankA = kRankLit; }     // :1492 (the literal edge comes last: strict)
-                else { cA = mc; srcA = (uint32_t)(kA >> 8) & 0xFFFFFFu; rankA = (uint32_t)kA & 0xFFu; }
-            }
-            // node B (its in-edges from f-1 and before are in; the literal edge of A in registers)
-            uint32_t cB, srcB, rankB;
-            {
-                const uint32_t mc = (uint32_t)(kB >> 32);
-                if (mc > cA + lA) { cB = cA + lA; srcB = f; rankB = kRankLit; }
-                else { cB = mc; srcB = (uint32_t)(kB >> 8) & 0xFFFFFFu; rankB = (uint32_t)kB & 0xFFu; }
-            }
-            // rep sets: of the source, plus the distance of a dict edge (RepModel::Add, :1160-1171)
-            auto node_set = [&](uint32_t node, uint32_t src, uint32_t rank, uint32_t lit_byte, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
-                                bool src_in_regs, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) __attribute__((always_inline)) {
-                uint32_t s0 = q0, s1 = q1, s2 = q2, s3 = q3;
-                if (!src_in_regs) {
-                    const uint32_t *sr = L()->nrep + (src & 511u) * 4;
-                    s0 = xw::readfirst(sr[0]); s1 = xw::readfirst(sr[1]); s2 = xw::readfirst(sr[2]); s3 = xw::readfirst(sr[3]);
+        if (tid == 0) {
+            L()->mprev[0] = ((unsigned long long)kSrcNone << 8) | kRankLit;
+            L()->mprev[1] = kKeyNone;
+            L()->node_link[0] = kSrcNone;
+            if (!quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
+        }
+        uint32_t end_p = 1, end_open = 1, b0 = 0;
+        uint32_t seg_len = 0;
+        xw::block_sync();
+        while (!seg_len) {
+            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
+            const unsigned long long ts = xw::tick();
+            if (b0 == end_p || b0 >= max_parse) {
+                // node b0 is the segment's last node: no edges leave it; its key is complete
+                if (tid == 0) {
+                    uint32_t r0, r1, r2, r3, link, delta;
+                    const unsigned long long k = L()->mprev[b0 & 511u];
+                    winner_set(seg_a, b0, k, r0, r1, r2, r3, link, delta);
+                    if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[6];      // the byte of position b0 - 1
+                    L()->node_link[b0] = link; L()->node_delta[b0] = delta;
                 }
-                uint32_t cmd = 0, delta = lit_byte, len = 0;
-                o0 = s0; o1 = s1; o2 = s2; o3 = s3;
-                if (rank != kRankLit) {
-                    len = node - src;
-                    if (rank >= kRankProbe) { cmd = 2; delta = rank - kRankProbe; }
-                    else {
-                        const uint32_t d = xw::readfirst(L()->edge_d[((seg_a + src) & 511u) * kMaxEdges + (rank >> 1)]);
-                        if (rank & 1u) { cmd = 2; delta = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
-                        else {
-                            cmd = 1; delta = d;
-                            if (!(d == s0 || d == s1 || d == s2 || d == s3)) { o0 = d; o1 = s0; o2 = s1; o3 = s2; }
+                seg_len = b0;
+                break;
+            }
+            if (w == 0) {
+                const uint32_t a_first = seg_a + b0;
+                if ((int32_t)(t_out_seen - (a_first + 1)) < 0) {
+                    if (quiet) {
+                        t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                        if ((int32_t)(t_out_seen - (a_first + 1)) < 0) quiet_abort = true;
+                    } else {
+                        const unsigned long long tw = xw::tick();
+                        if (!wait_word_ge(&V.hx->t_out, a_first + 1, V.hx, 4)) err = kErrInternal + 100;
+                        t_wait += xw::tick() - tw;
+                    }
+                }
+                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err && !quiet_abort) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                uint32_t nb = umin(64u, max_parse - b0);
+                if ((int32_t)(t_out_seen - (a_first + nb)) < 0) nb = t_out_seen - a_first;
+                if (i == 0) {
+                    L()->sh[0] = nb; L()->sh[4] = err | (quiet_abort ? 0x80000000u : 0u);
+                    if (!quiet) xw::st_agent(&V.hx->p_pos, a_first);
+                }
+            }
+            xw::block_sync();
+            const uint32_t nb = L()->sh[0];
+            if (L()->sh[4]) { if (L()->sh[4] & 0x80000000u) quiet_abort = true; else err = kErrInternal + 100; return 0; }
+            const bool inb = i < nb;
+            const uint32_t node = b0 + i, a = seg_a + node;
+            // within 264 of the forced cut the table is cut short (:1545): such records are re-listed first
+            if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax) {
+                if (w == 3) {
+                    const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+                    const uint32_t h0 = inb ? xw::ld_agent(rec) : 0u;
+                    const uint32_t ml = (h0 & 63u) ? (xw::ld_agent(rec + 3) & 0x1FFu) : 0u;
+                    for (unsigned long long m = xw::ballot(inb && ml > max_parse - node); m; m &= m - 1) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        resample(seg_a + b0 + j, max_parse - (b0 + j));
+                    }
+                }
+                xw::block_sync();
+            }
+            // ---- set-up: the block's records
+            const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+            const unsigned long long hd = inb ? xw::ld_agent64((const unsigned long long *)rec) : 0ull;
+            const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
+            uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // push waves: this wave's edges of the node (distance; length | price words)
+            uint32_t uniq = 0;                                      // probe wave: the valid edges that are the first of their distance
+            uint32_t litw = 0, max_len = 0;
+            if (w < kPushWaves) {
+#pragma unroll
+                for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                    const uint32_t k = w + kPushWaves * j;
+                    ed[j] = 0; ea[j] = 0;
+                    if (k < ne) {
+                        const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
+                        const uint32_t at = (uint32_t)(e >> 32);
+                        const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
+                        if (at >> 31) {
+                            const uint32_t lp = L()->len_price[lv];
+                            const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
+                            ed[j] = (uint32_t)e;
+                            ea[j] = tl | (wd << 9) | (lp << 21);    // wd < 4096, lp < 2048
                         }
                     }
                 }
-                if (i == 0) {
-                    L()->node_link[node] = src | (len << 13) | (cmd << 22);
-                    L()->node_delta[node] = delta;
-                    uint32_t *dr = L()->nrep + (node & 511u) * 4;
-                    dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3;
-                }
-            };
-            uint32_t a0r, a1r, a2r, a3r, b0r, b1r, b2r, b3r;
-            if (f == 0) {
-                a0r = rp0; a1r = rp1; a2r = rp2; a3r = rp3;
-                if (i == 0) { uint32_t *dr = L()->nrep; dr[0] = a0r; dr[1] = a1r; dr[2] = a2r; dr[3] = a3r; }
-            } else node_set(f, srcA, rankA, lit_prev, rp0, rp1, rp2, rp3, rankA == kRankLit, a0r, a1r, a2r, a3r);
-            if (lastA) { f = end_p; break; }
-            node_set(f + 1, srcB, rankB, litA, a0r, a1r, a2r, a3r, rankB == kRankLit, b0r, b1r, b2r, b3r);
-            xw::wave_sync();
-
-            pmark(1);
-            // ---- the edges: lanes 0..31 node A, lanes 32..63 node B
-            const bool isB = i >= 32;
-            const uint32_t k = i & 31u;
-            const uint32_t node = isB ? f + 1 : f, aN = seg_a + node;
-            // within 264 of the forced cut the table is cut short (:1545)
-            {
-                const uint32_t mlA = (hA & 63u) ? (xw::readfirst(L()->attr[(aA & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
-                if (mlA > max_parse - f) resample(aA, max_parse - f);
-                if (haveB) {
-                    const uint32_t mlB = (hB & 63u) ? (xw::readfirst(L()->attr[((aA + 1) & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
-                    if (mlB > max_parse - f - 1) resample(aA + 1, max_parse - f - 1);
-                }
-            }
-            const uint32_t neA = xw::readfirst(L()->hdr[aA & 127u]) & 63u, neB = haveB ? xw::readfirst(L()->hdr[(aA + 1) & 127u]) & 63u : 0u;
-            const uint32_t ne = isB ? neB : neA;
-            const bool have = k < ne;
-            const uint32_t ed = have ? L()->edge_d[(aN & 511u) * kMaxEdges + k] : 0u;
-            const uint32_t ea = have ? L()->attr[(aN & 127u) * kMaxEdges + k] : 0u;
-            const bool valid = have && (ea >> 31);
-            const uint32_t tl = ea & 0x1FFu, lv = (ea >> 9) & 0x1FFu, slot = (ea >> 18) & 63u, nx = (ea >> 24) & 31u;
-            const uint32_t r0 = isB ? b0r : a0r, r1 = isB ? b1r : a1r, r2 = isB ? b2r : a2r, r3 = isB ? b3r : a3r;
-            // GetMatch (:1173-1181): the first slot that holds the distance
-            const uint32_t ridx = !valid ? 4u : (ed == r0 ? 0u : (ed == r1 ? 1u : (ed == r2 ? 2u : (ed == r3 ? 3u : 4u))));
-            uint32_t checkedA = 0, checkedB = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const unsigned long long bm = xw::ballot(ridx == j);
-                if ((uint32_t)bm) checkedA |= 1u << j;
-                if ((uint32_t)(bm >> 32)) checkedB |= 1u << j;
-            }
-            const uint32_t max_lenA = neA ? (xw::readfirst(L()->attr[(aA & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
-            const uint32_t max_lenB = neB ? (xw::readfirst(L()->attr[((aA + 1) & 127u) * kMaxEdges]) & 0x1FFu) : 0u;
-            // explicit probes of the rep slots no sampled edge has met (:1598-1628): lanes 0..3 (A) and 32..35 (B)
-            const uint32_t pr = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
-            const uint32_t chk = isB ? checkedB : checkedA;
-            const bool pwant = k < 4 && (isB ? haveB : true) && !((chk >> k) & 1u) && pr < seg_q + node;      // :1601
-            const uint32_t pcap = umin(max_parse - node, kMatchMax);                        // :1605-1606
-            pmark(2);
-            const uint32_t pl = probe_len(pwant, aN, pr, pcap);
-            pmark(3);
-            const bool pok = pwant && pl >= match_min(pr);                                  // :1607
-            // end_p (:1550-1554, :1608-1612)
-            uint32_t reachA = f + max_lenA, reachB = f + 1 + max_lenB;
-            {
-                const uint32_t pe = pok ? node + pl : 0u;
-                uint32_t ra = isB ? 0u : pe, rb = isB ? pe : 0u;
-                for (uint32_t d = 1; d < 4; d <<= 1) { ra = umax(ra, xw::shfl(ra, i ^ d)); rb = umax(rb, xw::shfl(rb, i ^ d)); }
-                reachA = umax(reachA, xw::readlane(ra, 0));
-                reachB = umax(reachB, xw::readlane(rb, 32));
-            }
-            const uint32_t e1 = umax(end_p, reachA);
-            const bool liveB = haveB && f + 1 < e1;
-            if (pwant && (!isB || liveB)) n_cmp += pl + (pl < pcap);
-            const uint32_t e2 = liveB ? umax(e1, reachB) : e1;
-            for (uint32_t t = end_p + 1 + i; t <= e2; t += 64) L()->mkey[t & 511u] = kKeyNone;   // (:1552-1553)
-            if (e2 != end_p && i == 0 && !quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + e2));
-            end_p = e2;
-            xw::wave_sync();
-            pmark(4);
-            // relax (:1566-1595, :1614-1625)
-            const uint32_t cN = isB ? cB : cA;
-            if (valid && (!isB || liveB)) {
-                const uint32_t lp = L()->len_price[lv];
-                const uint32_t wd = pc_dict + lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];
-                xw::lds_min64(&L()->mkey[(node + tl) & 511u], ((unsigned long long)(cN + wd) << 32) | (node << 8) | (2 * k));
-                if (ridx < 4) {
-                    const uint32_t wr = pc_rep + lp + (2u << 5);                           // :1253-1272
-                    xw::lds_min64(&L()->mkey[(node + tl) & 511u], ((unsigned long long)(cN + wr) << 32) | (node << 8) | (2 * k + 1));
-                }
-            }
-            if (pok && (!isB || liveB)) {
-                const uint32_t wr = pc_rep + L()->len_price[pl - match_min(pr)] + (2u << 5);
-                xw::lds_min64(&L()->mkey[(node + pl) & 511u], ((unsigned long long)(cN + wr) << 32) | (node << 8) | (kRankProbe + k));
-            }
-            xw::wave_sync();
-            pmark(5);
-            if (liveB) {
-                f += 2;
-                c_prev = cB; l_prev = price_literal(litB); lit_prev = litB;
-                rp0 = b0r; rp1 = b1r; rp2 = b2r; rp3 = b3r;
             } else {
-                // node f+1 is the last node of the segment (it is final already), or its record was not out yet
-                f += 1;
-                if (f >= end_p) break;
-                c_prev = cA; l_prev = lA; lit_prev = litA;
-                rp0 = a0r; rp1 = a1r; rp2 = a2r; rp3 = a3r;
+                // every edge's distance into LDS (the winners' distances are looked up there), the distinct ones marked
+                uint32_t prev = 0;
+                for (uint32_t k = 0; k < ne; k++) {
+                    const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
+                    const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32);
+                    L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
+                    if (k == 0) max_len = at & 0x1FFu;
+                    if ((at >> 31) && d != prev) uniq |= 1u << k;
+                    if (at >> 31) prev = d;
+                }
+                if (inb) { L()->reach[i] = node + max_len; L()->live[i] = 0; }
+            }
+            uint32_t S = 0;
+            if (w == 0) {
+                litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
+                uint32_t inc = litw;                                // inclusive prefix sum of the literal prices
+                for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(inc, d); if (i >= d) inc += o; }
+                S = inc - litw;                                     // S[i] = price of the literals of nodes b0 .. b0+i-1
+                if (inb) { L()->nkey[node & 511u] = kKeyNone; L()->ncost[node & 511u] = kInf; }
+                if (i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
+            }
+            // probe wave: what it measured for the node's rep slots so far
+            uint32_t mr0 = 0, mr1 = 0, mr2 = 0, mr3 = 0, ml0 = 0, ml1 = 0, ml2 = 0, ml3 = 0;
+            xw::block_sync();
+            t_setup += xw::tick() - ts;
+            const unsigned long long tp0 = xw::tick();
+            n_blocks++;
+            // ---- passes
+            uint32_t pass = 0;
+            uint32_t istar = 64, blk_end = end_p;
+            for (;;) {
+                const uint32_t q = pass & 1u;
+                n_passes++;
+                // push: from the state of the previous pass (none in the first: nothing is pushed, the update seeds node b0)
+                if (pass > 0) {
+                    const bool lv = inb && L()->live[i] != 0;
+                    const uint32_t c = L()->ncost[node & 511u];
+                    const uint32_t *nr = L()->nrep + (node & 511u) * 4;
+                    const uint32_t r0 = nr[0], r1 = nr[1], r2 = nr[2], r3 = nr[3];
+                    if (w < kPushWaves) {
+                        if (lv) {
+#pragma unroll
+                            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                                const uint32_t k = w + kPushWaves * j;
+                                if (!ea[j]) continue;
+                                const uint32_t tl = ea[j] & 0x1FFu, wd = (ea[j] >> 9) & 0xFFFu, lp = ea[j] >> 21;
+                                unsigned long long *dst = &L()->mcur[q][(node + tl) & 511u];
+                                xw::lds_min64(dst, ((unsigned long long)(c + pc_dict + wd) << 32) | (node << 8) | (2 * k));       // :1567-1577
+                                const uint32_t d = ed[j];
+                                if (d == r0 || d == r1 || d == r2 || d == r3)                                                      // :1579-1595
+                                    xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
+                            }
+                        }
+                        // the other buffer is cleared for the next pass
+                        for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) L()->mcur[q ^ 1u][(b0 + t) & 511u] = kKeyNone;
+                    } else {
+                        // explicit probes of the rep slots no sampled edge has met (:1598-1628)
+                        uint32_t checked = 0;
+                        if (lv) {
+                            for (uint32_t um = uniq; um; um &= um - 1) {
+                                const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
+                                checked |= (d == r0 ? 1u : 0u) | (d == r1 ? 2u : 0u) | (d == r2 ? 4u : 0u) | (d == r3 ? 8u : 0u);
+                            }
+                        }
+                        const uint32_t pcap = umin(max_parse - node, kMatchMax);                        // :1605-1606
+                        uint32_t far = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const uint32_t r = j == 0 ? r0 : (j == 1 ? r1 : (j == 2 ? r2 : r3));
+                            uint32_t &mr = j == 0 ? mr0 : (j == 1 ? mr1 : (j == 2 ? mr2 : mr3));
+                            uint32_t &ml = j == 0 ? ml0 : (j == 1 ? ml1 : (j == 2 ? ml2 : ml3));
+                            const bool want = lv && !((checked >> j) & 1u) && r < seg_q + node;         // :1601
+                            const bool fresh = want && mr != r;
+                            if (xw::any(fresh)) { const uint32_t l = probe_len(fresh, a, r, pcap); if (fresh) { mr = r; ml = l; } }
+                            if (want && ml >= match_min(r)) {                                           // :1607
+                                const uint32_t wr = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5);
+                                xw::lds_min64(&L()->mcur[q][(node + ml) & 511u], ((unsigned long long)(c + wr) << 32) | (node << 8) | (kRankProbe + j));
+                                far = umax(far, node + ml);
+                            }
+                        }
+                        if (inb) L()->reach[i] = umax(node + max_len, far);                             // :1550-1554, :1608-1612
+                    }
+                } else if (w < kPushWaves) {
+                    for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) { L()->mcur[0][(b0 + t) & 511u] = kKeyNone; L()->mcur[1][(b0 + t) & 511u] = kKeyNone; }
+                }
+                xw::block_sync();
+                // update (wave 0): every node of the block from the keys
+                if (w == 0) {
+                    unsigned long long kin = kKeyNone;
+                    if (inb) {
+                        if (node <= end_open) kin = L()->mprev[node & 511u];
+                        if (i >= 1 && pass > 0) { const unsigned long long kc = L()->mcur[q][node & 511u]; if (kc < kin) kin = kc; }
+                    }
+                    const uint32_t mc = kin == kKeyNone ? kInf : (uint32_t)(kin >> 32);
+                    // cost through the literal edges: c[i] = min(mc[i], c[i-1] + litw[i-1]) = S[i] + min_{j<=i} (mc[j] - S[j])
+                    int32_t v = (int32_t)mc - (int32_t)S;
+                    for (uint32_t d = 1; d < 64; d <<= 1) { const int32_t o = (int32_t)xw::shfl_up((uint32_t)v, d); if (i >= d && o < v) v = o; }
+                    const uint32_t c = (uint32_t)(v + (int32_t)S);
+                    const bool litwin = i >= 1 && c < mc;                                                // :1492 (the literal edge comes last: strict)
+                    const unsigned long long key = litwin ? (((unsigned long long)c << 32) | ((node - 1) << 8) | kRankLit) : kin;
+                    // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
+                    const uint32_t rc = inb ? L()->reach[i] : 0u;
+                    const uint32_t rlive = (inb && L()->live[i]) ? rc : 0u;       // (a node's reach counts once it pushed: it was inside in the pass before)
+                    uint32_t pm = rlive;
+                    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(pm, d); if (i >= d) pm = umax(pm, o); }
+                    uint32_t before = xw::shfl_up(pm, 1);
+                    if (i == 0) before = 0;
+                    before = umax(before, end_p);
+                    const bool inside = inb && node < before;
+                    const unsigned long long dead = xw::ballot(!inside);
+                    istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;       // (lanes >= nb count as dead)
+                    const bool act = i <= istar && inb;              // nodes b0 .. b0+istar: inside, or the segment's last node
+                    const bool lv = i < istar && inb;
+                    // rep sets from the winners (the sources' sets as of the last pass)
+                    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, link = 0, delta = 0;
+                    if (act && key != kKeyNone) winner_set(seg_a, node, key, o0, o1, o2, o3, link, delta);
+                    {   // a run of literal winners carries the set of the node in front of the run (:1498): taken from that
+                        // lane in THIS pass, so that a literal run costs no pass
+                        uint32_t root = litwin ? 0u : i;
+                        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(root, d); if (i >= d) root = umax(root, o); }
+                        const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
+                        if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
+                    }
+                    const unsigned long long okey = inb ? L()->nkey[node & 511u] : 0ull;
+                    const uint32_t *nr = L()->nrep + (node & 511u) * 4;
+                    const bool same = !act || (okey == key && nr[0] == o0 && nr[1] == o1 && nr[2] == o2 && nr[3] == o3 && (L()->live[i] != 0) == lv);
+                    xw::wave_sync();
+                    if (act) {
+                        L()->nkey[node & 511u] = key; L()->ncost[node & 511u] = c;
+                        uint32_t *dr = L()->nrep + (node & 511u) * 4;
+                        dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3;
+                    }
+                    if (inb) L()->live[i] = lv ? 1u : 0u;
+                    const bool changed = xw::any(!same);
+                    blk_end = umax(end_p, xw::readlane(pm, umin(istar, nb) ? umin(istar, nb) - 1 : 0));
+                    if (istar == 0) blk_end = end_p;
+                    if (i == 0) { L()->sh[1] = changed ? 1u : 0u; L()->sh[7] = istar; L()->sh[8] = blk_end; }
+                }
+                xw::block_sync();
+                pass++;
+                if (!L()->sh[1]) break;
+            }
+            istar = L()->sh[7]; blk_end = L()->sh[8];
+            t_pass += xw::tick() - tp0;
+            // ---- the block is at its fixed point: final nodes, the edges that end beyond it
+            const uint32_t q = (pass - 1) & 1u;                      // the buffer the last update read
+            const uint32_t done = umin(istar, nb);                   // nodes b0 .. b0+done-1 are inside
+            if (w == 0) {
+                const uint32_t lit_before = xw::shfl_up(lit, 1);     // the byte of the position before the node
+                if (i <= istar && inb) {
+                    uint32_t o0, o1, o2, o3, link, delta;
+                    const unsigned long long key = L()->nkey[node & 511u];
+                    winner_set(seg_a, node, key, o0, o1, o2, o3, link, delta);
+                    if (((uint32_t)key & 0xFFu) == kRankLit && node > 0) delta = i ? lit_before : L()->sh[9];
+                    L()->node_link[node] = link; L()->node_delta[node] = delta;
+                }
+            }
+            if (w == 3 && i < done) {                                // bytes the final probes looked at (counter parity)
+                const uint32_t *nr = L()->nrep + (node & 511u) * 4;
+                const uint32_t pcap = umin(max_parse - node, kMatchMax);
+                uint32_t checked = 0;
+                for (uint32_t um = uniq; um; um &= um - 1) {
+                    const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
+                    checked |= (d == nr[0] ? 1u : 0u) | (d == nr[1] ? 2u : 0u) | (d == nr[2] ? 4u : 0u) | (d == nr[3] ? 8u : 0u);
+                }
+                if (!(checked & 1u) && nr[0] < seg_q + node) n_cmp += ml0 + (ml0 < pcap);
+                if (!(checked & 2u) && nr[1] < seg_q + node) n_cmp += ml1 + (ml1 < pcap);
+                if (!(checked & 4u) && nr[2] < seg_q + node) n_cmp += ml2 + (ml2 < pcap);
+                if (!(checked & 8u) && nr[3] < seg_q + node) n_cmp += ml3 + (ml3 < pcap);
+            }
+            xw::block_sync();
+            if (istar < nb) {
+                seg_len = b0 + istar;                               // the segment ends inside the block
+            } else {
+                // open the nodes the block has made reachable, then merge its edges into their keys; the literal edge of the
+                // block's last node goes the same way
+                const uint32_t new_end = blk_end;
+                for (uint32_t t = end_open + 1 + tid; t <= new_end; t += kParserThreads) L()->mprev[t & 511u] = kKeyNone;
+                xw::block_sync();
+                for (uint32_t t = b0 + nb + tid; t <= new_end; t += kParserThreads) {
+                    const unsigned long long kc = L()->mcur[q][t & 511u];
+                    if (kc < L()->mprev[t & 511u]) L()->mprev[t & 511u] = kc;
+                }
+                xw::block_sync();
+                if (tid == 0) {
+                    const uint32_t last = b0 + nb - 1;
+                    const unsigned long long kl = ((unsigned long long)(L()->ncost[last & 511u] + L()->sh[10]) << 32) | (last << 8) | kRankLit;
+                    if (kl < L()->mprev[(last + 1) & 511u]) L()->mprev[(last + 1) & 511u] = kl;     // (equal cost: the smaller source wins, :1492 strict)
+                    L()->sh[9] = L()->sh[6];
+                    if (!quiet && new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
+                }
+                if (new_end > end_open) end_open = new_end;
+                end_p = new_end;
+                b0 += nb;
+                xw::block_sync();
             }
         }
+        xw::block_sync();
         // backtrack (:1633-1650): node indices of the path, end first
-        uint32_t n = 0, cur = end_p;
-        while (cur != 0) {
-            if (i == 0) L()->cmdlist[n] = (uint16_t)cur;
-            n++;
-            cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
+        uint32_t n = 0;
+        if (w == 0) {
+            uint32_t cur = seg_len;
+            while (cur != 0) {
+                if (i == 0) L()->cmdlist[n] = (uint16_t)cur;
+                n++;
+                cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
+            }
+            if (i == 0) L()->sh[11] = n;
         }
-        xw::wave_sync();
-        ncmds = n;
-        // the rep set the model ends with is the last node's (:1819, :1834 applied along the path)
-        return end_p;
+        xw::block_sync();
+        ncmds = L()->sh[11];
+        return seg_len;
     }
 
     // one chunk = one frame (:1782-1886)
@@ -1421,90 +1531,58 @@ struct Parser {
         while (p < p_end && !err) {
             uint32_t ncmds = 0;
             const uint32_t seg_a = (uint32_t)chunk_abs + p;
-#ifdef NLZM_SIM
-            // experiment: would this segment's command list come out the same under the model as it was k
-            // segments ago?  (true rep set, stale prices)
-            static int stale_k = getenv("NLZM_SIM_STALE") ? atoi(getenv("NLZM_SIM_STALE")) : 0;
-            static uint16_t hist[1024][kNumCtx * 16];
-            static unsigned long long seg_no = 0, same = 0, tried = 0, same_pos = 0, tried_pos = 0;
-            uint32_t s_len = 0, s_n = 0;
-            static uint32_t s_cmd[3 * (kParseMax + 2)];
-            if (stale_k) {
-                if (xw::lane() == 0) memcpy(hist[seg_no & 1023], L()->price, sizeof hist[0]);
-                xw::wave_sync();
-                if (seg_no >= (unsigned long long)stale_k) {
-                    if (xw::lane() == 0) memcpy(L()->price, hist[(seg_no - stale_k) & 1023], sizeof hist[0]);
-                    xw::wave_sync();
-                    tab_dirty = true;
-                    quiet = true; quiet_abort = false;
-                    s_len = parse_segment(seg_a, p_end - p, s_n);
-                    quiet = false;
-                    if (quiet_abort) { err = 0; s_len = 0; }
-                    fetched = seg_a; t_out_seen = seg_a;            // (the records in LDS are re-read: the experiment ran ahead in the ring)
-                    if (xw::lane() == 0) {
-                        for (uint32_t k = 0; k < s_n; k++) { const uint32_t node = L()->cmdlist[k]; s_cmd[3 * k] = node; s_cmd[3 * k + 1] = L()->node_link[node]; s_cmd[3 * k + 2] = L()->node_delta[node]; }
-                        memcpy(L()->price, hist[seg_no & 1023], sizeof hist[0]);
-                    }
-                    xw::wave_sync();
-                    tab_dirty = true;
-                }
-            }
-#endif
             const uint32_t len = parse_segment(seg_a, p_end - p, ncmds);
-#ifdef NLZM_SIM
-            if (stale_k && xw::lane() == 0) {
-                if (seg_no >= (unsigned long long)stale_k && s_len) {
-                    bool eq = s_len == len && s_n == ncmds;
-                    for (uint32_t k = 0; eq && k < ncmds; k++) {
-                        const uint32_t node = L()->cmdlist[k];
-                        eq = s_cmd[3 * k] == node && s_cmd[3 * k + 1] == L()->node_link[node] && s_cmd[3 * k + 2] == L()->node_delta[node];
-                    }
-                    tried++; same += eq; tried_pos += len; same_pos += eq ? len : 0;
-                }
-                seg_no++;
-                if ((seg_no & 4095) == 0 || p + len >= p_end)
-                    fprintf(stderr, "stale %d: %llu of %llu segments the same (%.2f%%), %.2f%% of positions\n", stale_k, same, tried, 100.0 * same / (tried ? tried : 1), 100.0 * same_pos / (tried_pos ? tried_pos : 1));
-            }
-#endif
             if (err) break;
             n_seg++;
-            const unsigned long long te = xw::tick();
-            for (uint32_t k = ncmds; k-- > 0;) {                                // :1809-1843
-                const uint32_t node = xw::readfirst(L()->cmdlist[k]);
-                const uint32_t link = xw::readfirst(L()->node_link[node]);
-                const uint32_t delta = xw::readfirst(L()->node_delta[node]);
-                const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
-                if (cmd == 0) { emit_literal(delta); n_lit++; }
-                else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
-                else { emit_rep(delta, ln); n_rep++; }
+            if (xw::wave() == 0) {
+                const unsigned long long te = xw::tick();
+                for (uint32_t k = ncmds; k-- > 0;) {                            // :1809-1843
+                    const uint32_t node = xw::readfirst(L()->cmdlist[k]);
+                    const uint32_t link = xw::readfirst(L()->node_link[node]);
+                    const uint32_t delta = xw::readfirst(L()->node_delta[node]);
+                    const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
+                    if (cmd == 0) { emit_literal(delta); n_lit++; }
+                    else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
+                    else { emit_rep(delta, ln); n_rep++; }
+                }
+                t_emit += xw::tick() - te;
+                if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
+                if (xw::lane() == 0) {
+                    L()->sh[12] = rep0; L()->sh[13] = rep1; L()->sh[14] = rep2; L()->sh[15] = rep3;
+                    L()->sh[5] = tab_dirty ? 1u : 0u; L()->sh[4] = err;
+                }
             }
-            t_emit += xw::tick() - te;
+            xw::block_sync();
+            rep0 = L()->sh[12]; rep1 = L()->sh[13]; rep2 = L()->sh[14]; rep3 = L()->sh[15];     // (every wave follows the model's rep set)
+            tab_dirty = L()->sh[5] != 0;
+            if (L()->sh[4]) err = L()->sh[4];
             p += len;
-            if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
         }
-        for (int k = 0; k < 4; k++) {                                           // bit pad of Flush (:591-597)
-            if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
-            nbits++; word <<= 8;
-        }
-        if (xw::lane() == 0) {
-            FrameMeta &fm = G.fmeta[ci - G.chunk0];
-            fm.nsyms = nsyms; fm.nbits_bytes = nbits; fm.num_ops = num_ops; fm.out_len = 0;
-            Counters &c = L()->cnt;
-            c.n_literal += n_lit; c.n_dict += n_dict; c.n_rep += n_rep; c.segments += n_seg;
-            c.rans_syms += nsyms; c.bit_ops += num_ops - nsyms; c.frames += 1;
+        if (xw::wave() == 0) {
+            for (int k = 0; k < 4; k++) {                                       // bit pad of Flush (:591-597)
+                if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
+                nbits++; word <<= 8;
+            }
+            if (xw::lane() == 0) {
+                FrameMeta &fm = G.fmeta[ci - G.chunk0];
+                fm.nsyms = nsyms; fm.nbits_bytes = nbits; fm.num_ops = num_ops; fm.out_len = 0;
+                Counters &c = L()->cnt;
+                c.n_literal += n_lit; c.n_dict += n_dict; c.n_rep += n_rep; c.segments += n_seg;
+                c.rans_syms += nsyms; c.bit_ops += num_ops - nsyms; c.frames += 1;
+            }
         }
     }
 
     XW_FN void run(uint32_t c0, uint32_t c1)
     {
         Persist *P = G.persist;
-        const uint32_t i = xw::lane();
-        for (uint32_t k = i; k < kNumCtx * kCdfStride; k += 64) L()->cdf[k] = P->cdf[k];
-        for (uint32_t k = i; k < 256; k += 64) L()->lut[k] = log2_lut_entry(k);
-        for (uint32_t k = i; k < kEqSlots; k += 64) { L()->eq_r[k] = 0; L()->eq_b[k] = kNone; }
-        for (uint32_t k = i; k < sizeof(Counters) / 8; k += 64) ((unsigned long long *)&L()->cnt)[k] = 0;
-        xw::wave_sync();
-        for (uint32_t k = i; k < kNumCtx * 16; k += 64) {
+        const uint32_t tid = xw::thread();
+        for (uint32_t k = tid; k < kNumCtx * kCdfStride; k += kParserThreads) L()->cdf[k] = P->cdf[k];
+        for (uint32_t k = tid; k < 256; k += kParserThreads) L()->lut[k] = log2_lut_entry(k);
+        for (uint32_t k = tid; k < kEqSlots; k += kParserThreads) { L()->eq_r[k] = 0; L()->eq_b[k] = kNone; }
+        for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
+        xw::block_sync();
+        for (uint32_t k = tid; k < kNumCtx * 16; k += kParserThreads) {
             const uint32_t ctx = k >> 4, y = k & 15;
             const uint16_t *cell = L()->cdf + ctx * kCdfStride;
             L()->price[k] = (y < ctx_nsyms(ctx)) ? L()->lut[((uint32_t)cell[y + 1] - (uint32_t)cell[y]) >> 6] : 0;
@@ -1513,34 +1591,32 @@ struct Parser {
         base = xw::readfirst((uint32_t)P->reb_base);
         err = xw::readfirst(P->error);
         tab_dirty = true;
-        fetched = (uint32_t)((unsigned long long)c0 * g.chunk_size); t_out_seen = fetched;
-        n_steps = n_eq_fill = n_eq_rounds = n_cmp = n_redo = 0; t_wait = t_emit = t_fetch = 0;
+        t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        n_blocks = n_passes = n_eq_fill = n_eq_rounds = n_cmp = n_redo = 0; t_wait = t_emit = t_setup = t_pass = 0;
         const unsigned long long t_start = xw::tick();
-#ifdef NLZM_PROFILE
-        for (int k = 0; k < 8; k++) pf[k] = 0;
-        pf_t = t_start;
-#endif
-        xw::wave_sync();
+        xw::block_sync();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk(ci);
-        xw::wave_sync();
-        for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, i ^ d);       // (kept per lane: the probe lanes)
-        for (uint32_t k = i; k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];
-        if (i == 0) {
-            P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
-            P->next_chunk = ci;
-            unsigned long long *dst = (unsigned long long *)&P->cnt;
-            const unsigned long long *src = (const unsigned long long *)&L()->cnt;
-            for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
-            P->cnt.cmp_bytes += n_cmp;
-            P->prof[8] += n_steps; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo;
-            P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_fetch;
-#ifdef NLZM_PROFILE
-            for (int k = 0; k < 8; k++) P->prof[24 + k] += pf[k];
-#endif
-            const uint32_t xe = xw::ld_agent(&V.hx->err);
-            if (xe && !P->error) P->error = xe;
-            if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
+        xw::block_sync();
+        if (xw::wave() == 3) {
+            for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
+            if (xw::lane() == 0) { L()->cnt.cmp_bytes += n_cmp; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo; }
+        }
+        xw::block_sync();
+        if (xw::wave() == 0) {
+            for (uint32_t k = xw::lane(); k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];
+            if (xw::lane() == 0) {
+                P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
+                P->next_chunk = ci;
+                unsigned long long *dst = (unsigned long long *)&P->cnt;
+                const unsigned long long *src = (const unsigned long long *)&L()->cnt;
+                for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
+                P->prof[8] += n_blocks; P->prof[13] += n_passes;
+                P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_setup; P->prof[24] += t_pass;
+                const uint32_t xe = xw::ld_agent(&V.hx->err);
+                if (xe && !P->error) P->error = xe;
+                if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
+            }
         }
     }
 };

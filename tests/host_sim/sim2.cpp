@@ -228,8 +228,8 @@ static void role_entry(void *p)
 {
     const LaunchArgs &A = *(const LaunchArgs *)p;
     const uint32_t b = xw::block_index();
-    if (b == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
-    else if (b == 1) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
+    if (b == 0) { if (xw::wave() == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
+    else if (b == 1) { if (xw::wave() == 0) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
 }
 
@@ -307,7 +307,7 @@ int main(int argc, char **argv)
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;
-        xw::launch(3, 64, lds_bytes, role_entry, &A);
+        xw::launch(3, v2::kParserThreads, lds_bytes, role_entry, &A);
         wk.finish();
         if (P.error || hx->err) { printf("sim error %u / %u (info %u %u)\n", P.error, hx->err, P.error_info[0], P.error_info[1]); return 1; }
         if (g_ref.bad) break;
@@ -323,8 +323,8 @@ int main(int argc, char **argv)
     const double np = (double)(n ? n : 1);
     printf("finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
            P.prof[0], np / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
-    printf("table: %llu blocks, %llu on the slow path; parser: %llu steps (%.2f nodes each), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
-           P.prof[6], P.prof[7], P.prof[8], np / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11]);
+    printf("table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block, mask fills %llu, probe rounds %llu, re-sampled %llu\n",
+           P.prof[6], P.prof[7], P.prof[8], np / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11]);
     printf("workers: uncertain marks %llu (%.2f%%), dry runs %llu\n", unc_total, 100.0 * unc_total / np, wk.dry);
     const int bad = g_ref.bad || c.bad || P.cnt.positions != st.positions || P.cnt.nice_positions != st.nice_positions ||
                     P.cnt.segments != st.segments || P.cnt.bt_tests != st.bt_tests || P.cnt.bt_calls != st.bt_calls ||
