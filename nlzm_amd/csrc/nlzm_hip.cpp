@@ -451,6 +451,13 @@ int refresh_stats(Ctx &C)
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
+        if (P.prof[32]) {
+            const double np = (double)(P.prof[13] ? P.prof[13] : 1);
+            fprintf(stderr, "parser, cycles per pass (profile build): relax waves %.0f %.0f %.0f, probe wave %.0f (of it: sets that changed %.0f, mask fills %.0f), update %.0f, "
+                            "barrier waits per wave %.0f %.0f %.0f %.0f; block end %.0f cycles/position\n",
+                    P.prof[32] / np, P.prof[33] / np, P.prof[34] / np, P.prof[35] / np, P.prof[43] / np, P.prof[41] / np, P.prof[40] / np,
+                    P.prof[36] / np, P.prof[37] / np, P.prof[38] / np, P.prof[39] / np, P.prof[42] / n);
+        }
     }
     if (C.workers) {
         WorkerCounters wc;

@@ -466,11 +466,8 @@ struct Finder {
                     (int)rk_cand, rk_d, rk_eff, rk_len, rk_to, rk_end, bt_n, ec, od, np, cap);
 #endif
         // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
-        uint32_t pm = in_blk ? ec : 0u;                                         // inclusive prefix max of the closed ends
-        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(pm, d); if (i >= d) pm = umax(pm, o); }
-        uint32_t before = xw::shfl_up(pm, 1);
-        if (i == 0) before = 0;
-        before = umax(before, reach);
+        const uint32_t pm = xw::scan_max(in_blk ? ec : 0u);                     // inclusive prefix max of the closed ends
+        uint32_t before = umax(xw::lane_below(pm, 0u), reach);
         if (i >= jc && s_active) before = umax(before, s_end);                  // the former top entry, closed
         const bool nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
         const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
@@ -957,12 +954,12 @@ constexpr uint32_t kEdgesPerWave = (kMaxEdges + kPushWaves - 1) / kPushWaves;
 constexpr uint32_t kParserThreads = 256;
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 
+struct alignas(16) EqEnt { uint32_t r, b, mlo, mhi; };
 struct PLds {
     unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
     unsigned long long mcur[2][512];            // ... over the edges of the block being iterated (this pass / being cleared)
     unsigned long long nkey[512];               // winner of node n (state of the last pass; final once its block is done)
-    unsigned long long eq_mask[kEqSlots];       // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
-    uint32_t eq_r[kEqSlots], eq_b[kEqSlots];
+    EqEnt eq[kEqSlots];                         // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
     uint32_t nrep[512 * 4];                     // rep set of node n (CarriedState ring, :1460-1467)
     uint32_t ncost[512];
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
@@ -995,6 +992,12 @@ struct Parser {
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
     unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_setup, t_pass;
+    unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
+#ifdef NLZM_PROFILE
+    XW_FN unsigned long long ptick() const { return xw::tick(); }
+#else
+    XW_FN unsigned long long ptick() const { return 0; }
+#endif
 
     XW_FN PLds *L() const { return xw::lds<PLds>(); }
     XW_FN void fail(uint32_t code, uint32_t info)
@@ -1135,43 +1138,66 @@ struct Parser {
         xw::drain();
     }
 
-    // ---- explicit rep probes (:1598-1628): match length of (position a, distance r), at most c bytes ----------------
-    // Lanes with `want` ask; byte equality comes from the mask cache (one 64-byte block of the input against itself r
-    // bytes earlier per entry), filled for every lane that misses by the whole wave.  (Probe wave only.)
-    XW_FN uint32_t probe_len(bool want, uint32_t a, uint32_t r, uint32_t c)
+    // ---- explicit rep probes (:1598-1628): match lengths of position a at the node's four rep distances, at most c bytes.
+    // Byte equality comes from the mask cache (one 64-byte block of the input against itself r bytes earlier per entry); the
+    // four probes of a lane advance together, and what misses is filled by the whole wave, the bytes of up to four entries
+    // requested before any is looked at.  (Probe wave only.)
+    XW_FN void probe4(bool w0, bool w1, bool w2, bool w3, uint32_t a, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t c,
+                      uint32_t &l0, uint32_t &l1, uint32_t &l2, uint32_t &l3)
     {
-        uint32_t len = 0;
-        bool open = want && c > 0;
-        uint32_t x = a;                                             // next byte to look at
-        while (xw::any(open)) {
+        l0 = l1 = l2 = l3 = 0;
+        bool o0 = w0 && c > 0, o1 = w1 && c > 0, o2 = w2 && c > 0, o3 = w3 && c > 0;
+        while (xw::any(o0 || o1 || o2 || o3)) {
             n_eq_rounds++;
-            const uint32_t b = x >> 6, slot = (r * 0x9E3779B1u + b * 0x85EBCA77u) >> 24;
-            unsigned long long m = 0;
-            bool hit = false;
-            if (open) { hit = L()->eq_r[slot] == r && L()->eq_b[slot] == b; m = L()->eq_mask[slot]; }
-            unsigned long long miss = xw::ballot(open && !hit);
-            while (miss) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(miss);
-                const uint32_t rj = xw::readlane(r, j), bj = xw::readlane(b, j), sj = xw::readlane(slot, j);
-                const unsigned long long pos = (unsigned long long)bj * 64 + xw::lane();
-                const bool eq = pos >= rj && pos < g.n && G.in[pos] == G.in[pos - rj];
-                const unsigned long long mj = xw::ballot(eq);
-                n_eq_fill++;
-                if (xw::lane() == 0) { L()->eq_r[sj] = rj; L()->eq_b[sj] = bj; L()->eq_mask[sj] = mj; }
-                if (open && !hit && r == rj && b == bj) { m = mj; hit = true; }
-                miss &= ~xw::ballot(open && r == rj && b == bj);       // (lanes served by this fill are out of the list)
+            const uint32_t b0 = (a + l0) >> 6, b1 = (a + l1) >> 6, b2 = (a + l2) >> 6, b3 = (a + l3) >> 6;
+            const uint32_t s0 = (r0 * 0x9E3779B1u + b0 * 0x85EBCA77u) >> 24, s1 = (r1 * 0x9E3779B1u + b1 * 0x85EBCA77u) >> 24;
+            const uint32_t s2 = (r2 * 0x9E3779B1u + b2 * 0x85EBCA77u) >> 24, s3 = (r3 * 0x9E3779B1u + b3 * 0x85EBCA77u) >> 24;
+            EqEnt e0 = L()->eq[s0], e1 = L()->eq[s1], e2 = L()->eq[s2], e3 = L()->eq[s3];
+            bool h0 = e0.r == r0 && e0.b == b0, h1 = e1.r == r1 && e1.b == b1, h2 = e2.r == r2 && e2.b == b2, h3 = e3.r == r3 && e3.b == b3;
+            const unsigned long long m0 = xw::ballot(o0 && !h0), m1 = xw::ballot(o1 && !h1), m2 = xw::ballot(o2 && !h2), m3 = xw::ballot(o3 && !h3);
+            if (m0 | m1 | m2 | m3) {
+                // one entry per slot of the rep set and round: the first lane that misses names it
+                const unsigned long long f0 = ptick();
+                const uint32_t j0 = m0 ? (uint32_t)__builtin_ctzll(m0) : 0u, j1 = m1 ? (uint32_t)__builtin_ctzll(m1) : 0u;
+                const uint32_t j2 = m2 ? (uint32_t)__builtin_ctzll(m2) : 0u, j3 = m3 ? (uint32_t)__builtin_ctzll(m3) : 0u;
+                const uint32_t fr0 = xw::readlane(r0, j0), fb0 = xw::readlane(b0, j0), fs0 = xw::readlane(s0, j0);
+                const uint32_t fr1 = xw::readlane(r1, j1), fb1 = xw::readlane(b1, j1), fs1 = xw::readlane(s1, j1);
+                const uint32_t fr2 = xw::readlane(r2, j2), fb2 = xw::readlane(b2, j2), fs2 = xw::readlane(s2, j2);
+                const uint32_t fr3 = xw::readlane(r3, j3), fb3 = xw::readlane(b3, j3), fs3 = xw::readlane(s3, j3);
+                const unsigned long long p0 = (unsigned long long)fb0 * 64 + xw::lane(), p1 = (unsigned long long)fb1 * 64 + xw::lane();
+                const unsigned long long p2 = (unsigned long long)fb2 * 64 + xw::lane(), p3 = (unsigned long long)fb3 * 64 + xw::lane();
+                const bool g0 = m0 && p0 >= fr0 && p0 < g.n, g1 = m1 && p1 >= fr1 && p1 < g.n, g2 = m2 && p2 >= fr2 && p2 < g.n, g3 = m3 && p3 >= fr3 && p3 < g.n;
+                const uint8_t xa0 = g0 ? G.in[p0] : 0, xb0 = g0 ? G.in[p0 - fr0] : 1, xa1 = g1 ? G.in[p1] : 0, xb1 = g1 ? G.in[p1 - fr1] : 1;
+                const uint8_t xa2 = g2 ? G.in[p2] : 0, xb2 = g2 ? G.in[p2 - fr2] : 1, xa3 = g3 ? G.in[p3] : 0, xb3 = g3 ? G.in[p3 - fr3] : 1;
+                const unsigned long long k0 = xw::ballot(xa0 == xb0), k1 = xw::ballot(xa1 == xb1), k2 = xw::ballot(xa2 == xb2), k3 = xw::ballot(xa3 == xb3);
+                if (xw::lane() == 0) {
+                    if (m0) L()->eq[fs0] = EqEnt{ fr0, fb0, (uint32_t)k0, (uint32_t)(k0 >> 32) };
+                    if (m1) L()->eq[fs1] = EqEnt{ fr1, fb1, (uint32_t)k1, (uint32_t)(k1 >> 32) };
+                    if (m2) L()->eq[fs2] = EqEnt{ fr2, fb2, (uint32_t)k2, (uint32_t)(k2 >> 32) };
+                    if (m3) L()->eq[fs3] = EqEnt{ fr3, fb3, (uint32_t)k3, (uint32_t)(k3 >> 32) };
+                }
+                n_eq_fill += (m0 != 0) + (m1 != 0) + (m2 != 0) + (m3 != 0);
+                // the lanes these entries serve take them as they are (two entries may share a cache slot: every round moves
+                // at least the lanes that named an entry, so the loop ends)
+                if (m0 && !h0 && r0 == fr0 && b0 == fb0) { e0 = EqEnt{ fr0, fb0, (uint32_t)k0, (uint32_t)(k0 >> 32) }; h0 = true; }
+                if (m1 && !h1 && r1 == fr1 && b1 == fb1) { e1 = EqEnt{ fr1, fb1, (uint32_t)k1, (uint32_t)(k1 >> 32) }; h1 = true; }
+                if (m2 && !h2 && r2 == fr2 && b2 == fb2) { e2 = EqEnt{ fr2, fb2, (uint32_t)k2, (uint32_t)(k2 >> 32) }; h2 = true; }
+                if (m3 && !h3 && r3 == fr3 && b3 == fb3) { e3 = EqEnt{ fr3, fb3, (uint32_t)k3, (uint32_t)(k3 >> 32) }; h3 = true; }
+                xw::wave_sync();
+                t_fill += ptick() - f0;
             }
-            xw::wave_sync();
-            if (open) {
-                const uint32_t sh = x & 63u, room = 64 - sh;
+            auto step = [](bool &o, uint32_t &l, uint32_t a_, uint32_t c_, const EqEnt &e, bool h) __attribute__((always_inline)) {
+                if (!o || !h) return;
+                const unsigned long long m = ((unsigned long long)e.mhi << 32) | e.mlo;
+                const uint32_t sh = (a_ + l) & 63u, room = 64 - sh;
                 const unsigned long long z = ~(m >> sh);            // zero bits = equal bytes
                 const uint32_t run = z ? (uint32_t)__builtin_ctzll(z) : 64u;
-                const uint32_t got = umin(umin(run, room), c - len);
-                len += got; x += got;
-                if (got < room || len >= c) open = false;
-            }
+                const uint32_t got = umin(umin(run, room), c_ - l);
+                l += got;
+                if (got < room || l >= c_) o = false;
+            };
+            step(o0, l0, a, c, e0, h0); step(o1, l1, a, c, e1, h1); step(o2, l2, a, c, e2, h2); step(o3, l3, a, c, e3, h3);
         }
-        return len;
     }
 
     // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171); also what the emitter needs
@@ -1282,14 +1308,18 @@ struct Parser {
             const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // push waves: this wave's edges of the node (distance; length | price words)
             uint32_t uniq = 0;                                      // probe wave: the valid edges that are the first of their distance
+            uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, nd = 0;    // ... and the first eight of those distances
             uint32_t litw = 0, max_len = 0;
             if (w < kPushWaves) {
+                unsigned long long er[kEdgesPerWave];
+#pragma unroll
+                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = w + kPushWaves * j < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (w + kPushWaves * j))) : 0ull;
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                     const uint32_t k = w + kPushWaves * j;
                     ed[j] = 0; ea[j] = 0;
                     if (k < ne) {
-                        const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
+                        const unsigned long long e = er[j];
                         const uint32_t at = (uint32_t)(e >> 32);
                         const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
                         if (at >> 31) {
@@ -1303,27 +1333,40 @@ struct Parser {
             } else {
                 // every edge's distance into LDS (the winners' distances are looked up there), the distinct ones marked
                 uint32_t prev = 0;
-                for (uint32_t k = 0; k < ne; k++) {
-                    const unsigned long long e = xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k));
-                    const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32);
-                    L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
-                    if (k == 0) max_len = at & 0x1FFu;
-                    if ((at >> 31) && d != prev) uniq |= 1u << k;
-                    if (at >> 31) prev = d;
+#pragma unroll
+                for (uint32_t h = 0; h < kMaxEdges; h += 8) {           // eight records requested before any is used
+                    unsigned long long e[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) e[u] = h + u < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (h + u))) : 0ull;
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) {
+                        const uint32_t k = h + u;
+                        if (k >= ne) continue;
+                        const uint32_t d = (uint32_t)e[u], at = (uint32_t)(e[u] >> 32);
+                        L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
+                        if (k == 0) max_len = at & 0x1FFu;
+                        if ((at >> 31) && d != prev) {
+                            uniq |= 1u << k;
+#pragma unroll
+                            for (uint32_t z = 0; z < 8; z++) if (nd == z) dd[z] = d;
+                            nd++;
+                        }
+                        if (at >> 31) prev = d;
+                    }
+                    if (!xw::any(h + 8 < ne)) break;
                 }
                 if (inb) { L()->reach[i] = node + max_len; L()->live[i] = 0; }
             }
             uint32_t S = 0;
             if (w == 0) {
                 litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
-                uint32_t inc = litw;                                // inclusive prefix sum of the literal prices
-                for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(inc, d); if (i >= d) inc += o; }
-                S = inc - litw;                                     // S[i] = price of the literals of nodes b0 .. b0+i-1
+                S = xw::scan_add(litw) - litw;                      // S[i] = price of the literals of nodes b0 .. b0+i-1
                 if (inb) { L()->nkey[node & 511u] = kKeyNone; L()->ncost[node & 511u] = kInf; }
                 if (i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
             }
             // probe wave: what it measured for the node's rep slots so far
             uint32_t mr0 = 0, mr1 = 0, mr2 = 0, mr3 = 0, ml0 = 0, ml1 = 0, ml2 = 0, ml3 = 0;
+            uint32_t cr0 = 0, cr1 = 0, cr2 = 0, cr3 = 0, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, creach = 0;
             xw::block_sync();
             t_setup += xw::tick() - ts;
             const unsigned long long tp0 = xw::tick();
@@ -1334,6 +1377,7 @@ struct Parser {
             for (;;) {
                 const uint32_t q = pass & 1u;
                 n_passes++;
+                const unsigned long long k0 = ptick();
                 // push: from the state of the previous pass (none in the first: nothing is pushed, the update seeds node b0)
                 if (pass > 0) {
                     const bool lv = inb && L()->live[i] != 0;
@@ -1357,36 +1401,69 @@ struct Parser {
                         // the other buffer is cleared for the next pass
                         for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) L()->mcur[q ^ 1u][(b0 + t) & 511u] = kKeyNone;
                     } else {
-                        // explicit probes of the rep slots no sampled edge has met (:1598-1628)
-                        uint32_t checked = 0;
-                        if (lv) {
-                            for (uint32_t um = uniq; um; um &= um - 1) {
-                                const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
-                                checked |= (d == r0 ? 1u : 0u) | (d == r1 ? 2u : 0u) | (d == r2 ? 4u : 0u) | (d == r3 ? 8u : 0u);
-                            }
-                        }
-                        const uint32_t pcap = umin(max_parse - node, kMatchMax);                        // :1605-1606
-                        uint32_t far = 0;
+                        // explicit probes of the rep slots no sampled edge has met (:1598-1628).  What a node's rep set
+                        // makes of them is kept while the set stays the same: probe edge j has length pt_j and price pw_j (0: none)
+                        const bool dirty = lv && !(r0 == cr0 && r1 == cr1 && r2 == cr2 && r3 == cr3);
+                        const unsigned long long d0 = ptick();
+                        if (xw::any(dirty)) {
+                            uint32_t checked = 0;                                                       // :1579-1583
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
-                            const uint32_t r = j == 0 ? r0 : (j == 1 ? r1 : (j == 2 ? r2 : r3));
-                            uint32_t &mr = j == 0 ? mr0 : (j == 1 ? mr1 : (j == 2 ? mr2 : mr3));
-                            uint32_t &ml = j == 0 ? ml0 : (j == 1 ? ml1 : (j == 2 ? ml2 : ml3));
-                            const bool want = lv && !((checked >> j) & 1u) && r < seg_q + node;         // :1601
-                            const bool fresh = want && mr != r;
-                            if (xw::any(fresh)) { const uint32_t l = probe_len(fresh, a, r, pcap); if (fresh) { mr = r; ml = l; } }
-                            if (want && ml >= match_min(r)) {                                           // :1607
-                                const uint32_t wr = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5);
-                                xw::lds_min64(&L()->mcur[q][(node + ml) & 511u], ((unsigned long long)(c + wr) << 32) | (node << 8) | (kRankProbe + j));
-                                far = umax(far, node + ml);
+                            for (uint32_t z = 0; z < 8; z++)
+                                checked |= (dd[z] == r0 ? 1u : 0u) | (dd[z] == r1 ? 2u : 0u) | (dd[z] == r2 ? 4u : 0u) | (dd[z] == r3 ? 8u : 0u);
+                            if (xw::any(dirty && nd > 8)) {                                             // (more than eight distinct distances: the rest from LDS)
+                                if (dirty && nd > 8) {
+                                    for (uint32_t um = uniq; um; um &= um - 1) {
+                                        const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
+                                        checked |= (d == r0 ? 1u : 0u) | (d == r1 ? 2u : 0u) | (d == r2 ? 4u : 0u) | (d == r3 ? 8u : 0u);
+                                    }
+                                }
                             }
+                            const uint32_t pcap = umin(max_parse - node, kMatchMax);                    // :1605-1606
+                            uint32_t far = 0;
+                            {   // what is not measured yet for this node, all four slots together
+                                const bool f0 = dirty && !(checked & 1u) && r0 < seg_q + node && mr0 != r0, f1 = dirty && !(checked & 2u) && r1 < seg_q + node && mr1 != r1;
+                                const bool f2 = dirty && !(checked & 4u) && r2 < seg_q + node && mr2 != r2, f3 = dirty && !(checked & 8u) && r3 < seg_q + node && mr3 != r3;
+                                if (xw::any(f0 || f1 || f2 || f3)) {
+                                    uint32_t n0, n1, n2, n3;
+                                    probe4(f0, f1, f2, f3, a, r0, r1, r2, r3, pcap, n0, n1, n2, n3);
+                                    if (f0) { mr0 = r0; ml0 = n0; }
+                                    if (f1) { mr1 = r1; ml1 = n1; }
+                                    if (f2) { mr2 = r2; ml2 = n2; }
+                                    if (f3) { mr3 = r3; ml3 = n3; }
+                                }
+                            }
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) {
+                                const uint32_t r = j == 0 ? r0 : (j == 1 ? r1 : (j == 2 ? r2 : r3));
+                                uint32_t &ml = j == 0 ? ml0 : (j == 1 ? ml1 : (j == 2 ? ml2 : ml3));
+                                uint32_t &pw = j == 0 ? pw0 : (j == 1 ? pw1 : (j == 2 ? pw2 : pw3));
+                                uint32_t &pt = j == 0 ? pt0 : (j == 1 ? pt1 : (j == 2 ? pt2 : pt3));
+                                const bool want = dirty && !((checked >> j) & 1u) && r < seg_q + node;  // :1601
+                                if (dirty) {
+                                    pw = 0; pt = 0;
+                                    if (want && ml >= match_min(r)) {                                   // :1607
+                                        pw = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5); pt = ml;
+                                        far = umax(far, node + ml);
+                                    }
+                                }
+                            }
+                            if (dirty) { cr0 = r0; cr1 = r1; cr2 = r2; cr3 = r3; creach = umax(node + max_len, far); }
                         }
-                        if (inb) L()->reach[i] = umax(node + max_len, far);                             // :1550-1554, :1608-1612
+                        t_dirty += ptick() - d0;
+                        if (lv) {
+                            if (pw0) xw::lds_min64(&L()->mcur[q][(node + pt0) & 511u], ((unsigned long long)(c + pw0) << 32) | (node << 8) | (kRankProbe + 0));
+                            if (pw1) xw::lds_min64(&L()->mcur[q][(node + pt1) & 511u], ((unsigned long long)(c + pw1) << 32) | (node << 8) | (kRankProbe + 1));
+                            if (pw2) xw::lds_min64(&L()->mcur[q][(node + pt2) & 511u], ((unsigned long long)(c + pw2) << 32) | (node << 8) | (kRankProbe + 2));
+                            if (pw3) xw::lds_min64(&L()->mcur[q][(node + pt3) & 511u], ((unsigned long long)(c + pw3) << 32) | (node << 8) | (kRankProbe + 3));
+                        }
+                        if (inb) L()->reach[i] = lv ? creach : node + max_len;                          // :1550-1554, :1608-1612
                     }
                 } else if (w < kPushWaves) {
                     for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) { L()->mcur[0][(b0 + t) & 511u] = kKeyNone; L()->mcur[1][(b0 + t) & 511u] = kKeyNone; }
                 }
+                const unsigned long long k1 = ptick();
                 xw::block_sync();
+                const unsigned long long k2 = ptick();
                 // update (wave 0): every node of the block from the keys
                 if (w == 0) {
                     unsigned long long kin = kKeyNone;
@@ -1396,19 +1473,15 @@ struct Parser {
                     }
                     const uint32_t mc = kin == kKeyNone ? kInf : (uint32_t)(kin >> 32);
                     // cost through the literal edges: c[i] = min(mc[i], c[i-1] + litw[i-1]) = S[i] + min_{j<=i} (mc[j] - S[j])
-                    int32_t v = (int32_t)mc - (int32_t)S;
-                    for (uint32_t d = 1; d < 64; d <<= 1) { const int32_t o = (int32_t)xw::shfl_up((uint32_t)v, d); if (i >= d && o < v) v = o; }
+                    const int32_t v = xw::scan_min_i32((int32_t)mc - (int32_t)S);
                     const uint32_t c = (uint32_t)(v + (int32_t)S);
                     const bool litwin = i >= 1 && c < mc;                                                // :1492 (the literal edge comes last: strict)
                     const unsigned long long key = litwin ? (((unsigned long long)c << 32) | ((node - 1) << 8) | kRankLit) : kin;
                     // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
                     const uint32_t rc = inb ? L()->reach[i] : 0u;
                     const uint32_t rlive = (inb && L()->live[i]) ? rc : 0u;       // (a node's reach counts once it pushed: it was inside in the pass before)
-                    uint32_t pm = rlive;
-                    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(pm, d); if (i >= d) pm = umax(pm, o); }
-                    uint32_t before = xw::shfl_up(pm, 1);
-                    if (i == 0) before = 0;
-                    before = umax(before, end_p);
+                    const uint32_t pm = xw::scan_max(rlive);
+                    const uint32_t before = umax(xw::lane_below(pm, 0u), end_p);
                     const bool inside = inb && node < before;
                     const unsigned long long dead = xw::ballot(!inside);
                     istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;       // (lanes >= nb count as dead)
@@ -1419,8 +1492,7 @@ struct Parser {
                     if (act && key != kKeyNone) winner_set(seg_a, node, key, o0, o1, o2, o3, link, delta);
                     {   // a run of literal winners carries the set of the node in front of the run (:1498): taken from that
                         // lane in THIS pass, so that a literal run costs no pass
-                        uint32_t root = litwin ? 0u : i;
-                        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = xw::shfl_up(root, d); if (i >= d) root = umax(root, o); }
+                        const uint32_t root = xw::scan_max(litwin ? 0u : i);
                         const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
                         if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
                     }
@@ -1439,17 +1511,20 @@ struct Parser {
                     if (istar == 0) blk_end = end_p;
                     if (i == 0) { L()->sh[1] = changed ? 1u : 0u; L()->sh[7] = istar; L()->sh[8] = blk_end; }
                 }
+                const unsigned long long k3 = ptick();
                 xw::block_sync();
+                t_work += k1 - k0; t_upd += k3 - k2; t_bar += (k2 - k1) + (ptick() - k3);
                 pass++;
                 if (!L()->sh[1]) break;
             }
             istar = L()->sh[7]; blk_end = L()->sh[8];
             t_pass += xw::tick() - tp0;
+            const unsigned long long e0 = ptick();
             // ---- the block is at its fixed point: final nodes, the edges that end beyond it
             const uint32_t q = (pass - 1) & 1u;                      // the buffer the last update read
             const uint32_t done = umin(istar, nb);                   // nodes b0 .. b0+done-1 are inside
             if (w == 0) {
-                const uint32_t lit_before = xw::shfl_up(lit, 1);     // the byte of the position before the node
+                const uint32_t lit_before = xw::lane_below(lit, 0u);   // the byte of the position before the node
                 if (i <= istar && inb) {
                     uint32_t o0, o1, o2, o3, link, delta;
                     const unsigned long long key = L()->nkey[node & 511u];
@@ -1462,9 +1537,14 @@ struct Parser {
                 const uint32_t *nr = L()->nrep + (node & 511u) * 4;
                 const uint32_t pcap = umin(max_parse - node, kMatchMax);
                 uint32_t checked = 0;
-                for (uint32_t um = uniq; um; um &= um - 1) {
-                    const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
-                    checked |= (d == nr[0] ? 1u : 0u) | (d == nr[1] ? 2u : 0u) | (d == nr[2] ? 4u : 0u) | (d == nr[3] ? 8u : 0u);
+#pragma unroll
+                for (uint32_t z = 0; z < 8; z++)
+                    checked |= (dd[z] == nr[0] ? 1u : 0u) | (dd[z] == nr[1] ? 2u : 0u) | (dd[z] == nr[2] ? 4u : 0u) | (dd[z] == nr[3] ? 8u : 0u);
+                if (nd > 8) {
+                    for (uint32_t um = uniq; um; um &= um - 1) {
+                        const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
+                        checked |= (d == nr[0] ? 1u : 0u) | (d == nr[1] ? 2u : 0u) | (d == nr[2] ? 4u : 0u) | (d == nr[3] ? 8u : 0u);
+                    }
                 }
                 if (!(checked & 1u) && nr[0] < seg_q + node) n_cmp += ml0 + (ml0 < pcap);
                 if (!(checked & 2u) && nr[1] < seg_q + node) n_cmp += ml1 + (ml1 < pcap);
@@ -1497,6 +1577,7 @@ struct Parser {
                 b0 += nb;
                 xw::block_sync();
             }
+            t_fin += ptick() - e0;
         }
         xw::block_sync();
         // backtrack (:1633-1650): node indices of the path, end first
@@ -1579,7 +1660,7 @@ struct Parser {
         const uint32_t tid = xw::thread();
         for (uint32_t k = tid; k < kNumCtx * kCdfStride; k += kParserThreads) L()->cdf[k] = P->cdf[k];
         for (uint32_t k = tid; k < 256; k += kParserThreads) L()->lut[k] = log2_lut_entry(k);
-        for (uint32_t k = tid; k < kEqSlots; k += kParserThreads) { L()->eq_r[k] = 0; L()->eq_b[k] = kNone; }
+        for (uint32_t k = tid; k < kEqSlots; k += kParserThreads) { L()->eq[k].r = 0; L()->eq[k].b = kNone; L()->eq[k].mlo = 0; L()->eq[k].mhi = 0; }
         for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
         xw::block_sync();
         for (uint32_t k = tid; k < kNumCtx * 16; k += kParserThreads) {
@@ -1598,6 +1679,13 @@ struct Parser {
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk(ci);
         xw::block_sync();
+#ifdef NLZM_PROFILE
+        if (xw::lane() == 0) {      // per wave: work before the first barrier of a pass, barrier waits; wave 0: update; wave 3: mask fills
+            P->prof[32 + xw::wave()] += t_work; P->prof[36 + xw::wave()] += t_bar;
+            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; }
+            if (xw::wave() == 3) { P->prof[41] += t_fill; P->prof[43] += t_dirty; }
+        }
+#endif
         if (xw::wave() == 3) {
             for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
             if (xw::lane() == 0) { L()->cnt.cmp_bytes += n_cmp; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo; }

@@ -48,6 +48,44 @@ XW_FN unsigned long long shfl64(unsigned long long v, uint32_t src)
 // value of lane - d (own value for the first d lanes)
 XW_FN uint32_t shfl_up(uint32_t v, uint32_t d) { const uint32_t l = lane(); return shfl(v, l >= d ? l - d : l); }
 XW_FN unsigned long long shfl_up64(unsigned long long v, uint32_t d) { const uint32_t l = lane(); return shfl64(v, l >= d ? l - d : l); }
+// inclusive prefix scans over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips): lanes that a
+// step does not reach get the identity
+#define XW_DPP(old, v, ctrl, rm) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rm, 0xF, false))
+XW_FN uint32_t scan_max(uint32_t v)
+{
+    uint32_t t;
+    t = XW_DPP(0u, v, 0x111, 0xF); v = v > t ? v : t;
+    t = XW_DPP(0u, v, 0x112, 0xF); v = v > t ? v : t;
+    t = XW_DPP(0u, v, 0x114, 0xF); v = v > t ? v : t;
+    t = XW_DPP(0u, v, 0x118, 0xF); v = v > t ? v : t;
+    t = XW_DPP(0u, v, 0x142, 0xA); v = v > t ? v : t;       // row_bcast:15 into rows 1, 3
+    t = XW_DPP(0u, v, 0x143, 0xC); v = v > t ? v : t;       // row_bcast:31 into rows 2, 3
+    return v;
+}
+XW_FN int32_t scan_min_i32(int32_t x)
+{
+    const uint32_t id = 0x7FFFFFFFu;
+    uint32_t v = (uint32_t)x, t;
+    t = XW_DPP(id, v, 0x111, 0xF); v = (int32_t)t < (int32_t)v ? t : v;
+    t = XW_DPP(id, v, 0x112, 0xF); v = (int32_t)t < (int32_t)v ? t : v;
+    t = XW_DPP(id, v, 0x114, 0xF); v = (int32_t)t < (int32_t)v ? t : v;
+    t = XW_DPP(id, v, 0x118, 0xF); v = (int32_t)t < (int32_t)v ? t : v;
+    t = XW_DPP(id, v, 0x142, 0xA); v = (int32_t)t < (int32_t)v ? t : v;
+    t = XW_DPP(id, v, 0x143, 0xC); v = (int32_t)t < (int32_t)v ? t : v;
+    return (int32_t)v;
+}
+XW_FN uint32_t scan_add(uint32_t v)
+{
+    v += XW_DPP(0u, v, 0x111, 0xF);
+    v += XW_DPP(0u, v, 0x112, 0xF);
+    v += XW_DPP(0u, v, 0x114, 0xF);
+    v += XW_DPP(0u, v, 0x118, 0xF);
+    v += XW_DPP(0u, v, 0x142, 0xA);
+    v += XW_DPP(0u, v, 0x143, 0xC);
+    return v;
+}
+// value of the lane below (lane 0: fill)
+XW_FN uint32_t lane_below(uint32_t v, uint32_t fill) { return XW_DPP(fill, v, 0x138, 0xF); }     // wave_shr:1
 // LDS written by other lanes of this wave is visible after this point (DS operations of a wave execute in order)
 XW_FN void wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 // this wave's global stores have landed / its loads returned
@@ -159,6 +197,10 @@ inline unsigned long long shfl64(unsigned long long v, uint32_t src) { return co
 inline uint32_t shfl(uint32_t v, uint32_t src) { return (uint32_t)collective(cShfl, v, src & 63u); }
 inline uint32_t shfl_up(uint32_t v, uint32_t d) { const uint32_t l = lane(); return shfl(v, l >= d ? l - d : l); }
 inline unsigned long long shfl_up64(unsigned long long v, uint32_t d) { const uint32_t l = lane(); return shfl64(v, l >= d ? l - d : l); }
+inline uint32_t scan_max(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = shfl_up(v, d); if (lane() >= d && o > v) v = o; } return v; }
+inline int32_t scan_min_i32(int32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const int32_t o = (int32_t)shfl_up((uint32_t)v, d); if (lane() >= d && o < v) v = o; } return v; }
+inline uint32_t scan_add(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = shfl_up(v, d); if (lane() >= d) v += o; } return v; }
+inline uint32_t lane_below(uint32_t v, uint32_t fill) { const uint32_t o = shfl_up(v, 1); return lane() ? o : fill; }
 inline void wave_sync() { (void)collective(cSync, 0, 0); }
 inline void drain() {}
 inline void block_sync() { yield_to_sched(kBarrier); }
