@@ -948,24 +948,27 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
-constexpr uint32_t kEqSlots = 256;
-constexpr uint32_t kPushWaves = 3;              // waves 0..2 relax the sampled edges (edge k on wave k % 3), wave 3 the rep probes
-constexpr uint32_t kEdgesPerWave = (kMaxEdges + kPushWaves - 1) / kPushWaves;
-constexpr uint32_t kParserThreads = 256;
+constexpr uint32_t kPW = 4;                     // waves of the stage: wave w relaxes the sampled edges k = w (mod kPW) and probes rep slot w
+constexpr uint32_t kEdgesPerWave = kMaxEdges / kPW;
+constexpr uint32_t kParserThreads = 64 * kPW;
+constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
 constexpr uint32_t kInf = 0x3FFFFFFFu;
+constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
 struct alignas(16) EqEnt { uint32_t r, b, mlo, mhi; };
 struct PLds {
     unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
-    unsigned long long mcur[2][512];            // ... over the edges of the block being iterated (this pass / being cleared)
-    unsigned long long nkey[512];               // winner of node n (state of the last pass; final once its block is done)
-    EqEnt eq[kEqSlots];                         // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
-    uint32_t nrep[512 * 4];                     // rep set of node n (CarriedState ring, :1460-1467)
-    uint32_t ncost[512];
+    unsigned long long mcur[3][512];            // ... over the edges of the block being iterated: pass p relaxes into [p % 3]
+    EqEnt eq[kPW][kEqSlotsW];                   // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
+    uint32_t nrep[512 * 4];                     // rep set of the nodes of finished blocks (CarriedState ring, :1460-1467)
+    uint32_t brep[2][64 * 4];                   // ... of the block's nodes after pass p at [p & 1]
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
-    uint32_t reach[64];                         // per lane of the block: furthest node an edge of the node ends at
-    uint32_t live[64];                          // per lane: the node has edges (it lies inside the segment)
-    uint32_t sh[16];                            // wave 0 -> all: 0 block size, 1 pass changed something, 2 segment length (0: goes on), 3 records out, 4 error
+    uint32_t bdd[64 * 8];                       // per node of the block: its first eight distinct valid distances
+    uint32_t bnd[64], buniq[64];                // ... how many there are, which edges carry them
+    uint32_t sreach[64];                        // node + max_len (:1550)
+    uint32_t reach[3][64];                      // furthest node an edge or probe of the node ends at, as pass p found it at [p % 3]
+    uint32_t sh[16];                            // wave 0 -> all: 0 block size, 4 error, 5 price tables stale, 6 / 9 bytes of literal edges across
+                                                //   block borders, 10 / 11 price, cost of the literal edge out of the block, 12..15 model rep set
     uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22
     uint32_t node_delta[kParseMax + 2];         // distance (dict), rep index (rep), the byte (literal)
     uint16_t cmdlist[kParseMax + 2];
@@ -975,6 +978,7 @@ struct PLds {
     uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t sq_sym[2 * 8];
+    uint32_t ncmds;
     Counters cnt;
 };
 
@@ -986,7 +990,6 @@ struct Parser {
     uint32_t rep0, rep1, rep2, rep3;   // live model rep set
     uint32_t t_out_seen;
     bool tab_dirty;
-    bool quiet = false, quiet_abort = false;   // (simulation experiments: a parse whose progress is not published and that never waits)
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
@@ -1138,76 +1141,69 @@ struct Parser {
         xw::drain();
     }
 
-    // ---- explicit rep probes (:1598-1628): match lengths of position a at the node's four rep distances, at most c bytes.
-    // Byte equality comes from the mask cache (one 64-byte block of the input against itself r bytes earlier per entry); the
-    // four probes of a lane advance together, and what misses is filled by the whole wave, the bytes of up to four entries
-    // requested before any is looked at.  (Probe wave only.)
-    XW_FN void probe4(bool w0, bool w1, bool w2, bool w3, uint32_t a, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t c,
-                      uint32_t &l0, uint32_t &l1, uint32_t &l2, uint32_t &l3)
+    // ---- explicit rep probe (:1598-1628): match length of (position a, distance r), at most c bytes ------------------
+    // Byte equality comes from this wave's mask cache (one 64-byte block of the input against itself r bytes earlier per
+    // entry); what misses is filled by the whole wave, the bytes of up to four entries requested before any is looked at.
+    XW_FN uint32_t probe_len(bool want, uint32_t a, uint32_t r, uint32_t c)
     {
-        l0 = l1 = l2 = l3 = 0;
-        bool o0 = w0 && c > 0, o1 = w1 && c > 0, o2 = w2 && c > 0, o3 = w3 && c > 0;
-        while (xw::any(o0 || o1 || o2 || o3)) {
+        EqEnt *cache = L()->eq[xw::wave()];
+        uint32_t len = 0;
+        bool open = want && c > 0;
+        while (xw::any(open)) {
             n_eq_rounds++;
-            const uint32_t b0 = (a + l0) >> 6, b1 = (a + l1) >> 6, b2 = (a + l2) >> 6, b3 = (a + l3) >> 6;
-            const uint32_t s0 = (r0 * 0x9E3779B1u + b0 * 0x85EBCA77u) >> 24, s1 = (r1 * 0x9E3779B1u + b1 * 0x85EBCA77u) >> 24;
-            const uint32_t s2 = (r2 * 0x9E3779B1u + b2 * 0x85EBCA77u) >> 24, s3 = (r3 * 0x9E3779B1u + b3 * 0x85EBCA77u) >> 24;
-            EqEnt e0 = L()->eq[s0], e1 = L()->eq[s1], e2 = L()->eq[s2], e3 = L()->eq[s3];
-            bool h0 = e0.r == r0 && e0.b == b0, h1 = e1.r == r1 && e1.b == b1, h2 = e2.r == r2 && e2.b == b2, h3 = e3.r == r3 && e3.b == b3;
-            const unsigned long long m0 = xw::ballot(o0 && !h0), m1 = xw::ballot(o1 && !h1), m2 = xw::ballot(o2 && !h2), m3 = xw::ballot(o3 && !h3);
-            if (m0 | m1 | m2 | m3) {
-                // one entry per slot of the rep set and round: the first lane that misses names it
+            const uint32_t b = (a + len) >> 6, slot = (r * 0x9E3779B1u + b * 0x85EBCA77u) >> 26;
+            EqEnt e = cache[slot];
+            bool hit = e.r == r && e.b == b;
+            unsigned long long miss = xw::ballot(open && !hit);
+            if (miss) {
                 const unsigned long long f0 = ptick();
-                const uint32_t j0 = m0 ? (uint32_t)__builtin_ctzll(m0) : 0u, j1 = m1 ? (uint32_t)__builtin_ctzll(m1) : 0u;
-                const uint32_t j2 = m2 ? (uint32_t)__builtin_ctzll(m2) : 0u, j3 = m3 ? (uint32_t)__builtin_ctzll(m3) : 0u;
-                const uint32_t fr0 = xw::readlane(r0, j0), fb0 = xw::readlane(b0, j0), fs0 = xw::readlane(s0, j0);
-                const uint32_t fr1 = xw::readlane(r1, j1), fb1 = xw::readlane(b1, j1), fs1 = xw::readlane(s1, j1);
-                const uint32_t fr2 = xw::readlane(r2, j2), fb2 = xw::readlane(b2, j2), fs2 = xw::readlane(s2, j2);
-                const uint32_t fr3 = xw::readlane(r3, j3), fb3 = xw::readlane(b3, j3), fs3 = xw::readlane(s3, j3);
-                const unsigned long long p0 = (unsigned long long)fb0 * 64 + xw::lane(), p1 = (unsigned long long)fb1 * 64 + xw::lane();
-                const unsigned long long p2 = (unsigned long long)fb2 * 64 + xw::lane(), p3 = (unsigned long long)fb3 * 64 + xw::lane();
-                const bool g0 = m0 && p0 >= fr0 && p0 < g.n, g1 = m1 && p1 >= fr1 && p1 < g.n, g2 = m2 && p2 >= fr2 && p2 < g.n, g3 = m3 && p3 >= fr3 && p3 < g.n;
-                const uint8_t xa0 = g0 ? G.in[p0] : 0, xb0 = g0 ? G.in[p0 - fr0] : 1, xa1 = g1 ? G.in[p1] : 0, xb1 = g1 ? G.in[p1 - fr1] : 1;
-                const uint8_t xa2 = g2 ? G.in[p2] : 0, xb2 = g2 ? G.in[p2 - fr2] : 1, xa3 = g3 ? G.in[p3] : 0, xb3 = g3 ? G.in[p3 - fr3] : 1;
-                const unsigned long long k0 = xw::ballot(xa0 == xb0), k1 = xw::ballot(xa1 == xb1), k2 = xw::ballot(xa2 == xb2), k3 = xw::ballot(xa3 == xb3);
-                if (xw::lane() == 0) {
-                    if (m0) L()->eq[fs0] = EqEnt{ fr0, fb0, (uint32_t)k0, (uint32_t)(k0 >> 32) };
-                    if (m1) L()->eq[fs1] = EqEnt{ fr1, fb1, (uint32_t)k1, (uint32_t)(k1 >> 32) };
-                    if (m2) L()->eq[fs2] = EqEnt{ fr2, fb2, (uint32_t)k2, (uint32_t)(k2 >> 32) };
-                    if (m3) L()->eq[fs3] = EqEnt{ fr3, fb3, (uint32_t)k3, (uint32_t)(k3 >> 32) };
+                uint32_t fr[4], fb[4], fs[4];
+                uint8_t xa[4], xb[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ok[u] = miss != 0;
+                    const uint32_t j = ok[u] ? (uint32_t)__builtin_ctzll(miss) : 0u;
+                    fr[u] = xw::readlane(r, j); fb[u] = xw::readlane(b, j); fs[u] = xw::readlane(slot, j);
+                    miss &= ~xw::ballot(open && r == fr[u] && b == fb[u]);          // (the lanes this entry serves)
+                    const unsigned long long pos = (unsigned long long)fb[u] * 64 + xw::lane();
+                    const bool in_range = ok[u] && pos >= fr[u] && pos < g.n;
+                    xa[u] = in_range ? G.in[pos] : 0; xb[u] = in_range ? G.in[pos - fr[u]] : 1;
                 }
-                n_eq_fill += (m0 != 0) + (m1 != 0) + (m2 != 0) + (m3 != 0);
-                // the lanes these entries serve take them as they are (two entries may share a cache slot: every round moves
-                // at least the lanes that named an entry, so the loop ends)
-                if (m0 && !h0 && r0 == fr0 && b0 == fb0) { e0 = EqEnt{ fr0, fb0, (uint32_t)k0, (uint32_t)(k0 >> 32) }; h0 = true; }
-                if (m1 && !h1 && r1 == fr1 && b1 == fb1) { e1 = EqEnt{ fr1, fb1, (uint32_t)k1, (uint32_t)(k1 >> 32) }; h1 = true; }
-                if (m2 && !h2 && r2 == fr2 && b2 == fb2) { e2 = EqEnt{ fr2, fb2, (uint32_t)k2, (uint32_t)(k2 >> 32) }; h2 = true; }
-                if (m3 && !h3 && r3 == fr3 && b3 == fb3) { e3 = EqEnt{ fr3, fb3, (uint32_t)k3, (uint32_t)(k3 >> 32) }; h3 = true; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long k = xw::ballot(xa[u] == xb[u]);
+                    if (ok[u]) {
+                        n_eq_fill++;
+                        if (xw::lane() == 0) cache[fs[u]] = EqEnt{ fr[u], fb[u], (uint32_t)k, (uint32_t)(k >> 32) };
+                        if (open && !hit && r == fr[u] && b == fb[u]) { e = EqEnt{ fr[u], fb[u], (uint32_t)k, (uint32_t)(k >> 32) }; hit = true; }
+                    }
+                }
                 xw::wave_sync();
                 t_fill += ptick() - f0;
             }
-            auto step = [](bool &o, uint32_t &l, uint32_t a_, uint32_t c_, const EqEnt &e, bool h) __attribute__((always_inline)) {
-                if (!o || !h) return;
+            if (open && hit) {                                      // (a lane whose entry is not in yet looks again next round)
                 const unsigned long long m = ((unsigned long long)e.mhi << 32) | e.mlo;
-                const uint32_t sh = (a_ + l) & 63u, room = 64 - sh;
+                const uint32_t sh = (a + len) & 63u, room = 64 - sh;
                 const unsigned long long z = ~(m >> sh);            // zero bits = equal bytes
                 const uint32_t run = z ? (uint32_t)__builtin_ctzll(z) : 64u;
-                const uint32_t got = umin(umin(run, room), c_ - l);
-                l += got;
-                if (got < room || l >= c_) o = false;
-            };
-            step(o0, l0, a, c, e0, h0); step(o1, l1, a, c, e1, h1); step(o2, l2, a, c, e2, h2); step(o3, l3, a, c, e3, h3);
+                const uint32_t got = umin(umin(run, room), c - len);
+                len += got;
+                if (got < room || len >= c) open = false;
+            }
         }
+        return len;
     }
 
-    // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171); also what the emitter needs
-    // of the winner: cmd, length, distance / rep index / byte
-    XW_FN void winner_set(uint32_t seg_a, uint32_t node, unsigned long long key, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3,
-                          uint32_t &link, uint32_t &delta) const
+    // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171) and what the emitter needs of the
+    // winner: source | length << 13 | cmd << 22, and the distance / rep index.  The source's set: of a finished block from the
+    // ring, of this block as the pass before left it.
+    XW_FN void winner_set(uint32_t seg_a, uint32_t b0, uint32_t pbuf, uint32_t node, unsigned long long key, uint32_t &o0, uint32_t &o1,
+                          uint32_t &o2, uint32_t &o3, uint32_t &link, uint32_t &delta) const
     {
         const uint32_t src = (uint32_t)(key >> 8) & 0xFFFFFFu, rank = (uint32_t)key & 0xFFu;
         if (src == kSrcNone) { o0 = rep0; o1 = rep1; o2 = rep2; o3 = rep3; link = kSrcNone; delta = 0; return; }   // node 0 (:1476)
-        const uint32_t *sr = L()->nrep + (src & 511u) * 4;
+        const uint32_t *sr = src >= b0 ? L()->brep[pbuf] + (src - b0) * 4 : L()->nrep + (src & 511u) * 4;
         const uint32_t s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
         o0 = s0; o1 = s1; o2 = s2; o3 = s3;
         uint32_t cmd = 0, len = 0;
@@ -1244,54 +1240,46 @@ struct Parser {
             L()->mprev[0] = ((unsigned long long)kSrcNone << 8) | kRankLit;
             L()->mprev[1] = kKeyNone;
             L()->node_link[0] = kSrcNone;
-            if (!quiet) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
+            xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
         xw::block_sync();
         while (!seg_len) {
-            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
             const unsigned long long ts = xw::tick();
             if (b0 == end_p || b0 >= max_parse) {
                 // node b0 is the segment's last node: no edges leave it; its key is complete
                 if (tid == 0) {
                     uint32_t r0, r1, r2, r3, link, delta;
                     const unsigned long long k = L()->mprev[b0 & 511u];
-                    winner_set(seg_a, b0, k, r0, r1, r2, r3, link, delta);
-                    if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[6];      // the byte of position b0 - 1
+                    winner_set(seg_a, b0, 0, b0, k, r0, r1, r2, r3, link, delta);
+                    if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[9];      // the byte of position b0 - 1
                     L()->node_link[b0] = link; L()->node_delta[b0] = delta;
                 }
                 seg_len = b0;
                 break;
             }
+            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
             if (w == 0) {
                 const uint32_t a_first = seg_a + b0;
                 if ((int32_t)(t_out_seen - (a_first + 1)) < 0) {
-                    if (quiet) {
-                        t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
-                        if ((int32_t)(t_out_seen - (a_first + 1)) < 0) quiet_abort = true;
-                    } else {
-                        const unsigned long long tw = xw::tick();
-                        if (!wait_word_ge(&V.hx->t_out, a_first + 1, V.hx, 4)) err = kErrInternal + 100;
-                        t_wait += xw::tick() - tw;
-                    }
+                    const unsigned long long tw = xw::tick();
+                    if (!wait_word_ge(&V.hx->t_out, a_first + 1, V.hx, 4)) err = kErrInternal + 100;
+                    t_wait += xw::tick() - tw;
                 }
-                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err && !quiet_abort) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
                 uint32_t nb = umin(64u, max_parse - b0);
                 if ((int32_t)(t_out_seen - (a_first + nb)) < 0) nb = t_out_seen - a_first;
-                if (i == 0) {
-                    L()->sh[0] = nb; L()->sh[4] = err | (quiet_abort ? 0x80000000u : 0u);
-                    if (!quiet) xw::st_agent(&V.hx->p_pos, a_first);
-                }
+                if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; xw::st_agent(&V.hx->p_pos, a_first); }
             }
             xw::block_sync();
             const uint32_t nb = L()->sh[0];
-            if (L()->sh[4]) { if (L()->sh[4] & 0x80000000u) quiet_abort = true; else err = kErrInternal + 100; return 0; }
+            if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
             const bool inb = i < nb;
             const uint32_t node = b0 + i, a = seg_a + node;
             // within 264 of the forced cut the table is cut short (:1545): such records are re-listed first
             if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax) {
-                if (w == 3) {
+                if (w == kPW - 1) {
                     const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
                     const uint32_t h0 = inb ? xw::ld_agent(rec) : 0u;
                     const uint32_t ml = (h0 & 63u) ? (xw::ld_agent(rec + 3) & 0x1FFu) : 0u;
@@ -1306,33 +1294,28 @@ struct Parser {
             const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
             const unsigned long long hd = inb ? xw::ld_agent64((const unsigned long long *)rec) : 0ull;
             const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
-            uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // push waves: this wave's edges of the node (distance; length | price words)
-            uint32_t uniq = 0;                                      // probe wave: the valid edges that are the first of their distance
-            uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, nd = 0;    // ... and the first eight of those distances
-            uint32_t litw = 0, max_len = 0;
-            if (w < kPushWaves) {
+            uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
+            {
                 unsigned long long er[kEdgesPerWave];
 #pragma unroll
-                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = w + kPushWaves * j < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (w + kPushWaves * j))) : 0ull;
+                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = w + kPW * j < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (w + kPW * j))) : 0ull;
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
-                    const uint32_t k = w + kPushWaves * j;
                     ed[j] = 0; ea[j] = 0;
-                    if (k < ne) {
-                        const unsigned long long e = er[j];
-                        const uint32_t at = (uint32_t)(e >> 32);
+                    const uint32_t at = (uint32_t)(er[j] >> 32);
+                    if (at >> 31) {
                         const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-                        if (at >> 31) {
-                            const uint32_t lp = L()->len_price[lv];
-                            const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
-                            ed[j] = (uint32_t)e;
-                            ea[j] = tl | (wd << 9) | (lp << 21);    // wd < 4096, lp < 2048
-                        }
+                        const uint32_t lp = L()->len_price[lv];
+                        const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
+                        ed[j] = (uint32_t)er[j];
+                        ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
                     }
                 }
-            } else {
-                // every edge's distance into LDS (the winners' distances are looked up there), the distinct ones marked
-                uint32_t prev = 0;
+            }
+            if (w == kPW - 1) {
+                // every edge's distance into LDS (the winners' distances are looked up there); the distinct valid ones
+                uint32_t prev = 0, uniq = 0, nd = 0, max_len = 0;
+                uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
                 for (uint32_t h = 0; h < kMaxEdges; h += 8) {           // eight records requested before any is used
                     unsigned long long e[8];
@@ -1355,202 +1338,144 @@ struct Parser {
                     }
                     if (!xw::any(h + 8 < ne)) break;
                 }
-                if (inb) { L()->reach[i] = node + max_len; L()->live[i] = 0; }
+#pragma unroll
+                for (uint32_t z = 0; z < 8; z++) L()->bdd[i * 8 + z] = dd[z];
+                L()->bnd[i] = nd; L()->buniq[i] = uniq;
+                L()->sreach[i] = inb ? node + max_len : 0u;
+                L()->reach[1][i] = inb ? node + max_len : 0u;
             }
-            uint32_t S = 0;
-            if (w == 0) {
-                litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
-                S = xw::scan_add(litw) - litw;                      // S[i] = price of the literals of nodes b0 .. b0+i-1
-                if (inb) { L()->nkey[node & 511u] = kKeyNone; L()->ncost[node & 511u] = kInf; }
-                if (i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
-            }
-            // probe wave: what it measured for the node's rep slots so far
-            uint32_t mr0 = 0, mr1 = 0, mr2 = 0, mr3 = 0, ml0 = 0, ml1 = 0, ml2 = 0, ml3 = 0;
-            uint32_t cr0 = 0, cr1 = 0, cr2 = 0, cr3 = 0, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, creach = 0;
+            const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
+            const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
+            if (w == 0 && i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
+            for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
             xw::block_sync();
+            uint32_t dd[8];
+#pragma unroll
+            for (uint32_t z = 0; z < 8; z++) dd[z] = L()->bdd[i * 8 + z];
+            const uint32_t nd = L()->bnd[i], uniq = L()->buniq[i], sreach = L()->sreach[i];
             t_setup += xw::tick() - ts;
             const unsigned long long tp0 = xw::tick();
             n_blocks++;
-            // ---- passes
-            uint32_t pass = 0;
-            uint32_t istar = 64, blk_end = end_p;
+            // ---- passes.  Every wave keeps the state of its lane's node in registers (all waves compute the same update)
+            unsigned long long key = kKeyNone;
+            uint32_t c = kInf, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            bool lv = false;
+            uint32_t istar = 64, blk_end = end_p, pass = 0;
+            // this wave's rep slot: what was measured for which distance, and the probe edge it gives under the node's present set
+            uint32_t mr = 0, ml = 0, cr = 0, pw = 0, pt = 0;
+            bool want = false;
+            const uint32_t pcap = umin(max_parse - node, kMatchMax);                                    // :1605-1606
             for (;;) {
-                const uint32_t q = pass & 1u;
+                const uint32_t buf = pass % 3u, nbuf = (pass + 1) % 3u;
                 n_passes++;
                 const unsigned long long k0 = ptick();
-                // push: from the state of the previous pass (none in the first: nothing is pushed, the update seeds node b0)
-                if (pass > 0) {
-                    const bool lv = inb && L()->live[i] != 0;
-                    const uint32_t c = L()->ncost[node & 511u];
-                    const uint32_t *nr = L()->nrep + (node & 511u) * 4;
-                    const uint32_t r0 = nr[0], r1 = nr[1], r2 = nr[2], r3 = nr[3];
-                    if (w < kPushWaves) {
-                        if (lv) {
+                if (pass > 0 && lv) {
+                    // relax this wave's sampled edges of the node (:1566-1595)
 #pragma unroll
-                            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
-                                const uint32_t k = w + kPushWaves * j;
-                                if (!ea[j]) continue;
-                                const uint32_t tl = ea[j] & 0x1FFu, wd = (ea[j] >> 9) & 0xFFFu, lp = ea[j] >> 21;
-                                unsigned long long *dst = &L()->mcur[q][(node + tl) & 511u];
-                                xw::lds_min64(dst, ((unsigned long long)(c + pc_dict + wd) << 32) | (node << 8) | (2 * k));       // :1567-1577
-                                const uint32_t d = ed[j];
-                                if (d == r0 || d == r1 || d == r2 || d == r3)                                                      // :1579-1595
-                                    xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
-                            }
-                        }
-                        // the other buffer is cleared for the next pass
-                        for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) L()->mcur[q ^ 1u][(b0 + t) & 511u] = kKeyNone;
-                    } else {
-                        // explicit probes of the rep slots no sampled edge has met (:1598-1628).  What a node's rep set
-                        // makes of them is kept while the set stays the same: probe edge j has length pt_j and price pw_j (0: none)
-                        const bool dirty = lv && !(r0 == cr0 && r1 == cr1 && r2 == cr2 && r3 == cr3);
-                        const unsigned long long d0 = ptick();
-                        if (xw::any(dirty)) {
-                            uint32_t checked = 0;                                                       // :1579-1583
-#pragma unroll
-                            for (uint32_t z = 0; z < 8; z++)
-                                checked |= (dd[z] == r0 ? 1u : 0u) | (dd[z] == r1 ? 2u : 0u) | (dd[z] == r2 ? 4u : 0u) | (dd[z] == r3 ? 8u : 0u);
-                            if (xw::any(dirty && nd > 8)) {                                             // (more than eight distinct distances: the rest from LDS)
-                                if (dirty && nd > 8) {
-                                    for (uint32_t um = uniq; um; um &= um - 1) {
-                                        const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
-                                        checked |= (d == r0 ? 1u : 0u) | (d == r1 ? 2u : 0u) | (d == r2 ? 4u : 0u) | (d == r3 ? 8u : 0u);
-                                    }
-                                }
-                            }
-                            const uint32_t pcap = umin(max_parse - node, kMatchMax);                    // :1605-1606
-                            uint32_t far = 0;
-                            {   // what is not measured yet for this node, all four slots together
-                                const bool f0 = dirty && !(checked & 1u) && r0 < seg_q + node && mr0 != r0, f1 = dirty && !(checked & 2u) && r1 < seg_q + node && mr1 != r1;
-                                const bool f2 = dirty && !(checked & 4u) && r2 < seg_q + node && mr2 != r2, f3 = dirty && !(checked & 8u) && r3 < seg_q + node && mr3 != r3;
-                                if (xw::any(f0 || f1 || f2 || f3)) {
-                                    uint32_t n0, n1, n2, n3;
-                                    probe4(f0, f1, f2, f3, a, r0, r1, r2, r3, pcap, n0, n1, n2, n3);
-                                    if (f0) { mr0 = r0; ml0 = n0; }
-                                    if (f1) { mr1 = r1; ml1 = n1; }
-                                    if (f2) { mr2 = r2; ml2 = n2; }
-                                    if (f3) { mr3 = r3; ml3 = n3; }
-                                }
-                            }
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; j++) {
-                                const uint32_t r = j == 0 ? r0 : (j == 1 ? r1 : (j == 2 ? r2 : r3));
-                                uint32_t &ml = j == 0 ? ml0 : (j == 1 ? ml1 : (j == 2 ? ml2 : ml3));
-                                uint32_t &pw = j == 0 ? pw0 : (j == 1 ? pw1 : (j == 2 ? pw2 : pw3));
-                                uint32_t &pt = j == 0 ? pt0 : (j == 1 ? pt1 : (j == 2 ? pt2 : pt3));
-                                const bool want = dirty && !((checked >> j) & 1u) && r < seg_q + node;  // :1601
-                                if (dirty) {
-                                    pw = 0; pt = 0;
-                                    if (want && ml >= match_min(r)) {                                   // :1607
-                                        pw = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5); pt = ml;
-                                        far = umax(far, node + ml);
-                                    }
-                                }
-                            }
-                            if (dirty) { cr0 = r0; cr1 = r1; cr2 = r2; cr3 = r3; creach = umax(node + max_len, far); }
-                        }
-                        t_dirty += ptick() - d0;
-                        if (lv) {
-                            if (pw0) xw::lds_min64(&L()->mcur[q][(node + pt0) & 511u], ((unsigned long long)(c + pw0) << 32) | (node << 8) | (kRankProbe + 0));
-                            if (pw1) xw::lds_min64(&L()->mcur[q][(node + pt1) & 511u], ((unsigned long long)(c + pw1) << 32) | (node << 8) | (kRankProbe + 1));
-                            if (pw2) xw::lds_min64(&L()->mcur[q][(node + pt2) & 511u], ((unsigned long long)(c + pw2) << 32) | (node << 8) | (kRankProbe + 2));
-                            if (pw3) xw::lds_min64(&L()->mcur[q][(node + pt3) & 511u], ((unsigned long long)(c + pw3) << 32) | (node << 8) | (kRankProbe + 3));
-                        }
-                        if (inb) L()->reach[i] = lv ? creach : node + max_len;                          // :1550-1554, :1608-1612
+                    for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                        if (!ea[j]) continue;
+                        const uint32_t k = w + kPW * j;
+                        const uint32_t tl = ea[j] & 0x1FFu, wd = (ea[j] >> 9) & 0xFFFu, lp = ea[j] >> 21;
+                        unsigned long long *dst = &L()->mcur[buf][(node + tl) & 511u];
+                        xw::lds_min64(dst, ((unsigned long long)(c + pc_dict + wd) << 32) | (node << 8) | (2 * k));
+                        const uint32_t d = ed[j];
+                        if (d == r0 || d == r1 || d == r2 || d == r3)
+                            xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
                     }
-                } else if (w < kPushWaves) {
-                    for (uint32_t t = tid; t < 64 + kMatchMax + 2; t += kPushWaves * 64) { L()->mcur[0][(b0 + t) & 511u] = kKeyNone; L()->mcur[1][(b0 + t) & 511u] = kKeyNone; }
                 }
+                if (pass > 0) {
+                    // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628)
+                    const uint32_t r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+                    const bool dirty = lv && r != cr;
+                    if (xw::any(dirty)) {
+                        bool met = false;
+#pragma unroll
+                        for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
+                        if (xw::any(dirty && nd > 8)) {
+                            if (dirty && nd > 8) {
+                                for (uint32_t um = uniq; um; um &= um - 1)
+                                    met = met || L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)] == r;
+                            }
+                        }
+                        const bool wnt = dirty && !met && r < seg_q + node;                             // :1601
+                        const bool fresh = wnt && mr != r;
+                        if (xw::any(fresh)) { const uint32_t l = probe_len(fresh, a, r, pcap); if (fresh) { mr = r; ml = l; } }
+                        if (dirty) {
+                            cr = r; want = wnt; pw = 0; pt = 0;
+                            if (wnt && ml >= match_min(r)) { pw = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5); pt = ml; }   // :1607, :1614
+                        }
+                    }
+                    if (lv && pw) {
+                        xw::lds_min64(&L()->mcur[buf][(node + pt) & 511u], ((unsigned long long)(c + pw) << 32) | (node << 8) | (kRankProbe + w));
+                        xw::lds_max(&L()->reach[buf][i], node + pt);        // :1608-1612
+                    }
+                }
+                // the buffers of the next pass
+                for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
+                if (w == 0) L()->reach[nbuf][i] = sreach;
                 const unsigned long long k1 = ptick();
                 xw::block_sync();
                 const unsigned long long k2 = ptick();
-                // update (wave 0): every node of the block from the keys
-                if (w == 0) {
-                    unsigned long long kin = kKeyNone;
-                    if (inb) {
-                        if (node <= end_open) kin = L()->mprev[node & 511u];
-                        if (i >= 1 && pass > 0) { const unsigned long long kc = L()->mcur[q][node & 511u]; if (kc < kin) kin = kc; }
-                    }
-                    const uint32_t mc = kin == kKeyNone ? kInf : (uint32_t)(kin >> 32);
-                    // cost through the literal edges: c[i] = min(mc[i], c[i-1] + litw[i-1]) = S[i] + min_{j<=i} (mc[j] - S[j])
-                    const int32_t v = xw::scan_min_i32((int32_t)mc - (int32_t)S);
-                    const uint32_t c = (uint32_t)(v + (int32_t)S);
-                    const bool litwin = i >= 1 && c < mc;                                                // :1492 (the literal edge comes last: strict)
-                    const unsigned long long key = litwin ? (((unsigned long long)c << 32) | ((node - 1) << 8) | kRankLit) : kin;
-                    // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
-                    const uint32_t rc = inb ? L()->reach[i] : 0u;
-                    const uint32_t rlive = (inb && L()->live[i]) ? rc : 0u;       // (a node's reach counts once it pushed: it was inside in the pass before)
-                    const uint32_t pm = xw::scan_max(rlive);
-                    const uint32_t before = umax(xw::lane_below(pm, 0u), end_p);
-                    const bool inside = inb && node < before;
-                    const unsigned long long dead = xw::ballot(!inside);
-                    istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;       // (lanes >= nb count as dead)
-                    const bool act = i <= istar && inb;              // nodes b0 .. b0+istar: inside, or the segment's last node
-                    const bool lv = i < istar && inb;
-                    // rep sets from the winners (the sources' sets as of the last pass)
-                    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, link = 0, delta = 0;
-                    if (act && key != kKeyNone) winner_set(seg_a, node, key, o0, o1, o2, o3, link, delta);
-                    {   // a run of literal winners carries the set of the node in front of the run (:1498): taken from that
-                        // lane in THIS pass, so that a literal run costs no pass
-                        const uint32_t root = xw::scan_max(litwin ? 0u : i);
-                        const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
-                        if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
-                    }
-                    const unsigned long long okey = inb ? L()->nkey[node & 511u] : 0ull;
-                    const uint32_t *nr = L()->nrep + (node & 511u) * 4;
-                    const bool same = !act || (okey == key && nr[0] == o0 && nr[1] == o1 && nr[2] == o2 && nr[3] == o3 && (L()->live[i] != 0) == lv);
-                    xw::wave_sync();
-                    if (act) {
-                        L()->nkey[node & 511u] = key; L()->ncost[node & 511u] = c;
-                        uint32_t *dr = L()->nrep + (node & 511u) * 4;
-                        dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3;
-                    }
-                    if (inb) L()->live[i] = lv ? 1u : 0u;
-                    const bool changed = xw::any(!same);
-                    blk_end = umax(end_p, xw::readlane(pm, umin(istar, nb) ? umin(istar, nb) - 1 : 0));
-                    if (istar == 0) blk_end = end_p;
-                    if (i == 0) { L()->sh[1] = changed ? 1u : 0u; L()->sh[7] = istar; L()->sh[8] = blk_end; }
+                // ---- update: every node of the block from the keys (the same in every wave)
+                unsigned long long kin = kKeyNone;
+                if (inb) {
+                    if (node <= end_open) kin = L()->mprev[node & 511u];
+                    if (i >= 1 && pass > 0) { const unsigned long long kc = L()->mcur[buf][node & 511u]; if (kc < kin) kin = kc; }
                 }
-                const unsigned long long k3 = ptick();
-                xw::block_sync();
-                t_work += k1 - k0; t_upd += k3 - k2; t_bar += (k2 - k1) + (ptick() - k3);
+                const uint32_t mc = kin == kKeyNone ? kInf : (uint32_t)(kin >> 32);
+                // cost through the literal edges: c[i] = min(mc[i], c[i-1] + litw[i-1]) = S[i] + min_{j<=i} (mc[j] - S[j])
+                const uint32_t nc = (uint32_t)(xw::scan_min_i32((int32_t)mc - (int32_t)S) + (int32_t)S);
+                const bool litwin = i >= 1 && nc < mc;                                                   // :1492 (the literal edge comes last: strict)
+                const unsigned long long nkey = litwin ? (((unsigned long long)nc << 32) | ((node - 1) << 8) | kRankLit) : kin;
+                // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
+                const uint32_t rlive = (lv && pass > 0) ? L()->reach[buf][i] : 0u;     // (a node's reach counts once it was inside: it has relaxed its edges)
+                const uint32_t pm = xw::scan_max(rlive);
+                const uint32_t before = umax(xw::lane_below(pm, 0u), end_p);
+                const bool inside = inb && node < before;
+                const unsigned long long dead = xw::ballot(!inside);
+                istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;      // (lanes >= nb count as dead)
+                const bool act = i <= istar && inb;                 // nodes b0 .. b0+istar: inside, or the segment's last node
+                const bool nlv = i < istar && inb;
+                // rep sets from the winners (the sources' sets as of the last pass)
+                uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, link = 0, delta = 0;
+                if (act && nkey != kKeyNone) winner_set(seg_a, b0, (pass + 1) & 1u, node, nkey, o0, o1, o2, o3, link, delta);
+                {   // a run of literal winners carries the set of the node in front of the run (:1498): taken from that lane
+                    // in THIS pass, so that a literal run costs no pass
+                    const uint32_t root = xw::scan_max(litwin ? 0u : i);
+                    const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
+                    if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
+                }
+                const bool same = !act || (key == nkey && r0 == o0 && r1 == o1 && r2 == o2 && r3 == o3 && lv == nlv);
+                const bool changed = xw::any(!same);
+                if (act) { key = nkey; c = nc; r0 = o0; r1 = o1; r2 = o2; r3 = o3; }
+                lv = nlv;
+                if (w == 0 && act) { uint32_t *dr = L()->brep[pass & 1u] + i * 4; dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3; }
+                {
+                    const uint32_t done_n = umin(istar, nb);
+                    blk_end = done_n ? umax(end_p, xw::readlane(pm, done_n - 1)) : end_p;
+                }
+                t_work += k1 - k0; t_bar += k2 - k1; t_upd += ptick() - k2;
+                if (!changed) break;
                 pass++;
-                if (!L()->sh[1]) break;
             }
-            istar = L()->sh[7]; blk_end = L()->sh[8];
             t_pass += xw::tick() - tp0;
             const unsigned long long e0 = ptick();
             // ---- the block is at its fixed point: final nodes, the edges that end beyond it
-            const uint32_t q = (pass - 1) & 1u;                      // the buffer the last update read
+            const uint32_t lbuf = pass % 3u;                         // the buffer the last update read
             const uint32_t done = umin(istar, nb);                   // nodes b0 .. b0+done-1 are inside
             if (w == 0) {
                 const uint32_t lit_before = xw::lane_below(lit, 0u);   // the byte of the position before the node
                 if (i <= istar && inb) {
                     uint32_t o0, o1, o2, o3, link, delta;
-                    const unsigned long long key = L()->nkey[node & 511u];
-                    winner_set(seg_a, node, key, o0, o1, o2, o3, link, delta);
+                    winner_set(seg_a, b0, (pass + 1) & 1u, node, key, o0, o1, o2, o3, link, delta);
                     if (((uint32_t)key & 0xFFu) == kRankLit && node > 0) delta = i ? lit_before : L()->sh[9];
                     L()->node_link[node] = link; L()->node_delta[node] = delta;
+                    uint32_t *dr = L()->nrep + (node & 511u) * 4;
+                    dr[0] = r0; dr[1] = r1; dr[2] = r2; dr[3] = r3;
                 }
+                if (i == nb - 1) L()->sh[11] = c;
             }
-            if (w == 3 && i < done) {                                // bytes the final probes looked at (counter parity)
-                const uint32_t *nr = L()->nrep + (node & 511u) * 4;
-                const uint32_t pcap = umin(max_parse - node, kMatchMax);
-                uint32_t checked = 0;
-#pragma unroll
-                for (uint32_t z = 0; z < 8; z++)
-                    checked |= (dd[z] == nr[0] ? 1u : 0u) | (dd[z] == nr[1] ? 2u : 0u) | (dd[z] == nr[2] ? 4u : 0u) | (dd[z] == nr[3] ? 8u : 0u);
-                if (nd > 8) {
-                    for (uint32_t um = uniq; um; um &= um - 1) {
-                        const uint32_t d = L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)];
-                        checked |= (d == nr[0] ? 1u : 0u) | (d == nr[1] ? 2u : 0u) | (d == nr[2] ? 4u : 0u) | (d == nr[3] ? 8u : 0u);
-                    }
-                }
-                if (!(checked & 1u) && nr[0] < seg_q + node) n_cmp += ml0 + (ml0 < pcap);
-                if (!(checked & 2u) && nr[1] < seg_q + node) n_cmp += ml1 + (ml1 < pcap);
-                if (!(checked & 4u) && nr[2] < seg_q + node) n_cmp += ml2 + (ml2 < pcap);
-                if (!(checked & 8u) && nr[3] < seg_q + node) n_cmp += ml3 + (ml3 < pcap);
-            }
+            if (i < done && want) n_cmp += ml + (ml < pcap);          // bytes the final probe of this slot looked at (counter parity)
             xw::block_sync();
             if (istar < nb) {
                 seg_len = b0 + istar;                               // the segment ends inside the block
@@ -1561,16 +1486,16 @@ struct Parser {
                 for (uint32_t t = end_open + 1 + tid; t <= new_end; t += kParserThreads) L()->mprev[t & 511u] = kKeyNone;
                 xw::block_sync();
                 for (uint32_t t = b0 + nb + tid; t <= new_end; t += kParserThreads) {
-                    const unsigned long long kc = L()->mcur[q][t & 511u];
+                    const unsigned long long kc = L()->mcur[lbuf][t & 511u];
                     if (kc < L()->mprev[t & 511u]) L()->mprev[t & 511u] = kc;
                 }
                 xw::block_sync();
                 if (tid == 0) {
                     const uint32_t last = b0 + nb - 1;
-                    const unsigned long long kl = ((unsigned long long)(L()->ncost[last & 511u] + L()->sh[10]) << 32) | (last << 8) | kRankLit;
+                    const unsigned long long kl = ((unsigned long long)(L()->sh[11] + L()->sh[10]) << 32) | (last << 8) | kRankLit;
                     if (kl < L()->mprev[(last + 1) & 511u]) L()->mprev[(last + 1) & 511u] = kl;     // (equal cost: the smaller source wins, :1492 strict)
                     L()->sh[9] = L()->sh[6];
-                    if (!quiet && new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
+                    if (new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
                 }
                 if (new_end > end_open) end_open = new_end;
                 end_p = new_end;
@@ -1581,18 +1506,17 @@ struct Parser {
         }
         xw::block_sync();
         // backtrack (:1633-1650): node indices of the path, end first
-        uint32_t n = 0;
         if (w == 0) {
-            uint32_t cur = seg_len;
+            uint32_t n = 0, cur = seg_len;
             while (cur != 0) {
                 if (i == 0) L()->cmdlist[n] = (uint16_t)cur;
                 n++;
                 cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
             }
-            if (i == 0) L()->sh[11] = n;
+            if (i == 0) L()->ncmds = n;
         }
         xw::block_sync();
-        ncmds = L()->sh[11];
+        ncmds = L()->ncmds;
         return seg_len;
     }
 
@@ -1660,7 +1584,7 @@ struct Parser {
         const uint32_t tid = xw::thread();
         for (uint32_t k = tid; k < kNumCtx * kCdfStride; k += kParserThreads) L()->cdf[k] = P->cdf[k];
         for (uint32_t k = tid; k < 256; k += kParserThreads) L()->lut[k] = log2_lut_entry(k);
-        for (uint32_t k = tid; k < kEqSlots; k += kParserThreads) { L()->eq[k].r = 0; L()->eq[k].b = kNone; L()->eq[k].mlo = 0; L()->eq[k].mhi = 0; }
+        for (uint32_t k = tid; k < kPW * kEqSlotsW; k += kParserThreads) L()->eq[k / kEqSlotsW][k % kEqSlotsW] = EqEnt{ 0u, kNone, 0u, 0u };
         for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
         xw::block_sync();
         for (uint32_t k = tid; k < kNumCtx * 16; k += kParserThreads) {
@@ -1680,15 +1604,18 @@ struct Parser {
         for (; ci < c1 && !err; ci++) run_chunk(ci);
         xw::block_sync();
 #ifdef NLZM_PROFILE
-        if (xw::lane() == 0) {      // per wave: work before the first barrier of a pass, barrier waits; wave 0: update; wave 3: mask fills
+        if (xw::lane() == 0 && xw::wave() < 4) {   // per wave: relax + probe work of a pass, barrier wait, update; mask fills
             P->prof[32 + xw::wave()] += t_work; P->prof[36 + xw::wave()] += t_bar;
-            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; }
-            if (xw::wave() == 3) { P->prof[41] += t_fill; P->prof[43] += t_dirty; }
+            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; P->prof[41] += t_fill; }
         }
 #endif
-        if (xw::wave() == 3) {
+        {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
             for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
-            if (xw::lane() == 0) { L()->cnt.cmp_bytes += n_cmp; P->prof[9] += n_eq_fill; P->prof[10] += n_eq_rounds; P->prof[11] += n_redo; }
+            if (xw::lane() == 0) {
+                xw::lds_add64(&L()->cnt.cmp_bytes, n_cmp);
+                xw::lds_add64(&L()->cnt.stale_ht, n_eq_fill); xw::lds_add64(&L()->cnt.stale_rk, n_eq_rounds);     // (counters the new stages do not use otherwise)
+                xw::lds_add64(&L()->cnt.bt_slow, n_redo);
+            }
         }
         xw::block_sync();
         if (xw::wave() == 0) {
@@ -1696,10 +1623,12 @@ struct Parser {
             if (xw::lane() == 0) {
                 P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
                 P->next_chunk = ci;
+                P->prof[8] += n_blocks; P->prof[13] += n_passes;
+                P->prof[9] += L()->cnt.stale_ht; P->prof[10] += L()->cnt.stale_rk; P->prof[11] += L()->cnt.bt_slow;
+                L()->cnt.stale_ht = 0; L()->cnt.stale_rk = 0; L()->cnt.bt_slow = 0;
                 unsigned long long *dst = (unsigned long long *)&P->cnt;
                 const unsigned long long *src = (const unsigned long long *)&L()->cnt;
                 for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
-                P->prof[8] += n_blocks; P->prof[13] += n_passes;
                 P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_setup; P->prof[24] += t_pass;
                 const uint32_t xe = xw::ld_agent(&V.hx->err);
                 if (xe && !P->error) P->error = xe;
