@@ -629,13 +629,21 @@ struct Finder {
 // stage as a fresh pair per position.)
 constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
 
-struct TLds {
+constexpr uint32_t kTW = 3;                     // waves of the stage: each takes whole blocks, in turn
+struct TWave {
     unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
     uint32_t recs[64 * kFtStride];              // the block's finder records
+    uint32_t overflow;
+};
+struct TLds {
+    TWave w[kTW];
     unsigned long long carry[kFrontMax + 8];    // front after the last finished position
     unsigned long long tmp[2 * kFrontMax + 300];
     uint32_t carry_n;
-    uint32_t overflow;
+    uint32_t turn;                              // blocks are taken in turn: the wave whose sequence number this is cuts the next block
+    uint32_t cursor;                            // first position not yet in a block
+    uint32_t carry_seq;                         // ... and finished in that order: the block with this sequence number takes the carry
+    uint32_t stop;
 };
 
 NLZM_HD unsigned long long fr_key(uint32_t e, uint32_t d) { return ((unsigned long long)e << 32) | (0xFFFFFFFFu - d); }
@@ -649,6 +657,12 @@ struct Table {
     uint32_t err;
     uint32_t p_pos_seen;
     unsigned long long n_blocks, n_slow, t_wait;
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: gather, scan, carry + emit, wait for the carry
+#ifdef NLZM_PROFILE
+    XW_FN unsigned long long ptick() const { return xw::tick(); }
+#else
+    XW_FN unsigned long long ptick() const { return 0; }
+#endif
 
     // merge two fronts (each sorted by descending key, at most na / nb entries at pa / pb with stride 1) into out;
     // entries of b that end before `low` are left out.  Returns the count, or kNone if it exceeds cap.
@@ -684,14 +698,25 @@ struct Table {
         if (w0 & kFtTop) { if (n >= cap) return kNone; out[n++] = fr_key(a + rec[15], rec[14]); }
         if (w0 & kFtBt) {
             // the worker lane's record: the record-setters of the descent, lengths and distances growing along the list
+            // (count and first four pairs in one 64-byte record: requested together)
             const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
             const uint32_t *br = G.bt_ready + bi * kBtRec;
-            const uint32_t cnt = xw::ld_agent(br) & 0x1FFu;
-            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t d = k < 4 ? xw::ld_agent(br + 1 + 2 * k) : xw::ld_agent(pairs + 2 * k);
-                const uint32_t l = k < 4 ? xw::ld_agent(br + 2 + 2 * k) : xw::ld_agent(pairs + 2 * k + 1);
+            uint32_t bw[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) bw[k] = xw::ld_agent(br + k);
+            const uint32_t cnt = bw[0] & 0x1FFu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (k >= cnt) continue;
+                const uint32_t d = bw[1 + 2 * k], l = bw[2 + 2 * k];
                 if (l >= cap_len) continue;                     // as long as the lookahead allows: the finder stage's top entry covers it
+                if (n >= cap) return kNone;
+                out[n++] = fr_key(a + l, d);
+            }
+            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+            for (uint32_t k = 4; k < cnt; k++) {
+                const uint32_t d = xw::ld_agent(pairs + 2 * k), l = xw::ld_agent(pairs + 2 * k + 1);
+                if (l >= cap_len) continue;
                 if (n >= cap) return kNone;
                 out[n++] = fr_key(a + l, d);
             }
@@ -749,15 +774,28 @@ struct Table {
     XW_FN void capture(uint32_t a, const unsigned long long *f, uint32_t fn);
 
     // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end
-    XW_FN void block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    // wait for an LDS word of the stage to reach v
+    XW_FN bool wait_lds(const uint32_t *p, uint32_t v)
+    {
+        uint32_t spins = 0;
+        while (xw::readfirst(xw::lds_ld(p)) != v) {
+            if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) return false;
+            xw::pause();
+        }
+        return true;
+    }
+
+    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end; seq: the block's number
+    XW_FN void block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end, uint32_t seq)
     {
         TLds *L = xw::lds<TLds>();
+        TWave *W = &L->w[xw::wave()];
         const uint32_t i = xw::lane();
         const bool in_blk = i < n;
         const uint32_t a = a0 + i;
         const uint32_t cap_len = in_blk ? umin(la_end - a, kMatchMax) : 0u;
         const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
-        uint32_t *r = L->recs + i * kFtStride;
+        uint32_t *r = W->recs + i * kFtStride;
         if (in_blk) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -766,66 +804,77 @@ struct Table {
             }
         } else r[0] = 0;
         const uint32_t lit = (r[0] >> 8) & 0xFFu;
-        L->overflow = 0;
+        W->overflow = 0;
         xw::wave_sync();
+        const unsigned long long q0 = ptick();
         // the position's own pairs as a front
-        unsigned long long *mine = L->fr[0] + i * kFrCap;
+        unsigned long long *mine = W->fr[0] + i * kFrCap;
         uint32_t cnt = 0;
         if (in_blk) {
             cnt = gather(a, cap_len, r, mine, kFrCap);
-            if (cnt == kNone) { L->overflow = 1; cnt = 0; }
+            if (cnt == kNone) { W->overflow = 1; cnt = 0; }
             else cnt = sort_filter(mine, cnt);
         }
+        const unsigned long long q1 = ptick();
         // prefix scan: after the step with offset D lane i holds the front of the pairs of lanes (i - 2D, i]
         uint32_t cur = 0;
         for (uint32_t D = 1; D < 64; D <<= 1) {
             xw::wave_sync();
             const uint32_t ocnt = xw::shfl_up(cnt, D);
-            unsigned long long *dst = L->fr[cur ^ 1] + i * kFrCap;
-            const unsigned long long *own = L->fr[cur] + i * kFrCap;
+            unsigned long long *dst = W->fr[cur ^ 1] + i * kFrCap;
+            const unsigned long long *own = W->fr[cur] + i * kFrCap;
             uint32_t nn;
-            if (i >= D && in_blk) nn = merge(own, cnt, L->fr[cur] + (i - D) * kFrCap, ocnt, a + kMatchMin, dst, kFrCap);
+            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + kMatchMin, dst, kFrCap);
             else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
-            if (nn == kNone) { L->overflow = 1; nn = 0; }
+            if (nn == kNone) { W->overflow = 1; nn = 0; }
             cnt = nn;
             cur ^= 1;
         }
         xw::wave_sync();
-        // the front carried into the block
+        const unsigned long long q2 = ptick();
+        // ---- from here on in block order: the front carried into the block
+        if (!wait_lds(&L->carry_seq, seq)) { err = 1; return; }
+        const unsigned long long q3 = ptick();
         const uint32_t cn = xw::readfirst(L->carry_n);
-        unsigned long long *fin_f = L->fr[cur ^ 1] + i * kFrCap;
+        unsigned long long *fin_f = W->fr[cur ^ 1] + i * kFrCap;
         uint32_t fn = 0;
         if (in_blk) {
-            fn = merge(L->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + kMatchMin, fin_f, kFrCap);
-            if (fn == kNone) { L->overflow = 1; fn = 0; }
+            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + kMatchMin, fin_f, kFrCap);
+            if (fn == kNone) { W->overflow = 1; fn = 0; }
         }
         xw::wave_sync();
         n_blocks++;
-        if (xw::readfirst(L->overflow)) { slow_block(a0, n, a1, la_end); return; }
-        if (in_blk) emit(a, a1, lit, fin_f, fn);
-        if (G.cap_words) {
-            for (uint32_t j = 0; j < n; j++) capture(a0 + j, L->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
-        }
+        if (xw::readfirst(W->overflow)) slow_block(a0, n, a1, la_end);
+        else {
+            if (in_blk) emit(a, a1, lit, fin_f, fn);
+            if (G.cap_words) {
+                for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
+            }
 #ifdef NLZM_SIM
-        if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
+            if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
 #endif
-        // carry out: the last position's front
-        const uint32_t last_n = xw::readlane(fn, n - 1);
-        for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = L->fr[cur ^ 1][(n - 1) * kFrCap + k];
-        if (i == 0) L->carry_n = last_n;
+            // carry out: the last position's front
+            const uint32_t last_n = xw::readlane(fn, n - 1);
+            for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = W->fr[cur ^ 1][(n - 1) * kFrCap + k];
+            if (i == 0) L->carry_n = last_n;
+        }
+        xw::drain();
         xw::wave_sync();
+        if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->carry_seq, seq + 1); }
+        tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += ptick() - q3;
     }
 
     // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
     XW_FN void slow_block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
     {
         TLds *L = xw::lds<TLds>();
+        TWave *W = &L->w[xw::wave()];
         n_slow++;
         for (uint32_t j = 0; j < n; j++) {
             const uint32_t a = a0 + j;
             const uint32_t cap_len = umin(la_end - a, kMatchMax);
             const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
-            uint32_t *r = L->recs;
+            uint32_t *r = W->recs;
             if (xw::lane() < 8) {
                 const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * xw::lane()));
                 r[2 * xw::lane()] = (uint32_t)w; r[2 * xw::lane() + 1] = (uint32_t)(w >> 32);
@@ -856,52 +905,59 @@ struct Table {
     {
         TLds *L = xw::lds<TLds>();
         StateV2 *S = (StateV2 *)V.state;
-        const uint32_t i = xw::lane();
-        const uint32_t cn = xw::readfirst(S->front_n);
-        for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
-        if (i == 0) L->carry_n = cn;
+        const uint32_t i = xw::lane(), w = xw::wave();
+        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        unsigned long long a_last = (unsigned long long)c1 * g.chunk_size;
+        if (a_last > g.n) a_last = g.n;
+        if (w == 0) {
+            const uint32_t cn = xw::readfirst(S->front_n);
+            for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
+            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->stop = 0; }
+        }
+        xw::block_sync();
         err = 0; n_blocks = n_slow = 0; t_wait = 0;
         const unsigned long long t_start = xw::tick();
-        p_pos_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        xw::wave_sync();
-        uint32_t f_seen = p_pos_seen;
-        for (uint32_t ci = c0; ci < c1 && !err; ci++) {
+        uint32_t p_seen = a_first, f_seen = a_first;
+        for (uint32_t seq = w; !err; seq += kTW) {
+            // ---- take the next block (in turn)
+            const unsigned long long tw = xw::tick();
+            if (!wait_lds(&L->turn, seq)) { err = 1; break; }
+            const uint32_t a = xw::readfirst(xw::lds_ld(&L->cursor));
+            if ((unsigned long long)a >= a_last) { if (i == 0) xw::lds_st(&L->turn, seq + 1); break; }
+            const uint32_t ci = a / g.chunk_size;
             const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
             const unsigned long long remain = g.n - chunk_abs;
             const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
-            const uint32_t p_end = umin(g.chunk_size, chunk_read);
-            const uint32_t a1 = (uint32_t)chunk_abs + p_end, la_end = (uint32_t)chunk_abs + chunk_read;
-            uint32_t a = (uint32_t)chunk_abs;
-            while (a < a1 && !err) {
-                if ((int32_t)(f_seen - a) <= 0) {
-                    const unsigned long long tw = xw::tick();
-                    if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
-                    f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
-                    t_wait += xw::tick() - tw;
-                }
-                const uint32_t n = umin(64u, umin(a1, f_seen) - a);
-                if ((int32_t)(a + n - p_pos_seen - kTpRing) > 0) {
-                    const unsigned long long tw = xw::tick();
-                    if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
-                    p_pos_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
-                    t_wait += xw::tick() - tw;
-                }
-                block(a, n, a1, la_end);
-                xw::drain();
-#ifdef NLZM_SIM
-                if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "T block a %u n %u\n", a, n);
-#endif
-                a += n;
-                if (i == 0) { xw::st_agent(&V.hx->t_out, a); xw::st_agent(&V.hx->t_pos, a); }
+            const uint32_t a1 = (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), la_end = (uint32_t)chunk_abs + chunk_read;
+            if ((int32_t)(f_seen - a) <= 0) {
+                if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
             }
+            f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
+            const uint32_t n = umin(64u, umin(a1, f_seen) - a);
+            if ((int32_t)(a + n - p_seen - kTpRing) > 0) {
+                if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
+                p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
+            }
+            if (i == 0) { xw::lds_st(&L->cursor, a + n); xw::lds_st(&L->turn, seq + 1); }
+            t_wait += xw::tick() - tw;
+            block(a, n, a1, la_end, seq);
+#ifdef NLZM_SIM
+            if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "T block a %u n %u\n", a, n);
+#endif
         }
-        xw::wave_sync();
-        const uint32_t on = xw::readfirst(L->carry_n);
-        for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
-        if (i == 0) {
-            S->front_n = on;
-            G.persist->prof[6] += n_blocks; G.persist->prof[7] += n_slow;
-            G.persist->prof[18] += t_wait; G.persist->prof[19] += xw::tick() - t_start;
+        if (err && i == 0) xw::st_agent(&V.hx->err, kErrInternal + 200);
+        xw::block_sync();
+        if (i == 0) {       // accounting: summed over the waves
+            unsigned long long *pr = G.persist->prof;
+            xw::atomic_add64_agent(&pr[6], n_blocks); xw::atomic_add64_agent(&pr[7], n_slow);
+            xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
+            xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
+            if (w == 0) { pr[18] += t_wait; pr[19] += xw::tick() - t_start; }
+        }
+        if (w == 0) {
+            const uint32_t on = xw::readfirst(L->carry_n);
+            for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
+            if (i == 0) S->front_n = on;
         }
     }
 };

@@ -99,6 +99,7 @@ XW_FN uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMI
 XW_FN void st_agent64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // after a poll saw the flag: later plain loads of this wave read what the producer stored (buffer_inv sc1)
 XW_FN void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 XW_FN void lds_min64(unsigned long long *p, unsigned long long v)
@@ -212,6 +213,7 @@ inline uint32_t ld_agent(const uint32_t *p) { return *(volatile const uint32_t *
 inline void st_agent64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline unsigned long long ld_agent64(const unsigned long long *p) { return *(volatile const unsigned long long *)p; }
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
+inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
 inline void acquire_agent() {}
 inline void lds_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }

@@ -229,8 +229,8 @@ static void role_entry(void *p)
     const LaunchArgs &A = *(const LaunchArgs *)p;
     const uint32_t b = xw::block_index();
     if (b == 0) { if (xw::wave() == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
-    else if (b == 1) { if (xw::wave() == 0) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
-    else { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
+    else if (b == 1) { if (xw::wave() < v2::kTW) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
+    else if (xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
 }
 
 int main(int argc, char **argv)
@@ -307,7 +307,7 @@ int main(int argc, char **argv)
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;
-        xw::launch(3, v2::kParserThreads, lds_bytes, role_entry, &A);
+        xw::launch(3, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
         wk.finish();
         if (P.error || hx->err) { printf("sim error %u / %u (info %u %u)\n", P.error, hx->err, P.error_info[0], P.error_info[1]); return 1; }
         if (g_ref.bad) break;
