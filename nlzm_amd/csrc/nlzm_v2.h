@@ -1050,7 +1050,7 @@ struct Parser {
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
-    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, t_wait, t_emit, t_setup, t_pass;
+    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, n_fast = 0, t_wait, t_emit, t_setup, t_pass;
     unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
@@ -1300,7 +1300,51 @@ struct Parser {
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
+        if (w == 0) {
+            if ((int32_t)(t_out_seen - (seg_a + 1)) < 0) {
+                const unsigned long long tw = xw::tick();
+                if (!wait_word_ge(&V.hx->t_out, seg_a + 1, V.hx, 4)) err = kErrInternal + 100;
+                t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                t_wait += xw::tick() - tw;
+            }
+            if (i == 0) L()->sh[4] = err;
+        }
         xw::block_sync();
+        if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
+        {
+            // A position without any match is a segment of its own (more than half of all segments are): its node has no
+            // sampled edge, and if none of the four rep probes finds anything (:1598-1628) the only command is the literal.
+            const uint32_t *rec0 = V.tp + (unsigned long long)(seg_a & (kTpRing - 1)) * kTpStride;
+            const uint32_t h0 = xw::readfirst(xw::ld_agent(rec0));
+            if ((h0 & 63u) == 0) {
+                bool ok = false;
+                unsigned long long counted = 0;
+                if (w < 4) {
+                    const uint32_t r = w == 0 ? rep0 : (w == 1 ? rep1 : (w == 2 ? rep2 : rep3));
+                    const uint32_t pcap = umin(max_parse, kMatchMax);
+                    const bool want = i == 0 && r < seg_q;                                          // :1601
+                    const uint32_t l = xw::any(want) ? probe_len(want, seg_a, r, pcap) : 0u;
+                    if (want) { counted = l + (l < pcap); n_cmp += counted; }
+                    ok = xw::any(want && l >= match_min(r));
+                    if (i == 0) L()->sh[12 + w] = ok ? 1u : 0u;
+                }
+                xw::block_sync();
+                const bool any_ok = (L()->sh[12] | L()->sh[13] | L()->sh[14] | L()->sh[15]) != 0;
+                xw::block_sync();
+                if (!any_ok) {
+                    if (tid == 0) {
+                        L()->node_link[1] = 0; L()->node_delta[1] = (h0 >> 8) & 0xFFu;           // literal: from node 0, the byte
+                        L()->cmdlist[0] = 1; L()->ncmds = 1;
+                        xw::st_agent(&V.hx->p_pos, seg_a);
+                    }
+                    n_fast++;
+                    xw::block_sync();
+                    ncmds = 1;
+                    return 1;
+                }
+                n_cmp -= counted;       // (a probe matched: the block counts the probes' bytes itself)
+            }
+        }
         while (!seg_len) {
             const unsigned long long ts = xw::tick();
             if (b0 == end_p || b0 >= max_parse) {
