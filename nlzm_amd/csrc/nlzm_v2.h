@@ -1004,8 +1004,10 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
-constexpr uint32_t kPW = 4;                     // waves of the stage: wave w relaxes the sampled edges k = w (mod kPW) and probes rep slot w
-constexpr uint32_t kEdgesPerWave = kMaxEdges / kPW;
+constexpr uint32_t kPW = 8;                     // waves of the stage: waves 0..3 probe rep slot w and relax two of the sampled edges each,
+constexpr uint32_t kEdgesPerWave = 6;           // waves 4..7 relax six each
+// sampled edge j of wave w (kMaxEdges: none)
+NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j) { return w < 4 ? (j < 2 ? w + 4 * j : kMaxEdges) : 8 + (w - 4) + 4 * j; }
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
 constexpr uint32_t kInf = 0x3FFFFFFFu;
@@ -1015,7 +1017,7 @@ struct alignas(16) EqEnt { uint32_t r, b, mlo, mhi; };
 struct PLds {
     unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
     unsigned long long mcur[3][512];            // ... over the edges of the block being iterated: pass p relaxes into [p % 3]
-    EqEnt eq[kPW][kEqSlotsW];                   // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
+    EqEnt eq[4][kEqSlotsW];                   // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
     uint32_t nrep[512 * 4];                     // rep set of the nodes of finished blocks (CarriedState ring, :1460-1467)
     uint32_t brep[2][64 * 4];                   // ... of the block's nodes after pass p at [p & 1]
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
@@ -1398,7 +1400,7 @@ struct Parser {
             {
                 unsigned long long er[kEdgesPerWave];
 #pragma unroll
-                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = w + kPW * j < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (w + kPW * j))) : 0ull;
+                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = edge_of(w, j) < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * edge_of(w, j))) : 0ull;
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                     ed[j] = 0; ea[j] = 0;
@@ -1474,7 +1476,7 @@ struct Parser {
 #pragma unroll
                     for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                         if (!ea[j]) continue;
-                        const uint32_t k = w + kPW * j;
+                        const uint32_t k = edge_of(w, j);
                         const uint32_t tl = ea[j] & 0x1FFu, wd = (ea[j] >> 9) & 0xFFFu, lp = ea[j] >> 21;
                         unsigned long long *dst = &L()->mcur[buf][(node + tl) & 511u];
                         xw::lds_min64(dst, ((unsigned long long)(c + pc_dict + wd) << 32) | (node << 8) | (2 * k));
@@ -1483,7 +1485,7 @@ struct Parser {
                             xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
                     }
                 }
-                if (pass > 0) {
+                if (pass > 0 && w < 4) {
                     // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628)
                     const uint32_t r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
                     const bool dirty = lv && r != cr;
@@ -1575,7 +1577,7 @@ struct Parser {
                 }
                 if (i == nb - 1) L()->sh[11] = c;
             }
-            if (i < done && want) n_cmp += ml + (ml < pcap);          // bytes the final probe of this slot looked at (counter parity)
+            if (w < 4 && i < done && want) n_cmp += ml + (ml < pcap);  // bytes the final probe of this slot looked at (counter parity)
             xw::block_sync();
             if (istar < nb) {
                 seg_len = b0 + istar;                               // the segment ends inside the block
@@ -1684,7 +1686,7 @@ struct Parser {
         const uint32_t tid = xw::thread();
         for (uint32_t k = tid; k < kNumCtx * kCdfStride; k += kParserThreads) L()->cdf[k] = P->cdf[k];
         for (uint32_t k = tid; k < 256; k += kParserThreads) L()->lut[k] = log2_lut_entry(k);
-        for (uint32_t k = tid; k < kPW * kEqSlotsW; k += kParserThreads) L()->eq[k / kEqSlotsW][k % kEqSlotsW] = EqEnt{ 0u, kNone, 0u, 0u };
+        for (uint32_t k = tid; k < 4 * kEqSlotsW; k += kParserThreads) L()->eq[k / kEqSlotsW][k % kEqSlotsW] = EqEnt{ 0u, kNone, 0u, 0u };
         for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
         xw::block_sync();
         for (uint32_t k = tid; k < kNumCtx * 16; k += kParserThreads) {
