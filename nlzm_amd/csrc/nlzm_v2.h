@@ -824,7 +824,7 @@ struct Table {
             unsigned long long *dst = W->fr[cur ^ 1] + i * kFrCap;
             const unsigned long long *own = W->fr[cur] + i * kFrCap;
             uint32_t nn;
-            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + kMatchMin, dst, kFrCap);
+            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + 1, dst, kFrCap);
             else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
             if (nn == kNone) { W->overflow = 1; nn = 0; }
             cnt = nn;
@@ -839,7 +839,7 @@ struct Table {
         unsigned long long *fin_f = W->fr[cur ^ 1] + i * kFrCap;
         uint32_t fn = 0;
         if (in_blk) {
-            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + kMatchMin, fin_f, kFrCap);
+            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + 1, fin_f, kFrCap);
             if (fn == kNone) { W->overflow = 1; fn = 0; }
         }
         xw::wave_sync();
@@ -884,7 +884,7 @@ struct Table {
             if (xw::lane() == 0) {
                 uint32_t c = gather(a, cap_len, r, t0, 300);    // <= 7 + 256 pairs
                 c = sort_filter(t0, c);
-                const uint32_t fn = merge(t0, c, L->carry, L->carry_n, a + kMatchMin, t1, kFrontMax + 8);
+                const uint32_t fn = merge(t0, c, L->carry, L->carry_n, a + 1, t1, kFrontMax + 8);
                 for (uint32_t k = 0; k < fn; k++) L->carry[k] = t1[k];
                 L->carry_n = fn;
                 emit(a, a1, (r[0] >> 8) & 0xFFu, L->carry, fn);

@@ -182,8 +182,7 @@ void v2::Table::sim_on_front(void *, uint32_t a, const unsigned long long *f, ui
     const uint32_t *r = g_ref.words.data() + g_ref.off[a];
     const uint32_t max_len = r[0];
     const uint32_t mt = fn ? v2::fr_end(f[0]) - a : 0u;
-    // (a table of length 1 and an empty one are the same thing: the carry of the next position leaves 0, :823-833)
-    bool ok = (mt == max_len) || (mt <= 1 && max_len <= 1);
+    bool ok = mt == max_len;
     for (uint32_t l = 2; ok && l <= max_len; l++) {
         uint32_t d = 0;
         for (uint32_t k = 0; k < fn; k++) if (v2::fr_end(f[k]) >= a + l) d = v2::fr_dist(f[k]);
