@@ -25,17 +25,12 @@
 namespace nlzm {
 void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long pos0, unsigned long long pos1,
                     uint32_t *out, hipStream_t st);
-void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
 void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st);
 unsigned long long stream2_pack_size();
 uint32_t stream2_pack_capacity();
 uint32_t pipeline2_role_blocks();
 void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1);
 void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
-unsigned long long stream_pack_size();
-uint32_t stream_pack_capacity();
-void fill_stream_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, uint32_t c0, uint32_t c1);
-void launch_pipeline_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,

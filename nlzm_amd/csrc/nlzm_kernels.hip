@@ -5,9 +5,8 @@
 //                       1071-1083): pure, position-parallel, input tile staged in LDS.
 //   prefilter_*_kernel  marks the positions whose BT4 call cannot be decided from the input alone
 //   bin_kernel          groups each chunk's positions by BT4 hash head
-//   pipeline_kernel     block 0: the serial half (nlzm_core.h, seven waves): HT2/HT3/RK256 state, match-table
-//                       chain, forward-graph parse, model, symbol emit; blocks 1..: BT4 worker lanes
-//   pipeline_multi_kernel  the same for several independent streams in one launch (block mode)
+//   pipeline2_kernel    blocks 0, 1, 2: the finder, table and parser stage (nlzm_v2.h); blocks 3..: BT4 worker lanes
+//   pipeline2_multi_kernel  the same for several independent streams in one launch (block mode)
 //   rans_frames_kernel  CodeFrame::Flush (NLZM.cpp:590-640): 4 interleaved rANS states
 //                       per frame, renormalisation words placed by a prefix scan.
 //   gather_frames_kernel concatenates the frames into the output stream.
@@ -32,320 +31,6 @@ namespace xw {
 template <class T> XW_FN T *lds() { return reinterpret_cast<T *>(&nlzm::g_v2_lds); }
 }
 namespace nlzm {
-
-// ---------------------------------------------------------------------------
-// 64-lane wave policy for the master (block = one wave)
-// ---------------------------------------------------------------------------
-// LDS image of the master: a file-scope __shared__ object, so every access is a ds_* instruction
-// (a pointer kept in a struct would degrade to flat_* accesses and their full waits)
-__shared__ MasterLds g_master_lds;
-
-struct DevWave {
-    static __device__ __forceinline__ MasterLds *lds() { return &g_master_lds; }
-    static __device__ __forceinline__ void cnt_add(unsigned long long *p, unsigned long long v)
-    {
-        if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // lane i < n adds f(i) (one exec-masked LDS atomic for all of them)
-    template <class F>
-    static __device__ __forceinline__ void cnt_add_fn(unsigned long long *p, uint32_t n, F f)
-    {
-        const uint32_t v = f(lane());
-        if (lane() < n && v) (void)__hip_atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // One symbol through a nibble CDF (NLZM.cpp:348-382, 435-438): lane i holds cell[i] and cell[i+1]; the (start, freq)
-    // snapshot of symbol y is picked out of the registers, cell[i] += (mixin[y][i] - cell[i]) >> 7 for i < nsy with
-    // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298), and the price row follows from the new cells.
-    static __device__ __forceinline__ void cdf_step(uint16_t *cell, uint16_t *price_row, const uint16_t *lut, uint32_t nsy, uint32_t y,
-                                                    uint32_t &start, uint32_t &freq)
-    {
-        const uint32_t i = lane();
-        uint32_t c0 = 0, c1 = 0;
-        if (i <= 16) { c0 = cell[i]; c1 = cell[i + 1]; }
-        start = (uint32_t)__builtin_amdgcn_readlane((int)c0, (int)y);
-        freq = (uint32_t)__builtin_amdgcn_readlane((int)c1, (int)y) - start;
-        auto upd = [=](uint32_t j, uint32_t c) {
-            const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
-            return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
-        };
-        const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
-        if (i < nsy) { cell[i] = (uint16_t)n0; price_row[i] = lut[(n1 - n0) >> 6]; }
-    }
-    // Up to 8 symbols of distinct contexts (list in LDS: context, symbol), four per pass on sixteen lanes each: see
-    // cdf_step for one symbol.  The lane that holds the symbol's cell writes its (freq << 16) + start word.
-    static __device__ __forceinline__ void cdf_multi(uint16_t *cdf, uint16_t *price, const uint16_t *lut, const uint32_t *list, uint32_t n,
-                                                     uint32_t *out)
-    {
-        const uint32_t grp = lane() >> 4, i = lane() & 15u;
-        for (uint32_t base = 0; base < n; base += 4) {
-            const uint32_t k = base + grp;
-            if (k < n) {
-                const uint32_t ctx = list[2 * k], y = list[2 * k + 1];
-                const uint32_t nsy = ctx == kCtxCmd ? 4u : ((ctx == kCtxLenDirect || ctx >= kCtxSlotHi) ? 8u : 16u);
-                uint16_t *cell = cdf + ctx * kCdfStride;
-                const uint32_t c0 = cell[i], c1 = cell[i + 1];
-                if (i == y) out[k] = ((c1 - c0) << 16) + c0;
-                auto upd = [=](uint32_t j, uint32_t c) {
-                    const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
-                    return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
-                };
-                const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
-                if (i < nsy) { cell[i] = (uint16_t)n0; price[ctx * 16 + i] = lut[(n1 - n0) >> 6]; }
-            }
-        }
-    }
-    // value of lane l (wave-uniform l)
-    static __device__ __forceinline__ uint32_t pick(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-    static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
-    static __device__ __forceinline__ uint32_t width() { return 64u; }
-    // per look-ahead slot state kept in the lane that evaluated the slot (slot j = lane j, kPf == 64)
-    struct PfLane { uint32_t idx, rkslot, stale, v4, row1, sl, sd, cmpb, simple, wrote; };
-    // idx: HT2 bucket | HT3 bucket << 16 (0xFFFFFFFF: the slot touches no HT row); sl/sd: summary of its table updates;
-    // simple: everything about the slot was settled by the look-ahead (see Master::pf_fill)
-    static __device__ __forceinline__ void pfl_set(PfLane &p, uint32_t, uint32_t idx, uint32_t rkslot, uint32_t v4, uint32_t row1,
-                                                   uint32_t sl, uint32_t sd, uint32_t cmpb, bool simple)
-    {
-        p.idx = idx; p.rkslot = rkslot; p.stale = 0; p.v4 = v4; p.row1 = row1; p.sl = sl; p.sd = sd; p.cmpb = cmpb; p.simple = simple;
-        p.wrote = 0;
-    }
-    // stale bit 1: an earlier slot of the batch writes an HT row this slot has read (bucket b owns rows b and b+1, :912)
-    static __device__ __forceinline__ void pfl_conflicts(PfLane &p, uint32_t n)
-    {
-        const uint32_t o2 = p.idx & 0xFFFFu, o3 = p.idx >> 16;
-        bool conf = false;
-        for (uint32_t k = 0; k + 1 < n; k++) {
-            const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)p.idx, (int)k);
-            const uint32_t i2 = ik & 0xFFFFu, i3 = ik >> 16;
-            conf = conf || (lane() > k && ik != 0xFFFFFFFFu && (o2 == i2 || o3 == i3 || o3 == i3 + 1 || o3 + 1 == i3));
-        }
-        p.stale |= (conf && lane() < n) ? 1u : 0u;
-    }
-    // slots the finder wave may pass over without looking at them one by one
-    static __device__ __forceinline__ unsigned long long pfl_run_mask(const PfLane &p, uint32_t n)
-    {
-        return __ballot(lane() < n && p.simple && !(p.stale & 5u));
-    }
-    // HT2/HT3 rows of slots [s0, s0+cnt) rotate (:935-936); no two of them, nor an earlier slot of the batch, share a row
-    static __device__ __forceinline__ void pfl_run_store(PfLane &p, uint32_t s0, uint32_t cnt, uint32_t *ht2, uint32_t *ht3,
-                                                         uint32_t q0, uint32_t wbits, uint32_t tag_mask, uint32_t ht3_shift)
-    {
-        if (lane() >= s0 && lane() < s0 + cnt) {
-            const uint32_t q = q0 + (lane() - s0);
-            const uint32_t h2 = hash4(p.v4 & 0xFFFFu), h3 = hash4(p.v4 & 0xFFFFFFu);
-            const uint32_t i2 = h2 >> 20, i3 = h3 >> ht3_shift;
-            ht2[i2] = q | ((h2 & tag_mask) << wbits);
-            ht3[i3] = q | ((h3 & tag_mask) << wbits);
-            ht3[i3 + 1] = p.row1;
-            p.wrote = 1;
-        }
-    }
-    // (called by the lane of slot j itself) the BT4 result of the slot has arrived after the look-ahead
-    static __device__ __forceinline__ void pfl_update(PfLane &p, uint32_t, uint32_t sl, uint32_t sd, bool simple)
-    {
-        p.sl = sl; p.sd = sd; p.simple = simple;
-    }
-    // slot s has rotated its HT rows; v1 is what it moved into HT3 row bucket+1
-    static __device__ __forceinline__ void pfl_wrote(PfLane &p, uint32_t s, uint32_t v1)
-    {
-        if (lane() == s) { p.wrote = 1; p.row1 = v1; }
-    }
-    // HT2 row i2 and HT3 rows i3, i3+1 as the slots before j of this batch have left them (row[] comes in as the
-    // look-ahead read them).  Slot k stored: HT2[i2_k] = E2_k, HT3[i3_k] = E3_k, HT3[i3_k + 1] = row1_k (:935-936).
-    static __device__ __forceinline__ void pfl_rows_now(const PfLane &p, uint32_t j, uint32_t i2, uint32_t i3, uint32_t q0, uint32_t wbits,
-                                                        uint32_t tag_mask, uint32_t ht3_shift, uint32_t row[3])
-    {
-        const bool act = p.wrote && lane() < j;
-        const uint32_t o2 = p.idx & 0xFFFFu, o3 = p.idx >> 16, qk = q0 + lane();
-        const uint32_t e2 = qk | ((hash4(p.v4 & 0xFFFFu) & tag_mask) << wbits), e3 = qk | ((hash4(p.v4 & 0xFFFFFFu) & tag_mask) << wbits);
-        const bool mA = act && o3 == i3, mB = act && o3 + 1 == i3, mC = act && o3 == i3 + 1;
-        const unsigned long long b0 = __ballot(act && o2 == i2), b1 = __ballot(mA || mB), b2 = __ballot(mC || mA);
-        (void)ht3_shift;
-        if (b0) row[0] = (uint32_t)__builtin_amdgcn_readlane((int)e2, 63 - __builtin_clzll(b0));
-        if (b1) row[1] = (uint32_t)__builtin_amdgcn_readlane((int)(mA ? e3 : p.row1), 63 - __builtin_clzll(b1));
-        if (b2) row[2] = (uint32_t)__builtin_amdgcn_readlane((int)(mC ? e3 : p.row1), 63 - __builtin_clzll(b2));
-    }
-    static __device__ __forceinline__ uint32_t pfl_sl(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sl, (int)s); }
-    static __device__ __forceinline__ uint32_t pfl_sd(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.sd, (int)s); }
-    static __device__ __forceinline__ uint32_t pfl_cmpb(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.cmpb, (int)s); }
-    static __device__ __forceinline__ void pfl_mark_rk(PfLane &p, uint32_t s, uint32_t n, uint32_t slot)
-    {
-        p.stale |= (lane() > s && lane() < n && p.rkslot == slot) ? 4u : 0u;
-    }
-    static __device__ __forceinline__ uint32_t pfl_stale(const PfLane &p, uint32_t s) { return (uint32_t)__builtin_amdgcn_readlane((int)p.stale, (int)s); }
-    // explicit rep probes: lane i = probe i>>4, dword i&15 of the kRepPf bytes in front of the distance and at the position
-    struct RepPf { uint32_t s, c; };
-    static __device__ __forceinline__ RepPf rep_prefetch(const uint8_t *in, unsigned long long n, uint32_t a, uint32_t r0, uint32_t r1,
-                                                         uint32_t r2, uint32_t r3)
-    {
-        const uint32_t i = lane(), k = i >> 4, j = (i & 15u) * 4;
-        const uint32_t d = k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : r3));
-        RepPf r;
-        r.c = (unsigned long long)a + j + 4 <= n + 64 ? load32u(in + a + j) : 0;        // the input is followed by >= 128 bytes
-        r.s = d <= a ? load32u(in + (a - d) + j) : ~r.c;                                 // distance beyond the start: no match
-        return r;
-    }
-    static __device__ __forceinline__ void rep_lengths(RepPf r, uint32_t len[4])
-    {
-        const uint32_t x = r.s ^ r.c;
-        const unsigned long long bal = __ballot(x != 0);
-        const uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t f = (uint32_t)(bal >> (16 * k)) & 0xFFFFu;
-            if (f) {
-                const uint32_t l = (uint32_t)__builtin_ctz(f);
-                len[k] = 4 * l + (uint32_t)__builtin_amdgcn_readlane((int)nb, 16 * k + (int)l);
-            } else len[k] = kRepPf;
-        }
-    }
-    // the value is the same in every lane: move it to a scalar register so that the arithmetic and
-    // the branches that depend on it run on the scalar unit
-    // a small record read with ONE LDS instruction (lane k holds word k), its words picked by v_readlane
-    struct Rec { uint32_t v; };
-    static __device__ __forceinline__ Rec rec_load(const uint32_t *base) { return Rec{ base[lane() & 31u] }; }
-    // lanes of a record as a vector: ballot of a predicate / sum over lanes 1, 3, 5, 7
-    template <class F>
-    static __device__ __forceinline__ unsigned long long rec_mask(const Rec &r, F f) { return __ballot(f(lane(), r.v)); }
-    template <class F>
-    static __device__ __forceinline__ uint32_t rec_sum_odd4(const Rec &r, F f)
-    {
-        const uint32_t c = f(lane(), r.v);
-        return (uint32_t)__builtin_amdgcn_readlane((int)c, 1) + (uint32_t)__builtin_amdgcn_readlane((int)c, 3) +
-               (uint32_t)__builtin_amdgcn_readlane((int)c, 5) + (uint32_t)__builtin_amdgcn_readlane((int)c, 7);
-    }
-    // 16 words of HBM shared with the worker lanes (agent scope), lane k takes word k
-    static __device__ __forceinline__ Rec rec_load_agent(const uint32_t *base)
-    {
-        return Rec{ __hip_atomic_load(base + (lane() & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
-    }
-    template <class F>
-    static __device__ __forceinline__ Rec rec_load_fn(F f) { return Rec{ f(lane() & 7u) }; }
-    template <class F>
-    static __device__ __forceinline__ Rec rec_load_fn32(F f) { return Rec{ f(lane() & 31u) }; }
-    // records as vectors: a or b whole / lanes 1..4 stored to dst[1..4] / lanes 1..4 equal
-    static __device__ __forceinline__ Rec rec_sel(bool c, Rec a, Rec b) { return Rec{ c ? a.v : b.v }; }
-    static __device__ __forceinline__ void rec_store4(uint32_t *dst, Rec r) { if (lane() - 1u < 4u) dst[lane()] = r.v; }
-    static __device__ __forceinline__ uint32_t rec_eq4(Rec a, Rec b) { return ((uint32_t)__ballot(a.v == b.v) & 0x1Eu) == 0x1Eu ? 1u : 0u; }
-    // the three values are all loaded before any of them is used (the loads overlap)
-    static __device__ __forceinline__ void join3(uint32_t &a, uint32_t &b, uint32_t &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
-    // word k set (v_writelane) / lanes 0..n-1 stored to dst[0..n-1] / lane k moved to lane k + 2 (lanes 0, 1 undefined)
-    static __device__ __forceinline__ Rec rec_set(Rec r, uint32_t k, uint32_t v)
-    {
-        const uint32_t sv = uni(v);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(r.v) : "s"(sv), "n"(k));      // (no builtin for it in this compiler)
-        return r;
-    }
-    static __device__ __forceinline__ void rec_store_n(uint32_t *dst, Rec r, uint32_t n) { if (lane() < n) dst[lane()] = r.v; }
-    // lane k + 3 / k + 8 moved to lane k (within the 16 lanes a record uses)
-    static __device__ __forceinline__ Rec rec_shl3(Rec r) { return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x103 /* row_shl:3 */, 0xF, 0xF, false) }; }
-    static __device__ __forceinline__ Rec rec_shl8(Rec r) { return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x108 /* row_shl:8 */, 0xF, 0xF, false) }; }
-    static __device__ __forceinline__ Rec rec_shift2(Rec r)
-    {
-        return Rec{ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.v, 0x112 /* row_shr:2 */, 0xF, 0xF, false) };
-    }
-    static __device__ __forceinline__ uint32_t rec_get(Rec r, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)r.v, (int)k); }
-    static __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    // The master is ONE wave: LDS and same-CU global accesses of a wave complete in
-    // program order, so a workgroup-scope fence (the waits) plus a scheduling barrier
-    // is all the cross-lane ordering it needs -- no s_barrier.
-    static __device__ __forceinline__ void sync()
-    {
-        // LDS only: DS operations of one wave execute in order, so other lanes' earlier LDS
-        // writes are visible to later reads without any wait; only the compiler must not
-        // move or cache LDS accesses across this point
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    }
-    static __device__ __forceinline__ void sync_global()
-    {
-        // lane 0's global stores (HT rows, RK table, BT links) before every lane's later loads
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // agent-scope (sc1, write-through / L1-bypassing) accesses for words shared with worker lanes
-    static __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
-    {
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
-    {
-        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ void lds_min(uint32_t *p, uint32_t v)
-    {
-        // result unused: a ds_min_u32 without return, nothing to wait for
-        (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    template <class F>
-    static __device__ __forceinline__ unsigned long long mask64(F f) { return __ballot(f(lane())); }
-    // words shared by the waves of the serial half (same CU, LDS)
-    static __device__ __forceinline__ void xw_store(uint32_t *p, uint32_t v)
-    {
-        asm volatile("" ::: "memory");
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    static __device__ __forceinline__ uint32_t xw_load(const uint32_t *p)
-    {
-        const uint32_t v = uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        asm volatile("" ::: "memory");
-        return v;
-    }
-    static __device__ __forceinline__ void xw_add(uint32_t *p, uint32_t v)
-    {
-        asm volatile("" ::: "memory");
-        if (lane() == 0) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    static __device__ __forceinline__ void xw_pause() { __builtin_amdgcn_s_sleep(0); }      // (hand-offs between the waves are on the critical chain)
-    static __device__ __forceinline__ void sleep() { __builtin_amdgcn_s_sleep(4); }
-    static __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }      // 100 MHz
-    static __device__ __forceinline__ unsigned long long timeout_ticks() { return 2000000000ull; } // 20 s
-    static __device__ __forceinline__ void wait_hook(void *, uint32_t) {}
-    static __device__ __forceinline__ unsigned long long tick() { return __builtin_readcyclecounter(); }
-    static __device__ __forceinline__ uint32_t rmin(uint32_t v)
-    {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v = umin(v, (uint32_t)__shfl_xor((int)v, m, 64));
-        return v;
-    }
-    static __device__ __forceinline__ uint32_t ror(uint32_t v)
-    {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m, 64);
-        return v;
-    }
-    // Up to 8 byte compares at once: group k (8 lanes x 8 bytes) compares
-    // in[sp[k] ..] with in[a ..] up to cap[k] bytes; len[k] = common prefix.
-    // Up to three byte compares against the bytes at `a` at once (HT2 row, two HT3 rows): job k on lanes 8k..8k+7, eight
-    // bytes per lane and round; the first mismatch of a job is the lowest set bit of its byte of one ballot.
-    static __device__ __forceinline__ void cmp_multi(const uint8_t *in, const uint32_t sp[8], uint32_t a,
-                                                     const uint32_t cap[8], uint32_t valid, uint32_t len[8])
-    {
-        const uint32_t l = lane(), grp = l >> 3, j = l & 7;
-        const uint32_t mysp = grp == 0 ? sp[0] : (grp == 1 ? sp[1] : sp[2]);
-        const uint32_t mycap = grp == 0 ? cap[0] : (grp == 1 ? cap[1] : cap[2]);
-        uint32_t todo = valid & 7u;                     // jobs without a result yet (wave-uniform)
-        len[0] = 0; len[1] = 0; len[2] = 0;
-        for (uint32_t off = 0; todo; off += 64) {
-            const uint32_t my = off + j * 8;
-            uint32_t pos = kNone;
-            if (grp < 3 && ((todo >> grp) & 1u) && my < mycap) {
-                const unsigned long long d = load64u(in + mysp + my) ^ load64u(in + a + my);
-                if (d) {
-                    const uint32_t p = my + ((uint32_t)__builtin_ctzll(d) >> 3);
-                    if (p < mycap) pos = p;
-                }
-            }
-            const uint32_t bal = (uint32_t)__ballot(pos != kNone);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (!((todo >> k) & 1u)) continue;
-                const uint32_t byte = (bal >> (8 * k)) & 0xFFu;
-                if (byte) { len[k] = (uint32_t)__builtin_amdgcn_readlane((int)pos, 8 * k + (int)__builtin_ctz(byte)); todo &= ~(1u << k); }
-                else if (off + 64 >= cap[k]) { len[k] = cap[k]; todo &= ~(1u << k); }       // no mismatch below the cap
-            }
-        }
-    }
-};
 
 // ---------------------------------------------------------------------------
 // RK256 hash of every window: rkhash[a] = sum_{j<256} in[a+j] * ADDH^(256-j)
@@ -541,8 +226,6 @@ struct LaneIO {
 
 // The stores of a dry run, noted in LDS (a worker block does not use the master's LDS image): kLogCap (address, value)
 // pairs per lane, interleaved by lane so that a wave's k-th entries sit in different banks.
-static_assert(sizeof(MasterLds) >= 512 * kLogCap * 8, "store log does not fit the block's LDS");
-struct LogInMaster { static __device__ __forceinline__ uint32_t *base() { return (uint32_t *)&g_master_lds; } };
 struct LogInV2 { static __device__ __forceinline__ uint32_t *base() { return (uint32_t *)&g_v2_lds; } };
 template <class LB>
 struct StoreLog {
@@ -674,59 +357,6 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
         atomicAdd(&G.wcnt->dry_runs, n_dry); atomicAdd(&G.wcnt->flag_waits, n_wait);
         atomicAdd(&G.wcnt->call_cycles, n_cyc); atomicAdd(&G.wcnt->call_tests, n_cyc_tests);
     }
-}
-
-// the roles of one stream's blocks: block 0 of the stream is its serial half, the others its worker lanes
-__device__ __forceinline__ void pipeline_roles(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t local_block,
-                                               uint32_t wblocks)
-{
-    if (local_block == 0) {
-        // wave 0: finders (HT2/HT3/RK256 state, nice decision, decisions for the worker lanes)
-        // wave 1: the match table (carry / extend / update), published per position
-        // wave 2: forward-graph parse, model, symbol emit
-        // wave 3: relaxes the listed edges of each node; waves 4 / 5, 6: list the sampled-length edges / the rep probes (even, odd positions)
-        if (threadIdx.x < 64) Master<DevWave>::init_shared(G, (uint32_t)((unsigned long long)c0 * g.chunk_size));
-        __syncthreads();
-        if (threadIdx.x >= 448) return;
-        if ((threadIdx.x & 63u) == 0 && threadIdx.x < 256)   // diagnostics: which SIMD each role's wave landed on (HW_ID bits 5:4)
-            atomicOr(&G.persist->prof[30], (unsigned long long)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xFFFFu) << (16 * (threadIdx.x >> 6)));
-        Master<DevWave> m;
-        m.g = g; m.G = G;
-        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        switch (threadIdx.x >> 6) {
-        case 0: m.run_finder(c0, c1); break;
-        case 1: m.run_table(c0, c1); break;
-        case 2: m.run_parser(c0, c1); break;
-        case 3: m.run_edge_apply(a_first); break;       // the four waves of the dependency chain get a SIMD each
-        case 4: m.run_edge_list(a_first); break;        // (waves 4..6 share them: list makers, mostly waiting)
-        case 5: m.run_rep_list(a_first, 0); break;
-        default: m.run_rep_list(a_first, 1); break;
-        }
-    } else {
-        worker_role<LogInMaster>(g, G, c0, c1, wblocks, local_block - 1);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// the persistent launch: block 0 = the serial half (seven waves), blocks 1.. = worker lanes.
-// 512-thread blocks with 136 KB of LDS: exactly one block per CU, and the grid is kept
-// below the CU count, so every block is resident at once (the roles wait on each other).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void pipeline_kernel(Geom g, Globals G, uint32_t c0, uint32_t c1)
-{
-    pipeline_roles(g, G, c0, c1, blockIdx.x, gridDim.x - 1);
-}
-
-// Several independent streams in ONE launch (block mode): stream s owns blocks [s*bps, (s+1)*bps).  One launch
-// keeps them all resident by construction (separate launches run at most 8 at a time on this device).
-struct StreamArgs { Geom g; Globals G; uint32_t c0, c1; };
-constexpr uint32_t kMaxStreamsPerLaunch = 12;           // the pack travels in the kernel-argument segment (4 KB)
-struct StreamPack { StreamArgs s[kMaxStreamsPerLaunch]; };
-static_assert(sizeof(StreamPack) <= 4000, "kernel arguments are limited to 4 KB");
-__global__ __launch_bounds__(512) void pipeline_multi_kernel(StreamPack pack, uint32_t bps)
-{
-    const uint32_t s = blockIdx.x / bps, local = blockIdx.x % bps;
-    pipeline_roles(pack.s[s].g, pack.s[s].G, pack.s[s].c0, pack.s[s].c1, local, bps - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -870,11 +500,6 @@ void launch_rk_hash(const uint8_t *in, unsigned long long n, unsigned long long 
     hipLaunchKernelGGL(rk_hash_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, in, n, pos0, pos1, out);
 }
 
-void launch_pipeline(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
-{
-    hipLaunchKernelGGL(pipeline_kernel, dim3(1 + (G.workers ? worker_blocks : 0)), dim3(512), 0, st, g, G, c0, c1);
-}
-
 void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, uint32_t worker_blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(pipeline2_kernel, dim3(kV2Roles + worker_blocks), dim3(512), 0, st, g, G, V, c0, c1);
@@ -891,20 +516,6 @@ void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t w
 {
     hipLaunchKernelGGL(pipeline2_multi_kernel, dim3(nstreams * (kV2Roles + worker_blocks)), dim3(512), 0, st, *(const Stream2Pack *)host_pack,
                        kV2Roles + worker_blocks);
-}
-
-// several streams in one launch: fill slot i of a host-side pack, then launch
-unsigned long long stream_pack_size() { return sizeof(StreamPack); }
-uint32_t stream_pack_capacity() { return kMaxStreamsPerLaunch; }
-void fill_stream_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, uint32_t c0, uint32_t c1)
-{
-    StreamArgs &a = ((StreamPack *)host_pack)->s[i];
-    a.g = g; a.G = G; a.c0 = c0; a.c1 = c1;
-}
-void launch_pipeline_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)
-{
-    hipLaunchKernelGGL(pipeline_multi_kernel, dim3(nstreams * (1 + worker_blocks)), dim3(512), 0, st, *(const StreamPack *)host_pack,
-                       1 + worker_blocks);
 }
 
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,

@@ -44,6 +44,18 @@ BIG_CASES = [
 ]
 
 
+# the full-size BASELINE configurations (SURVEY.md appendix D.2 regimes), reference SHA in tests/golden/full.json
+# (oracle/make_golden_full.py):
+#   cfg 3  100,000,000 B at -window:26: no rebase, the last ~33 MB in the p >= W masking regime of HT/RK
+#   cfg 5  one 125,000,000-B block at -window:28: the header must read 27 (NLZM.cpp:1716-1718), every position < W
+#   cfg 4  1,000,000,000 B at -window:28: rebases near 537 MB and 805 MB (checked by bench.py --full, not by pytest)
+FULL_CASES = [
+    ("text_100m_w26", "syn_text", 100_000_000, 0, 26),
+    ("block_125m_w28", "syn_text", 125_000_000, 1, 28),
+    ("text_1g_w28", "syn_text", 1_000_000_000, 0, 28),
+]
+
+
 def make_case(case) -> np.ndarray:
     _, kind, size, seed_off, _ = case
     return corpus.make(kind, size, corpus.SEED + seed_off)
