@@ -17,11 +17,15 @@ GPU; there is no data-path collective, only the final gather of t
 which is inside the timed region.  value = input bytes all ranks consumed in the timed steps / max-rank time.
 
 The JSON line also carries:
-  roofline      dominant kernel (pipeline_kernel) against the HBM roof: algorithmic bytes per launch from
+  roofline      dominant kernel (pipeline2_kernel) against the HBM roof: algorithmic bytes per launch from
                 the device's own operation counters / the kernel's mean launch time measured
-                with HIP events on the library's stream
+                with HIP events on the library's stream; peak_measured = a device copy on this GPU; b_min = the bytes
+                that must move at least (input + output)
   cpu_baseline  the reference itself (oracle/_ref/nlzm_ref, built from /root/reference at build time) or, if
-                that binary is absent, the oracle port, timed on a bounded sample of the same workload
+                that binary is absent, the oracle port, pinned to one core (taskset), on the bytes
+                [0, (warmup + steps) * B * 122,368) of the same stream as a file of its own; gpu_same_bytes is
+                the GPU's rate over exactly those bytes (warm-up launches included)
+  --full        the whole stream; its SHA-256 is compared with the reference's (tests/golden/full.json)
   blocks        (N = 1) the same stream split into --block-streams independent blocks, all in flight on the one
                 GPU: the path's only shard axis used inside a GPU.  A second measurement next to
                 `value`, never part of it (the streams differ from the single-stream output).
@@ -62,15 +66,22 @@ def algorithmic_bytes(st: dict) -> int:
 
 
 def cpu_baseline(sample: np.ndarray) -> dict:
-    """Time the reference's single-threaded CPU path on a bounded sample (rank 0, N=1 only)."""
+    """Time the reference's single-threaded CPU path on a bounded sample (rank 0, N=1 only), pinned to one core."""
+    import shutil
     ref = os.path.join(ROOT, "oracle", "_ref", "nlzm_ref")
-    desc = f"first {sample.size} B of the workload as its own file, -window:{WINDOW}"
+    geo = nlzm_amd.geometry(int(sample.size), WINDOW)
+    desc = (f"bytes [0, {sample.size}) of the workload as a file of its own, -window:{WINDOW} "
+            f"(the reference shrinks it to {geo['hist_bits']} for a file of this size, NLZM.cpp:1716-1718)")
+    pin = []
+    if shutil.which("taskset"):
+        cores = sorted(os.sched_getaffinity(0))
+        pin = ["taskset", "-c", str(cores[len(cores) // 2])]
     if os.path.exists(ref):
         with tempfile.TemporaryDirectory() as tmp:
             inp, out = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.nlzm")
             sample.tofile(inp)
             t0 = time.perf_counter()
-            subprocess.run([ref, f"-window:{WINDOW}", "c", inp, out], check=True, capture_output=True)
+            subprocess.run(pin + [ref, f"-window:{WINDOW}", "c", inp, out], check=True, capture_output=True)
             dt = time.perf_counter() - t0
         kind = "reference"
     else:
@@ -80,7 +91,23 @@ def cpu_baseline(sample: np.ndarray) -> dict:
         dt = time.perf_counter() - t0
         kind = "port"
     return {"value": round(sample.size / 1e6 / dt, 4), "unit": "MB/s", "cores": 1, "kind": kind, "sample": desc,
-            "seconds": round(dt, 2), "host_cores_present": os.cpu_count()}
+            "seconds": round(dt, 2), "pinned": " ".join(pin) if pin else None, "host_cores_present": os.cpu_count()}
+
+
+def copy_peak_gbs(torch, dev) -> float:
+    """HBM bandwidth a plain device copy reaches on this GPU (read + write bytes / time), next to the nominal 8 TB/s."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def blocks_leg(lib, torch, dev, k: int, B: int, steps: int, warmup: int) -> dict:
@@ -128,7 +155,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-chunks", type=int, default=8)
     ap.add_argument("--full", action="store_true", help="compress the whole stream (steps = all batches, warmup 0)")
-    ap.add_argument("--cpu-sample-mb", type=float, default=12.0)
+    ap.add_argument("--cpu-sample-mb", type=float, default=30.0, help="upper bound of the CPU leg's sample (it covers the GPU leg's bytes up to this)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--block-streams", type=int, default=16,
                     help="N=1 only: also time the independent-block mode with this many streams in flight on the GPU (0: skip)")
@@ -189,8 +216,12 @@ def main():
         if r:
             raise SystemExit(f"stream_step failed: {lib.nlzm_hip_last_error().decode()}")
 
+    torch.cuda.synchronize()
+    t_w0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter() - t_w0
     st0, tm0 = nlzm_amd.stats(), nlzm_amd.timing()
     in0, out0 = in_done.value, out_done.value
 
@@ -237,15 +268,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": data_kind,
             "config": {
                 "workload": f"enwik9 stand-in: {STREAM_BYTES} B stream, -window:{WINDOW}"
-                            + (f" split into {world} independent blocks (window auto-shrinks to 27)" if world > 1 else "")
+                            + (f" split into {world} independent blocks of {n} B (RCCL world size {dist.get_world_size()}, window "
+                               f"{nlzm_amd.geometry(n, WINDOW)['hist_bits']} after the reference's auto-shrink)" if world > 1 else "")
                             + f"; step = {B} chunks ({B * CHUNK} B) of the stream, timed steps = batches {args.warmup}.."
                               f"{args.warmup + done_steps - 1} of {nbatches}",
                 "window_bits": WINDOW, "batch_chunks": B, "bytes_timed": int(total_in),
                 "bit_exact_with_reference": "checked by tests/test_gpu_parity.py (same code path)",
             },
-            "roofline": {"bound": "hbm", "kernel": "pipeline_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "pipeline2_kernel", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "peak_measured": round(copy_peak_gbs(torch, dev), 1),
                          "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms_per_launch": round(k_ms, 3),
+                         "b_min_bytes_per_launch": int((d["in_bytes_step"] + d["out_bytes_step"]) / launches),
                          "algorithmic_bytes_per_input_byte": round(algorithmic_bytes(d) / max(1, d["in_bytes_step"]), 2)},
             "kernel_ms": {"prep": round(tm1["prep_ms"] - tm0["prep_ms"], 3),
                           "match_parse": round(tm1["match_parse_ms"] - tm0["match_parse_ms"], 3),
@@ -263,11 +297,29 @@ def main():
                 res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT)
         except Exception:
             pass
-        if world == 1 and not args.no_cpu:
-            sample_n = int(min(need, args.cpu_sample_mb * 1e6))
+        if world == 1 and not args.no_cpu and not args.full:
+            # the CPU leg covers the bytes the GPU consumed from offset 0 (warm-up launches included), bounded
+            sample_n = int(min(in_done.value, args.cpu_sample_mb * 1e6))
             res["cpu_baseline"] = cpu_baseline(host[:sample_n])
+            res["cpu_baseline"]["gpu_same_bytes"] = {"value": round(in_done.value / 1e6 / (t_warm + dt), 4), "unit": "MB/s",
+                                                     "bytes": int(in_done.value), "note": "GPU rate over bytes [0, bytes), warm-up launches included"}
         else:
             res["cpu_baseline"] = None
+        if args.full and world == 1:
+            # the whole stream: its bytes must be the reference's (tests/golden/full.json, generated from the reference build)
+            import hashlib
+            dst_len = C.c_uint64(0)
+            if lib.nlzm_hip_stream_finish(C.byref(dst_len)):
+                raise SystemExit(f"stream_finish failed: {lib.nlzm_hip_last_error().decode()}")
+            got = d_out[:dst_len.value].cpu().numpy().tobytes()
+            sha = hashlib.sha256(got).hexdigest()
+            res["stream_bytes"], res["stream_sha256"] = int(dst_len.value), sha
+            gold = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))["cases"]}.get("text_1g_w28")
+            if data_kind == "synthetic" and gold:
+                res["bit_exact"] = bool(gold["stream_size"] == dst_len.value and gold["stream_sha256"] == sha)
+                if not res["bit_exact"]:
+                    print(json.dumps(res))
+                    raise SystemExit("bench --full: the stream differs from the reference's")
         if world == 1 and args.block_streams > 0 and not args.full:
             del d_in, d_out
             torch.cuda.empty_cache()

@@ -723,7 +723,12 @@ static uint32_t parse_segment(enc_t *e, parse_t *ps, const model_t *m, mtab_t *c
                 /* the reference reads rep4.table[ri] through a reference into the
                  * ring; entry p is never a relax target (np > p), so a copy is equal */
                 if ((checked >> ri) & 1 || rp[ri] >= q) continue;
-                uint32_t l = common_len_signed(e, q - rp[ri], q, (uint16_t)(max_parse - p), 0) & 0x7FFFFFFFu;
+                const uint32_t pcap = (uint16_t)(max_parse - p);
+                uint32_t l = common_len_signed(e, q - rp[ri], q, pcap, 0) & 0x7FFFFFFFu;
+                {   /* bytes compared beyond the 264 that can matter */
+                    const uint32_t ncap = u32min(pcap, NLZM_MATCH_MAX), nl = u32min(l, NLZM_MATCH_MAX);
+                    e->st->cmp_bytes_needed -= (uint64_t)(l + (l < pcap)) - (uint64_t)(nl + (nl < ncap));   /* (cmp_bytes is added at the end) */
+                }
                 l = u32min(l, NLZM_MATCH_MAX);
                 if (l >= nlzm_oracle_match_min(rp[ri])) {
                     if (end_p < l + p) e->st->seg_rep_grow++;
@@ -880,6 +885,7 @@ int nlzm_oracle_compress(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
     dst[out++] = 0; dst[out++] = 0; dst[out++] = 0; dst[out++] = 0;  /* NLZM.cpp:1891-1895 */
     stats->frames = frame_idx;
     stats->in_bytes = n; stats->out_bytes = out;
+    stats->cmp_bytes_needed += stats->cmp_bytes;      /* (held minus the probes' excess until here) */
     *dst_len = out;
 done:
     free(fbuf); free(fr.bits); free(fr.syms); free(ps); free(model);

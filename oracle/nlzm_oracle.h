@@ -43,6 +43,9 @@ typedef struct nlzm_oracle_stats {
     uint64_t n_literal, n_dict, n_rep;
     uint64_t rans_syms, bit_ops, frames;
     uint64_t shifts;        /* window rebases (NLZM.cpp:1786) */
+    uint64_t cmp_bytes_needed; /* cmp_bytes without the bytes an explicit rep probe compares beyond 264: the reference
+                              * measures up to max_parse_len - p <= 4096 bytes and then caps the length at 264
+                              * (NLZM.cpp:1605-1606), so those bytes cannot change the result */
 } nlzm_oracle_stats;
 
 /* One parsed command as emitted by the driver loop (NLZM.cpp:1809-1843). */

@@ -105,7 +105,7 @@ int main(int argc, char **argv)
                    "\"cmp_bytes\": %llu, \"ht_rows\": %llu, \"rk_probes\": %llu, \"rk_inserts\": %llu, "
                    "\"positions\": %llu, \"nice_positions\": %llu, \"segments\": %llu, \"seg_rep_grow\": %llu, "
                    "\"n_literal\": %llu, \"n_dict\": %llu, \"n_rep\": %llu, \"rans_syms\": %llu, "
-                   "\"bit_ops\": %llu, \"frames\": %llu, \"shifts\": %llu, \"seconds\": %.3f}\n",
+                   "\"bit_ops\": %llu, \"frames\": %llu, \"shifts\": %llu, \"cmp_bytes_needed\": %llu, \"seconds\": %.3f}\n",
                    (unsigned long long)st.in_bytes, (unsigned long long)st.out_bytes,
                    (unsigned long long)st.bt_calls, (unsigned long long)st.bt_tests,
                    (unsigned long long)st.cmp_bytes, (unsigned long long)st.ht_rows,
@@ -115,7 +115,7 @@ int main(int argc, char **argv)
                    (unsigned long long)st.n_literal, (unsigned long long)st.n_dict,
                    (unsigned long long)st.n_rep, (unsigned long long)st.rans_syms,
                    (unsigned long long)st.bit_ops, (unsigned long long)st.frames,
-                   (unsigned long long)st.shifts, t1 - t0);
+                   (unsigned long long)st.shifts, (unsigned long long)st.cmp_bytes_needed, t1 - t0);
         }
         free(out); free(in);
         return 0;

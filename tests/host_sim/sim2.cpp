@@ -327,13 +327,14 @@ int main(int argc, char **argv)
     printf("workers: uncertain marks %llu (%.2f%%), dry runs %llu\n", unc_total, 100.0 * unc_total / np, wk.dry);
     const int bad = g_ref.bad || c.bad || P.cnt.positions != st.positions || P.cnt.nice_positions != st.nice_positions ||
                     P.cnt.segments != st.segments || P.cnt.bt_tests != st.bt_tests || P.cnt.bt_calls != st.bt_calls ||
-                    P.cnt.ht_rows != st.ht_rows || P.cnt.rk_probes != st.rk_probes || P.cnt.rk_inserts != st.rk_inserts;
+                    P.cnt.ht_rows != st.ht_rows || P.cnt.rk_probes != st.rk_probes || P.cnt.rk_inserts != st.rk_inserts ||
+                    P.cnt.cmp_bytes != st.cmp_bytes_needed;
     printf("%s: %s  (chunks %u, tables checked %llu, positions %llu/%llu nice %llu/%llu segments %llu/%llu bt_tests %llu/%llu ht_rows %llu/%llu "
            "rk_probes %llu/%llu rk_inserts %llu/%llu cmp_bytes %llu/%llu)\n",
            argv[1], bad ? "MISMATCH" : "OK", g.nchunks, g_ref.checked, P.cnt.positions, (unsigned long long)st.positions,
            P.cnt.nice_positions, (unsigned long long)st.nice_positions, P.cnt.segments, (unsigned long long)st.segments,
            P.cnt.bt_tests, (unsigned long long)st.bt_tests, P.cnt.ht_rows, (unsigned long long)st.ht_rows,
            P.cnt.rk_probes, (unsigned long long)st.rk_probes, P.cnt.rk_inserts, (unsigned long long)st.rk_inserts,
-           P.cnt.cmp_bytes, (unsigned long long)st.cmp_bytes);
+           P.cnt.cmp_bytes, (unsigned long long)st.cmp_bytes_needed);
     return bad;
 }

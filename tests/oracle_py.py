@@ -21,7 +21,7 @@ class OStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "in_bytes", "out_bytes", "bt_calls", "bt_tests", "cmp_bytes", "ht_rows", "rk_probes", "rk_inserts",
         "positions", "nice_positions", "segments", "seg_rep_grow", "n_literal", "n_dict", "n_rep", "rans_syms",
-        "bit_ops", "frames", "shifts")]
+        "bit_ops", "frames", "shifts", "cmp_bytes_needed")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -42,6 +42,24 @@ def test_stream_bit_exact_big(gpu, case):
         assert st[k] == ost[k], k
 
 
+@pytest.mark.parametrize("name", ["text_100m_w26", "block_125m_w28"])
+def test_full_size_configs(gpu, name):
+    """BASELINE configs 3 and 5 at full size against the REFERENCE's own stream (tests/golden/full.json, made by
+    oracle/make_golden_full.py from the compiled reference):
+      text_100m_w26   100,000,000 B at -window:26 -- no rebase, the last ~33 MB in the p >= W masking regime of HT/RK
+      block_125m_w28  one 125,000,000-B block at -window:28 -- the header must read 27 (NLZM.cpp:1716-1718)"""
+    full = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "full.json")))["cases"]}
+    g = full[name]
+    case = next(c for c in cases.FULL_CASES if c[0] == name)
+    data = cases.make_case(case)
+    assert hashlib.sha256(data.tobytes()).hexdigest() == g["input_sha256"]
+    got = gpu.compress(data, case[4])
+    assert (got[0] << 8 | got[1]) == g["hist_bits"] == (26 if name == "text_100m_w26" else 27)
+    assert (len(got), hashlib.sha256(got).hexdigest()) == (g["stream_size"], g["stream_sha256"])
+    st = gpu.stats()
+    assert st["positions"] == data.size and st["shifts"] == 0
+
+
 def test_batching_is_invisible(gpu):
     """State carried across persistent launches (model, finders, carry table) is exact."""
     data = corpus.syn_text(700_000, corpus.SEED + 21)
