@@ -136,6 +136,7 @@ struct Globals {
     const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by bin, ascending
     uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
     uint32_t *abort_word;       // nonzero: every role leaves its loops
+    const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)
     WorkerCounters *wcnt;
     void *hook_user;            // host simulation only
 };

@@ -80,6 +80,8 @@ struct Ctx {
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
     int64_t opt_worker_blocks = 240;        // + the three stage blocks: below the 256 CUs, one 512-thread block per CU
+    int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
+    int cu_count = 0;
 
 
     // stream state
@@ -216,6 +218,13 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     C.batch = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
     if (C.batch > g.nchunks && g.nchunks) C.batch = g.nchunks;
     if (!C.batch) C.batch = 1;
+    {   // the per-launch arrays take about 2.3 KB per position of a launch: a launch that does not fit is cut down
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double room = 0.6 * (double)free_b - 4.0 * (double)(1ull << (g.wbits + 5 > 32 ? 32 : g.wbits + 5));
+        const double per_chunk = 2300.0 * g.chunk_size + 8.0 * g.chunk_size * 4;
+        if (room > per_chunk && (double)C.batch * per_chunk > room) C.batch = (uint32_t)(room / per_chunk);
+    }
     C.syms_stride = 3ull * g.chunk_size + 4096;          // <= 3 symbols per input byte
     C.bits_stride = 2ull * g.chunk_size + 64;            // <= 13 raw bits per input byte
     C.frame_stride = 12 + C.bits_stride + 16 + 2 * C.syms_stride;
@@ -227,8 +236,17 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     HIPCHK(hipMalloc(&C.dst_off, C.batch * sizeof(unsigned long long)));
 
     // worker mode: pre-filter tables, per-launch hand-off arrays, bins
-    C.workers = C.opt_workers != 0;
+    C.workers = true;
     C.nheads = 1u << (32 - g.bt_shift);
+    {   // The persistent launch needs every block resident at once (the stages and the worker lanes wait on each other):
+        // 512-thread blocks with > 80 KB of LDS, one per CU.  Fewer CUs than blocks (a partitioned or masked device)
+        // would spin until the timeouts fire, so the worker blocks are clamped to what the device holds.
+        int cus = C.cu_count;
+        if (!cus) { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, C.device)); cus = prop.multiProcessorCount; C.cu_count = cus; }
+        const int64_t room = (int64_t)cus - (int64_t)pipeline2_role_blocks();
+        if (room < 1) return set_err(NLZM_HIP_E_ARG, "device has %d CUs: the pipeline needs at least %u", cus, pipeline2_role_blocks() + 1);
+        if (C.opt_worker_blocks > room) C.opt_worker_blocks = room;
+    }
     {   // one bin per worker lane (or per head when there are fewer heads than lanes)
         const unsigned long long lanes = (unsigned long long)(C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks) * 512;
         if (lanes < C.nheads) C.nheads = (uint32_t)lanes;
@@ -237,6 +255,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
         uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
         C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
+        if ((int64_t)C.t_bits > C.opt_tbits_max) C.t_bits = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);   // (smaller: only more `unc` marks)
         C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
         HIPCHK(hipMalloc(&C.pf_T, (size_t)4 << C.t_bits));
         HIPCHK(hipMalloc(&C.pf_M, (size_t)4 << C.m_bits));
@@ -335,6 +354,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         h.p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
         P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state;
+        G.progress = &C.v2_hx->f_pos;
     }
     HIPCHK(hipEventRecord(C.ev[6], C.st));
     return 0;
@@ -503,6 +523,7 @@ int nlzm_hip_init(int device)
     if (C.inited && C.device == device) return 0;
     if (C.inited) nlzm_hip_shutdown();
     C.device = device;
+    C.cu_count = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking));
     for (auto &ev : C.ev) HIPCHK(hipEventCreate(&ev));
     C.inited = true;
@@ -645,6 +666,10 @@ int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off, const ui
         if (bits_off[f + 1] - bits_off[f] > max_bits) max_bits = bits_off[f + 1] - bits_off[f];
     }
     uint32_t *d_syms = nullptr, *d_scr = nullptr; uint8_t *d_bits = nullptr, *d_out = nullptr; FrameMeta *d_fm = nullptr;
+    struct Guard {      // the device buffers go with the call, on every path out
+        uint32_t *&a, *&b; uint8_t *&c, *&d; FrameMeta *&e;
+        ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); if (d) (void)hipFree(d); if (e) (void)hipFree(e); }
+    } guard{ d_syms, d_scr, d_bits, d_out, d_fm };
     const unsigned long long fstride = 12 + max_bits + 16 + 2 * max_syms;
     HIPCHK(hipMalloc(&d_syms, nframes * max_syms * 4));
     HIPCHK(hipMalloc(&d_scr, nframes * max_syms * 4));
@@ -669,7 +694,6 @@ int nlzm_hip_rans_frames(const uint32_t *syms, const uint64_t *sym_off, const ui
         if (hm[f].out_len > out_stride) { rc = set_err(NLZM_HIP_E_CAPACITY, "frame %u needs %u bytes", f, hm[f].out_len); break; }
         HIPCHK(hipMemcpy(out + f * out_stride, d_out + f * fstride, hm[f].out_len, hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_syms); (void)hipFree(d_scr); (void)hipFree(d_bits); (void)hipFree(d_out); (void)hipFree(d_fm);
     return rc;
 }
 
@@ -806,6 +830,25 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;
     if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs", nblocks, prop.multiProcessorCount);
     g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
+    // Every stream holds its own tables and hand-off arrays: the pre-filter table (4 << t_bits bytes) and the per-launch
+    // arrays (about 2.2 KB per position of a launch) are sized so that all streams fit the free memory.
+    int64_t tbits_max = 32, batch = C.opt_batch;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const double per_stream = 0.85 * (double)free_b / nblocks;
+        Geom g0;
+        make_geom((n + nblocks - 1) / nblocks, hist_bits_req, g0);
+        const double fixed = 8.0 * ((double)g0.wmask + 1) * 2 + 4.0 * (double)g0.n + 5e7;     // BT4 tree (widened), RK hashes, the rest
+        double left = per_stream - fixed;
+        if (left < 2e8) return set_err(NLZM_HIP_E_NOMEM, "%u streams of %llu bytes at -window:%u do not fit %.1f GB of free memory", nblocks,
+                                       (unsigned long long)g0.n, g0.wbits, free_b / 1e9);
+        while (tbits_max > 16 && 4.0 * (double)(1ull << tbits_max) > 0.4 * left) tbits_max--;
+        left -= 4.0 * (double)(1ull << (tbits_max < (int64_t)g0.wbits + 5 ? tbits_max : (int64_t)g0.wbits + 5));
+        const int64_t fit = (int64_t)(left / (2300.0 * g0.chunk_size + 8.0 * g0.chunk_size * 4));
+        if (fit < 1) return set_err(NLZM_HIP_E_NOMEM, "%u streams do not fit the device memory", nblocks);
+        if (batch > fit) batch = fit;
+    }
     const uint64_t per = (n + nblocks - 1) / nblocks;              // block i = [i*per, min(n, (i+1)*per))
     g_jobs.resize(nblocks);
     for (uint32_t i = 0; i < nblocks; i++) {
@@ -815,9 +858,9 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         g_jobs[i].bound = nlzm_hip_compress_bound(g_jobs[i].n);
     }
     const int device = C.device;
-    const int64_t batch = C.opt_batch;
     for_blocks(nblocks, [&](uint32_t i, BlockJob &j) {
         j.rc = block_ctx_init(j.c, device, wb, batch);
+        j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
         if (!j.rc && hipMalloc(&j.d_out, j.bound) != hipSuccess) j.rc = set_err(NLZM_HIP_E_NOMEM, "block %u: output buffer", i);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
     });
@@ -945,8 +988,10 @@ int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, u
     const uint64_t bound = nlzm_hip_compress_bound(n) + (uint64_t)nblocks * (16 + 131072);
     HIPCHK(hipMalloc(&d_in, n + 512));
     if (hipMalloc(&d_out, bound) != hipSuccess) { (void)hipFree(d_in); return set_err(NLZM_HIP_E_NOMEM, "output buffer"); }
-    (void)hipMemset(d_in + n, 0, 512);
-    if (n) (void)hipMemcpy(d_in, src, n, hipMemcpyHostToDevice);
+    if (hipMemset(d_in + n, 0, 512) != hipSuccess || (n && hipMemcpy(d_in, src, n, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipFree(d_in); (void)hipFree(d_out);
+        return set_err(NLZM_HIP_E_NODEVICE, "copying the input to the device failed");
+    }
     uint64_t len = 0;
     int rc = nlzm_hip_compress_blocks_dev(d_in, n, nblocks, hist_bits_req, d_out, bound, block_len, &len);
     if (!rc && len > dst_cap) rc = set_err(NLZM_HIP_E_CAPACITY, "streams are %llu bytes, dst_cap %llu", (unsigned long long)len, (unsigned long long)dst_cap);

@@ -266,7 +266,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dry_t = 0, dry_c = 0, n_cyc = 0, n_cyc_tests = 0;
     StoreLog<LB> slog{ 0, false };
     unsigned long long t_wait0 = 0;
-    uint32_t idle = 0;
+    uint32_t idle = 0, prog_seen = 0;
     bool fail = false;
 
     while (__any(active)) {
@@ -336,9 +336,12 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                     n_wait++;
                     if ((++idle & 1023u) == 0) {
                         if (LaneIO::ld_agent(G.abort_word)) active = false;
+                        // give up only when the finder stage itself has not moved for 30 s (a lane that is far ahead of it
+                        // waits as long as the launch takes)
                         const unsigned long long now = wall_clock64();
-                        if (!t_wait0) t_wait0 = now;
-                        else if (now - t_wait0 > 3000000000ull) { fail = true; }   // 30 s
+                        const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
+                        if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
+                        else if (now - t_wait0 > 3000000000ull) { fail = true; }
                     }
                 }
             }

@@ -1322,7 +1322,8 @@ struct Parser {
                 bool ok = false;
                 unsigned long long counted = 0;
                 if (w < 4) {
-                    const uint32_t r = w == 0 ? rep0 : (w == 1 ? rep1 : (w == 2 ? rep2 : rep3));
+                    const uint32_t m0 = xw::opaque(rep0), m1 = xw::opaque(rep1), m2 = xw::opaque(rep2), m3 = xw::opaque(rep3);
+                    const uint32_t r = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
                     const uint32_t pcap = umin(max_parse, kMatchMax);
                     const bool want = i == 0 && r < seg_q;                                          // :1601
                     const uint32_t l = xw::any(want) ? probe_len(want, seg_a, r, pcap) : 0u;

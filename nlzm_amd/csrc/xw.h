@@ -114,6 +114,9 @@ XW_FN uint32_t lds_inc(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATO
 XW_FN void lds_max(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the value as it is, but not to be reasoned about (keeps the compiler from turning a choice between two members of a
+// stage's state into ONE indexed access, which would put the whole state into scratch memory)
+XW_FN uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 XW_FN unsigned long long clock100() { return wall_clock64(); }          // 100 MHz
 XW_FN unsigned long long tick() { return __builtin_readcyclecounter(); }
 XW_FN void need_bt(void *, uint32_t) {}                                 // (simulation hook: worker lanes run lazily there)
@@ -221,6 +224,7 @@ inline uint32_t lds_inc(uint32_t *p) { return (*p)++; }
 inline void lds_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 inline void lds_st(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t lds_ld(const uint32_t *p) { return *(volatile const uint32_t *)p; }
+inline uint32_t opaque(uint32_t v) { return v; }
 inline unsigned long long clock100() { return sim().now; }
 inline unsigned long long tick() { return sim().now; }
 void need_bt(void *user, uint32_t a);                                   // defined by the simulator: run the worker lanes up to `a`

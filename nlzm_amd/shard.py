@@ -64,8 +64,13 @@ def split_streams(blob: bytes) -> list[bytes]:
             if ops == 0:
                 pos += 4
                 break
+            if pos + 12 > n:
+                raise ValueError("truncated frame header")
             nb = int.from_bytes(blob[pos + 4:pos + 8], "big")
             nr = int.from_bytes(blob[pos + 8:pos + 12], "big")
+            # a frame holds its 12 header bytes and 4 bit-flush bytes, then the four rANS states (NLZM.cpp:591-628)
+            if nb < 12 or nr < 16 or pos + nb + nr > n:
+                raise ValueError(f"malformed frame at byte {pos}: sizes {nb}, {nr}")
             pos += nb + nr
         out.append(blob[start:pos])
     return out

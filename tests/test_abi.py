@@ -42,7 +42,7 @@ def test_library_has_gfx950_code_object():
                           f"--input={nlzm_amd.LIB_PATH}"], capture_output=True, text=True)
     blob = open(nlzm_amd.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
-    assert b"pipeline_kernel" in blob and b"rans_frames_kernel" in blob and b"prefilter_hash_kernel" in blob
+    assert b"pipeline2_kernel" in blob and b"rans_frames_kernel" in blob and b"prefilter_hash_kernel" in blob
 
 
 def test_persistent_kernel_has_no_scratch_flat_or_calls():
