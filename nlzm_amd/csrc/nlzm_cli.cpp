@@ -253,8 +253,18 @@ int main(int argc, char **argv)
         if (nlzm_hip_init(0)) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
         uint32_t hb, fb, cs, feed;
         nlzm_hip_geometry(in.size(), hist_bits, &hb, &fb, &cs, &feed);
-        printf("Dictionary: %d KB\n", (int)(((1ull << hb) + 1023) >> 10));
-        printf("Frame: %d KB\n", (int)(((1u << fb) + 1023) >> 10));
+        {   // the reference's summary (:1755-1759): sizes of its own structures for this window
+            const uint32_t c1 = hb < 15 ? 15 : (hb > 17 ? 17 : hb), c2 = hb < 16 ? 16 : (hb > 20 ? 20 : hb), c3 = hb < 16 ? 16 : (hb > 22 ? 22 : hb);
+            const uint64_t mf = (4ull << 12) + (8ull << (12 + c1 - 15)) + (4ull << (13 + c2 - 16)) + (8ull << hb) + (4ull << (15 + c3 - 16));
+            printf("Model: %d KB\n", 2);
+            printf("Parser: %d KB\n", 65);
+            printf("Dictionary: %d KB\n", (int)(((1ull << hb) + 1023) >> 10));
+            printf("Frame: %d KB\n", (int)(((1u << fb) + 1023) >> 10));
+            printf("Dictionary search: %d KB\n", (int)((mf + 1023) >> 10));
+        }
+        if (nblocks > 1)
+            printf("Note: -blocks:%u writes %u independent streams back to back; this program's d/t read them, the reference's d "
+                   "stops after the first\n", nblocks, nblocks);
         printf("Working...\r");
         std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nblocks * (16 + 131072));
         uint64_t out_n = 0;
@@ -292,7 +302,14 @@ int main(int argc, char **argv)
         for (size_t pos = 0; pos < in.size();) {
             const Span rest{ in.data() + pos, in.size() - pos };
             const size_t len = stream_length(rest);
-            if (!len) { parts.clear(); break; }
+            if (!len) {
+                // what follows is not a stream: the reference stops at the first terminator (:646-648) and so do we;
+                // a container that is cut off inside its first stream is malformed
+                if (parts.empty()) break;
+                if (rest.n >= 4 && rest.p[0] == 0 && (rest.p[1] >= 10 && rest.p[1] <= 28)) { parts.clear(); break; }   // looks like a cut-off block
+                printf("Note: %zu bytes after the last stream ignored\n", rest.n);
+                break;
+            }
             parts.push_back(Span{ rest.p, len });
             pos += len;
         }

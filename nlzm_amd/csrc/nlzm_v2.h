@@ -104,11 +104,11 @@ XW_FN uint32_t wave_cmp(const uint8_t *in, uint32_t s, uint32_t t, uint32_t init
 // bounded wait for a progress word to reach v; false: another stage failed or the wait timed out (err set)
 XW_FN bool wait_word_ge(const uint32_t *w, uint32_t v, Hx *hx, uint32_t code)
 {
-    if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) return true;
+    if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) { xw::after_poll(); return true; }
     const unsigned long long t0 = xw::clock100();
     uint32_t spins = 0;
     for (;;) {
-        if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) return true;
+        if ((int32_t)(xw::readfirst(xw::ld_agent(w)) - v) >= 0) { xw::after_poll(); return true; }
         if ((++spins & 63u) == 0) {
             if (xw::readfirst(xw::ld_agent(&hx->err))) return false;
 #ifndef NLZM_SIM
@@ -209,6 +209,7 @@ struct Finder {
                 for (;;) {
                     const unsigned long long ps = xw::readfirst64(xw::ld_agent64(&V.hx->p_seg));
                     if ((int32_t)((uint32_t)ps - (a0 + 1)) >= 0) {
+                        xw::after_poll();
                         seg_s = (uint32_t)(ps >> 32);
 #ifdef NLZM_SIM
                         if (i == 0 && getenv("NLZM_SIM_TRACE_SEG")) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a0, seg_s, (uint32_t)ps);
@@ -437,6 +438,7 @@ struct Finder {
             for (;;) {
                 uint32_t w0 = bt_wait ? xw::ld_agent(G.bt_ready + bi * kBtRec) : kBtReady;
                 if (!xw::any(!(w0 & kBtReady))) {
+                    xw::after_poll();
                     if (bt_wait) {
                         bt_n = w0 & 0x1FFu;
                         if (bt_n) {
@@ -782,6 +784,7 @@ struct Table {
             if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) return false;
             xw::pause();
         }
+        xw::after_poll();
         return true;
     }
 
@@ -933,6 +936,7 @@ struct Table {
                 if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
             }
             f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
+            xw::after_poll();
             const uint32_t n = umin(64u, umin(a1, f_seen) - a);
             if ((int32_t)(a + n - p_seen - kTpRing) > 0) {
                 if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
@@ -1370,7 +1374,7 @@ struct Parser {
                     if (!wait_word_ge(&V.hx->t_out, a_first + 1, V.hx, 4)) err = kErrInternal + 100;
                     t_wait += xw::tick() - tw;
                 }
-                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err) t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
+                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err) { t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out)); xw::after_poll(); }
                 uint32_t nb = umin(64u, max_parse - b0);
                 if ((int32_t)(t_out_seen - (a_first + nb)) < 0) nb = t_out_seen - a_first;
                 if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; xw::st_agent(&V.hx->p_pos, a_first); }

@@ -102,6 +102,9 @@ XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_o
 XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // after a poll saw the flag: later plain loads of this wave read what the producer stored (buffer_inv sc1)
 XW_FN void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// after a poll saw its word: nothing that follows in the program may be moved in front of the poll by the compiler (the
+// payload is read with sc1 loads, which need no cache invalidate: guide, Guideline 16)
+XW_FN void after_poll() { asm volatile("" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 XW_FN void lds_min64(unsigned long long *p, unsigned long long v)
 {
     (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -218,6 +221,7 @@ inline unsigned long long ld_agent64(const unsigned long long *p) { return *(vol
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
 inline void acquire_agent() {}
+inline void after_poll() {}
 inline void lds_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 inline uint32_t lds_inc(uint32_t *p) { return (*p)++; }
