@@ -192,7 +192,37 @@ def dups(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
-_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups}
+def chains(size: int, seed: int = SEED) -> np.ndarray:
+    """Parse segments that run into the forced cut at 4,096 positions (NLZM.cpp:1469) or stop just short of it.
+
+    A segment only ends where no match crosses (or at the forced cut), so each unit is: a pool of 40-byte pieces of a
+    random string B taken every 30 bytes (every position of B is then inside some match: the segment cannot end), B
+    itself, of a length a little below / at / above 4,096, two fresh bytes (a natural end inside the last 264
+    positions before the forced cut when B is short of it), and a 300-byte copy of earlier bytes (matches of the full
+    264 that the segment before them may only see cut short, the next one whole)."""
+    rng = np.random.default_rng(seed ^ 0xC4A1)
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    unit = 0
+    while pos < size:
+        nb = (3_900, 3_990, 4_050, 4_096, 4_200, 3_840, 8_100)[unit % 7] + int(rng.integers(0, 40))
+        b = rng.integers(0, 256, nb, dtype=np.uint8)
+        parts = []
+        for k in range(0, nb - 10, 30):
+            parts.append(b[k:k + 40])
+            parts.append(rng.integers(0, 256, 3, dtype=np.uint8))
+        src = rng.integers(0, 256, 300, dtype=np.uint8)
+        parts += [src, rng.integers(0, 256, 5, dtype=np.uint8), b, rng.integers(0, 256, 2, dtype=np.uint8), src,
+                  rng.integers(0, 256, 7, dtype=np.uint8)]
+        u = np.concatenate(parts)
+        k = min(u.size, size - pos)
+        out[pos:pos + k] = u[:k]
+        pos += k
+        unit += 1
+    return out
+
+
+_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

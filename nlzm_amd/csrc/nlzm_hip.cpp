@@ -111,6 +111,7 @@ struct Ctx {
     // three-stage pipeline (nlzm_v2.h): hand-off rings, progress words, stage state
     uint32_t *v2_ft = nullptr, *v2_tp = nullptr, *v2_tf = nullptr, *v2_state = nullptr;
     v2::Hx *v2_hx = nullptr;
+    v2::Hx hx_host;
 
     // capture (stage tests)
     uint32_t *cap_words = nullptr; unsigned long long cap_cap = 0, cap_lo = 0, cap_hi = 0; unsigned long long *cap_used = nullptr;
@@ -348,7 +349,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
     }
     {   // progress words of the stages: everything before the launch's first position is done
-        v2::Hx h;
+        v2::Hx &h = C.hx_host;          // (lives until the copy has been made)
         memset(&h, 0, sizeof h);
         h.f_pos = h.t_pos = h.t_out = h.p_pos = (uint32_t)a0;
         h.p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;

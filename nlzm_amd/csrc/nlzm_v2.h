@@ -631,7 +631,10 @@ struct Finder {
 // stage as a fresh pair per position.)
 constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
 
-constexpr uint32_t kTW = 3;                     // waves of the stage: each takes whole blocks, in turn
+#ifndef NLZM_KTW
+#define NLZM_KTW 3
+#endif
+constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn
 struct TWave {
     unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
     uint32_t recs[64 * kFtStride];              // the block's finder records
@@ -1056,7 +1059,7 @@ struct Parser {
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
-    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, n_fast = 0, t_wait, t_emit, t_setup, t_pass;
+    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, n_undo = 0, n_fast = 0, t_wait, t_emit, t_setup, t_pass;
     unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
@@ -1289,6 +1292,7 @@ struct Parser {
     // in cmdlist (ncmds entries, end first)
     XW_FN uint32_t parse_segment(uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
     {
+        const uint32_t chunk_left = max_parse;                      // positions from seg_a to the end of the chunk
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
@@ -1377,6 +1381,13 @@ struct Parser {
                 if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err) { t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out)); xw::after_poll(); }
                 uint32_t nb = umin(64u, max_parse - b0);
                 if ((int32_t)(t_out_seen - (a_first + nb)) < 0) nb = t_out_seen - a_first;
+#ifdef NLZM_SIM
+                {   // (simulation: blocks cut at random, as they are on the GPU when this stage catches up with the table stage)
+                    static const int rnd = getenv("NLZM_SIM_RANDOM_BLOCKS") ? atoi(getenv("NLZM_SIM_RANDOM_BLOCKS")) : 0;
+                    static uint32_t lcg = 12345;
+                    if (rnd) { lcg = lcg * 1664525u + 1013904223u; const uint32_t cut = 1 + (lcg >> 16) % (uint32_t)rnd; if (cut < nb) nb = cut; }
+                }
+#endif
                 if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; xw::st_agent(&V.hx->p_pos, a_first); }
             }
             xw::block_sync();
@@ -1586,6 +1597,20 @@ struct Parser {
             xw::block_sync();
             if (istar < nb) {
                 seg_len = b0 + istar;                               // the segment ends inside the block
+                // The positions after it belong to the next segment, whose cut is elsewhere: what was re-listed for this
+                // segment's forced cut goes back to the full sampling (:1545 with the new max_parse).
+                if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax && w == kPW - 1) {
+                    const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+                    const uint32_t h0 = (inb && i >= istar) ? xw::ld_agent(rec) : 0u;
+                    const uint32_t ml = (h0 & 63u) ? (xw::ld_agent(rec + 3) & 0x1FFu) : 0u;
+                    uint32_t full = umin((h0 >> 16) & 0x1FFu, chunk_left - node);
+                    if (full < kMatchMin) full = 0;
+                    for (unsigned long long m = xw::ballot(inb && i >= istar && ml != full); m; m &= m - 1) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        resample(seg_a + b0 + j, xw::readlane(full, j));
+                        n_undo++;
+                    }
+                }
             } else {
                 // open the nodes the block has made reachable, then merge its edges into their keys; the literal edge of the
                 // block's last node goes the same way
@@ -1716,6 +1741,7 @@ struct Parser {
             if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; P->prof[41] += t_fill; }
         }
 #endif
+        if (xw::lane() == 0 && xw::wave() == kPW - 1 && n_undo) { xw::atomic_add64_agent(&P->prof[14], n_undo); n_undo = 0; }
         {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
             for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
             if (xw::lane() == 0) {

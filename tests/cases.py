@@ -5,7 +5,8 @@ The edge cases are the ones SURVEY.md section 8c lists: empty input, < 2 KiB inp
 shrinks below the decoder's minimum), exactly chunk_size +-1, EOF inside the 265-byte
 overlap, input > 2W (window rebases and the p >= W masking regime of HT/RK), long
 duplicated spans (RK carry, uint16 truncation), long runs (nice-length skip, BT4 early
-return), random bytes (expansion).
+return), random bytes (expansion), segments that reach the forced cut at 4,096 positions or end
+just before it (the sampled lengths near the cut depend on the segment the position ends up in).
 """
 from __future__ import annotations
 
@@ -35,6 +36,7 @@ CASES = [
     ("runs_300k_w18", "runs", 300_000, 11, 18),
     ("random_100k_w15", "random", 100_000, 12, 15),
     ("text_2m_w15", "syn_text", 2_000_000, 13, 15),
+    ("chains_150k_w17", "chains", 150_000, 14, 17),
 ]
 
 # larger cases: checked on the GPU box against the oracle run live (and golden sha)

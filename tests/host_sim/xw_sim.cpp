@@ -131,6 +131,10 @@ void launch(uint32_t nblocks, uint32_t nthreads, const unsigned long long *lds_b
         blocks[b].index = b; blocks[b].nwaves = nw;
         blocks[b].waves = new Wave[nw];
         blocks[b].lds = calloc(1, lds_bytes[b] ? lds_bytes[b] : 16);
+        if (const char *e = getenv("NLZM_SIM_POISON")) {       // LDS is not cleared on the device either
+            uint32_t l = (uint32_t)atoi(e) * 40503u + b + 7;
+            for (unsigned long long k = 0; k + 4 <= lds_bytes[b]; k += 4) { l = l * 1664525u + 1013904223u; memcpy((char *)blocks[b].lds + k, &l, 4); }
+        }
         for (uint32_t k = 0; k < nw; k++) {
             Wave &w = blocks[b].waves[k];
             w.blk = &blocks[b]; w.index = k;

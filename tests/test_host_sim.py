@@ -40,3 +40,16 @@ def test_stages_match_oracle_rebased_duplicates(sim, name, tmp_path):
     cases.make_case(case).tofile(p)
     r = subprocess.run([sim, str(p), str(case[4]), "2", "2"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{}, {"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}])
+def test_forced_cuts_and_block_sizes(sim, env, tmp_path):
+    """Segments that run into the forced cut at 4,096 positions or end just before it (records re-listed for the cut, and
+    put back when the segment ends early); with the parser's blocks cut at random and every buffer the kernel does not
+    initialise itself full of junk, as both are on the device."""
+    case = next(c for c in cases.CASES if c[0] == "chains_150k_w17")
+    p = tmp_path / "in.bin"
+    cases.make_case(case).tofile(p)
+    r = subprocess.run([sim, str(p), str(case[4]), "1", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "put back 0)" not in r.stdout, "the case no longer exercises the put-back path"
