@@ -292,7 +292,7 @@ def main():
             import glob
             prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
             pj = json.load(open(prof))
-            if pj["bench_line_under_profiler"]["config"]["batch_chunks"] == B and world == 1:
+            if pj.get("kernel") == "pipeline2_kernel" and pj["bench_line_under_profiler"]["config"]["batch_chunks"] == B and world == 1:
                 res["roofline"]["traffic"] = int(pj["traffic_bytes_per_launch"]["total_with_fetch_x2"])
                 res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT)
         except Exception:

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round (run on the GPU box through gpurun):
-#   bash tests/prof_run.sh r01
+#   bash tests/prof_run.sh r02
 # kernel trace + stats of the bench command, then two separate PMC passes (never combined with traces).
-R=${1:-r01}
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$R

@@ -7,12 +7,12 @@ os.makedirs("profiles", exist_ok=True)
 newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)[-1]
 ks = newest(f"{src}/trace/**/*_kernel_stats.csv")
 shutil.copy(ks, f"profiles/{R}_kernel_stats.csv")
-out = {"round": R, "command": "python3 bench.py --no-cpu --block-streams 0", "kernel": "pipeline_kernel"}
+out = {"round": R, "command": "python3 bench.py --no-cpu --block-streams 0", "kernel": "pipeline2_kernel"}
 for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
     f = newest(f"{src}/{name}/**/*_counter_collection.csv")
     agg, n = {}, {}
     for r in csv.DictReader(open(f)):
-        if "pipeline_kernel" in r["Kernel_Name"]:
+        if "pipeline2_kernel" in r["Kernel_Name"]:
             k = r["Counter_Name"]
             agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
             n[k] = n.get(k, 0) + 1
