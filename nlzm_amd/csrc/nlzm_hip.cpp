@@ -452,7 +452,7 @@ int refresh_stats(Ctx &C)
     HIPCHK(hipMemcpy(&P, C.persist, sizeof P, hipMemcpyDeviceToHost));
     nlzm_hip_stats &s = C.stats;
     s.out_bytes = C.out_pos;
-    s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes + P.prof[46]; s.ht_rows = P.cnt.ht_rows;
+    s.bt_calls = P.cnt.bt_calls; s.bt_tests = P.cnt.bt_tests; s.cmp_bytes = P.cnt.cmp_bytes; s.ht_rows = P.cnt.ht_rows;
     s.rk_probes = P.cnt.rk_probes; s.rk_inserts = P.cnt.rk_inserts; s.positions = P.cnt.positions;
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
@@ -474,6 +474,11 @@ int refresh_stats(Ctx &C)
                             "barrier waits per wave %.0f %.0f %.0f %.0f; block end %.0f cycles/position\n",
                     P.prof[32] / np, P.prof[33] / np, P.prof[34] / np, P.prof[35] / np, P.prof[43] / np, P.prof[41] / np, P.prof[40] / np,
                     P.prof[36] / np, P.prof[37] / np, P.prof[38] / np, P.prof[39] / np, P.prof[42] / n);
+            const double nbk = (double)(P.prof[8] ? P.prof[8] : 1);
+            fprintf(stderr, "parser loader wave, cycles per block set-up: block size + barrier %.0f, re-list %.0f, own edges %.0f, all edges %.0f, literal scan + clear + barrier %.0f\n",
+                    P.prof[56] / nbk, P.prof[57] / nbk, P.prof[58] / nbk, P.prof[59] / nbk, P.prof[60] / nbk);
+            fprintf(stderr, "parser wave 0, cycles per pass: relax %.0f, probe %.0f, clear %.0f | update: keys + cost scan %.0f, membership %.0f, winner sets %.0f, rest %.0f\n",
+                    P.prof[48] / np, P.prof[49] / np, P.prof[50] / np, P.prof[51] / np, P.prof[52] / np, P.prof[53] / np, P.prof[54] / np);
         }
     }
     if (C.workers) {

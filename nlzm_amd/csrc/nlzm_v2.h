@@ -30,7 +30,8 @@ constexpr uint32_t kFtRing = 1u << 14;          // finder -> table: positions in
 constexpr uint32_t kFtStride = 16;              // words per position
 constexpr uint32_t kTpRing = 1u << 13;          // table -> parser
 constexpr uint32_t kMaxEdges = 32;              // sampled lengths per position (:1558-1560: at most 32, at max_len 33)
-constexpr uint32_t kTpStride = 2 + 2 * kMaxEdges + 2;   // header (2), edges (distance, attributes), pad to 16 bytes
+constexpr uint32_t kTpStride = 2 + 2 * kMaxEdges + 2;   // header (2), edges (distance, attributes), the mask of samples with a new distance (2)
+constexpr uint32_t kTpUniq = 2 + 2 * kMaxEdges;
 constexpr uint32_t kFrontMax = 264;             // entries of a front (one per length at most)
 constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the front ring (end, distance)
 
@@ -754,7 +755,7 @@ struct Table {
         const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
         uint32_t max_len = umin(mt_max, a1 - a);                // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
         if (max_len < kMatchMin) max_len = 0;
-        uint32_t ne = 0;
+        uint32_t ne = 0, uniq = 0, dprev = 0;
         if (max_len) {
             uint32_t step = (max_len - kMatchMin) >> 4;         // :1558-1560
             step += step == 0;
@@ -768,10 +769,13 @@ struct Table {
                 const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
                 xw::st_agent64((unsigned long long *)(rec + 2 + 2 * ne),
                                (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32));
+                if (valid && d != dprev) uniq |= 1u << ne;      // the valid samples that bring a distance the one before did not have
+                if (valid) dprev = d;
                 ne++;
             }
         }
         xw::st_agent64((unsigned long long *)rec, (unsigned long long)(ne | (lit << 8) | (mt_max << 16)) | ((unsigned long long)fn << 32));
+        xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
         for (uint32_t k = 0; k < fn; k++)
             xw::st_agent64((unsigned long long *)(fo + 2 * k), (unsigned long long)(fr_end(f[k]) - a) | ((unsigned long long)fr_dist(f[k]) << 32));
     }
@@ -1011,12 +1015,23 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
-constexpr uint32_t kPW = 8;                     // waves of the stage: waves 0..3 probe rep slot w and relax two of the sampled edges each,
-constexpr uint32_t kEdgesPerWave = 6;           // waves 4..7 relax six each
+#ifndef NLZM_KPW
+#define NLZM_KPW 8
+#endif
+constexpr uint32_t kPW = NLZM_KPW;              // waves of the stage (4 or 8): waves 0..3 probe rep slot w; the sampled edges are dealt
+constexpr uint32_t kEdgesPerWave = kPW == 4 ? 8 : 6;    // round: four waves take edge w, w+4, ..; eight: waves 0..3 two each, 4..7 six each
 // sampled edge j of wave w (kMaxEdges: none)
-NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j) { return w < 4 ? (j < 2 ? w + 4 * j : kMaxEdges) : 8 + (w - 4) + 4 * j; }
+NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)
+{
+    if (kPW == 4) return w + 4 * j;
+    return w < 4 ? (j < 2 ? w + 4 * j : kMaxEdges) : 8 + (w - 4) + 4 * j;
+}
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
+constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
+constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
+constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
+constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave (4 x 64 words = 15 records a step)
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
@@ -1028,15 +1043,11 @@ struct PLds {
     uint32_t nrep[512 * 4];                     // rep set of the nodes of finished blocks (CarriedState ring, :1460-1467)
     uint32_t brep[2][64 * 4];                   // ... of the block's nodes after pass p at [p & 1]
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
-    uint32_t bdd[64 * 8];                       // per node of the block: its first eight distinct valid distances
-    uint32_t bnd[64], buniq[64];                // ... how many there are, which edges carry them
-    uint32_t sreach[64];                        // node + max_len (:1550)
     uint32_t reach[3][64];                      // furthest node an edge or probe of the node ends at, as pass p found it at [p % 3]
     uint32_t sh[16];                            // wave 0 -> all: 0 block size, 4 error, 5 price tables stale, 6 / 9 bytes of literal edges across
-                                                //   block borders, 10 / 11 price, cost of the literal edge out of the block, 12..15 model rep set
+                                                //   block borders, 10 / 11 price, cost of the literal edge out of the block, 12..15 model rep set; 1: staged records end here
     uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22
     uint32_t node_delta[kParseMax + 2];         // distance (dict), rep index (rep), the byte (literal)
-    uint16_t cmdlist[kParseMax + 2];
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];               // log2_lut[freq >> 6] per (context, symbol) (:435-438)
     uint16_t lut[256];
@@ -1044,6 +1055,12 @@ struct PLds {
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t sq_sym[2 * 8];
     uint32_t ncmds;
+    unsigned long long acc[9];                  // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
+    uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
+    unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
+                                                //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
+    // the path of a parsed segment (node indices, end first) lives in mcur: nothing relaxes between a parse and its emission
+    XW_FN uint16_t *cmdlist() { return (uint16_t *)&mcur[0][0]; }
     Counters cnt;
 };
 
@@ -1055,11 +1072,18 @@ struct Parser {
     uint32_t rep0, rep1, rep2, rep3;   // live model rep set
     uint32_t t_out_seen;
     bool tab_dirty;
+    // wave kPW-1: the loader of the record stage (8-byte words counted from the launch's first position)
+    uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
+    unsigned long long pend_v[kPumpLoads];
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
     uint32_t err;
-    unsigned long long n_blocks, n_passes, n_eq_fill, n_eq_rounds, n_cmp, n_redo, n_undo = 0, n_fast = 0, t_wait, t_emit, t_setup, t_pass;
+    uint32_t n_eq_fill, n_eq_rounds;            // (per launch)
+    unsigned long long n_cmp, t_s[7] = {}, t_q[5] = {};
+    // the stage's accounting lives in LDS (L()->acc: it is touched once a block or less, and scalar registers are short)
+    enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccN };
+    XW_FN void acc(uint32_t k, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(&L()->acc[k], v); }
     unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
@@ -1173,12 +1197,72 @@ struct Parser {
         put_bits(idx, 2);
     }
 
+    // ---- the record stage (wave kPW-1).  One step: what was requested by the last step goes into LDS, the next 64 words are
+    // requested (positions below the table stage's t_out as the last step saw it, and below lo + 128: lo is the first
+    // position still needed), t_out is requested again.  Nothing is waited for here except the last step's loads.
+    XW_FN const unsigned long long *staged(uint32_t a) const { return L()->stage + (a & (kStagePos - 1)) * kStageQ; }
+    XW_FN uint32_t staged_hi() const { return xw::readfirst(L()->stg[4]); }
+    XW_FN void pump(uint32_t lo)
+    {
+        const uint32_t i = xw::lane();
+        const uint32_t stage_a0 = G.chunk0 * g.chunk_size;          // the launch's first position: words are counted from there
+        uint32_t st_req = xw::readfirst(L()->stg[0]), st_wr = xw::readfirst(L()->stg[1]);
+        const uint32_t pend_q = xw::readfirst(L()->stg[2]), pend_n = xw::readfirst(L()->stg[3]);
+        if (pend_n) {
+#pragma unroll
+            for (uint32_t u = 0; u < kPumpLoads; u++) {
+                const uint32_t q = pend_q + 64 * u + i;
+                if (64 * u + i < pend_n) L()->stage[((stage_a0 + q / kStageQ) & (kStagePos - 1)) * kStageQ + q % kStageQ] = pend_v[u];
+            }
+            st_wr = pend_q + pend_n;
+        }
+        t_out_seen = xw::readfirst(pend_t);
+        xw::after_poll();
+        uint32_t lim = lo + kStagePos;
+        if ((int32_t)(t_out_seen - lim) < 0) lim = t_out_seen;
+        const uint32_t lim_q = (lim - stage_a0) * kStageQ;
+        const uint32_t n = (int32_t)(lim_q - st_req) > 0 ? umin(64u * kPumpLoads, lim_q - st_req) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < kPumpLoads; u++) {
+            const uint32_t q = st_req + 64 * u + i, pos = stage_a0 + q / kStageQ, k = q % kStageQ;
+            if (64 * u + i < n) pend_v[u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)(pos & (kTpRing - 1)) * kTpStride) + (k == kStageQ - 1 ? kTpUniq / 2 : k));
+        }
+        pend_t = xw::ld_agent(&V.hx->t_out);
+        if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[2] = st_req; L()->stg[3] = n; L()->stg[4] = stage_a0 + st_wr / kStageQ; }
+    }
+    // until the record of position a is staged (false: another stage failed, or the wait timed out)
+    XW_FN bool stage_need(uint32_t a)
+    {
+        if ((int32_t)(staged_hi() - (a + 1)) >= 0) return true;
+        const unsigned long long tw = xw::tick(), t0 = xw::clock100();
+        uint32_t spins = 0;
+        bool ok = true;
+        for (;;) {
+            pump(a);
+            if ((int32_t)(staged_hi() - (a + 1)) >= 0) break;
+            if ((++spins & 63u) == 0) {
+                if (xw::readfirst(xw::ld_agent(&V.hx->err))) { ok = false; break; }
+#ifndef NLZM_SIM
+                if (xw::clock100() - t0 > 3000000000ull) {            // 30 s
+                    if (xw::lane() == 0) xw::st_agent(&V.hx->err, kErrTimeout * 100 + 4);
+                    ok = false; break;
+                }
+#else
+                (void)t0;
+#endif
+            }
+            if (!xw::readfirst(L()->stg[3])) xw::pause();
+        }
+        acc(kAccWait, xw::tick() - tw);
+        return ok;
+    }
+
     // The segment is within 264 of its forced cut (:1469): the sampled lengths of position a change with the smaller
     // max_len (:1545, :1558-1560).  Re-listed from the position's front into its ring record (lanes = samples; the
     // record is this stage's until p_pos passes it).
     XW_FN void resample(uint32_t a, uint32_t max_len)
     {
-        n_redo++;
+        acc(kAccRedo, 1);
         uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
         const unsigned long long h = xw::readfirst64(xw::ld_agent64((const unsigned long long *)rec));
         const uint32_t fn = (uint32_t)(h >> 32);
@@ -1188,9 +1272,9 @@ struct Parser {
         const uint32_t k = xw::lane();
         uint32_t ne = 0;
         if (max_len >= kMatchMin) ne = (max_len - kMatchMin) / step + 1;
+        uint32_t d = 0, valid = 0;
         if (k < ne) {
             const uint32_t tl = max_len - k * step;
-            uint32_t d = 0;
             for (uint32_t j = 0; j < fn; j++) {                     // the last entry (smallest end) that still has >= tl bytes
                 const unsigned long long e = xw::ld_agent64((const unsigned long long *)(fo + 2 * j));
                 if ((uint32_t)e >= tl) d = (uint32_t)(e >> 32);
@@ -1198,11 +1282,22 @@ struct Parser {
             const uint32_t mm = match_min(d);
             uint32_t nx, ex;
             const uint32_t slot = dist_slot(d - 1, nx, ex);
-            const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
-            xw::st_agent64((unsigned long long *)(rec + 2 + 2 * k),
-                           (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32));
+            valid = tl >= mm ? 1u : 0u;
+            const uint32_t lv = valid ? tl - mm : 0u;
+            const unsigned long long e = (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32);
+            xw::st_agent64((unsigned long long *)(rec + 2 + 2 * k), e);
+            if (k < kStageEdges) L()->stage[(a & (kStagePos - 1)) * kStageQ + 1 + k] = e;
         }
-        if (k == 0) xw::st_agent64((unsigned long long *)rec, (h & ~63ull) | ne);
+        // the valid samples that bring a distance the valid one before did not have (as the table stage lists them)
+        const unsigned long long vm = xw::ballot(valid != 0), below = vm & ((1ull << k) - 1ull);
+        const uint32_t dprev = xw::shfl(d, below ? 63u - (uint32_t)__builtin_clzll(below) : k);
+        const uint32_t uniq = (uint32_t)xw::ballot(valid && (!below || d != dprev));
+        if (k == 0) {
+            xw::st_agent64((unsigned long long *)rec, (h & ~63ull) | ne);
+            xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
+            L()->stage[(a & (kStagePos - 1)) * kStageQ] = (h & ~63ull) | ne;
+            L()->stage[(a & (kStagePos - 1)) * kStageQ + kStageQ - 1] = uniq;
+        }
         xw::drain();
     }
 
@@ -1310,13 +1405,8 @@ struct Parser {
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
-        if (w == 0) {
-            if ((int32_t)(t_out_seen - (seg_a + 1)) < 0) {
-                const unsigned long long tw = xw::tick();
-                if (!wait_word_ge(&V.hx->t_out, seg_a + 1, V.hx, 4)) err = kErrInternal + 100;
-                t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out));
-                t_wait += xw::tick() - tw;
-            }
+        if (w == kPW - 1) {
+            if (!stage_need(seg_a)) err = kErrInternal + 100;
             if (i == 0) L()->sh[4] = err;
         }
         xw::block_sync();
@@ -1324,8 +1414,7 @@ struct Parser {
         {
             // A position without any match is a segment of its own (more than half of all segments are): its node has no
             // sampled edge, and if none of the four rep probes finds anything (:1598-1628) the only command is the literal.
-            const uint32_t *rec0 = V.tp + (unsigned long long)(seg_a & (kTpRing - 1)) * kTpStride;
-            const uint32_t h0 = xw::readfirst(xw::ld_agent(rec0));
+            const uint32_t h0 = xw::readfirst((uint32_t)staged(seg_a)[0]);
             if ((h0 & 63u) == 0) {
                 bool ok = false;
                 unsigned long long counted = 0;
@@ -1345,10 +1434,9 @@ struct Parser {
                 if (!any_ok) {
                     if (tid == 0) {
                         L()->node_link[1] = 0; L()->node_delta[1] = (h0 >> 8) & 0xFFu;           // literal: from node 0, the byte
-                        L()->cmdlist[0] = 1; L()->ncmds = 1;
+                        L()->cmdlist()[0] = 1; L()->ncmds = 1;
                         xw::st_agent(&V.hx->p_pos, seg_a);
                     }
-                    n_fast++;
                     xw::block_sync();
                     ncmds = 1;
                     return 1;
@@ -1358,6 +1446,7 @@ struct Parser {
         }
         while (!seg_len) {
             const unsigned long long ts = xw::tick();
+            const unsigned long long q0 = ptick();
             if (b0 == end_p || b0 >= max_parse) {
                 // node b0 is the segment's last node: no edges leave it; its key is complete
                 if (tid == 0) {
@@ -1371,16 +1460,12 @@ struct Parser {
                 break;
             }
             // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
-            if (w == 0) {
+            if (w == kPW - 1) {
                 const uint32_t a_first = seg_a + b0;
-                if ((int32_t)(t_out_seen - (a_first + 1)) < 0) {
-                    const unsigned long long tw = xw::tick();
-                    if (!wait_word_ge(&V.hx->t_out, a_first + 1, V.hx, 4)) err = kErrInternal + 100;
-                    t_wait += xw::tick() - tw;
-                }
-                if ((int32_t)(t_out_seen - (a_first + 64)) < 0 && !err) { t_out_seen = xw::readfirst(xw::ld_agent(&V.hx->t_out)); xw::after_poll(); }
+                if (!stage_need(a_first)) err = kErrInternal + 100;
                 uint32_t nb = umin(64u, max_parse - b0);
-                if ((int32_t)(t_out_seen - (a_first + nb)) < 0) nb = t_out_seen - a_first;
+                const uint32_t sh_hi = staged_hi();
+                if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
 #ifdef NLZM_SIM
                 {   // (simulation: blocks cut at random, as they are on the GPU when this stage catches up with the table stage)
                     static const int rnd = getenv("NLZM_SIM_RANDOM_BLOCKS") ? atoi(getenv("NLZM_SIM_RANDOM_BLOCKS")) : 0;
@@ -1391,6 +1476,7 @@ struct Parser {
                 if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; xw::st_agent(&V.hx->p_pos, a_first); }
             }
             xw::block_sync();
+            const unsigned long long q1 = ptick();
             const uint32_t nb = L()->sh[0];
             if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
             const bool inb = i < nb;
@@ -1398,9 +1484,8 @@ struct Parser {
             // within 264 of the forced cut the table is cut short (:1545): such records are re-listed first
             if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax) {
                 if (w == kPW - 1) {
-                    const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-                    const uint32_t h0 = inb ? xw::ld_agent(rec) : 0u;
-                    const uint32_t ml = (h0 & 63u) ? (xw::ld_agent(rec + 3) & 0x1FFu) : 0u;
+                    const uint32_t h0 = inb ? (uint32_t)staged(a)[0] : 0u;
+                    const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
                     for (unsigned long long m = xw::ballot(inb && ml > max_parse - node); m; m &= m - 1) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(m);
                         resample(seg_a + b0 + j, max_parse - (b0 + j));
@@ -1408,18 +1493,31 @@ struct Parser {
                 }
                 xw::block_sync();
             }
-            // ---- set-up: the block's records
+            const unsigned long long q2 = ptick();
+            // ---- set-up: the block's records, from the stage.  Every wave: the node's header, its distinct distances (for
+            // the probes' "already met" test) and the wave's own edges; their distances also go into the ring the winners'
+            // distances are looked up in.
             const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-            const unsigned long long hd = inb ? xw::ld_agent64((const unsigned long long *)rec) : 0ull;
+            const unsigned long long *srec = staged(a);
+            const unsigned long long hd = inb ? srec[0] : 0ull;
             const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
+            const uint32_t uniq = ne ? (uint32_t)srec[kStageQ - 1] : 0u;
+            const uint32_t nd = (uint32_t)__builtin_popcount(uniq);
+            const uint32_t max_len = ne ? ((uint32_t)(srec[1] >> 32) & 0x1FFu) : 0u;
+            const uint32_t sreach = inb ? node + max_len : 0u;                      // :1550
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
             {
                 unsigned long long er[kEdgesPerWave];
 #pragma unroll
-                for (uint32_t j = 0; j < kEdgesPerWave; j++) er[j] = edge_of(w, j) < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * edge_of(w, j))) : 0ull;
+                for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                    const uint32_t k = edge_of(w, j);
+                    er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k))) : 0ull;
+                }
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                    const uint32_t k = edge_of(w, j);
                     ed[j] = 0; ea[j] = 0;
+                    if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
                     const uint32_t at = (uint32_t)(er[j] >> 32);
                     if (at >> 31) {
                         const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
@@ -1430,50 +1528,27 @@ struct Parser {
                     }
                 }
             }
-            if (w == kPW - 1) {
-                // every edge's distance into LDS (the winners' distances are looked up there); the distinct valid ones
-                uint32_t prev = 0, uniq = 0, nd = 0, max_len = 0;
-                uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            const unsigned long long q3 = ptick();
+            uint32_t dd[8];                                         // the node's first eight distinct valid distances
+            {
+                uint32_t um = uniq;
 #pragma unroll
-                for (uint32_t h = 0; h < kMaxEdges; h += 8) {           // eight records requested before any is used
-                    unsigned long long e[8];
-#pragma unroll
-                    for (uint32_t u = 0; u < 8; u++) e[u] = h + u < ne ? xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * (h + u))) : 0ull;
-#pragma unroll
-                    for (uint32_t u = 0; u < 8; u++) {
-                        const uint32_t k = h + u;
-                        if (k >= ne) continue;
-                        const uint32_t d = (uint32_t)e[u], at = (uint32_t)(e[u] >> 32);
-                        L()->edge_d[(a & 511u) * kMaxEdges + k] = d;
-                        if (k == 0) max_len = at & 0x1FFu;
-                        if ((at >> 31) && d != prev) {
-                            uniq |= 1u << k;
-#pragma unroll
-                            for (uint32_t z = 0; z < 8; z++) if (nd == z) dd[z] = d;
-                            nd++;
-                        }
-                        if (at >> 31) prev = d;
-                    }
-                    if (!xw::any(h + 8 < ne)) break;
+                for (uint32_t z = 0; z < 8; z++) {
+                    const uint32_t k = um ? (uint32_t)__builtin_ctz(um) : 0u;
+                    dd[z] = um ? (k < kStageEdges ? (uint32_t)srec[1 + k] : xw::ld_agent(rec + 2 + 2 * k)) : 0u;
+                    um &= um - 1;
                 }
-#pragma unroll
-                for (uint32_t z = 0; z < 8; z++) L()->bdd[i * 8 + z] = dd[z];
-                L()->bnd[i] = nd; L()->buniq[i] = uniq;
-                L()->sreach[i] = inb ? node + max_len : 0u;
-                L()->reach[1][i] = inb ? node + max_len : 0u;
             }
+            if (w == 0) L()->reach[1][i] = sreach;
+            const unsigned long long q4 = ptick();
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
             const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
             if (w == 0 && i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
             for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
             xw::block_sync();
-            uint32_t dd[8];
-#pragma unroll
-            for (uint32_t z = 0; z < 8; z++) dd[z] = L()->bdd[i * 8 + z];
-            const uint32_t nd = L()->bnd[i], uniq = L()->buniq[i], sreach = L()->sreach[i];
-            t_setup += xw::tick() - ts;
+            if (w == 0) acc(kAccSetup, xw::tick() - ts);
+            t_q[0] += q1 - q0; t_q[1] += q2 - q1; t_q[2] += q3 - q2; t_q[3] += q4 - q3; t_q[4] += ptick() - q4;
             const unsigned long long tp0 = xw::tick();
-            n_blocks++;
             // ---- passes.  Every wave keeps the state of its lane's node in registers (all waves compute the same update)
             unsigned long long key = kKeyNone;
             uint32_t c = kInf, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -1485,8 +1560,8 @@ struct Parser {
             const uint32_t pcap = umin(max_parse - node, kMatchMax);                                    // :1605-1606
             for (;;) {
                 const uint32_t buf = pass % 3u, nbuf = (pass + 1) % 3u;
-                n_passes++;
                 const unsigned long long k0 = ptick();
+                if (w == kPW - 1) pump(seg_a + b0);                 // (the records of the blocks to come)
                 if (pass > 0 && lv) {
                     // relax this wave's sampled edges of the node (:1566-1595)
 #pragma unroll
@@ -1501,6 +1576,7 @@ struct Parser {
                             xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
                     }
                 }
+                const unsigned long long k0a = ptick();
                 if (pass > 0 && w < 4) {
                     // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628)
                     const uint32_t r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
@@ -1528,6 +1604,7 @@ struct Parser {
                         xw::lds_max(&L()->reach[buf][i], node + pt);        // :1608-1612
                     }
                 }
+                const unsigned long long k0b = ptick();
                 // the buffers of the next pass
                 for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
                 if (w == 0) L()->reach[nbuf][i] = sreach;
@@ -1545,6 +1622,7 @@ struct Parser {
                 const uint32_t nc = (uint32_t)(xw::scan_min_i32((int32_t)mc - (int32_t)S) + (int32_t)S);
                 const bool litwin = i >= 1 && nc < mc;                                                   // :1492 (the literal edge comes last: strict)
                 const unsigned long long nkey = litwin ? (((unsigned long long)nc << 32) | ((node - 1) << 8) | kRankLit) : kin;
+                const unsigned long long u1 = ptick();
                 // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
                 const uint32_t rlive = (lv && pass > 0) ? L()->reach[buf][i] : 0u;     // (a node's reach counts once it was inside: it has relaxed its edges)
                 const uint32_t pm = xw::scan_max(rlive);
@@ -1554,6 +1632,7 @@ struct Parser {
                 istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;      // (lanes >= nb count as dead)
                 const bool act = i <= istar && inb;                 // nodes b0 .. b0+istar: inside, or the segment's last node
                 const bool nlv = i < istar && inb;
+                const unsigned long long u2 = ptick();
                 // rep sets from the winners (the sources' sets as of the last pass)
                 uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, link = 0, delta = 0;
                 if (act && nkey != kKeyNone) winner_set(seg_a, b0, (pass + 1) & 1u, node, nkey, o0, o1, o2, o3, link, delta);
@@ -1563,6 +1642,7 @@ struct Parser {
                     const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
                     if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
                 }
+                const unsigned long long u3 = ptick();
                 const bool same = !act || (key == nkey && r0 == o0 && r1 == o1 && r2 == o2 && r3 == o3 && lv == nlv);
                 const bool changed = xw::any(!same);
                 if (act) { key = nkey; c = nc; r0 = o0; r1 = o1; r2 = o2; r3 = o3; }
@@ -1573,10 +1653,11 @@ struct Parser {
                     blk_end = done_n ? umax(end_p, xw::readlane(pm, done_n - 1)) : end_p;
                 }
                 t_work += k1 - k0; t_bar += k2 - k1; t_upd += ptick() - k2;
+                t_s[0] += k0a - k0; t_s[1] += k0b - k0a; t_s[2] += k1 - k0b; t_s[3] += u1 - k2; t_s[4] += u2 - u1; t_s[5] += u3 - u2; t_s[6] += ptick() - u3;
                 if (!changed) break;
                 pass++;
             }
-            t_pass += xw::tick() - tp0;
+            if (w == 0) { acc(kAccPass, xw::tick() - tp0); acc(kAccBlocks, 1); acc(kAccPasses, pass + 1); }
             const unsigned long long e0 = ptick();
             // ---- the block is at its fixed point: final nodes, the edges that end beyond it
             const uint32_t lbuf = pass % 3u;                         // the buffer the last update read
@@ -1600,15 +1681,14 @@ struct Parser {
                 // The positions after it belong to the next segment, whose cut is elsewhere: what was re-listed for this
                 // segment's forced cut goes back to the full sampling (:1545 with the new max_parse).
                 if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax && w == kPW - 1) {
-                    const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-                    const uint32_t h0 = (inb && i >= istar) ? xw::ld_agent(rec) : 0u;
-                    const uint32_t ml = (h0 & 63u) ? (xw::ld_agent(rec + 3) & 0x1FFu) : 0u;
+                    const uint32_t h0 = (inb && i >= istar) ? (uint32_t)staged(a)[0] : 0u;
+                    const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
                     uint32_t full = umin((h0 >> 16) & 0x1FFu, chunk_left - node);
                     if (full < kMatchMin) full = 0;
                     for (unsigned long long m = xw::ballot(inb && i >= istar && ml != full); m; m &= m - 1) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(m);
                         resample(seg_a + b0 + j, xw::readlane(full, j));
-                        n_undo++;
+                        acc(kAccUndo, 1);
                     }
                 }
             } else {
@@ -1641,7 +1721,7 @@ struct Parser {
         if (w == 0) {
             uint32_t n = 0, cur = seg_len;
             while (cur != 0) {
-                if (i == 0) L()->cmdlist[n] = (uint16_t)cur;
+                if (i == 0) L()->cmdlist()[n] = (uint16_t)cur;
                 n++;
                 cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
             }
@@ -1674,7 +1754,7 @@ struct Parser {
             if (xw::wave() == 0) {
                 const unsigned long long te = xw::tick();
                 for (uint32_t k = ncmds; k-- > 0;) {                            // :1809-1843
-                    const uint32_t node = xw::readfirst(L()->cmdlist[k]);
+                    const uint32_t node = xw::readfirst(L()->cmdlist()[k]);
                     const uint32_t link = xw::readfirst(L()->node_link[node]);
                     const uint32_t delta = xw::readfirst(L()->node_delta[node]);
                     const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
@@ -1682,12 +1762,14 @@ struct Parser {
                     else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
                     else { emit_rep(delta, ln); n_rep++; }
                 }
-                t_emit += xw::tick() - te;
+                acc(kAccEmit, xw::tick() - te);
                 if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
                 if (xw::lane() == 0) {
                     L()->sh[12] = rep0; L()->sh[13] = rep1; L()->sh[14] = rep2; L()->sh[15] = rep3;
                     L()->sh[5] = tab_dirty ? 1u : 0u; L()->sh[4] = err;
                 }
+            } else if (xw::wave() == kPW - 1) {
+                pump(seg_a + len);                                              // (meanwhile: records of the next segment)
             }
             xw::block_sync();
             rep0 = L()->sh[12]; rep1 = L()->sh[13]; rep2 = L()->sh[14]; rep3 = L()->sh[15];     // (every wave follows the model's rep set)
@@ -1729,25 +1811,27 @@ struct Parser {
         err = xw::readfirst(P->error);
         tab_dirty = true;
         t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        n_blocks = n_passes = n_eq_fill = n_eq_rounds = n_cmp = n_redo = 0; t_wait = t_emit = t_setup = t_pass = 0;
-        const unsigned long long t_start = xw::tick();
+        if (tid < 5) L()->stg[tid] = tid == 4 ? t_out_seen : 0u;
+        pend_t = t_out_seen;                                        // (as if t_out had been read before the table stage started)
+        n_eq_fill = n_eq_rounds = 0; n_cmp = 0;
+        if (tid < kAccN) L()->acc[tid] = 0;
         xw::block_sync();
+        if (tid == 0) L()->acc[kAccTotal] = 0ull - xw::tick();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk(ci);
         xw::block_sync();
 #ifdef NLZM_PROFILE
+        if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) P->prof[56 + z] += t_q[z];
         if (xw::lane() == 0 && xw::wave() < 4) {   // per wave: relax + probe work of a pass, barrier wait, update; mask fills
             P->prof[32 + xw::wave()] += t_work; P->prof[36 + xw::wave()] += t_bar;
-            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; P->prof[41] += t_fill; }
+            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; P->prof[41] += t_fill; for (int z = 0; z < 7; z++) { P->prof[48 + z] += t_s[z]; t_s[z] = 0; } }
         }
 #endif
-        if (xw::lane() == 0 && xw::wave() == kPW - 1 && n_undo) { xw::atomic_add64_agent(&P->prof[14], n_undo); n_undo = 0; }
         {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
             for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
             if (xw::lane() == 0) {
                 xw::lds_add64(&L()->cnt.cmp_bytes, n_cmp);
                 xw::lds_add64(&L()->cnt.stale_ht, n_eq_fill); xw::lds_add64(&L()->cnt.stale_rk, n_eq_rounds);     // (counters the new stages do not use otherwise)
-                xw::lds_add64(&L()->cnt.bt_slow, n_redo);
             }
         }
         xw::block_sync();
@@ -1756,13 +1840,13 @@ struct Parser {
             if (xw::lane() == 0) {
                 P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
                 P->next_chunk = ci;
-                P->prof[8] += n_blocks; P->prof[13] += n_passes;
-                P->prof[9] += L()->cnt.stale_ht; P->prof[10] += L()->cnt.stale_rk; P->prof[11] += L()->cnt.bt_slow;
+                P->prof[8] += L()->acc[kAccBlocks]; P->prof[13] += L()->acc[kAccPasses]; P->prof[14] += L()->acc[kAccUndo];
+                P->prof[9] += L()->cnt.stale_ht; P->prof[10] += L()->cnt.stale_rk; P->prof[11] += L()->acc[kAccRedo];
                 L()->cnt.stale_ht = 0; L()->cnt.stale_rk = 0; L()->cnt.bt_slow = 0;
                 unsigned long long *dst = (unsigned long long *)&P->cnt;
                 const unsigned long long *src = (const unsigned long long *)&L()->cnt;
                 for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
-                P->prof[20] += t_wait; P->prof[21] += xw::tick() - t_start; P->prof[22] += t_emit; P->prof[23] += t_setup; P->prof[24] += t_pass;
+                P->prof[20] += L()->acc[kAccWait]; P->prof[21] += L()->acc[kAccTotal] + xw::tick(); P->prof[22] += L()->acc[kAccEmit]; P->prof[23] += L()->acc[kAccSetup]; P->prof[24] += L()->acc[kAccPass];
                 const uint32_t xe = xw::ld_agent(&V.hx->err);
                 if (xe && !P->error) P->error = xe;
                 if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
