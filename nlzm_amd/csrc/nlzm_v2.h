@@ -1019,12 +1019,12 @@ constexpr uint32_t kSrcNone = 0x1FFF;
 #define NLZM_KPW 8
 #endif
 constexpr uint32_t kPW = NLZM_KPW;              // waves of the stage (4 or 8): waves 0..3 probe rep slot w; the sampled edges are dealt
-constexpr uint32_t kEdgesPerWave = kPW == 4 ? 8 : 6;    // round: four waves take edge w, w+4, ..; eight: waves 0..3 two each, 4..7 six each
+constexpr uint32_t kEdgesPerWave = 8;           // round: four waves take edge w, w+4, ..; eight: waves 0..3 probe only, 4..7 relax edge w-4, w, ..
 // sampled edge j of wave w (kMaxEdges: none)
 NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)
 {
     if (kPW == 4) return w + 4 * j;
-    return w < 4 ? (j < 2 ? w + 4 * j : kMaxEdges) : 8 + (w - 4) + 4 * j;
+    return w < 4 ? kMaxEdges : (w - 4) + 4 * j;
 }
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
@@ -1562,7 +1562,7 @@ struct Parser {
                 const uint32_t buf = pass % 3u, nbuf = (pass + 1) % 3u;
                 const unsigned long long k0 = ptick();
                 if (w == kPW - 1) pump(seg_a + b0);                 // (the records of the blocks to come)
-                if (pass > 0 && lv) {
+                if (pass > 0 && lv && (kPW == 4 || w >= 4)) {
                     // relax this wave's sampled edges of the node (:1566-1595)
 #pragma unroll
                     for (uint32_t j = 0; j < kEdgesPerWave; j++) {
