@@ -1053,7 +1053,6 @@ struct PLds {
     uint16_t lut[256];
     uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
-    uint32_t sq_sym[2 * 8];
     uint32_t ncmds;
     unsigned long long acc[9];                  // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
@@ -1078,6 +1077,7 @@ struct Parser {
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
+    unsigned long long q_lo, q_hi;
     uint32_t err;
     uint32_t n_eq_fill, n_eq_rounds;            // (per launch)
     unsigned long long n_cmp, t_s[7] = {}, t_q[5] = {};
@@ -1127,15 +1127,20 @@ struct Parser {
     // lane i of a group holds cell[i] and cell[i+1]; (start, freq) snapshot (:559-572), adaptation
     // cell[i] += (mixin[y][i] - cell[i]) >> 7 with mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298, :348-382),
     // and the price row of the new cells (:435-438).
-    XW_FN void put_sym(uint32_t ctx, uint32_t y) { L()->sq_sym[2 * nq] = ctx; L()->sq_sym[2 * nq + 1] = y; nq++; }
+    // (the queue: ctx << 4 | symbol in sixteen bits each, four to a word, in registers -- an LDS round trip per command otherwise)
+    XW_FN void put_sym(uint32_t ctx, uint32_t y)
+    {
+        const unsigned long long e = (unsigned long long)((ctx << 4) | y) << (16 * (nq & 3u));
+        if (nq < 4) q_lo |= e; else q_hi |= e;
+        nq++;
+    }
     XW_FN void flush_syms()
     {
-        xw::wave_sync();
         const uint32_t grp = xw::lane() >> 4, i = xw::lane() & 15u;
         for (uint32_t b = 0; b < nq; b += 4) {
             const uint32_t k = b + grp;
             if (k < nq) {
-                const uint32_t ctx = L()->sq_sym[2 * k], y = L()->sq_sym[2 * k + 1];
+                const uint32_t qe = (uint32_t)((b ? q_hi : q_lo) >> (16 * grp)) & 0xFFFFu, ctx = qe >> 4, y = qe & 15u;
                 const uint32_t nsy = ctx_nsyms(ctx);
                 uint16_t *cell = L()->cdf + ctx * kCdfStride;
                 const uint32_t c0 = cell[i], c1 = cell[i + 1];
@@ -1149,7 +1154,7 @@ struct Parser {
                 if (i < nsy) { cell[i] = (uint16_t)n0; L()->price[ctx * 16 + i] = L()->lut[(n1 - n0) >> 6]; }
             }
         }
-        nsyms += nq; num_ops += nq; nq = 0;
+        nsyms += nq; num_ops += nq; nq = 0; q_lo = q_hi = 0;
         xw::wave_sync();
     }
     XW_FN void put_bits(uint32_t v, uint32_t nb)                    // :574-588
@@ -1741,7 +1746,7 @@ struct Parser {
         const uint32_t p_end = umin(g.chunk_size, chunk_read);
         fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
         fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
-        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0;
+        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0; q_lo = q_hi = 0;
         if (chunk_abs - base >= 2ull * (g.wmask + 1)) base += g.wmask + 1;      // :1786
         unsigned long long n_lit = 0, n_dict = 0, n_rep = 0, n_seg = 0;
         uint32_t p = 0;
@@ -1753,14 +1758,22 @@ struct Parser {
             n_seg++;
             if (xw::wave() == 0) {
                 const unsigned long long te = xw::tick();
-                for (uint32_t k = ncmds; k-- > 0;) {                            // :1809-1843
-                    const uint32_t node = xw::readfirst(L()->cmdlist()[k]);
-                    const uint32_t link = xw::readfirst(L()->node_link[node]);
-                    const uint32_t delta = xw::readfirst(L()->node_delta[node]);
-                    const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
-                    if (cmd == 0) { emit_literal(delta); n_lit++; }
-                    else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
-                    else { emit_rep(delta, ln); n_rep++; }
+                for (uint32_t k0 = ncmds; k0 > 0;) {                            // :1809-1843
+                    // (64 commands are looked up at once, a lane each: two LDS round trips for all of them)
+                    const uint32_t cnt = umin(64u, k0);
+                    uint32_t link_v = 0, delta_v = 0;
+                    if (xw::lane() < cnt) {
+                        const uint32_t node = L()->cmdlist()[k0 - 1 - xw::lane()];
+                        link_v = L()->node_link[node]; delta_v = L()->node_delta[node];
+                    }
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t link = xw::readlane(link_v, j), delta = xw::readlane(delta_v, j);
+                        const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
+                        if (cmd == 0) { emit_literal(delta); n_lit++; }
+                        else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
+                        else { emit_rep(delta, ln); n_rep++; }
+                    }
+                    k0 -= cnt;
                 }
                 acc(kAccEmit, xw::tick() - te);
                 if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
