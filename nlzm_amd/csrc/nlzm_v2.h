@@ -1511,7 +1511,9 @@ struct Parser {
             const uint32_t max_len = ne ? ((uint32_t)(srec[1] >> 32) & 0x1FFu) : 0u;
             const uint32_t sreach = inb ? node + max_len : 0u;                      // :1550
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
-            {
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) { ed[j] = 0; ea[j] = 0; }
+            if (kPW == 4 || w >= 4) {
                 unsigned long long er[kEdgesPerWave];
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
@@ -1521,7 +1523,6 @@ struct Parser {
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                     const uint32_t k = edge_of(w, j);
-                    ed[j] = 0; ea[j] = 0;
                     if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
                     const uint32_t at = (uint32_t)(er[j] >> 32);
                     if (at >> 31) {
@@ -1534,8 +1535,8 @@ struct Parser {
                 }
             }
             const unsigned long long q3 = ptick();
-            uint32_t dd[8];                                         // the node's first eight distinct valid distances
-            {
+            uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };            // the node's first eight distinct valid distances (probe waves)
+            if (w < 4) {
                 uint32_t um = uniq;
 #pragma unroll
                 for (uint32_t z = 0; z < 8; z++) {
