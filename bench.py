@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="compress the whole stream (steps = all batches, warmup 0)")
     ap.add_argument("--cpu-sample-mb", type=float, default=30.0, help="upper bound of the CPU leg's sample (it covers the GPU leg's bytes up to this)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--block-streams", type=int, default=16,
+    ap.add_argument("--block-streams", type=int, default=32,
                     help="N=1 only: also time the independent-block mode with this many streams in flight on the GPU (0: skip)")
     args = ap.parse_args()
 

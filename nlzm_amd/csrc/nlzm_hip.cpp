@@ -16,6 +16,7 @@
 #include <array>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/nlzm_hip.h"
@@ -30,7 +31,7 @@ unsigned long long stream2_pack_size();
 uint32_t stream2_pack_capacity();
 uint32_t pipeline2_role_blocks();
 void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1);
-void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
+void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
@@ -786,6 +787,7 @@ namespace {
 std::vector<BlockJob> g_jobs;       // the open block set (nlzm_hip_blocks_begin .. _end)
 std::vector<hipStream_t> g_group_st;             // one HIP stream and an event pair per shared launch of a round
 std::vector<std::array<hipEvent_t, 2>> g_group_ev;
+void *g_pack_host = nullptr, *g_pack_dev = nullptr;     // the streams' launch arguments of a round: pinned host copy, device copy
 uint64_t g_blocks_n = 0;
 const uint8_t *g_blocks_src = nullptr;
 uint32_t g_blocks_hist = 0;
@@ -798,6 +800,9 @@ void blocks_close()
     for (auto &st : g_group_st) (void)hipStreamDestroy(st);
     for (auto &ev : g_group_ev) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
     g_group_st.clear(); g_group_ev.clear();
+    if (g_pack_host) (void)hipHostFree(g_pack_host);
+    if (g_pack_dev) (void)hipFree(g_pack_dev);
+    g_pack_host = g_pack_dev = nullptr;
 }
 
 // run f(block) for every open block, `conc` at a time, each on a host thread of its own
@@ -871,6 +876,8 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
+    HIPCHK(hipHostMalloc(&g_pack_host, stream2_pack_size(), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&g_pack_dev, stream2_pack_size()));
     const uint32_t ngroups = (nblocks + stream2_pack_capacity() - 1) / stream2_pack_capacity();
     for (uint32_t gi = 0; gi < ngroups; gi++) {
         hipStream_t st; std::array<hipEvent_t, 2> ev;
@@ -897,7 +904,6 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
     // Rounds in lockstep: every unfinished stream advances by one batch, and the streams of a round share persistent
     // launches (groups of up to stream_pack_capacity() streams per launch, all launches of a round in flight together)
     const uint32_t cap = stream2_pack_capacity();
-    std::vector<uint8_t> pack(stream2_pack_size());
     std::vector<StepPlan> plan(nj);
     for (;;) {
         std::vector<uint32_t> act;
@@ -913,10 +919,11 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
             for (uint32_t k = lo; k < hi; k++) {
                 Ctx &c = g_jobs[act[k]].c;
                 HIPCHK(hipStreamWaitEvent(gs, c.ev[6], 0));            // its pre-pass is done
-                fill_stream2_args(pack.data(), k - lo, c.g, plan[act[k]].G, plan[act[k]].V, plan[act[k]].c0, plan[act[k]].c1);
+                fill_stream2_args(g_pack_host, k - lo, c.g, plan[act[k]].G, plan[act[k]].V, plan[act[k]].c0, plan[act[k]].c1);
             }
             HIPCHK(hipEventRecord(g_group_ev[gi][0], gs));
-            launch_pipeline2_multi(pack.data(), hi - lo, (uint32_t)g_blocks_wb, gs);
+            HIPCHK(hipMemcpyAsync(g_pack_dev, g_pack_host, stream2_pack_size(), hipMemcpyHostToDevice, gs));
+            launch_pipeline2_multi(g_pack_dev, hi - lo, (uint32_t)g_blocks_wb, gs);
             HIPCHK(hipEventRecord(g_group_ev[gi][1], gs));
             for (uint32_t k = lo; k < hi; k++) HIPCHK(hipStreamWaitEvent(g_jobs[act[k]].c.st, g_group_ev[gi][1], 0));
         }
@@ -977,11 +984,21 @@ void nlzm_hip_blocks_abandon(void) { blocks_close(); }
 int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req, void *d_dst,
                                  uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = nlzm_hip_blocks_begin(d_src, n, nblocks, hist_bits_req);
     if (rc) return rc;
-    rc = nlzm_hip_blocks_step(0, nullptr, nullptr, nullptr);
+    const auto t1 = std::chrono::steady_clock::now();
+    double dev_ms = 0;
+    rc = nlzm_hip_blocks_step(0, nullptr, nullptr, &dev_ms);
     if (rc) { blocks_close(); return rc; }
-    return nlzm_hip_blocks_finish(d_dst, dst_cap, block_len, dst_len);
+    const auto t2 = std::chrono::steady_clock::now();
+    rc = nlzm_hip_blocks_finish(d_dst, dst_cap, block_len, dst_len);
+    if (getenv("NLZM_WAIT_PRINT")) {
+        const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "block set of %u: begin (tables, pre-filter) %.0f ms, steps %.0f ms (device %.0f ms), finish (gather) %.0f ms\n", nblocks,
+                ms(t0, t1), ms(t1, t2), dev_ms, ms(t2, std::chrono::steady_clock::now()));
+    }
+    return rc;
 }
 
 int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req, uint8_t *dst,

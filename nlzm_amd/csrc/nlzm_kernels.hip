@@ -11,6 +11,7 @@
 //                       per frame, renormalisation words placed by a prefix scan.
 //   gather_frames_kernel concatenates the frames into the output stream.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "nlzm_core.h"
@@ -387,13 +388,21 @@ __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::G
     pipeline2_roles(g, G, V, c0, c1, blockIdx.x, gridDim.x - kV2Roles);
 }
 struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; };
-constexpr uint32_t kMaxStreams2PerLaunch = 10;          // the pack travels in the kernel-argument segment (4 KB)
-struct Stream2Pack { Stream2Args s[kMaxStreams2PerLaunch]; };
-static_assert(sizeof(Stream2Pack) <= 4000, "kernel arguments are limited to 4 KB");
-__global__ __launch_bounds__(512) void pipeline2_multi_kernel(Stream2Pack pack, uint32_t bps)
+constexpr uint32_t kMaxStreams2PerLaunch = 64;          // (the pack lives in device memory: the kernel-argument segment holds 4 KB)
+__global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args *__restrict__ pack, uint32_t bps)
 {
     const uint32_t s = blockIdx.x / bps, local = blockIdx.x % bps;
-    pipeline2_roles(pack.s[s].g, pack.s[s].G, pack.s[s].V, pack.s[s].c0, pack.s[s].c1, local, bps - kV2Roles);
+    Stream2Args a = pack[s];
+    // pointers read from memory: tell the compiler they are global ones (flat accesses would count on both wait counters)
+#define NLZM_GLOBAL_PTR(p) p = (decltype(p))(__attribute__((address_space(1))) std::remove_pointer_t<decltype(p)> *)(unsigned long long)(p)
+    NLZM_GLOBAL_PTR(a.G.in); NLZM_GLOBAL_PTR(a.G.rkhash); NLZM_GLOBAL_PTR(a.G.ht2); NLZM_GLOBAL_PTR(a.G.ht3); NLZM_GLOBAL_PTR(a.G.rk_table);
+    NLZM_GLOBAL_PTR(a.G.bt_heads); NLZM_GLOBAL_PTR(a.G.bt_tree); NLZM_GLOBAL_PTR(a.G.persist); NLZM_GLOBAL_PTR(a.G.syms); NLZM_GLOBAL_PTR(a.G.bits);
+    NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs);
+    NLZM_GLOBAL_PTR(a.G.bt_flag); NLZM_GLOBAL_PTR(a.G.unc); NLZM_GLOBAL_PTR(a.G.bin_off); NLZM_GLOBAL_PTR(a.G.bin_pos); NLZM_GLOBAL_PTR(a.G.abort_word);
+    NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt);
+    NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state);
+#undef NLZM_GLOBAL_PTR
+    pipeline2_roles(a.g, a.G, a.V, a.c0, a.c1, local, bps - kV2Roles);
 }
 
 // ---------------------------------------------------------------------------
@@ -507,17 +516,18 @@ void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, u
 {
     hipLaunchKernelGGL(pipeline2_kernel, dim3(kV2Roles + worker_blocks), dim3(512), 0, st, g, G, V, c0, c1);
 }
-unsigned long long stream2_pack_size() { return sizeof(Stream2Pack); }
+unsigned long long stream2_pack_size() { return sizeof(Stream2Args) * kMaxStreams2PerLaunch; }
 uint32_t stream2_pack_capacity() { return kMaxStreams2PerLaunch; }
 uint32_t pipeline2_role_blocks() { return kV2Roles; }
 void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1)
 {
-    Stream2Args &a = ((Stream2Pack *)host_pack)->s[i];
+    Stream2Args &a = ((Stream2Args *)host_pack)[i];
     a.g = g; a.G = G; a.V = V; a.c0 = c0; a.c1 = c1;
 }
-void launch_pipeline2_multi(const void *host_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)
+// dev_pack: the streams' arguments in device memory (stream2_pack_size() bytes, filled with fill_stream2_args on the host)
+void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pipeline2_multi_kernel, dim3(nstreams * (kV2Roles + worker_blocks)), dim3(512), 0, st, *(const Stream2Pack *)host_pack,
+    hipLaunchKernelGGL(pipeline2_multi_kernel, dim3(nstreams * (kV2Roles + worker_blocks)), dim3(512), 0, st, (const Stream2Args *)dev_pack,
                        kV2Roles + worker_blocks);
 }
 
