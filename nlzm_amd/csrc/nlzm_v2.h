@@ -296,6 +296,29 @@ struct Finder {
             if ((r0 >> g.wbits) == tag3 && s1 < q && q - s1 <= g.wmask) cd[1] = q - s1;
             if ((r1 >> g.wbits) == tag3 && s2 < q && q - s2 <= g.wmask) cd[2] = q - s2;
         }
+        // RK256's probe (:1090-1098): a slot whose tag fits gives a candidate; most are tag collisions that differ within
+        // a few bytes, which the lane tells itself (below) -- only what survives 16 bytes is measured by the whole wave
+        const bool rk_act = rk_len > 0 && q - rk_to < rk_len;       // the carried match still covers this position (:1056-1069)
+        const uint32_t rk_eff = rk_act ? rk_len : 0u;
+        const bool rk_probe = rk_call && rk_eff < 256;              // :1090
+        bool rk_cand = false;
+        uint32_t rk_d = 0;
+        if (rk_probe) {
+            const uint32_t sp = rkv & g.wmask;
+            if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) { rk_cand = true; rk_d = q - sp; }
+        }
+        uint32_t rk_l16 = 16;
+        if (rk_cand) {
+            const unsigned long long x0 = load64u(cur - rk_d) ^ own0;
+            if (x0) rk_l16 = (uint32_t)__builtin_ctzll(x0) >> 3;
+            else {
+                const unsigned long long x1 = load64u(cur - rk_d + 8) ^ own1;
+                rk_l16 = x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
+            }
+        }
+        // a mismatch inside the 16 bytes and inside the (uint16) length cap: the length is final; not taken (:1099): no event
+        const bool rk_short = rk_cand && rk_l16 < 16 && rk_l16 < (avail & 0xFFFFu);
+        const bool rk_dropped = rk_short && !(rk_l16 >= rk_eff && rk_l16 >= match_min(rk_d));
         uint32_t cl[3] = { 0, 0, 0 };
         L->njobs = 0;
         xw::wave_sync();
@@ -372,13 +395,10 @@ struct Finder {
         }
 
         // ---- RK256 (:1055-1113)
-        const bool rk_act = rk_len > 0 && q - rk_to < rk_len;       // the carried match still covers this position (:1056-1069)
         if (rk_call && rk_act) {
             const uint32_t d = rk_to - rk_from, l = rk_len - (q - rk_to);
             if (l >= match_min(d)) add_pair(d, umin(l, kMatchMax));
         }
-        const uint32_t rk_eff = rk_act ? rk_len : 0u;
-        const bool rk_probe = rk_call && rk_eff < 256;              // :1090
         // an aligned insert (:1109-1112) of an earlier lane rewrites the slot this lane read: cut there
         uint32_t cut_slot = 64;
         {
@@ -390,16 +410,11 @@ struct Finder {
                 if (hit) cut_slot = umin(cut_slot, (uint32_t)__builtin_ctzll(hit));
             }
         }
-        bool rk_cand = false;
-        uint32_t rk_d = 0;
-        if (rk_probe) {
-            const uint32_t sp = rkv & g.wmask;
-            if ((rkv >> g.wbits) == (rkh & g.tag_mask) && sp < q && q - sp <= g.wmask) { rk_cand = true; rk_d = q - sp; }
-        }
+        if (rk_dropped) cmpb += rk_l16 + 1;                             // (the bytes the reference's compare looked at)
         uint32_t cut_ev = 64, ev_d = 0, ev_l = 0;
         bool ev_ok = false;
-        {   // the first candidate is measured by the whole wave (up to 65,535 bytes: uint16 parameter, :760, :1096)
-            const unsigned long long evm = xw::ballot(rk_cand);
+        {   // the first candidate that is left is measured by the whole wave (up to 65,535 bytes: uint16 parameter, :760, :1096)
+            const unsigned long long evm = xw::ballot(rk_cand && !rk_dropped);
             if (evm) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(evm);
                 const uint32_t kd = xw::readlane(rk_d, k), kav = xw::readlane(avail, k) & 0xFFFFu, keff = xw::readlane(rk_eff, k);
@@ -1031,6 +1046,7 @@ constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
+constexpr uint32_t kGatherNodes = 32, kGatherRounds = 3;   // a block waits this many loader steps for this many records before it runs shorter
 constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave (4 x 64 words = 15 records a step)
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
@@ -1469,7 +1485,18 @@ struct Parser {
                 const uint32_t a_first = seg_a + b0;
                 if (!stage_need(a_first)) err = kErrInternal + 100;
                 uint32_t nb = umin(64u, max_parse - b0);
-                const uint32_t sh_hi = staged_hi();
+                uint32_t sh_hi = staged_hi();
+                if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) < 0) {
+                    // A block costs about the same whatever its size: when this stage has caught up with the table stage, it
+                    // gives it a moment (bounded: the finder may be waiting for this stage's word) rather than run on a few nodes
+                    const unsigned long long tg = xw::tick();
+                    for (uint32_t round = 0; round < kGatherRounds; round++) {      // (a step waits for the loads of the one before)
+                        pump(a_first);
+                        sh_hi = staged_hi();
+                        if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) >= 0) break;
+                    }
+                    acc(kAccWait, xw::tick() - tg);
+                }
                 if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
 #ifdef NLZM_SIM
                 {   // (simulation: blocks cut at random, as they are on the GPU when this stage catches up with the table stage)
