@@ -461,8 +461,8 @@ int refresh_stats(Ctx &C)
     if (getenv("NLZM_WAIT_PRINT")) {
         // per-stage accounting of the three-stage pipeline (Persist::prof, filled by nlzm_v2.h)
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
-        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (block set-up %.0f, passes %.0f, emit %.0f)\n",
-                P.prof[17] / n, P.prof[16] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[24] / n, P.prof[22] / n);
+        fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f (%.0f of it for worker results) | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (block set-up %.0f, passes %.0f, emit %.0f)\n",
+                P.prof[17] / n, P.prof[16] / n, P.prof[25] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[24] / n, P.prof[22] / n);
         fprintf(stderr, "finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
                 P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",

@@ -151,7 +151,7 @@ struct Finder {
     uint32_t t_pos_seen;
     uint32_t err;
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
-    unsigned long long t_wait, t_total;
+    unsigned long long t_wait, t_wait_bt = 0, t_total;
 
     XW_FN void fail(uint32_t code, uint32_t info)
     {
@@ -474,7 +474,7 @@ struct Finder {
                 }
                 xw::pause();
             }
-            t_wait += xw::tick() - tw;
+            t_wait += xw::tick() - tw; t_wait_bt += xw::tick() - tw;
         }
 
 #ifdef NLZM_SIM
@@ -628,7 +628,7 @@ struct Finder {
             c.ht_rows += 3 * n_ht; c.rk_probes += n_rkp; c.rk_inserts += n_rki; c.cmp_bytes += n_cmp; c.shifts += shifts;
             P->prof[0] += n_blocks; P->prof[1] += n_cut0; P->prof[2] += n_cut1; P->prof[3] += n_cut2; P->prof[4] += n_cut3; P->prof[5] += n_cut4;
             P->prof[12] += n_cut5;
-            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start;
+            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start; P->prof[25] += t_wait_bt;
         }
     }
 };
