@@ -1071,6 +1071,7 @@ struct PLds {
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t ncmds;
     unsigned long long acc[9];                  // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
+    unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
     uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
                                                 //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
@@ -1086,6 +1087,7 @@ struct Parser {
     uint32_t base;                  // absolute offset of rebased 0
     uint32_t rep0, rep1, rep2, rep3;   // live model rep set
     uint32_t t_out_seen;
+    uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
     // wave kPW-1: the loader of the record stage (8-byte words counted from the launch's first position)
     uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
@@ -1096,7 +1098,8 @@ struct Parser {
     unsigned long long q_lo, q_hi;
     uint32_t err;
     uint32_t n_eq_fill, n_eq_rounds;            // (per launch)
-    unsigned long long n_cmp, t_s[7] = {}, t_q[5] = {};
+    uint32_t n_cmp;                             // (per lane and launch: well below 2^32)
+    unsigned long long t_s[7] = {}, t_q[5] = {};
     // the stage's accounting lives in LDS (L()->acc: it is touched once a block or less, and scalar registers are short)
     enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccN };
     XW_FN void acc(uint32_t k, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(&L()->acc[k], v); }
@@ -1125,9 +1128,8 @@ struct Parser {
     }
     // per-model price tables of the match edges, rebuilt (by every thread of the stage) after an emit touched a length or
     // distance context.  Ends with a workgroup barrier either way.
-    XW_FN void seg_tables()
+    XW_FN void seg_tables(bool dirty)
     {
-        const uint32_t dirty = L()->sh[5];
         if (dirty) {
             for (uint32_t lv = xw::thread(); lv <= kMatchMax; lv += kParserThreads) L()->len_price[lv] = (uint16_t)price_len(lv);
             for (uint32_t k = xw::thread(); k < 4 * 64; k += kParserThreads) {
@@ -1409,12 +1411,15 @@ struct Parser {
     XW_FN uint32_t parse_segment(uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
     {
         const uint32_t chunk_left = max_parse;                      // positions from seg_a to the end of the chunk
+        nsegs = 1;
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
-        if (tid == 0) L()->sh[5] = tab_dirty ? 1u : 0u;
-        xw::block_sync();
-        seg_tables();
+        if (w == kPW - 1) {                                         // (meanwhile: the first node's record, staged)
+            if (!stage_need(seg_a)) err = kErrInternal + 100;
+            if (i == 0) L()->sh[4] = err;
+        }
+        seg_tables(tab_dirty);                                      // (tab_dirty is the same in every wave: run_chunk, run)
         tab_dirty = false;
         const uint32_t pc_dict = price(kCtxCmd, 1), pc_rep = price(kCtxCmd, 2), pc_lit = price(kCtxCmd, 0);
         // node 0 (:1472-1482)
@@ -1426,43 +1431,49 @@ struct Parser {
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
-        if (w == kPW - 1) {
-            if (!stage_need(seg_a)) err = kErrInternal + 100;
-            if (i == 0) L()->sh[4] = err;
-        }
-        xw::block_sync();
         if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
         {
             // A position without any match is a segment of its own (more than half of all segments are): its node has no
             // sampled edge, and if none of the four rep probes finds anything (:1598-1628) the only command is the literal.
-            const uint32_t h0 = xw::readfirst((uint32_t)staged(seg_a)[0]);
-            if ((h0 & 63u) == 0) {
-                bool ok = false;
-                unsigned long long counted = 0;
+            // Literals leave the rep set alone and prices do not matter here, so a RUN of such positions is found at once
+            // (lanes = the positions from seg_a on; about half of these segments follow another one directly).
+            const uint32_t sh_hi = staged_hi();
+            const uint32_t kmax = umin(64u, umin(sh_hi - seg_a, chunk_left));
+            const uint32_t hj = i < kmax ? (uint32_t)staged(seg_a + i)[0] : 1u;
+            const unsigned long long withm = xw::ballot((hj & 63u) != 0);        // (lanes >= kmax count as having a match)
+            const uint32_t p0 = withm ? (uint32_t)__builtin_ctzll(withm) : 64u;    // the leading positions without any match
+            if (p0) {
+                uint32_t counted = 0;
                 if (w < 4) {
                     const uint32_t m0 = xw::opaque(rep0), m1 = xw::opaque(rep1), m2 = xw::opaque(rep2), m3 = xw::opaque(rep3);
                     const uint32_t r = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
-                    const uint32_t pcap = umin(max_parse, kMatchMax);
-                    const bool want = i == 0 && r < seg_q;                                          // :1601
-                    const uint32_t l = xw::any(want) ? probe_len(want, seg_a, r, pcap) : 0u;
+                    const uint32_t pcap = umin(umin(chunk_left - umin(i, chunk_left - 1), kParseMax), kMatchMax);
+                    const bool want = i < p0 && r < seg_q + i;                                      // :1601
+                    const uint32_t l = xw::any(want) ? probe_len(want, seg_a + i, r, pcap) : 0u;
                     if (want) { counted = l + (l < pcap); n_cmp += counted; }
-                    ok = xw::any(want && l >= match_min(r));
-                    if (i == 0) L()->sh[12 + w] = ok ? 1u : 0u;
+                    const unsigned long long okm = xw::ballot(want && l >= match_min(r));
+                    if (i == 0) L()->fpm[w] = okm;
                 }
                 xw::block_sync();
-                const bool any_ok = (L()->sh[12] | L()->sh[13] | L()->sh[14] | L()->sh[15]) != 0;
+                const unsigned long long hit = L()->fpm[0] | L()->fpm[1] | L()->fpm[2] | L()->fpm[3];
+                const uint32_t run = hit ? umin(p0, (uint32_t)__builtin_ctzll(hit)) : p0;           // positions that are segments of one literal
                 xw::block_sync();
-                if (!any_ok) {
+                if (i >= run) n_cmp -= counted;     // (not part of the run: their probes are made, and counted, when their segment is parsed)
+                if (run) {
+                    if (w == 0 && i < run) {
+                        L()->node_link[i + 1] = 0; L()->node_delta[i + 1] = (hj >> 8) & 0xFFu;       // literal: from the node before, the byte
+                        L()->cmdlist()[run - 1 - i] = (uint16_t)(i + 1);
+                    }
                     if (tid == 0) {
-                        L()->node_link[1] = 0; L()->node_delta[1] = (h0 >> 8) & 0xFFu;           // literal: from node 0, the byte
-                        L()->cmdlist()[0] = 1; L()->ncmds = 1;
+                        L()->ncmds = run;
                         xw::st_agent(&V.hx->p_pos, seg_a);
+                        if (run > 1) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)(seg_a + run - 1) << 32) | (seg_a + run));
                     }
                     xw::block_sync();
-                    ncmds = 1;
-                    return 1;
+                    ncmds = run;
+                    nsegs = run;
+                    return run;
                 }
-                n_cmp -= counted;       // (a probe matched: the block counts the probes' bytes itself)
             }
         }
         while (!seg_len) {
@@ -1769,13 +1780,15 @@ struct Parser {
     XW_FN void run_chunk(uint32_t ci)
     {
         const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
-        const unsigned long long remain = g.n - chunk_abs;
-        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
-        const uint32_t p_end = umin(g.chunk_size, chunk_read);
+        // (positions are 32-bit: stream_begin refuses inputs of 0xFFFF0000 bytes and more; the feed is longer than a chunk)
+        const uint32_t p_end = umin(g.chunk_size, (uint32_t)g.n - (uint32_t)chunk_abs);
         fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
         fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
         nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0; q_lo = q_hi = 0;
-        if (chunk_abs - base >= 2ull * (g.wmask + 1)) base += g.wmask + 1;      // :1786
+        {   // (the window's size made opaque here: or twice it is kept in two registers, and spilled, for the whole launch)
+            const unsigned long long wsize = (unsigned long long)xw::opaque(g.wmask) + 1;
+            if (chunk_abs - base >= 2 * wsize) base += (uint32_t)wsize;         // :1786
+        }
         unsigned long long n_lit = 0, n_dict = 0, n_rep = 0, n_seg = 0;
         uint32_t p = 0;
         while (p < p_end && !err) {
@@ -1783,7 +1796,7 @@ struct Parser {
             const uint32_t seg_a = (uint32_t)chunk_abs + p;
             const uint32_t len = parse_segment(seg_a, p_end - p, ncmds);
             if (err) break;
-            n_seg++;
+            n_seg += nsegs;
             if (xw::wave() == 0) {
                 const unsigned long long te = xw::tick();
                 for (uint32_t k0 = ncmds; k0 > 0;) {                            // :1809-1843
@@ -1869,15 +1882,16 @@ struct Parser {
         }
 #endif
         {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
-            for (uint32_t d = 32; d; d >>= 1) n_cmp += xw::shfl64(n_cmp, xw::lane() ^ d);      // (kept per lane)
+            unsigned long long n_cmp64 = n_cmp;
+            for (uint32_t d = 32; d; d >>= 1) n_cmp64 += xw::shfl64(n_cmp64, xw::lane() ^ d);      // (kept per lane)
             if (xw::lane() == 0) {
-                xw::lds_add64(&L()->cnt.cmp_bytes, n_cmp);
+                xw::lds_add64(&L()->cnt.cmp_bytes, n_cmp64);
                 xw::lds_add64(&L()->cnt.stale_ht, n_eq_fill); xw::lds_add64(&L()->cnt.stale_rk, n_eq_rounds);     // (counters the new stages do not use otherwise)
             }
         }
         xw::block_sync();
         if (xw::wave() == 0) {
-            for (uint32_t k = xw::lane(); k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];
+            for (uint32_t k = xw::opaque(xw::lane()); k < kNumCtx * kCdfStride; k += 64) P->cdf[k] = L()->cdf[k];    // (opaque: or the index is kept, and spilled, from the start of the launch)
             if (xw::lane() == 0) {
                 P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
                 P->next_chunk = ci;
