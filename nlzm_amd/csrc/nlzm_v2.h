@@ -1457,7 +1457,7 @@ struct Parser {
                 xw::block_sync();
                 const unsigned long long hit = L()->fpm[0] | L()->fpm[1] | L()->fpm[2] | L()->fpm[3];
                 const uint32_t run = hit ? umin(p0, (uint32_t)__builtin_ctzll(hit)) : p0;           // positions that are segments of one literal
-                xw::block_sync();
+                // (fpm is written again only after another barrier: the one below, or the first block's)
                 if (i >= run) n_cmp -= counted;     // (not part of the run: their probes are made, and counted, when their segment is parsed)
                 if (run) {
                     if (w == 0 && i < run) {
