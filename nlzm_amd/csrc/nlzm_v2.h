@@ -1070,7 +1070,7 @@ struct PLds {
     uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t ncmds;
-    unsigned long long acc[9];                  // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
+    unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
     uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
@@ -1101,7 +1101,7 @@ struct Parser {
     uint32_t n_cmp;                             // (per lane and launch: well below 2^32)
     unsigned long long t_s[7] = {}, t_q[5] = {};
     // the stage's accounting lives in LDS (L()->acc: it is touched once a block or less, and scalar registers are short)
-    enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccN };
+    enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccNeed, kAccAhead, kAccN };
     XW_FN void acc(uint32_t k, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(&L()->acc[k], v); }
     unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
@@ -1277,6 +1277,7 @@ struct Parser {
             if (!xw::readfirst(L()->stg[3])) xw::pause();
         }
         acc(kAccWait, xw::tick() - tw);
+        acc(kAccNeed, 1); acc(kAccAhead, t_out_seen - a);             // (how far the table stage was ahead when this stage had to wait for its loader)
         return ok;
     }
 
@@ -1895,7 +1896,7 @@ struct Parser {
             if (xw::lane() == 0) {
                 P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
                 P->next_chunk = ci;
-                P->prof[8] += L()->acc[kAccBlocks]; P->prof[13] += L()->acc[kAccPasses]; P->prof[14] += L()->acc[kAccUndo];
+                P->prof[8] += L()->acc[kAccBlocks]; P->prof[13] += L()->acc[kAccPasses]; P->prof[14] += L()->acc[kAccUndo]; P->prof[26] += L()->acc[kAccNeed]; P->prof[27] += L()->acc[kAccAhead];
                 P->prof[9] += L()->cnt.stale_ht; P->prof[10] += L()->cnt.stale_rk; P->prof[11] += L()->acc[kAccRedo];
                 L()->cnt.stale_ht = 0; L()->cnt.stale_rk = 0; L()->cnt.bt_slow = 0;
                 unsigned long long *dst = (unsigned long long *)&P->cnt;
