@@ -468,6 +468,7 @@ int refresh_stats(Ctx &C)
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
+        fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "parser: waited for its record loader %llu times, the table stage %.0f positions ahead on average then\n", P.prof[26], (double)P.prof[27] / (double)(P.prof[26] ? P.prof[26] : 1));
         if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position, profile build): gather %.0f, scan %.0f, emit %.0f\n", P.prof[44] / n, P.prof[45] / n, P.prof[46] / n);
         if (P.prof[32]) {

@@ -152,6 +152,7 @@ struct Finder {
     uint32_t err;
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long t_wait, t_wait_bt = 0, t_total;
+    uint32_t n_late_unc = 0, n_late_other = 0;
 
     XW_FN void fail(uint32_t code, uint32_t info)
     {
@@ -453,6 +454,11 @@ struct Finder {
             if (bt_wait) xw::need_bt(G.hook_user, a);
             for (;;) {
                 uint32_t w0 = bt_wait ? xw::ld_agent(G.bt_ready + bi * kBtRec) : kBtReady;
+                if (spins == 0) {       // (accounting: whose results are not there when the block asks first)
+                    const unsigned long long late = xw::ballot(!(w0 & kBtReady));
+                    n_late_unc += (uint32_t)__builtin_popcountll(late & xw::ballot(unc));
+                    n_late_other += (uint32_t)__builtin_popcountll(late & ~xw::ballot(unc));
+                }
                 if (!xw::any(!(w0 & kBtReady))) {
                     xw::after_poll();
                     if (bt_wait) {
@@ -628,7 +634,7 @@ struct Finder {
             c.ht_rows += 3 * n_ht; c.rk_probes += n_rkp; c.rk_inserts += n_rki; c.cmp_bytes += n_cmp; c.shifts += shifts;
             P->prof[0] += n_blocks; P->prof[1] += n_cut0; P->prof[2] += n_cut1; P->prof[3] += n_cut2; P->prof[4] += n_cut3; P->prof[5] += n_cut4;
             P->prof[12] += n_cut5;
-            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start; P->prof[25] += t_wait_bt;
+            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start; P->prof[25] += t_wait_bt; P->prof[28] += n_late_unc; P->prof[29] += n_late_other;
         }
     }
 };
