@@ -122,10 +122,11 @@ def test_large_window_properties(gpu):
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(oracle_py.compress(data, 28)).hexdigest()
 
 
-@pytest.mark.parametrize("nblocks,hb", [(4, 20), (8, 16), (16, 22)])
+@pytest.mark.parametrize("nblocks,hb", [(4, 20), (8, 16), (16, 22), (40, 18)])
 def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
     """Block mode on ONE GPU: every block's stream is compressed at the same time (one master CU + worker CUs each)
-    and equals what the oracle gives for that byte range alone (the reference: encode_file per block)."""
+    and equals what the oracle gives for that byte range alone (the reference: encode_file per block).  40 blocks: more than
+    the kernel-argument segment could carry (the launch arguments travel through device memory), two worker CUs each."""
     from nlzm_amd import shard
     data = corpus.mixed(1_500_000, corpus.SEED + 5)
     got = gpu.compress_blocks(data, nblocks, hb)
