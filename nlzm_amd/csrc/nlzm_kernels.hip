@@ -385,7 +385,11 @@ __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G,
 }
 __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::GlobalsV2 V, uint32_t c0, uint32_t c1)
 {
-    pipeline2_roles(g, G, V, c0, c1, blockIdx.x, gridDim.x - kV2Roles);
+    // blocks 0, 8, 16 are the three stages: workgroups go to the XCDs round-robin, so they share XCD 0 (and its L2)
+    const uint32_t b = blockIdx.x;
+    const uint32_t before = b ? (b + 7) / 8 < kV2Roles ? (b + 7) / 8 : kV2Roles : 0u;     // stage blocks below b
+    const uint32_t local = (b % 8 == 0 && b / 8 < kV2Roles && gridDim.x > 16) ? b / 8 : (gridDim.x > 16 ? kV2Roles + (b - before) : b);
+    pipeline2_roles(g, G, V, c0, c1, local, gridDim.x - kV2Roles);
 }
 struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; };
 constexpr uint32_t kMaxStreams2PerLaunch = 64;          // (the pack lives in device memory: the kernel-argument segment holds 4 KB)
