@@ -134,11 +134,13 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
 /* The reference has no block mode: k blocks = k runs of encode_file (NLZM.cpp:1711) on the byte ranges
  * [i*ceil(n/k), min(n, (i+1)*ceil(n/k))), each with its own header, window, model and terminator; the streams are
  * self-delimiting (frame headers carry sizes, :645-663; terminator :646-648) and are written back to back in block
- * order.  On one GPU all k streams (k <= 64) are in flight at once, in one persistent launch per round: a stream
- * needs three CUs for the stages of its serial half and at least one CU of BT4 worker lanes (the CUs left are divided among
- * the streams); an MI355X does best with 32 to 40.  d_src needs 128 readable bytes behind it (the host-buffer entry points allocate 512).
+ * order.  On one GPU all k streams are in flight at once, in one persistent launch per round: a stream needs three CUs for
+ * the stages of its serial half and at least one CU of BT4 worker lanes, so k <= CUs / 4 (64 on an MI355X; the CUs left
+ * are divided among the streams); an MI355X does best with 32 to 40.  d_src needs 128 readable bytes behind it (the host-buffer entry points allocate 512).
  * begin binds the input and allocates every stream's state, each step advances every stream by max_chunks chunks
- * (0: to its end), finish appends the terminators and concatenates into d_dst. */
+ * (0: to its end), finish appends the terminators and concatenates into d_dst.  A begin or step that fails has closed
+ * the set (every stream's buffers freed, nothing left queued that reads d_src): there is nothing to abandon then;
+ * nlzm_hip_blocks_abandon() drops a set the caller does not want to finish. */
 int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req);
 int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms);
 int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);

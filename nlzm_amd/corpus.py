@@ -222,7 +222,45 @@ def chains(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
-_GENS = {"syn_text": syn_text, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def cutnice(size: int, seed: int = SEED) -> np.ndarray:
+    """A nice region (carried match >= 64, NLZM.cpp:1514) that starts exactly where a segment is cut at 4,096 positions
+    (:1469), one position before it, one after it, ...
+
+    Each unit: 300 fresh bytes `src`; a pool of 40-byte pieces of a random string b taken every 30 bytes (so inside b every
+    position lies in some short match and the segment that starts with b cannot end); b itself, 4,095 + off bytes long,
+    followed directly by a copy of `src`: the first match of 65 bytes or more is found at b's position 4,095 + off, i.e.
+    the nice region starts at the segment's position 4,096 + off.  With off = 0 no edge of the segment spans its cut and
+    the next segment starts inside a region whose phase (:1529) depends on where it started."""
+    rng = np.random.default_rng(seed ^ 0xC07A1CE)
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    unit = 0
+    while pos < size:
+        nb = 4_095 + (0, -1, 1, 0, 2, 0, -2)[unit % 7]
+        src = rng.integers(0, 256, 300, dtype=np.uint8)
+        b = rng.integers(0, 256, nb, dtype=np.uint8)
+        bb = np.concatenate([b, src])
+        parts = [src, rng.integers(0, 256, 4, dtype=np.uint8)]
+        for k in range(0, nb, 30):
+            parts.append(bb[k:k + 40])
+            parts.append(rng.integers(0, 256, 3, dtype=np.uint8))
+        parts += [rng.integers(0, 256, 5, dtype=np.uint8), b, src, rng.integers(0, 256, 7, dtype=np.uint8)]
+        u = np.concatenate(parts)
+        k = min(u.size, size - pos)
+        out[pos:pos + k] = u[:k]
+        pos += k
+        unit += 1
+    return out
+
+
+def block_set(size: int, seed: int = SEED) -> np.ndarray:
+    """The input of bench.py's block-mode leg in small: 32 independent texts of size/32 bytes each (block i is
+    syn_text(size/32, seed + 100 + i), as there), back to back."""
+    per = size // 32
+    return np.concatenate([syn_text(per, seed + 100 + i) for i in range(32)])
+
+
+_GENS = {"syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

@@ -109,6 +109,7 @@ struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
     unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
     unsigned long long lead[6];                     // NLZM_LEAD_DIAG: calls by how far ahead of the master they ended
+    unsigned long long stuck_lanes, stuck_pos_inv;  // lanes that left while waiting for a decision (a launch that failed); ~(smallest such position)
 };
 
 // Everything the master needs from HBM.

@@ -47,7 +47,7 @@ using namespace nlzm;
 
 namespace {
 
-char g_err[512] = "";
+char g_err[2048] = "";
 std::mutex g_err_mu;            // block streams run on host threads
 int set_err(int code, const char *fmt, ...)
 {
@@ -378,14 +378,32 @@ int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
     HIPCHK(hipMemcpyAsync(&Pst, C.persist, sizeof Pst, hipMemcpyDeviceToHost, C.st));
     uint32_t aborted = 0;
     if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipMemcpyAsync(&C.hx_host, C.v2_hx, sizeof(v2::Hx), hipMemcpyDeviceToHost, C.st));
     HIPCHK(hipStreamSynchronize(C.st));
     HIPCHK(hipGetLastError());
     float rk_ms = 0, pre_ms = 0;
     HIPCHK(hipEventElapsedTime(&rk_ms, C.ev[7], C.ev[5]));
     HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
     C.tm.prep_ms += rk_ms + pre_ms; C.tm.prep_launches += C.workers ? 5 : 1; C.tm.total_ms += rk_ms + pre_ms;
-    if (Pst.error) return set_err(NLZM_HIP_E_KERNEL, "device error %u at chunk %u (info %u %u %u)", Pst.error, Pst.next_chunk,
-                                  Pst.error_info[0], Pst.error_info[1], Pst.error_info[2]);
+    if (Pst.error || C.hx_host.err) {
+        // the first error any stage raised, and where every stage was when it left (nlzm_v2.h: raise(), Hx::dbg)
+        const v2::Hx &h = C.hx_host;
+        WorkerCounters wc{};
+        if (C.workers) (void)hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost);
+        return set_err(NLZM_HIP_E_KERNEL,
+                       "device error %u in chunks [%u,%u) (parser stopped at chunk %u): raised by stage %u at wait site %u, position %u, saw %u %u | "
+                       "progress: finder %u, table in %u out %u, parser %u, segment %u covered to %u | "
+                       "finder: block at %u reach %u top entry %u d %u end %u prev_nice %u seg_s %u rk_len %u t_pos_seen %u err %u base %u | "
+                       "table: cursor %u turn %u carry_seq %u f_seen %u p_seen %u carry_n %u | "
+                       "parser: chunk %u segment %u block node %u max_parse %u staged to %u t_out_seen %u err %u | "
+                       "worker lanes left waiting %llu, first of them at position %u",
+                       Pst.error ? Pst.error : h.err, c0, c1, Pst.next_chunk, h.err_info[0], h.err_info[1], h.err_info[2], h.err_info[3], h.err_info[4],
+                       h.f_pos, h.t_pos, h.t_out, h.p_pos, (uint32_t)(h.p_seg >> 32), (uint32_t)h.p_seg,
+                       h.dbg[0][0], h.dbg[0][1], h.dbg[0][2], h.dbg[0][3], h.dbg[0][4], h.dbg[0][5], h.dbg[0][6], h.dbg[0][7], h.dbg[0][8], h.dbg[0][9], h.dbg[0][10],
+                       h.dbg[1][0], h.dbg[1][1], h.dbg[1][2], h.dbg[1][3], h.dbg[1][4], h.dbg[1][5],
+                       h.dbg[2][0], h.dbg[2][1], h.dbg[2][2], h.dbg[2][3], h.dbg[2][4], h.dbg[2][5], h.dbg[2][6],
+                       wc.stuck_lanes, wc.stuck_lanes ? (uint32_t)~(uint32_t)wc.stuck_pos_inv : 0u);
+    }
     if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
     if (Pst.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", Pst.next_chunk, c1);
     unsigned long long pos = C.out_pos;
@@ -839,9 +857,13 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     // every block is in flight at once: one master CU + its worker CUs per stream, all resident together
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, C.device));
-    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - (int64_t)pipeline2_role_blocks() - (nblocks > 1 ? 1 : 0);
+    // (a spare CU per stream while there is room for it; every workgroup of the launch has a CU of its own either way:
+    //  at most CUs / 4 streams -- three stage CUs and one worker CU each -- which is 64 on an MI355X)
+    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - (int64_t)pipeline2_role_blocks();
+    if (wb > 1 && nblocks > 1) wb--;
     if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;
-    if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs", nblocks, prop.multiProcessorCount);
+    if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs (at most %d)", nblocks, prop.multiProcessorCount,
+                               prop.multiProcessorCount / (int)(pipeline2_role_blocks() + 1));
     g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
     // Every stream holds its own tables and hand-off arrays: the pre-filter table (4 << t_bits bytes) and the per-launch
     // arrays (about 2.2 KB per position of a launch) are sized so that all streams fit the free memory.
@@ -878,22 +900,43 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
-    HIPCHK(hipHostMalloc(&g_pack_host, stream2_pack_size(), hipHostMallocDefault));
-    HIPCHK(hipMalloc(&g_pack_dev, stream2_pack_size()));
-    const uint32_t ngroups = (nblocks + stream2_pack_capacity() - 1) / stream2_pack_capacity();
-    for (uint32_t gi = 0; gi < ngroups; gi++) {
-        hipStream_t st; std::array<hipEvent_t, 2> ev;
-        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIPCHK(hipEventCreate(&ev[0])); HIPCHK(hipEventCreate(&ev[1]));
-        g_group_st.push_back(st); g_group_ev.push_back(ev);
-    }
-    return 0;
+    const int rc = [&]() -> int {
+        HIPCHK(hipHostMalloc(&g_pack_host, stream2_pack_size(), hipHostMallocDefault));
+        HIPCHK(hipMalloc(&g_pack_dev, stream2_pack_size()));
+        const uint32_t ngroups = (nblocks + stream2_pack_capacity() - 1) / stream2_pack_capacity();
+        for (uint32_t gi = 0; gi < ngroups; gi++) {
+            hipStream_t st; std::array<hipEvent_t, 2> ev;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            HIPCHK(hipEventCreate(&ev[0])); HIPCHK(hipEventCreate(&ev[1]));
+            g_group_st.push_back(st); g_group_ev.push_back(ev);
+        }
+        return 0;
+    }();
+    if (rc) blocks_close();         // (nothing of a block set that failed to open stays allocated)
+    return rc;
 }
 
+static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms);
 int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms)
 {
-    Ctx &C = g_ctx;
     if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
+    const int rc = blocks_step_impl(max_chunks_per_block, in_done_total, finished, device_ms);
+    if (rc) {
+        // A failed round ends the block set: wait for whatever is still queued (every device wait is bounded), then free
+        // every stream's buffers -- the caller's source buffer is not read after this returns.
+        char keep[sizeof g_err];
+        { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(keep, g_err, sizeof keep); }
+        for (auto &st : g_group_st) (void)hipStreamSynchronize(st);
+        for (auto &j : g_jobs) if (j.c.st) (void)hipStreamSynchronize(j.c.st);
+        (void)hipGetLastError();
+        blocks_close();
+        { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, keep, sizeof keep); }
+    }
+    return rc;
+}
+static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms)
+{
+    Ctx &C = g_ctx;
     const size_t nj = g_jobs.size();
     hipEvent_t e0 = C.ev[5], e1 = C.ev[6];
     HIPCHK(hipEventRecord(e0, C.st));
@@ -929,7 +972,19 @@ int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total,
             HIPCHK(hipEventRecord(g_group_ev[gi][1], gs));
             for (uint32_t k = lo; k < hi; k++) HIPCHK(hipStreamWaitEvent(g_jobs[act[k]].c.st, g_group_ev[gi][1], 0));
         }
-        for (uint32_t i : act) { const int rc = step_post(g_jobs[i].c, plan[i], 0.0f); if (rc) return rc; }
+        {   // (every stream of the round is looked at, so that the first failure is reported with its own diagnostics)
+            int first_rc = 0;
+            char first_msg[sizeof g_err] = "";
+            for (uint32_t i : act) {
+                const int rc = step_post(g_jobs[i].c, plan[i], 0.0f);
+                if (rc && !first_rc) {
+                    first_rc = rc;
+                    std::lock_guard<std::mutex> lk(g_err_mu);
+                    snprintf(first_msg, sizeof first_msg, "block %u: %.*s", i, (int)sizeof first_msg - 32, g_err);
+                }
+            }
+            if (first_rc) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, first_msg, sizeof g_err); return first_rc; }
+        }
         for (uint32_t gi = 0; gi < ngroups; gi++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, g_group_ev[gi][0], g_group_ev[gi][1]));
@@ -992,7 +1047,7 @@ int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks
     const auto t1 = std::chrono::steady_clock::now();
     double dev_ms = 0;
     rc = nlzm_hip_blocks_step(0, nullptr, nullptr, &dev_ms);
-    if (rc) { blocks_close(); return rc; }
+    if (rc) return rc;              // (the failed step has closed the set)
     const auto t2 = std::chrono::steady_clock::now();
     rc = nlzm_hip_blocks_finish(d_dst, dst_cap, block_len, dst_len);
     if (getenv("NLZM_WAIT_PRINT")) {

@@ -350,6 +350,10 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
         }
         if (!__any(active && !waiting)) __builtin_amdgcn_s_sleep(8);
     }
+    if (stage == 1) {       // left while waiting for a decision: the launch failed; say where (error report)
+        atomicAdd(&G.wcnt->stuck_lanes, 1ull);
+        atomicMax(&G.wcnt->stuck_pos_inv, (unsigned long long)(uint32_t)~a);
+    }
     // counters: one atomic per wave
     for (int m = 32; m >= 1; m >>= 1) {
         n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);

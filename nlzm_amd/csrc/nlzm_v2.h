@@ -51,9 +51,11 @@ struct Hx {                                     // progress words, one 128-byte 
     alignas(128) uint32_t t_out;                // table: parser records of positions < t_out are written
     alignas(128) uint32_t p_pos;                // parser: records of positions < p_pos are consumed
     alignas(128) unsigned long long p_seg;      // parser: segment start << 32 | positions below this lie in that segment
-    alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves
-    alignas(128) uint32_t pad;
+    alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves (the FIRST code stays: raise())
+    uint32_t err_info[7];                       // of the stage that raised it: stage (11 finder, 12 table, 13 parser), wait site, position, what it saw
+    alignas(128) uint32_t dbg[4][32];           // per stage (0 finder, 1 table, 2 parser): where it was when it left because of an error
 };
+enum : uint32_t { kStFinder = 11, kStTable = 12, kStParser = 13 };
 
 struct GlobalsV2 {
     uint32_t *ft;                               // [kFtRing][kFtStride]
@@ -102,6 +104,15 @@ XW_FN uint32_t wave_cmp(const uint8_t *in, uint32_t s, uint32_t t, uint32_t init
     return cap;
 }
 
+// The first error of a launch is the one reported: later ones (stages that leave because another one failed) do not
+// overwrite it.  Called by ONE lane.
+XW_FN void raise(Hx *hx, uint32_t code, uint32_t stage, uint32_t site, uint32_t pos, uint32_t x0 = 0, uint32_t x1 = 0)
+{
+    if (xw::cas_agent(&hx->err, 0u, code) != 0u) return;
+    xw::st_agent(&hx->err_info[0], stage); xw::st_agent(&hx->err_info[1], site); xw::st_agent(&hx->err_info[2], pos);
+    xw::st_agent(&hx->err_info[3], x0); xw::st_agent(&hx->err_info[4], x1);
+}
+
 // bounded wait for a progress word to reach v; false: another stage failed or the wait timed out (err set)
 XW_FN bool wait_word_ge(const uint32_t *w, uint32_t v, Hx *hx, uint32_t code)
 {
@@ -114,7 +125,7 @@ XW_FN bool wait_word_ge(const uint32_t *w, uint32_t v, Hx *hx, uint32_t code)
             if (xw::readfirst(xw::ld_agent(&hx->err))) return false;
 #ifndef NLZM_SIM
             if (xw::clock100() - t0 > 3000000000ull) {            // 30 s
-                if (xw::lane() == 0) xw::st_agent(&hx->err, kErrTimeout * 100 + code);
+                if (xw::lane() == 0) raise(hx, kErrTimeout * 100 + code, code == 1 ? kStFinder : (code <= 3 ? kStTable : kStParser), code, v, xw::ld_agent(w));
                 return false;
             }
 #else
@@ -150,17 +161,15 @@ struct Finder {
     uint32_t prev_nice, seg_s;
     uint32_t t_pos_seen;
     uint32_t err;
+    uint32_t dbg_a = 0;         // start of the block being evaluated (error dump)
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long t_wait, t_wait_bt = 0, t_total;
     uint32_t n_late_unc = 0, n_late_other = 0;
 
-    XW_FN void fail(uint32_t code, uint32_t info)
+    XW_FN void fail(uint32_t code, uint32_t pos, uint32_t site = 0, uint32_t x0 = 0, uint32_t x1 = 0)
     {
         err = code;
-        if (xw::lane() == 0) {
-            G.persist->error = code; G.persist->error_info[0] = info; G.persist->error_info[1] = 11;
-            xw::st_agent(&V.hx->err, code);
-        }
+        if (xw::lane() == 0) raise(V.hx, code, kStFinder, site, pos, x0, x1);
     }
 
     // The growing top entry (distance s_d): find where it stops matching, as far as `limit` (:1507-1509).
@@ -213,15 +222,13 @@ struct Finder {
                     if ((int32_t)((uint32_t)ps - (a0 + 1)) >= 0) {
                         xw::after_poll();
                         seg_s = (uint32_t)(ps >> 32);
-#ifdef NLZM_SIM
-                        if (i == 0 && getenv("NLZM_SIM_TRACE_SEG")) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a0, seg_s, (uint32_t)ps);
-#endif
+                        xw::trace(1, a0, seg_s, (uint32_t)ps);
                         break;
                     }
                     if ((++spins & 63u) == 0) {
                         if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
 #ifndef NLZM_SIM
-                        if (xw::clock100() - t0 > 3000000000ull) { fail(kErrTimeout, a0); return 1; }
+                        if (xw::clock100() - t0 > 3000000000ull) { fail(kErrTimeout, a0, 5, (uint32_t)ps, (uint32_t)(ps >> 32)); return 1; }
 #else
                         (void)t0;
 #endif
@@ -473,7 +480,14 @@ struct Finder {
                 if ((++spins & 63u) == 0) {
                     if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
 #ifndef NLZM_SIM
-                    if (xw::clock100() - t0 > 3000000000ull) { fail(kErrTimeout, a0); return 1; }
+                    if (xw::clock100() - t0 > 3000000000ull) {
+                        // (which positions are missing, and whether the first of them is one whose call this stage decides)
+                        const unsigned long long late = xw::ballot(!(w0 & kBtReady));
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(late | (1ull << 63));
+                        fail(kErrTimeout, a0 + fl, 6, (uint32_t)__builtin_popcountll(late) | (xw::readlane(unc ? 1u : 0u, fl) << 8) | (n << 16),
+                             xw::readlane((hash4(v4) >> g.bt_shift) % G.nheads, fl));
+                        return 1;
+                    }
 #else
                     (void)t0;
 #endif
@@ -483,12 +497,6 @@ struct Finder {
             t_wait += xw::tick() - tw; t_wait_bt += xw::tick() - tw;
         }
 
-#ifdef NLZM_SIM
-        if (getenv("NLZM_SIM_DEBUG_POS") && in_blk && a == (uint32_t)atoi(getenv("NLZM_SIM_DEBUG_POS")))
-            fprintf(stderr, "dbg pos %u q %u base %u: ct full %d some %d ht %d rk %d | cd %u %u %u cl %u %u %u | rkh %08x rkv %08x rk_cand %d rk_d %u rk_eff %u rk_len %u rk_to %u rk_end %u | bt_n %u ec %u od %u np %u cap %u\n",
-                    a, q, base, (int)call_full, (int)call_some, (int)ht_call, (int)rk_call, cd[0], cd[1], cd[2], cl[0], cl[1], cl[2], rkh, rkv,
-                    (int)rk_cand, rk_d, rk_eff, rk_len, rk_to, rk_end, bt_n, ec, od, np, cap);
-#endif
         // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
         const uint32_t pm = xw::scan_max(in_blk ? ec : 0u);                     // inclusive prefix max of the closed ends
         uint32_t before = umax(xw::lane_below(pm, 0u), reach);
@@ -502,7 +510,7 @@ struct Finder {
         const unsigned long long om = xw::ballot(in_blk && od != kNone && (!s_here || od < s_d));
         const uint32_t jo = om ? (uint32_t)__builtin_ctzll(om) : 64u;
         uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
-        if (m == 0) { fail(kErrInternal, a0); return 1; }
+        if (m == 0) { fail(kErrInternal, a0, 7); return 1; }
         n_blocks++;
         if (m < n) {        // (why the block was cut; diagnostics)
             // (adds, not a chain of branches: the compiler turns the chain into ONE indexed access and the stage's state goes to scratch)
@@ -512,7 +520,7 @@ struct Finder {
         const bool fin = i < m;
 
         // a position that the pre-filter promised to be a BT4 position must not be nice
-        if (xw::any(fin && nice_real && !unc && avail >= 4 && G.workers)) { fail(kErrV2Promise, a0); return 1; }
+        if (xw::any(fin && nice_real && !unc && avail >= 4 && G.workers)) { fail(kErrV2Promise, a0, 8); return 1; }
 
         // ---- commit
         // HT rows in position order (the last writer of a row wins)
@@ -566,9 +574,7 @@ struct Finder {
             n_cmp += xw::readfirst(c);
         }
         if (i == 0) xw::st_agent(&V.hx->f_pos, a0 + m);
-#ifdef NLZM_SIM
-        if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "F block a0 %u n %u m %u reach %u slider %u d %u end %u\n", a0, n, m, reach, s_active, s_d, s_end);
-#endif
+        xw::trace(2, a0, n, m, reach, s_active, s_d, s_end);
         return m;
     }
 
@@ -611,6 +617,7 @@ struct Finder {
             uint32_t a = (uint32_t)chunk_abs;
             while (a < a1 && !err) {
                 const uint32_t n = umin(64u, a1 - a);
+                dbg_a = a;
                 // ring space: the table stage must have consumed position a + n - kFtRing
                 if ((int32_t)(a + n - t_pos_seen - kFtRing) > 0) {
                     const unsigned long long tw = xw::tick();
@@ -629,12 +636,25 @@ struct Finder {
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
             S->reach = reach; S->s_active = s_active; S->s_d = s_d; S->s_end = s_end; S->s_seen = s_seen;
             S->prev_nice = prev_nice; S->seg_s = seg_s;
+            // (every stage adds the counters it owns, with agent-scope atomics: the stages run on different CUs, in
+            //  block mode on different XCDs, and finish within microseconds of each other)
             Counters &c = P->cnt;
-            c.positions += n_pos; c.nice_positions += n_nice; c.uncertain_positions += n_unc;
-            c.ht_rows += 3 * n_ht; c.rk_probes += n_rkp; c.rk_inserts += n_rki; c.cmp_bytes += n_cmp; c.shifts += shifts;
-            P->prof[0] += n_blocks; P->prof[1] += n_cut0; P->prof[2] += n_cut1; P->prof[3] += n_cut2; P->prof[4] += n_cut3; P->prof[5] += n_cut4;
-            P->prof[12] += n_cut5;
-            P->prof[16] += t_wait; P->prof[17] += xw::tick() - t_start; P->prof[25] += t_wait_bt; P->prof[28] += n_late_unc; P->prof[29] += n_late_other;
+            xw::atomic_add64_agent(&c.positions, n_pos); xw::atomic_add64_agent(&c.nice_positions, n_nice);
+            xw::atomic_add64_agent(&c.uncertain_positions, n_unc); xw::atomic_add64_agent(&c.ht_rows, 3 * n_ht);
+            xw::atomic_add64_agent(&c.rk_probes, n_rkp); xw::atomic_add64_agent(&c.rk_inserts, n_rki);
+            xw::atomic_add64_agent(&c.cmp_bytes, n_cmp); xw::atomic_add64_agent(&c.shifts, shifts);
+            unsigned long long *pr = P->prof;
+            xw::atomic_add64_agent(&pr[0], n_blocks); xw::atomic_add64_agent(&pr[1], n_cut0); xw::atomic_add64_agent(&pr[2], n_cut1);
+            xw::atomic_add64_agent(&pr[3], n_cut2); xw::atomic_add64_agent(&pr[4], n_cut3); xw::atomic_add64_agent(&pr[5], n_cut4);
+            xw::atomic_add64_agent(&pr[12], n_cut5);
+            xw::atomic_add64_agent(&pr[16], t_wait); xw::atomic_add64_agent(&pr[17], xw::tick() - t_start); xw::atomic_add64_agent(&pr[25], t_wait_bt);
+            xw::atomic_add64_agent(&pr[28], n_late_unc); xw::atomic_add64_agent(&pr[29], n_late_other);
+            if (err || xw::ld_agent(&V.hx->err)) {                  // where this stage was when it left
+                uint32_t *d = V.hx->dbg[0];
+                xw::st_agent(d + 0, dbg_a); xw::st_agent(d + 1, reach); xw::st_agent(d + 2, s_active); xw::st_agent(d + 3, s_d);
+                xw::st_agent(d + 4, s_end); xw::st_agent(d + 5, prev_nice); xw::st_agent(d + 6, seg_s); xw::st_agent(d + 7, rk_len);
+                xw::st_agent(d + 8, t_pos_seen); xw::st_agent(d + 9, err); xw::st_agent(d + 10, base);
+            }
         }
     }
 };
@@ -973,18 +993,21 @@ struct Table {
             if (i == 0) { xw::lds_st(&L->cursor, a + n); xw::lds_st(&L->turn, seq + 1); }
             t_wait += xw::tick() - tw;
             block(a, n, a1, la_end, seq);
-#ifdef NLZM_SIM
-            if (i == 0 && getenv("NLZM_SIM_TRACE")) fprintf(stderr, "T block a %u n %u\n", a, n);
-#endif
+            xw::trace(3, a, n);
         }
-        if (err && i == 0) xw::st_agent(&V.hx->err, kErrInternal + 200);
+        if (err && i == 0) raise(V.hx, kErrInternal + 200, kStTable, 9, xw::lds_ld(&L->cursor));   // (only if no stage has raised anything: the first code stays)
         xw::block_sync();
+        if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {     // where this stage was when it left
+            uint32_t *d = V.hx->dbg[1];
+            xw::st_agent(d + 0, xw::lds_ld(&L->cursor)); xw::st_agent(d + 1, xw::lds_ld(&L->turn)); xw::st_agent(d + 2, xw::lds_ld(&L->carry_seq));
+            xw::st_agent(d + 3, f_seen); xw::st_agent(d + 4, p_seen); xw::st_agent(d + 5, L->carry_n);
+        }
         if (i == 0) {       // accounting: summed over the waves
             unsigned long long *pr = G.persist->prof;
             xw::atomic_add64_agent(&pr[6], n_blocks); xw::atomic_add64_agent(&pr[7], n_slow);
             xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
             xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
-            if (w == 0) { pr[18] += t_wait; pr[19] += xw::tick() - t_start; }
+            if (w == 0) { xw::atomic_add64_agent(&pr[18], t_wait); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
         }
         if (w == 0) {
             const uint32_t on = xw::readfirst(L->carry_n);
@@ -1001,7 +1024,7 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
     const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
     const unsigned long long used = xw::readfirst64(*G.cap_used);
     const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
-    if (used + need > G.cap_cap) { err = kErrCapture; if (xw::lane() == 0) xw::st_agent(&V.hx->err, kErrCapture); return; }
+    if (used + need > G.cap_cap) { err = kErrCapture; if (xw::lane() == 0) raise(V.hx, kErrCapture, kStTable, 10, a); return; }
     if (xw::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
     for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) {
         uint32_t d = 0;
@@ -1076,6 +1099,7 @@ struct PLds {
     uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t ncmds;
+    uint32_t dbgw[4];                           // error dump: the segment being parsed, its block, the node count so far
     unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
     uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
@@ -1120,10 +1144,7 @@ struct Parser {
     XW_FN void fail(uint32_t code, uint32_t info)
     {
         err = code;
-        if (xw::thread() == 0) {
-            G.persist->error = code; G.persist->error_info[0] = info; G.persist->error_info[1] = 13;
-            xw::st_agent(&V.hx->err, code);
-        }
+        if (xw::thread() == 0) raise(V.hx, code, kStParser, 11, info);
     }
     XW_FN uint32_t price(uint32_t ctx, uint32_t y) const { return L()->price[ctx * 16 + y]; }
     XW_FN uint32_t price_len(uint32_t lv) const                     // :1214-1225
@@ -1273,7 +1294,7 @@ struct Parser {
                 if (xw::readfirst(xw::ld_agent(&V.hx->err))) { ok = false; break; }
 #ifndef NLZM_SIM
                 if (xw::clock100() - t0 > 3000000000ull) {            // 30 s
-                    if (xw::lane() == 0) xw::st_agent(&V.hx->err, kErrTimeout * 100 + 4);
+                    if (xw::lane() == 0) raise(V.hx, kErrTimeout * 100 + 4, kStParser, 4, a, staged_hi(), t_out_seen);
                     ok = false; break;
                 }
 #else
@@ -1422,6 +1443,10 @@ struct Parser {
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
+        // A segment starts at seg_a: said BEFORE this stage asks for the position's record.  The finder stage may be waiting
+        // for exactly this word at seg_a (a nice region that starts where the segment before was cut at 4,096 positions,
+        // :1469: no edge spans the cut, so nothing else tells it) and the record of seg_a comes only after it.
+        if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         if (w == kPW - 1) {                                         // (meanwhile: the first node's record, staged)
             if (!stage_need(seg_a)) err = kErrInternal + 100;
             if (i == 0) L()->sh[4] = err;
@@ -1431,10 +1456,10 @@ struct Parser {
         const uint32_t pc_dict = price(kCtxCmd, 1), pc_rep = price(kCtxCmd, 2), pc_lit = price(kCtxCmd, 0);
         // node 0 (:1472-1482)
         if (tid == 0) {
+            L()->dbgw[0] = seg_a; L()->dbgw[1] = 0; L()->dbgw[2] = max_parse;
             L()->mprev[0] = ((unsigned long long)kSrcNone << 8) | kRankLit;
             L()->mprev[1] = kKeyNone;
             L()->node_link[0] = kSrcNone;
-            xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
@@ -1516,14 +1541,9 @@ struct Parser {
                     acc(kAccWait, xw::tick() - tg);
                 }
                 if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
-#ifdef NLZM_SIM
-                {   // (simulation: blocks cut at random, as they are on the GPU when this stage catches up with the table stage)
-                    static const int rnd = getenv("NLZM_SIM_RANDOM_BLOCKS") ? atoi(getenv("NLZM_SIM_RANDOM_BLOCKS")) : 0;
-                    static uint32_t lcg = 12345;
-                    if (rnd) { lcg = lcg * 1664525u + 1013904223u; const uint32_t cut = 1 + (lcg >> 16) % (uint32_t)rnd; if (cut < nb) nb = cut; }
-                }
-#endif
-                if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; xw::st_agent(&V.hx->p_pos, a_first); }
+                nb = xw::test_cut(nb);                              // (identity on the device; the simulation cuts blocks at random here, as
+                                                                    //  the device does when this stage catches up with the table stage)
+                if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; xw::st_agent(&V.hx->p_pos, a_first); }
             }
             xw::block_sync();
             const unsigned long long q1 = ptick();
@@ -1882,10 +1902,13 @@ struct Parser {
         for (; ci < c1 && !err; ci++) run_chunk(ci);
         xw::block_sync();
 #ifdef NLZM_PROFILE
-        if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) P->prof[56 + z] += t_q[z];
+        if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) xw::atomic_add64_agent(&P->prof[56 + z], t_q[z]);
         if (xw::lane() == 0 && xw::wave() < 4) {   // per wave: relax + probe work of a pass, barrier wait, update; mask fills
-            P->prof[32 + xw::wave()] += t_work; P->prof[36 + xw::wave()] += t_bar;
-            if (xw::wave() == 0) { P->prof[40] += t_upd; P->prof[42] += t_fin; P->prof[41] += t_fill; for (int z = 0; z < 7; z++) { P->prof[48 + z] += t_s[z]; t_s[z] = 0; } }
+            xw::atomic_add64_agent(&P->prof[32 + xw::wave()], t_work); xw::atomic_add64_agent(&P->prof[36 + xw::wave()], t_bar);
+            if (xw::wave() == 0) {
+                xw::atomic_add64_agent(&P->prof[40], t_upd); xw::atomic_add64_agent(&P->prof[42], t_fin); xw::atomic_add64_agent(&P->prof[41], t_fill);
+                for (int z = 0; z < 7; z++) { xw::atomic_add64_agent(&P->prof[48 + z], t_s[z]); t_s[z] = 0; }
+            }
         }
 #endif
         {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
@@ -1902,15 +1925,23 @@ struct Parser {
             if (xw::lane() == 0) {
                 P->rep[0] = rep0; P->rep[1] = rep1; P->rep[2] = rep2; P->rep[3] = rep3;
                 P->next_chunk = ci;
-                P->prof[8] += L()->acc[kAccBlocks]; P->prof[13] += L()->acc[kAccPasses]; P->prof[14] += L()->acc[kAccUndo]; P->prof[26] += L()->acc[kAccNeed]; P->prof[27] += L()->acc[kAccAhead];
-                P->prof[9] += L()->cnt.stale_ht; P->prof[10] += L()->cnt.stale_rk; P->prof[11] += L()->acc[kAccRedo];
-                L()->cnt.stale_ht = 0; L()->cnt.stale_rk = 0; L()->cnt.bt_slow = 0;
-                unsigned long long *dst = (unsigned long long *)&P->cnt;
-                const unsigned long long *src = (const unsigned long long *)&L()->cnt;
-                for (uint32_t k = 0; k < sizeof(Counters) / 8; k++) dst[k] += src[k];
-                P->prof[20] += L()->acc[kAccWait]; P->prof[21] += L()->acc[kAccTotal] + xw::tick(); P->prof[22] += L()->acc[kAccEmit]; P->prof[23] += L()->acc[kAccSetup]; P->prof[24] += L()->acc[kAccPass];
+                // (this stage's counters only, agent-scope atomics: see the finder's)
+                unsigned long long *pr = P->prof;
+                auto add = [](unsigned long long *q, unsigned long long v) __attribute__((always_inline)) { xw::atomic_add64_agent(q, v); };
+                add(&pr[8], L()->acc[kAccBlocks]); add(&pr[13], L()->acc[kAccPasses]); add(&pr[14], L()->acc[kAccUndo]); add(&pr[26], L()->acc[kAccNeed]); add(&pr[27], L()->acc[kAccAhead]);
+                add(&pr[9], L()->cnt.stale_ht); add(&pr[10], L()->cnt.stale_rk); add(&pr[11], L()->acc[kAccRedo]);
+                Counters &c = P->cnt;
+                const Counters &lc = L()->cnt;
+                add(&c.n_literal, lc.n_literal); add(&c.n_dict, lc.n_dict); add(&c.n_rep, lc.n_rep); add(&c.segments, lc.segments);
+                add(&c.rans_syms, lc.rans_syms); add(&c.bit_ops, lc.bit_ops); add(&c.frames, lc.frames); add(&c.cmp_bytes, lc.cmp_bytes);
+                add(&pr[20], L()->acc[kAccWait]); add(&pr[21], L()->acc[kAccTotal] + xw::tick()); add(&pr[22], L()->acc[kAccEmit]); add(&pr[23], L()->acc[kAccSetup]); add(&pr[24], L()->acc[kAccPass]);
                 const uint32_t xe = xw::ld_agent(&V.hx->err);
-                if (xe && !P->error) P->error = xe;
+                if (xe) {                                           // (this stage is the only writer of the sticky error word)
+                    P->error = xe;
+                    uint32_t *d = V.hx->dbg[2];                     // where this stage was when it left
+                    xw::st_agent(d + 0, ci); xw::st_agent(d + 1, L()->dbgw[0]); xw::st_agent(d + 2, L()->dbgw[1]); xw::st_agent(d + 3, L()->dbgw[2]);
+                    xw::st_agent(d + 4, L()->stg[4]); xw::st_agent(d + 5, t_out_seen); xw::st_agent(d + 6, err);
+                }
                 if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
             }
         }

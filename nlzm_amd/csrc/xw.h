@@ -100,6 +100,12 @@ XW_FN void st_agent64(unsigned long long *p, unsigned long long v) { __hip_atomi
 XW_FN unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// *p = v if *p == expect; returns what was there
+XW_FN uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v)
+{
+    (void)__hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+}
 // after a poll saw the flag: later plain loads of this wave read what the producer stored (buffer_inv sc1)
 XW_FN void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // after a poll saw its word: nothing that follows in the program may be moved in front of the poll by the compiler (the
@@ -122,7 +128,9 @@ XW_FN uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_
 XW_FN uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 XW_FN unsigned long long clock100() { return wall_clock64(); }          // 100 MHz
 XW_FN unsigned long long tick() { return __builtin_readcyclecounter(); }
-XW_FN void need_bt(void *, uint32_t) {}                                 // (simulation hook: worker lanes run lazily there)
+XW_FN void need_bt(void *, uint32_t) {}                                 // (simulation hooks: worker lanes run lazily there;
+XW_FN void trace(int, uint32_t = 0, uint32_t = 0, uint32_t = 0, uint32_t = 0, uint32_t = 0, uint32_t = 0, uint32_t = 0) {}   //  stage traces;
+XW_FN uint32_t test_cut(uint32_t n) { return n; }                       //  parser blocks cut at random)
 template <class T> XW_FN T *lds();                                      // defined by the kernel file (one __shared__ image)
 
 }  // namespace xw
@@ -220,6 +228,7 @@ inline void st_agent64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline unsigned long long ld_agent64(const unsigned long long *p) { return *(volatile const unsigned long long *)p; }
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
+inline uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v) { const uint32_t o = *p; if (o == expect) *p = v; return o; }
 inline void acquire_agent() {}
 inline void after_poll() {}
 inline void lds_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
@@ -232,6 +241,8 @@ inline uint32_t opaque(uint32_t v) { return v; }
 inline unsigned long long clock100() { return sim().now; }
 inline unsigned long long tick() { return sim().now; }
 void need_bt(void *user, uint32_t a);                                   // defined by the simulator: run the worker lanes up to `a`
+void trace(int what, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0, uint32_t d = 0, uint32_t e = 0, uint32_t f = 0, uint32_t g = 0);   // NLZM_SIM_TRACE
+uint32_t test_cut(uint32_t n);                                          // NLZM_SIM_RANDOM_BLOCKS
 template <class T> inline T *lds() { return (T *)sim().cw->blk->lds; }
 
 // run `entry(arg)` on nblocks x nthreads lanes (block b gets lds_bytes[b] bytes of zeroed LDS); returns when every lane

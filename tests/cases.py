@@ -6,7 +6,9 @@ shrinks below the decoder's minimum), exactly chunk_size +-1, EOF inside the 265
 overlap, input > 2W (window rebases and the p >= W masking regime of HT/RK), long
 duplicated spans (RK carry, uint16 truncation), long runs (nice-length skip, BT4 early
 return), random bytes (expansion), segments that reach the forced cut at 4,096 positions or end
-just before it (the sampled lengths near the cut depend on the segment the position ends up in).
+just before it (the sampled lengths near the cut depend on the segment the position ends up in), a nice region that
+starts exactly at such a cut (round 2's block-mode stall: the finder stage waited for the parser's word on the segment,
+the parser for the finder's record of the segment's first position).
 """
 from __future__ import annotations
 
@@ -37,6 +39,7 @@ CASES = [
     ("random_100k_w15", "random", 100_000, 12, 15),
     ("text_2m_w15", "syn_text", 2_000_000, 13, 15),
     ("chains_150k_w17", "chains", 150_000, 14, 17),
+    ("cutnice_60k_w17", "cutnice", 60_000, 15, 17),
 ]
 
 # larger cases: checked on the GPU box against the oracle run live (and golden sha)
@@ -50,8 +53,11 @@ BIG_CASES = [
 # (oracle/make_golden_full.py):
 #   cfg 3  100,000,000 B at -window:26: no rebase, the last ~33 MB in the p >= W masking regime of HT/RK
 #   cfg 5  one 125,000,000-B block at -window:28: the header must read 27 (NLZM.cpp:1716-1718), every position < W
-#   cfg 4  1,000,000,000 B at -window:28: rebases near 537 MB and 805 MB (checked by bench.py --full, not by pytest)
+#   cfg 4  1,000,000,000 B at -window:28: rebases near 537 MB and 805 MB
+#   cfg 1  100,000,000 B at -window:24: five rebases with 128 KiB frames (NLZM.cpp:1786-1792), most of the file in the
+#          p >= W regime
 FULL_CASES = [
+    ("text_100m_w24", "syn_text", 100_000_000, 0, 24),
     ("text_100m_w26", "syn_text", 100_000_000, 0, 26),
     ("block_125m_w28", "syn_text", 125_000_000, 1, 28),
     ("text_1g_w28", "syn_text", 1_000_000_000, 0, 28),
@@ -61,3 +67,11 @@ FULL_CASES = [
 def make_case(case) -> np.ndarray:
     _, kind, size, seed_off, _ = case
     return corpus.make(kind, size, corpus.SEED + seed_off)
+
+
+# bench.py's block-mode leg in small (its geometry: 32 streams in flight, -window:28 -> 25, more than 130 chunks per block):
+# every block against the reference run on that block alone (tests/golden/blocks.json, oracle/make_golden_blocks.py)
+BLOCK_SET = ("blocks32_w28", "block_set", 32 * 17_000_000, 0, 28, 32)
+# the leg itself: the 1e9-byte stand-in of config 4 split into 32 blocks (tests/golden/blocks_1g.json; bench.py checks
+# every block's stream against it)
+BLOCK_SET_1G = ("blocks_1g_w28", "syn_text", 1_000_000_000, 0, 28, 32)

@@ -159,6 +159,25 @@ struct SimWorkers {
 };
 static SimWorkers *g_workers = nullptr;
 void xw::need_bt(void *, uint32_t a) { if (g_workers) g_workers->need(a); }
+// stage traces (NLZM_SIM_TRACE=1: blocks of the finder and table stage; NLZM_SIM_TRACE_SEG=1: the segment a nice region is in)
+void xw::trace(int what, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f, uint32_t g)
+{
+    static const bool all = getenv("NLZM_SIM_TRACE") != nullptr, seg = getenv("NLZM_SIM_TRACE_SEG") != nullptr;
+    if (xw::lane() != 0) return;
+    if (what == 1 && seg) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a, b, c);
+    if (what == 2 && all) fprintf(stderr, "F block a0 %u n %u m %u reach %u slider %u d %u end %u\n", a, b, c, d, e, f, g);
+    if (what == 3 && all) fprintf(stderr, "T block a %u n %u\n", a, b);
+}
+// NLZM_SIM_RANDOM_BLOCKS=k: the parser's blocks are cut to 1..k nodes at random
+uint32_t xw::test_cut(uint32_t nb)
+{
+    static const int rnd = getenv("NLZM_SIM_RANDOM_BLOCKS") ? atoi(getenv("NLZM_SIM_RANDOM_BLOCKS")) : 0;
+    static uint32_t lcg = 12345;
+    if (!rnd) return nb;
+    lcg = lcg * 1664525u + 1013904223u;
+    const uint32_t cut = 1 + (lcg >> 16) % (uint32_t)rnd;
+    return cut < nb ? cut : nb;
+}
 
 // ---- the oracle's match tables, kept to check the table stage position by position ------------------------------
 struct RefTables {
