@@ -80,7 +80,7 @@ struct Persist {
     uint32_t error;             // 0 ok; see kErr*
     uint32_t error_info[3];
     Counters cnt;
-    unsigned long long prof[64];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
+    unsigned long long prof[128];    // cycles per master phase (diagnostic builds: NLZM_PROFILE); 16..21: wait/total cycles per wave
 };
 
 constexpr uint32_t kErrFrameOverflow = 1;

@@ -495,6 +495,13 @@ int refresh_stats(Ctx &C)
                             "barrier waits per wave %.0f %.0f %.0f %.0f; block end %.0f cycles/position\n",
                     P.prof[32] / np, P.prof[33] / np, P.prof[34] / np, P.prof[35] / np, P.prof[43] / np, P.prof[41] / np, P.prof[40] / np,
                     P.prof[36] / np, P.prof[37] / np, P.prof[38] / np, P.prof[39] / np, P.prof[42] / n);
+            fprintf(stderr, "parser, cycles per pass by wave 0..7 (profile build): work");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[64 + w] / np);
+            fprintf(stderr, " | barrier wait");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[72 + w] / np);
+            fprintf(stderr, " | update");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[80 + w] / np);
+            fprintf(stderr, "\n");
             const double nbk = (double)(P.prof[8] ? P.prof[8] : 1);
             fprintf(stderr, "parser loader wave, cycles per block set-up: block size + barrier %.0f, re-list %.0f, own edges %.0f, all edges %.0f, literal scan + clear + barrier %.0f\n",
                     P.prof[56] / nbk, P.prof[57] / nbk, P.prof[58] / nbk, P.prof[59] / nbk, P.prof[60] / nbk);

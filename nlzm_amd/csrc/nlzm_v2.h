@@ -1076,7 +1076,8 @@ constexpr uint32_t kStagePos = 128;             // table records kept ahead in L
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
 constexpr uint32_t kGatherNodes = 32, kGatherRounds = 3;   // a block waits this many loader steps for this many records before it runs shorter
-constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave (4 x 64 words = 15 records a step)
+constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave ...
+constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: twelve records a step
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
@@ -1102,7 +1103,7 @@ struct PLds {
     uint32_t dbgw[4];                           // error dump: the segment being parsed, its block, the node count so far
     unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
-    uint32_t stg[5];                            // loader wave: words requested, words written, the last step's first word and count; 4: records staged up to here
+    uint32_t stg[5];                            // loader wave: records requested up to / written up to this position, (2 unused), records of the last step; 4: records staged up to here
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
                                                 //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
     // the path of a parsed segment (node indices, end first) lives in mcur: nothing relaxes between a parse and its emission
@@ -1254,31 +1255,35 @@ struct Parser {
     XW_FN uint32_t staged_hi() const { return xw::readfirst(L()->stg[4]); }
     XW_FN void pump(uint32_t lo)
     {
+        // (counted in records: a load instruction fetches the 18 words of three records on lanes 0..53, so that a lane's
+        //  place in a record is the same in every step and no step divides by 18)
         const uint32_t i = xw::lane();
-        const uint32_t stage_a0 = G.chunk0 * g.chunk_size;          // the launch's first position: words are counted from there
+        const uint32_t ri = i / kStageQ, wi = i - ri * kStageQ;
+        const bool on = i < kPumpRecs * kStageQ;
         uint32_t st_req = xw::readfirst(L()->stg[0]), st_wr = xw::readfirst(L()->stg[1]);
-        const uint32_t pend_q = xw::readfirst(L()->stg[2]), pend_n = xw::readfirst(L()->stg[3]);
+        const uint32_t pend_n = xw::readfirst(L()->stg[3]);
         if (pend_n) {
 #pragma unroll
             for (uint32_t u = 0; u < kPumpLoads; u++) {
-                const uint32_t q = pend_q + 64 * u + i;
-                if (64 * u + i < pend_n) L()->stage[((stage_a0 + q / kStageQ) & (kStagePos - 1)) * kStageQ + q % kStageQ] = pend_v[u];
+                const uint32_t rr = kPumpRecs * u + ri;
+                if (on && rr < pend_n) L()->stage[((st_wr + rr) & (kStagePos - 1)) * kStageQ + wi] = pend_v[u];
             }
-            st_wr = pend_q + pend_n;
+            st_wr += pend_n;
         }
         t_out_seen = xw::readfirst(pend_t);
         xw::after_poll();
         uint32_t lim = lo + kStagePos;
         if ((int32_t)(t_out_seen - lim) < 0) lim = t_out_seen;
-        const uint32_t lim_q = (lim - stage_a0) * kStageQ;
-        const uint32_t n = (int32_t)(lim_q - st_req) > 0 ? umin(64u * kPumpLoads, lim_q - st_req) : 0u;
+        const uint32_t n = (int32_t)(lim - st_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - st_req) : 0u;
+        const uint32_t wsrc = wi == kStageQ - 1 ? kTpUniq / 2 : wi;
 #pragma unroll
         for (uint32_t u = 0; u < kPumpLoads; u++) {
-            const uint32_t q = st_req + 64 * u + i, pos = stage_a0 + q / kStageQ, k = q % kStageQ;
-            if (64 * u + i < n) pend_v[u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)(pos & (kTpRing - 1)) * kTpStride) + (k == kStageQ - 1 ? kTpUniq / 2 : k));
+            const uint32_t rr = kPumpRecs * u + ri;
+            if (on && rr < n)
+                pend_v[u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)((st_req + rr) & (kTpRing - 1)) * kTpStride) + wsrc);
         }
         pend_t = xw::ld_agent(&V.hx->t_out);
-        if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[2] = st_req; L()->stg[3] = n; L()->stg[4] = stage_a0 + st_wr / kStageQ; }
+        if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[3] = n; L()->stg[4] = st_wr; }
     }
     // until the record of position a is staged (false: another stage failed, or the wait timed out)
     XW_FN bool stage_need(uint32_t a)
@@ -1892,7 +1897,7 @@ struct Parser {
         err = xw::readfirst(P->error);
         tab_dirty = true;
         t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        if (tid < 5) L()->stg[tid] = tid == 4 ? t_out_seen : 0u;
+        if (tid < 5) L()->stg[tid] = (tid == 3 || tid == 2) ? 0u : t_out_seen;
         pend_t = t_out_seen;                                        // (as if t_out had been read before the table stage started)
         n_eq_fill = n_eq_rounds = 0; n_cmp = 0;
         if (tid < kAccN) L()->acc[tid] = 0;
@@ -1903,6 +1908,7 @@ struct Parser {
         xw::block_sync();
 #ifdef NLZM_PROFILE
         if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) xw::atomic_add64_agent(&P->prof[56 + z], t_q[z]);
+        if (xw::lane() == 0) { xw::atomic_add64_agent(&P->prof[64 + xw::wave()], t_work); xw::atomic_add64_agent(&P->prof[72 + xw::wave()], t_bar); xw::atomic_add64_agent(&P->prof[80 + xw::wave()], t_upd); }
         if (xw::lane() == 0 && xw::wave() < 4) {   // per wave: relax + probe work of a pass, barrier wait, update; mask fills
             xw::atomic_add64_agent(&P->prof[32 + xw::wave()], t_work); xw::atomic_add64_agent(&P->prof[36 + xw::wave()], t_bar);
             if (xw::wave() == 0) {
