@@ -1059,19 +1059,16 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
-#ifndef NLZM_KPW
-#define NLZM_KPW 8
-#endif
-constexpr uint32_t kPW = NLZM_KPW;              // waves of the stage (4 or 8): waves 0..3 probe rep slot w; the sampled edges are dealt
-constexpr uint32_t kEdgesPerWave = 8;           // round: four waves take edge w, w+4, ..; eight: waves 0..3 probe only, 4..7 relax edge w-4, w, ..
-// sampled edge j of wave w (kMaxEdges: none)
-NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)
+constexpr uint32_t kPW = 8;                     // waves of the stage.  A node has up to 32 sampled edges, nearly always fewer than 16:
+constexpr uint32_t kEdgesPerWave = 5;           //   waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
+                                                //   ahead), waves 0..3 four of the rare ones each and make the explicit probe of rep slot w
+NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
 {
-    if (kPW == 4) return w + 4 * j;
-    return w < 4 ? kMaxEdges : (w - 4) + 4 * j;
+    if (w < 4) return j < 4 ? 16 + w + 4 * j : kMaxEdges;
+    if (w < 7) return (w - 4) + 3 * j;
+    return j == 0 ? 15u : kMaxEdges;
 }
 constexpr uint32_t kParserThreads = 64 * kPW;
-constexpr uint32_t kEqSlotsW = 64;              // mask cache entries per wave
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
@@ -1081,25 +1078,24 @@ constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of thr
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
-struct alignas(16) EqEnt { uint32_t r, b, mlo, mhi; };
 struct PLds {
     unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
     unsigned long long mcur[3][512];            // ... over the edges of the block being iterated: pass p relaxes into [p % 3]
-    EqEnt eq[4][kEqSlotsW];                   // explicit rep probes: bit j of the entry for (distance r, block b) = in[64b+j] == in[64b+j-r]
     uint32_t nrep[512 * 4];                     // rep set of the nodes of finished blocks (CarriedState ring, :1460-1467)
     uint32_t brep[2][64 * 4];                   // ... of the block's nodes after pass p at [p & 1]
     uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
     uint32_t reach[3][64];                      // furthest node an edge or probe of the node ends at, as pass p found it at [p % 3]
     uint32_t sh[16];                            // wave 0 -> all: 0 block size, 4 error, 5 price tables stale, 6 / 9 bytes of literal edges across
                                                 //   block borders, 10 / 11 price, cost of the literal edge out of the block, 12..15 model rep set; 1: staged records end here
-    uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22
-    uint32_t node_delta[kParseMax + 2];         // distance (dict), rep index (rep), the byte (literal)
+    uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22 | rep index << 24
+    uint32_t node_delta[kParseMax + 2];         // distance (dict, rep), the byte (literal)
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];               // log2_lut[freq >> 6] per (context, symbol) (:435-438)
     uint16_t lut[256];
     uint16_t len_price[kMatchMax + 8];          // price of the length symbols by length value (:1214-1225)
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t ncmds;
+    uint32_t bitbuf[64];                        // raw bits of a batch of commands (wave 7)
     uint32_t dbgw[4];                           // error dump: the segment being parsed, its block, the node count so far
     unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
@@ -1125,8 +1121,7 @@ struct Parser {
     unsigned long long pend_v[kPumpLoads];
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
-    uint32_t nsyms, nbits, word, word_bits, num_ops, nq;
-    unsigned long long q_lo, q_hi;
+    uint32_t nsyms, nbits, word, word_bits, num_ops;       // (every wave follows the counts; `word`, the bits of the byte not yet full, is wave 7's)
     uint32_t err;
     uint32_t n_eq_fill, n_eq_rounds;            // (per launch)
     uint32_t n_cmp;                             // (per lane and launch: well below 2^32)
@@ -1168,84 +1163,162 @@ struct Parser {
         xw::block_sync();
     }
 
-    // ---- symbol output (WriteRange/WriteBits + cdf_update), as in the reference's model_encode_* (wave 0) -----------
-    // Up to 8 symbols of DISTINCT contexts go through their nibble CDFs together, four per pass on sixteen lanes each:
-    // lane i of a group holds cell[i] and cell[i+1]; (start, freq) snapshot (:559-572), adaptation
-    // cell[i] += (mixin[y][i] - cell[i]) >> 7 with mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298, :348-382),
-    // and the price row of the new cells (:435-438).
-    // (the queue: ctx << 4 | symbol in sixteen bits each, four to a word, in registers -- an LDS round trip per command otherwise)
-    XW_FN void put_sym(uint32_t ctx, uint32_t y)
+    // ---- symbol output: model_encode_* (:1274-1367, :1428-1439) = WriteRange / WriteBits + cdf_update --------------------
+    // The commands of a segment are emitted 64 at a time with the lanes as COMMANDS.  What the reference does one symbol after
+    // the other splits into independent chains: a nibble CDF only sees the symbols coded in its own context, in command
+    // order (a command never uses a context twice), and a symbol's place in the frame's symbol array is a prefix sum over
+    // the commands.  So every wave owns a set of contexts, holds their cells in registers (16 lanes per context: cell i on
+    // lane i; four contexts side by side, four such sets) and walks the commands that use one of them:
+    //   wave 0  cmd                 wave 4  lit_lo[16]
+    //   wave 1  lit_hi              wave 5  len_ext_lo[16]
+    //   wave 2  len_direct          wave 6  dist_slot_lo[0..1][8]
+    //   wave 3  len_ext_hi,         wave 7  dist_slot_lo[2..3][8]; the raw bits of the batch (WriteBits, :574-588)
+    //           dist_slot_hi[4]
+    // (start, freq) of a symbol is read before its update (:559-572); adaptation cell[i] += (mixin[y][i] - cell[i]) >> 7 with
+    // mixin[y][i] = i <= y ? i : 16384 + i + (127 - nsy) (:284-298, :348-382); the price rows of the touched contexts (:435-438)
+    // are rebuilt when the batch is done.
+    XW_FN static uint32_t em_ctx(uint32_t w, uint32_t q)        // context of local index q of wave w
     {
-        const unsigned long long e = (unsigned long long)((ctx << 4) | y) << (16 * (nq & 3u));
-        if (nq < 4) q_lo |= e; else q_hi |= e;
-        nq++;
+        if (w == 0) return kCtxCmd;
+        if (w == 1) return kCtxLitHi;
+        if (w == 2) return kCtxLenDirect;
+        if (w == 3) return q < 4 ? kCtxLenExtHi : kCtxSlotHi + (q - 4);
+        if (w == 4) return kCtxLitLo + q;
+        if (w == 5) return kCtxLenExtLo + q;
+        return kCtxSlotLo + (w - 6) * 16 + q;
     }
-    XW_FN void flush_syms()
+    XW_FN static bool em_has(uint32_t w, uint32_t q)            // is local index q a context of wave w?
     {
-        const uint32_t grp = xw::lane() >> 4, i = xw::lane() & 15u;
-        for (uint32_t b = 0; b < nq; b += 4) {
-            const uint32_t k = b + grp;
-            if (k < nq) {
-                const uint32_t qe = (uint32_t)((b ? q_hi : q_lo) >> (16 * grp)) & 0xFFFFu, ctx = qe >> 4, y = qe & 15u;
-                const uint32_t nsy = ctx_nsyms(ctx);
-                uint16_t *cell = L()->cdf + ctx * kCdfStride;
-                const uint32_t c0 = cell[i], c1 = cell[i + 1];
-                if (i == y) fsyms[nsyms + k] = ((c1 - c0) << 16) + c0;
-                auto upd = [=](uint32_t j, uint32_t c) __attribute__((always_inline)) {
-                    const int mix = (j <= y) ? (int)j : (int)(16384 + j + (127 - nsy));
-                    return j < nsy ? (uint32_t)(uint16_t)(c + (uint32_t)((mix - (int)c) >> 7)) : c;
-                };
-                const uint32_t n0 = upd(i, c0), n1 = upd(i + 1, c1);
-                // (lane i writes cell i only, after the lanes that read it: same wave, DS operations in order)
-                if (i < nsy) { cell[i] = (uint16_t)n0; L()->price[ctx * 16 + i] = L()->lut[(n1 - n0) >> 6]; }
+        if (w < 3) return q == 0;
+        if (w == 3) return q == 0 || (q >= 4 && q < 8);
+        return q < 16;
+    }
+    // one chain: the commands of `mask` use local context qv with symbol yv, written to symbol slot pv
+    XW_FN void em_chain(unsigned long long mask, uint32_t qv, uint32_t yv, uint32_t pv, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                        uint32_t &dirty)
+    {
+        const uint32_t w = xw::wave(), l = xw::lane(), i = l & 15u, gl = l >> 4;
+        for (; mask; mask &= mask - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mask);
+            const uint32_t q = xw::readlane(qv, j), y = xw::readlane(yv, j), pos = xw::readlane(pv, j);
+            const uint32_t st = q >> 2, gq = q & 3u, nsy = w == 3 ? (q < 4 ? 16u : 8u) : (w < 6 ? 16u : 8u);
+            // (the set is picked by arithmetic: a choice between the four registers becomes ONE indexed access, which puts them into scratch)
+            const uint32_t k0 = 0u - (uint32_t)(st == 0), k1 = 0u - (uint32_t)(st == 1), k2 = 0u - (uint32_t)(st == 2), k3 = 0u - (uint32_t)(st == 3);
+            const uint32_t sel = (c0 & k0) | (c1 & k1) | (c2 & k2) | (c3 & k3);
+            const uint32_t start = xw::readlane(sel, 16 * gq + y);
+            const uint32_t nxt = y + 1 == 16 ? 16384u : xw::readlane(sel, (16 * gq + y + 1) & 63u);
+            if (l == 0) fsyms[nsyms + pos] = ((nxt - start) << 16) + start;
+            const int mix = i <= y ? (int)i : (int)(16384 + i + (127 - nsy));
+            const uint32_t upd = (uint32_t)((int)sel + ((mix - (int)sel) >> 7)) & 0xFFFFu;
+            const bool mine = gl == gq && i < nsy;
+            const uint32_t ch = mine ? (upd ^ sel) : 0u;            // (what changes in the picked set, on this lane)
+            c0 ^= ch & k0; c1 ^= ch & k1; c2 ^= ch & k2; c3 ^= ch & k3;
+            dirty |= 1u << q;
+        }
+    }
+    // ... of a wave with ONE context of kNsy symbols (waves 0..2: the long chains), cells on lanes 0..16
+    template <uint32_t kNsy>
+    XW_FN void em_chain1(unsigned long long mask, uint32_t yv, uint32_t pv, uint32_t &c0, uint32_t &dirty)
+    {
+        const uint32_t l = xw::lane();
+        if (mask) dirty = 1;
+        for (; mask; mask &= mask - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mask);
+            const uint32_t y = xw::readlane(yv, j), pos = xw::readlane(pv, j);
+            const uint32_t start = xw::readlane(c0, y), nxt = xw::readlane(c0, y + 1);
+            if (l == 0) fsyms[nsyms + pos] = ((nxt - start) << 16) + start;
+            const int mix = l <= y ? (int)l : (int)(16384 + l + (127 - kNsy));
+            const uint32_t upd = (uint32_t)((int)c0 + ((mix - (int)c0) >> 7)) & 0xFFFFu;
+            c0 = l < kNsy ? upd : c0;
+        }
+    }
+    XW_FN void emit_commands(uint32_t ncmds, unsigned long long &n_lit, unsigned long long &n_dict, unsigned long long &n_rep)
+    {
+        const uint32_t e = xw::lane(), w = xw::wave(), i = e & 15u, gl = e >> 4;
+        // this wave's cells
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, dirty = 0;
+        if (w < 3) c0 = e < kCdfStride - 1 ? L()->cdf[em_ctx(w, 0) * kCdfStride + e] : 0u;       // (one context: its 17 cells on lanes 0..16)
+        else if (em_has(w, gl)) c0 = L()->cdf[em_ctx(w, gl) * kCdfStride + i];
+        if (em_has(w, 4 + gl)) c1 = L()->cdf[em_ctx(w, 4 + gl) * kCdfStride + i];
+        if (w > 3) { c2 = L()->cdf[em_ctx(w, 8 + gl) * kCdfStride + i]; c3 = L()->cdf[em_ctx(w, 12 + gl) * kCdfStride + i]; }
+        for (uint32_t k0 = ncmds; k0 > 0;) {                        // :1809-1843
+            const uint32_t cnt = umin(64u, k0);
+            uint32_t cmd = 3, len = 0, idx = 0, dv = 0;             // (cmd 3: no command on this lane)
+            if (e < cnt) {
+                const uint32_t node = L()->cmdlist()[k0 - 1 - e];
+                const uint32_t link = L()->node_link[node];
+                dv = L()->node_delta[node];
+                cmd = (link >> 22) & 3u; len = (link >> 13) & 0x1FFu; idx = link >> 24;
             }
+            const bool islit = cmd == 0, ismatch = cmd == 1, isrep = cmd == 2, haslen = ismatch || isrep;
+            const uint32_t lv = haslen ? len - match_min(dv) : 0u;  // :1281, :1350
+            const bool ext = haslen && lv >= 7;
+            const uint32_t lc = umin(lv, 3);
+            uint32_t nx = 0, ex = 0, slot = 0;
+            if (ismatch) slot = dist_slot(dv - 1, nx, ex);
+            const uint32_t nsym = islit ? 3u : (ismatch ? (ext ? 6u : 4u) : (isrep ? (ext ? 4u : 2u) : 0u));
+            const uint32_t nbit = ismatch ? nx : (isrep ? 2u : 0u);
+            const uint32_t s_inc = xw::scan_add(nsym), b_inc = xw::scan_add(nbit);
+            const uint32_t sym_off = s_inc - nsym, bit_off = b_inc - nbit;
+            const uint32_t tot_sym = xw::readlane(s_inc, 63), tot_bit = xw::readlane(b_inc, 63);
+            // WriteBits calls (:1328-1340, :1365): none below distance 5, one up to four bits, else two; a rep index is one
+            const uint32_t n_op = (uint32_t)__builtin_popcountll(xw::ballot((ismatch && nx) || isrep)) + (uint32_t)__builtin_popcountll(xw::ballot(ismatch && nx > 4));
+            if (nsyms + tot_sym + 16 > G.syms_stride || nbits + (tot_bit >> 3) + 64 > G.bits_stride) { fail(kErrFrameOverflow, nsyms); return; }
+            // ---- this wave's chains (symbol slots inside a command: cmd; literal: hi, lo; else: len [, ext hi, ext lo]; match: slot hi, slot lo)
+            const uint32_t p_slot = sym_off + (ext ? 4u : 2u);
+            if (w == 0) em_chain1<4>(xw::ballot(cmd < 3), cmd, sym_off, c0, dirty);
+            else if (w == 1) em_chain1<16>(xw::ballot(islit), dv >> 4, sym_off + 1, c0, dirty);
+            else if (w == 2) em_chain1<8>(xw::ballot(haslen), umin(lv, 7), sym_off + 1, c0, dirty);
+            else if (w == 3) {
+                em_chain(xw::ballot(ext), 0, (lv - 7) >> 4, sym_off + 2, c0, c1, c2, c3, dirty);
+                em_chain(xw::ballot(ismatch), 4 + lc, slot >> 3, p_slot, c0, c1, c2, c3, dirty);
+            }
+            else if (w == 4) em_chain(xw::ballot(islit), (dv >> 4) & 15u, dv & 15u, sym_off + 2, c0, c1, c2, c3, dirty);
+            else if (w == 5) em_chain(xw::ballot(ext), ((lv - 7) >> 4) & 15u, (lv - 7) & 15u, sym_off + 3, c0, c1, c2, c3, dirty);
+            else em_chain(xw::ballot(ismatch && (lc >> 1) == w - 6), (lc & 1u) * 8 + (slot >> 3), slot & 7u, p_slot + 1, c0, c1, c2, c3, dirty);
+            if (w == kPW - 1 && tot_bit) {
+                // ---- raw bits, MSB first (:574-588): every field at its bit offset in a staging buffer, whole bytes out
+                uint32_t *bb = L()->bitbuf;
+                bb[e] = e == 0 ? word : 0u;                         // (the bits of the byte that is not full yet)
+                xw::wave_sync();
+                if (nbit) {
+                    const uint32_t P = word_bits + bit_off;
+                    const unsigned long long v = (unsigned long long)(ismatch ? ex : idx) << (64 - nbit - (P & 31u));
+                    xw::lds_or(&bb[P >> 5], (uint32_t)(v >> 32));
+                    if ((uint32_t)v) xw::lds_or(&bb[(P >> 5) + 1], (uint32_t)v);
+                }
+                xw::wave_sync();
+                const uint32_t tb = word_bits + tot_bit, nfull = tb >> 3;
+                for (uint32_t t = e; t < nfull; t += 64) fbits[nbits + t] = (uint8_t)(bb[t >> 2] >> (24 - 8 * (t & 3u)));
+                word = (tb & 7u) ? ((bb[nfull >> 2] << (8 * (nfull & 3u))) & 0xFF000000u) : 0u;
+                xw::wave_sync();
+            }
+            nbits += (word_bits + tot_bit) >> 3; word_bits = (word_bits + tot_bit) & 7u;
+            nsyms += tot_sym; num_ops += tot_sym + n_op;
+            n_lit += (uint32_t)__builtin_popcountll(xw::ballot(islit)); n_dict += (uint32_t)__builtin_popcountll(xw::ballot(ismatch));
+            n_rep += (uint32_t)__builtin_popcountll(xw::ballot(isrep));
+            if (xw::any(haslen)) tab_dirty = true;
+            k0 -= cnt;
         }
-        nsyms += nq; num_ops += nq; nq = 0; q_lo = q_hi = 0;
-        xw::wave_sync();
-    }
-    XW_FN void put_bits(uint32_t v, uint32_t nb)                    // :574-588
-    {
-        num_ops++;
-        word |= v << (32 - word_bits - nb);
-        word_bits += nb;
-        while (word_bits >= 8) {
-            if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
-            nbits++; word <<= 8; word_bits -= 8;
+        // ---- cells and price rows of the contexts this wave touched
+        auto put = [&](uint32_t q, uint32_t cv) __attribute__((always_inline)) {
+            const uint32_t up = xw::shfl(cv, (e + 1) & 63u);
+            if (em_has(w, q) && ((dirty >> q) & 1u)) {
+                const uint32_t ctx = em_ctx(w, q), nsy = ctx_nsyms(ctx);
+                const uint32_t nxt = i + 1 == 16 ? 16384u : up;
+                if (i < nsy) { L()->cdf[ctx * kCdfStride + i] = (uint16_t)cv; L()->price[ctx * 16 + i] = L()->lut[(nxt - cv) >> 6]; }
+            }
+        };
+        if (w < 3) {
+            const uint32_t up = xw::shfl(c0, (e + 1) & 63u);
+            if (dirty) {
+                const uint32_t ctx = em_ctx(w, 0), nsy = ctx_nsyms(ctx);
+                if (e < nsy) { L()->cdf[ctx * kCdfStride + e] = (uint16_t)c0; L()->price[ctx * 16 + e] = L()->lut[(up - c0) >> 6]; }
+            }
+        } else {
+            put(gl, c0); put(4 + gl, c1);
+            if (w > 3) { put(8 + gl, c2); put(12 + gl, c3); }
         }
-    }
-    XW_FN uint32_t emit_len(uint32_t lv)                            // :1281-1297
-    {
-        tab_dirty = true;
-        put_sym(kCtxLenDirect, umin(lv, 7));
-        if (lv >= 7) { const uint32_t e = lv - 7; put_sym(kCtxLenExtHi, e >> 4); put_sym(kCtxLenExtLo + (e >> 4), e & 15); }
-        return umin(lv, 3);
-    }
-    XW_FN void emit_literal(uint32_t y)                             // :1428-1439
-    {
-        put_sym(kCtxCmd, 0); put_sym(kCtxLitHi, y >> 4); put_sym(kCtxLitLo + (y >> 4), y & 15);
-        flush_syms();
-    }
-    XW_FN void emit_match(uint32_t d, uint32_t len)                 // :1274-1342
-    {
-        put_sym(kCtxCmd, 1);
-        const uint32_t lc = emit_len(len - match_min(d));
-        uint32_t nx, ex;
-        const uint32_t slot = dist_slot(d - 1, nx, ex);
-        put_sym(kCtxSlotHi + lc, slot >> 3);
-        put_sym(kCtxSlotLo + lc * 8 + (slot >> 3), slot & 7);
-        flush_syms();
-        if (d - 1 >= 4) {
-            if (nx < 4) put_bits(ex, nx);
-            else { if (nx > 4) put_bits(ex >> 4, nx - 4); put_bits(ex & 15, 4); }
-        }
-        if (!(rep0 == d || rep1 == d || rep2 == d || rep3 == d)) { rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = d; }   // RepModel::Add (:1160-1171, :1819)
-    }
-    XW_FN void emit_rep(uint32_t idx, uint32_t len)                 // :1344-1367; rep4.Add of a distance that is present is a no-op (:1834)
-    {
-        put_sym(kCtxCmd, 2);
-        emit_len(len - match_min(idx == 0 ? rep0 : (idx == 1 ? rep1 : (idx == 2 ? rep2 : rep3))));
-        flush_syms();
-        put_bits(idx, 2);
     }
 
     // ---- the record stage (wave kPW-1).  One step: what was requested by the last step goes into LDS, the next 64 words are
@@ -1358,61 +1431,30 @@ struct Parser {
     }
 
     // ---- explicit rep probe (:1598-1628): match length of (position a, distance r), at most c bytes ------------------
-    // Byte equality comes from this wave's mask cache (one 64-byte block of the input against itself r bytes earlier per
-    // entry); what misses is filled by the whole wave, the bytes of up to four entries requested before any is looked at.
-    XW_FN uint32_t probe_len(bool want, uint32_t a, uint32_t r, uint32_t c)
+    // Every lane compares for itself, eight bytes a round: `own` holds the eight bytes at a (loaded once per block), `first` the
+    // eight bytes at a - r (requested by the caller ahead of time, so that their latency passes behind other work).
+    // Nearly every probe ends inside its first eight bytes; the others go on round by round.
+    XW_FN uint32_t probe_finish(bool want, uint32_t a, uint32_t r, uint32_t c, unsigned long long own, unsigned long long first)
     {
-        EqEnt *cache = L()->eq[xw::wave()];
         uint32_t len = 0;
         bool open = want && c > 0;
-        while (xw::any(open)) {
+        unsigned long long x = first, y = own;
+        for (;;) {
+            if (open) {
+                const unsigned long long d = x ^ y;
+                const uint32_t nb = d ? (uint32_t)__builtin_ctzll(d) >> 3 : 8u;
+                len += umin(nb, c - len);
+                if (nb < 8 || len >= c) open = false;
+            }
+            if (!xw::any(open)) break;
             n_eq_rounds++;
-            const uint32_t b = (a + len) >> 6, slot = (r * 0x9E3779B1u + b * 0x85EBCA77u) >> 26;
-            EqEnt e = cache[slot];
-            bool hit = e.r == r && e.b == b;
-            unsigned long long miss = xw::ballot(open && !hit);
-            if (miss) {
-                const unsigned long long f0 = ptick();
-                uint32_t fr[4], fb[4], fs[4];
-                uint8_t xa[4], xb[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    ok[u] = miss != 0;
-                    const uint32_t j = ok[u] ? (uint32_t)__builtin_ctzll(miss) : 0u;
-                    fr[u] = xw::readlane(r, j); fb[u] = xw::readlane(b, j); fs[u] = xw::readlane(slot, j);
-                    miss &= ~xw::ballot(open && r == fr[u] && b == fb[u]);          // (the lanes this entry serves)
-                    const unsigned long long pos = (unsigned long long)fb[u] * 64 + xw::lane();
-                    const bool in_range = ok[u] && pos >= fr[u] && pos < g.n;
-                    xa[u] = in_range ? G.in[pos] : 0; xb[u] = in_range ? G.in[pos - fr[u]] : 1;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned long long k = xw::ballot(xa[u] == xb[u]);
-                    if (ok[u]) {
-                        n_eq_fill++;
-                        if (xw::lane() == 0) cache[fs[u]] = EqEnt{ fr[u], fb[u], (uint32_t)k, (uint32_t)(k >> 32) };
-                        if (open && !hit && r == fr[u] && b == fb[u]) { e = EqEnt{ fr[u], fb[u], (uint32_t)k, (uint32_t)(k >> 32) }; hit = true; }
-                    }
-                }
-                xw::wave_sync();
-                t_fill += ptick() - f0;
-            }
-            if (open && hit) {                                      // (a lane whose entry is not in yet looks again next round)
-                const unsigned long long m = ((unsigned long long)e.mhi << 32) | e.mlo;
-                const uint32_t sh = (a + len) & 63u, room = 64 - sh;
-                const unsigned long long z = ~(m >> sh);            // zero bits = equal bytes
-                const uint32_t run = z ? (uint32_t)__builtin_ctzll(z) : 64u;
-                const uint32_t got = umin(umin(run, room), c - len);
-                len += got;
-                if (got < room || len >= c) open = false;
-            }
+            if (open) { x = load64u(G.in + a + len - r); y = load64u(G.in + a + len); }
         }
         return len;
     }
 
     // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171) and what the emitter needs of the
-    // winner: source | length << 13 | cmd << 22, and the distance / rep index.  The source's set: of a finished block from the
+    // winner: source | length << 13 | cmd << 22 | rep index << 24, and the distance (dict, rep).  The source's set: of a finished block from the
     // ring, of this block as the pass before left it.
     XW_FN void winner_set(uint32_t seg_a, uint32_t b0, uint32_t pbuf, uint32_t node, unsigned long long key, uint32_t &o0, uint32_t &o1,
                           uint32_t &o2, uint32_t &o3, uint32_t &link, uint32_t &delta) const
@@ -1422,21 +1464,22 @@ struct Parser {
         const uint32_t *sr = src >= b0 ? L()->brep[pbuf] + (src - b0) * 4 : L()->nrep + (src & 511u) * 4;
         const uint32_t s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
         o0 = s0; o1 = s1; o2 = s2; o3 = s3;
-        uint32_t cmd = 0, len = 0;
+        uint32_t cmd = 0, len = 0, idx = 0;
         delta = 0;
         if (rank != kRankLit) {
             len = node - src;
-            if (rank >= kRankProbe) { cmd = 2; delta = rank - kRankProbe; }
+            if (rank >= kRankProbe) { cmd = 2; idx = rank - kRankProbe; delta = idx == 0 ? s0 : (idx == 1 ? s1 : (idx == 2 ? s2 : s3)); }
             else {
                 const uint32_t d = L()->edge_d[((seg_a + src) & 511u) * kMaxEdges + (rank >> 1)];
-                if (rank & 1u) { cmd = 2; delta = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
+                delta = d;
+                if (rank & 1u) { cmd = 2; idx = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
                 else {
-                    cmd = 1; delta = d;
+                    cmd = 1;
                     if (!(d == s0 || d == s1 || d == s2 || d == s3)) { o0 = d; o1 = s0; o2 = s1; o3 = s2; }
                 }
             }
         }
-        link = src | (len << 13) | (cmd << 22);
+        link = src | (len << 13) | (cmd << 22) | (idx << 24);
     }
 
     // ---- one parse segment: nodes 0.. of positions seg_a.. (every thread of the stage); returns its length, the path
@@ -1486,7 +1529,11 @@ struct Parser {
                     const uint32_t r = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
                     const uint32_t pcap = umin(umin(chunk_left - umin(i, chunk_left - 1), kParseMax), kMatchMax);
                     const bool want = i < p0 && r < seg_q + i;                                      // :1601
-                    const uint32_t l = xw::any(want) ? probe_len(want, seg_a + i, r, pcap) : 0u;
+                    uint32_t l = 0;
+                    if (xw::any(want)) {
+                        const unsigned long long yo = want ? load64u(G.in + seg_a + i) : 0ull, xo = want ? load64u(G.in + seg_a + i - r) : 0ull;
+                        l = probe_finish(want, seg_a + i, r, pcap, yo, xo);
+                    }
                     if (want) { counted = l + (l < pcap); n_cmp += counted; }
                     const unsigned long long okm = xw::ballot(want && l >= match_min(r));
                     if (i == 0) L()->fpm[w] = okm;
@@ -1502,6 +1549,7 @@ struct Parser {
                         L()->cmdlist()[run - 1 - i] = (uint16_t)(i + 1);
                     }
                     if (tid == 0) {
+                        L()->sh[12] = rep0; L()->sh[13] = rep1; L()->sh[14] = rep2; L()->sh[15] = rep3;    // (literals leave the rep set alone)
                         L()->ncmds = run;
                         xw::st_agent(&V.hx->p_pos, seg_a);
                         if (run > 1) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)(seg_a + run - 1) << 32) | (seg_a + run));
@@ -1524,6 +1572,7 @@ struct Parser {
                     winner_set(seg_a, b0, 0, b0, k, r0, r1, r2, r3, link, delta);
                     if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[9];      // the byte of position b0 - 1
                     L()->node_link[b0] = link; L()->node_delta[b0] = delta;
+                    L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3;    // the model's rep set after the segment
                 }
                 seg_len = b0;
                 break;
@@ -1583,7 +1632,7 @@ struct Parser {
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) { ed[j] = 0; ea[j] = 0; }
-            if (kPW == 4 || w >= 4) {
+            {
                 unsigned long long er[kEdgesPerWave];
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
@@ -1615,6 +1664,7 @@ struct Parser {
                     um &= um - 1;
                 }
             }
+            const unsigned long long own8 = (w < 4 && inb) ? load64u(G.in + a) : 0ull;     // (probe waves: the bytes at the node's position)
             if (w == 0) L()->reach[1][i] = sreach;
             const unsigned long long q4 = ptick();
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
@@ -1638,7 +1688,30 @@ struct Parser {
                 const uint32_t buf = pass % 3u, nbuf = (pass + 1) % 3u;
                 const unsigned long long k0 = ptick();
                 if (w == kPW - 1) pump(seg_a + b0);                 // (the records of the blocks to come)
-                if (pass > 0 && lv && (kPW == 4 || w >= 4)) {
+                // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628): what is to be
+                // measured anew is decided first and its bytes are requested, so that they arrive behind the relaxation
+                bool dirty = false, wnt = false, fresh = false;
+                uint32_t r = 0;
+                unsigned long long px = 0;
+                if (pass > 0 && w < 4) {
+                    r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+                    dirty = lv && r != cr;
+                    if (xw::any(dirty)) {
+                        bool met = false;
+#pragma unroll
+                        for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
+                        if (xw::any(dirty && nd > 8)) {
+                            if (dirty && nd > 8) {
+                                for (uint32_t um = uniq; um; um &= um - 1)
+                                    met = met || L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)] == r;
+                            }
+                        }
+                        wnt = dirty && !met && r < seg_q + node;                                        // :1601
+                        fresh = wnt && mr != r && pcap > 0;
+                        if (fresh) px = load64u(G.in + a - r);
+                    }
+                }
+                if (pass > 0 && lv) {
                     // relax this wave's sampled edges of the node (:1566-1595)
 #pragma unroll
                     for (uint32_t j = 0; j < kEdgesPerWave; j++) {
@@ -1654,22 +1727,9 @@ struct Parser {
                 }
                 const unsigned long long k0a = ptick();
                 if (pass > 0 && w < 4) {
-                    // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628)
-                    const uint32_t r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
-                    const bool dirty = lv && r != cr;
                     if (xw::any(dirty)) {
-                        bool met = false;
-#pragma unroll
-                        for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
-                        if (xw::any(dirty && nd > 8)) {
-                            if (dirty && nd > 8) {
-                                for (uint32_t um = uniq; um; um &= um - 1)
-                                    met = met || L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)] == r;
-                            }
-                        }
-                        const bool wnt = dirty && !met && r < seg_q + node;                             // :1601
-                        const bool fresh = wnt && mr != r;
-                        if (xw::any(fresh)) { const uint32_t l = probe_len(fresh, a, r, pcap); if (fresh) { mr = r; ml = l; } }
+                        if (xw::any(fresh)) { const uint32_t l = probe_finish(fresh, a, r, pcap, own8, px); if (fresh) { mr = r; ml = l; } }
+                        if (wnt && mr != r) { mr = r; ml = 0; }     // (nothing to compare: no room for a match)
                         if (dirty) {
                             cr = r; want = wnt; pw = 0; pt = 0;
                             if (wnt && ml >= match_min(r)) { pw = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5); pt = ml; }   // :1607, :1614
@@ -1747,6 +1807,7 @@ struct Parser {
                     L()->node_link[node] = link; L()->node_delta[node] = delta;
                     uint32_t *dr = L()->nrep + (node & 511u) * 4;
                     dr[0] = r0; dr[1] = r1; dr[2] = r2; dr[3] = r3;
+                    if (i == istar) { L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3; }   // (the segment's last node, if it ends here)
                 }
                 if (i == nb - 1) L()->sh[11] = c;
             }
@@ -1816,7 +1877,7 @@ struct Parser {
         const uint32_t p_end = umin(g.chunk_size, (uint32_t)g.n - (uint32_t)chunk_abs);
         fsyms = G.syms + (unsigned long long)(ci - G.chunk0) * G.syms_stride;
         fbits = G.bits + (unsigned long long)(ci - G.chunk0) * G.bits_stride;
-        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0; nq = 0; q_lo = q_hi = 0;
+        nsyms = 0; nbits = 0; word = 0; word_bits = 0; num_ops = 0;
         {   // (the window's size made opaque here: or twice it is kept in two registers, and spilled, for the whole launch)
             const unsigned long long wsize = (unsigned long long)xw::opaque(g.wmask) + 1;
             if (chunk_abs - base >= 2 * wsize) base += (uint32_t)wsize;         // :1786
@@ -1829,45 +1890,20 @@ struct Parser {
             const uint32_t len = parse_segment(seg_a, p_end - p, ncmds);
             if (err) break;
             n_seg += nsegs;
-            if (xw::wave() == 0) {
+            {
                 const unsigned long long te = xw::tick();
-                for (uint32_t k0 = ncmds; k0 > 0;) {                            // :1809-1843
-                    // (64 commands are looked up at once, a lane each: two LDS round trips for all of them)
-                    const uint32_t cnt = umin(64u, k0);
-                    uint32_t link_v = 0, delta_v = 0;
-                    if (xw::lane() < cnt) {
-                        const uint32_t node = L()->cmdlist()[k0 - 1 - xw::lane()];
-                        link_v = L()->node_link[node]; delta_v = L()->node_delta[node];
-                    }
-                    for (uint32_t j = 0; j < cnt; j++) {
-                        const uint32_t link = xw::readlane(link_v, j), delta = xw::readlane(delta_v, j);
-                        const uint32_t cmd = link >> 22, ln = (link >> 13) & 0x1FFu;
-                        if (cmd == 0) { emit_literal(delta); n_lit++; }
-                        else if (cmd == 1) { emit_match(delta, ln); n_dict++; }
-                        else { emit_rep(delta, ln); n_rep++; }
-                    }
-                    k0 -= cnt;
-                }
-                acc(kAccEmit, xw::tick() - te);
-                if (nsyms + 16 > G.syms_stride || nbits + 64 > G.bits_stride) fail(kErrFrameOverflow, ci);
-                if (xw::lane() == 0) {
-                    L()->sh[12] = rep0; L()->sh[13] = rep1; L()->sh[14] = rep2; L()->sh[15] = rep3;
-                    L()->sh[5] = tab_dirty ? 1u : 0u; L()->sh[4] = err;
-                }
-            } else if (xw::wave() == kPW - 1) {
-                pump(seg_a + len);                                              // (meanwhile: records of the next segment)
+                if (xw::wave() == kPW - 1) pump(seg_a + len);                   // (records of the next segment: requested now, in LDS by the next step)
+                emit_commands(ncmds, n_lit, n_dict, n_rep);
+                if (xw::wave() == 0) acc(kAccEmit, xw::tick() - te);
             }
             xw::block_sync();
-            rep0 = L()->sh[12]; rep1 = L()->sh[13]; rep2 = L()->sh[14]; rep3 = L()->sh[15];     // (every wave follows the model's rep set)
-            tab_dirty = L()->sh[5] != 0;
-            if (L()->sh[4]) err = L()->sh[4];
+            rep0 = L()->sh[12]; rep1 = L()->sh[13]; rep2 = L()->sh[14]; rep3 = L()->sh[15];     // (the model's rep set after the segment: the set of its last node)
+            if (xw::readfirst(xw::lds_ld(&L()->sh[4]))) err = L()->sh[4];
             p += len;
         }
+        if (xw::wave() == kPW - 1 && xw::lane() < 4) fbits[nbits + xw::lane()] = xw::lane() == 0 ? (uint8_t)(word >> 24) : (uint8_t)0;   // bit pad of Flush (:591-597)
+        nbits += 4;
         if (xw::wave() == 0) {
-            for (int k = 0; k < 4; k++) {                                       // bit pad of Flush (:591-597)
-                if (xw::lane() == 0) fbits[nbits] = (uint8_t)(word >> 24);
-                nbits++; word <<= 8;
-            }
             if (xw::lane() == 0) {
                 FrameMeta &fm = G.fmeta[ci - G.chunk0];
                 fm.nsyms = nsyms; fm.nbits_bytes = nbits; fm.num_ops = num_ops; fm.out_len = 0;
@@ -1884,7 +1920,6 @@ struct Parser {
         const uint32_t tid = xw::thread();
         for (uint32_t k = tid; k < kNumCtx * kCdfStride; k += kParserThreads) L()->cdf[k] = P->cdf[k];
         for (uint32_t k = tid; k < 256; k += kParserThreads) L()->lut[k] = log2_lut_entry(k);
-        for (uint32_t k = tid; k < 4 * kEqSlotsW; k += kParserThreads) L()->eq[k / kEqSlotsW][k % kEqSlotsW] = EqEnt{ 0u, kNone, 0u, 0u };
         for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
         xw::block_sync();
         for (uint32_t k = tid; k < kNumCtx * 16; k += kParserThreads) {

@@ -25,7 +25,7 @@
 namespace xw {
 
 XW_FN uint32_t lane() { return threadIdx.x & 63u; }
-XW_FN uint32_t wave() { return threadIdx.x >> 6; }
+XW_FN uint32_t wave() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }    // (a scalar: what depends on it branches, not masks)
 XW_FN uint32_t thread() { return threadIdx.x; }
 XW_FN unsigned long long ballot(bool p) { return __ballot(p); }
 XW_FN bool any(bool p) { return __ballot(p) != 0; }
@@ -119,6 +119,7 @@ XW_FN void lds_add64(unsigned long long *p, unsigned long long v)
 {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+XW_FN void lds_or(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_inc(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_max(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -233,6 +234,7 @@ inline void acquire_agent() {}
 inline void after_poll() {}
 inline void lds_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
+inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_inc(uint32_t *p) { return (*p)++; }
 inline void lds_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 inline void lds_st(uint32_t *p, uint32_t v) { *p = v; }
