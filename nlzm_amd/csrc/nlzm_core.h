@@ -92,18 +92,24 @@ struct FrameMeta {
     uint32_t nsyms, nbits_bytes, num_ops, out_len;
 };
 
-// BT4 result of one position, written by a worker lane and read by the master:
-//   bt_ready[i * kBtRec] = 0 (not yet) | 0x80000000 | tests<<9 | count, words 1..8 of the record: the first four pairs
-//   (one 64-byte record per position: a waiting master reads word and pairs with ONE load instruction)
-//   bt_pairs[i * 2*kBtMaxPairs ...] = `count` (distance, length) pairs -- the
-// record-setters of the descent (a descent visits candidates by increasing distance,
-// so only a longer match changes the table: :835-852).  The stride is the worst case
-// (one pair per test, <= 256 tests, :777): 2 KiB per position, sized for HBM, so no
-// allocator and no overflow path exists.
+// BT4 result of one position, written by a worker lane, read by the finder and the table stage: ONE 64-byte record of four
+// 16-byte quads, each written by one store and each valid by itself (the array is cleared before a launch):
+//   quad 0   ready | tests << 9 | count,  distance and length of the longest record-setter (0, 0: none),  0
+//   quad 1   d0, l0, d1, TAG         quad 2   l1, d2, l2, TAG         quad 3   d3, l3, 0, TAG
+// (d, l) = the record-setters of the descent (a descent visits candidates by increasing distance, so only a longer match
+// changes the table: :835-852), the first four of them.  A reader that has seen the ready bit takes the rest of quad 0 as it
+// is; quads 1..3 it takes when their TAG is there.  The rare fifth and later record-setters go to
+//   bt_pairs[i * 2*kBtMaxPairs + 2k ...]   (k >= 4; written, and drained, before quad 0)
+// whose stride is the worst case (one pair per test, <= 256 tests, :777): 2 KiB per position, sized for HBM, so no allocator
+// and no overflow path exists.
 constexpr uint32_t kBtMaxPairs = 256;
 constexpr uint32_t kBtReady = 0x80000000u;
+constexpr uint32_t kBtTag = 0x80000000u;
 constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
 constexpr uint32_t kBtRec = 16;         // words per bt_ready record
+// where pair k < 4 sits in the record: distance, length
+NLZM_HD uint32_t bt_rec_d(uint32_t k) { return k == 0 ? 4u : (k == 1 ? 6u : (k == 2 ? 9u : 12u)); }
+NLZM_HD uint32_t bt_rec_l(uint32_t k) { return k == 0 ? 5u : (k == 1 ? 8u : (k == 2 ? 10u : 13u)); }
 
 struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
@@ -277,17 +283,28 @@ struct LaneCmp {
 template <class IO>
 struct ResultSink {
     uint32_t *pairs;        // nullptr: do not publish
-    uint32_t *rec;          // the position's bt_ready record (first four pairs go there too)
     uint32_t count, best;
     uint32_t best_d = 0;
+    uint32_t d0 = 0, l0 = 0, d1 = 0, l1 = 0, d2 = 0, l2 = 0, d3 = 0, l3 = 0;      // the first four record-setters, kept until the call is over
     NLZM_HD void operator()(uint32_t d, uint32_t l)
     {
         if (!pairs || l <= best) return;    // only record-setters change the table
         best = l; best_d = d;
-        IO::st_agent(pairs + 2 * count, d);
-        IO::st_agent(pairs + 2 * count + 1, l);
-        if (count < 4) { IO::st_agent(rec + 1 + 2 * count, d); IO::st_agent(rec + 2 + 2 * count, l); }
+        // (selects: a branch per slot becomes ONE indexed access to the eight, in scratch)
+        const bool s0 = count == 0, s1 = count == 1, s2 = count == 2, s3 = count == 3;
+        d0 = s0 ? d : d0; l0 = s0 ? l : l0; d1 = s1 ? d : d1; l1 = s1 ? l : l1;
+        d2 = s2 ? d : d2; l2 = s2 ? l : l2; d3 = s3 ? d : d3; l3 = s3 ? l : l3;
+        if (count >= 4) { IO::st_agent(pairs + 2 * count, d); IO::st_agent(pairs + 2 * count + 1, l); }
         count++;
+    }
+    // the record: quads 1..3, then quad 0 (pairs beyond the record are in memory before it)
+    NLZM_HD void publish(uint32_t *rec, uint32_t tests)
+    {
+        if (count > 4) IO::drain();
+        IO::st_quad(rec + 4, d0, l0, d1, kBtTag);
+        IO::st_quad(rec + 8, l1, d2, l2, kBtTag);
+        IO::st_quad(rec + 12, d3, l3, 0u, kBtTag);
+        IO::st_quad(rec, kBtReady | (tests << 9) | count, best_d, count ? best : 0u, 0u);
     }
 };
 
@@ -298,15 +315,12 @@ NLZM_HD void worker_bt_dry(const Geom &g, const Globals &G, uint32_t a, uint32_t
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), G.bt_ready + bi * kBtRec, 0, 1 };
+    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update_st(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests, st);
     n_tests += tests;
-    IO::st_agent(G.bt_ready + bi * kBtRec + 9, sink.best_d);       // the longest record-setter (the last one), for the finder stage
-    IO::st_agent(G.bt_ready + bi * kBtRec + 10, sink.count ? sink.best : 0u);
-    IO::drain();                            // every pair has been written through before the ready word
-    IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
+    sink.publish(G.bt_ready + bi * kBtRec, tests);
 }
 
 template <class IO, bool kWrite>
@@ -315,17 +329,12 @@ NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, G.bt_ready + bi * kBtRec, 0, 1 };
+    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
     uint32_t tests = 0;
     const uint32_t h4 = hash4(load32u(G.in + a));
     bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
-    if (publish) {
-        IO::st_agent(G.bt_ready + bi * kBtRec + 9, sink.best_d);
-        IO::st_agent(G.bt_ready + bi * kBtRec + 10, sink.count ? sink.best : 0u);
-        IO::drain();                        // every pair has been written through before the ready word
-        IO::st_agent(G.bt_ready + bi * kBtRec, kBtReady | (tests << 9) | sink.count);
-    }
+    if (publish) sink.publish(G.bt_ready + bi * kBtRec, tests);
 }
 
 }  // namespace nlzm

@@ -223,6 +223,15 @@ struct LaneIO {
     // every write-through store of this wave has completed (inline asm: the compiler
     // may not drop or move it, cf. guide "Compiler hazard")
     static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // sixteen bytes in ONE write-through store (global_store_dwordx4 sc1: lands whole, and costs what a plain one does)
+    static __device__ __forceinline__ void st_quad(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+    {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 v = { a, b, c, d };
+        // (s_nop: the data registers of a store of more than eight bytes may not be written in the cycle after it -- a hazard the
+        //  compiler resolves for its own stores, not for this one)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"((__attribute__((address_space(1))) uint32_t *)p), "v"(v) : "memory");
+    }
 };
 
 // The stores of a dry run, noted in LDS (a worker block does not use the master's LDS image): kLogCap (address, value)

@@ -471,7 +471,7 @@ struct Finder {
                     if (bt_wait) {
                         bt_n = w0 & 0x1FFu;
                         if (bt_n) {
-                            const uint32_t d = xw::ld_agent(G.bt_ready + bi * kBtRec + 9), l = xw::ld_agent(G.bt_ready + bi * kBtRec + 10);
+                            const uint32_t d = xw::ld_agent(G.bt_ready + bi * kBtRec + 1), l = xw::ld_agent(G.bt_ready + bi * kBtRec + 2);   // (quad 0: with the ready word)
                             if (l >= cap) od = umin(od, d); else ec = umax(ec, a + l);
                         }
                     }
@@ -748,14 +748,21 @@ struct Table {
             // (count and first four pairs in one 64-byte record: requested together)
             const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
             const uint32_t *br = G.bt_ready + bi * kBtRec;
-            uint32_t bw[9];
+            // (the finder stage saw quad 0 before it wrote this position's record; quads 1..3 were stored before quad 0 and carry a tag:
+            //  looked at again in the rare case that one is not there yet)
+            uint32_t bw[16];
+            for (;;) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) bw[k] = xw::ld_agent(br + k);
+                for (int k = 0; k < 16; k++) bw[k] = xw::ld_agent(br + k);
+                if ((bw[7] & bw[11] & bw[15] & kBtTag) != 0) break;
+                if (xw::ld_agent(&V.hx->err)) break;
+                xw::pause();
+            }
             const uint32_t cnt = bw[0] & 0x1FFu;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 if (k >= cnt) continue;
-                const uint32_t d = bw[1 + 2 * k], l = bw[2 + 2 * k];
+                const uint32_t d = bw[bt_rec_d(k)], l = bw[bt_rec_l(k)];
                 if (l >= cap_len) continue;                     // as long as the lookahead allows: the finder stage's top entry covers it
                 if (n >= cap) return kNone;
                 out[n++] = fr_key(a + l, d);
@@ -1617,6 +1624,7 @@ struct Parser {
                 }
                 xw::block_sync();
             }
+            const unsigned long long own8 = (w < 4 && inb) ? load64u(G.in + a) : 0ull;     // (probe waves: the bytes at the node's position, on their way during the set-up)
             const unsigned long long q2 = ptick();
             // ---- set-up: the block's records, from the stage.  Every wave: the node's header, its distinct distances (for
             // the probes' "already met" test) and the wave's own edges; their distances also go into the ring the winners'
@@ -1664,7 +1672,6 @@ struct Parser {
                     um &= um - 1;
                 }
             }
-            const unsigned long long own8 = (w < 4 && inb) ? load64u(G.in + a) : 0ull;     // (probe waves: the bytes at the node's position)
             if (w == 0) L()->reach[1][i] = sreach;
             const unsigned long long q4 = ptick();
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426

@@ -25,6 +25,7 @@ struct HostIO {
     static void st_agent(uint32_t *p, uint32_t v) { *p = v; }
     static uint32_t ld_agent(const uint32_t *p) { return *p; }
     static void drain() {}
+    static void st_quad(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 };
 
 static void make_geom(uint64_t n, uint32_t hist_bits_req, uint32_t nlaunch, Geom &g)
