@@ -1836,23 +1836,20 @@ struct Parser {
                     }
                 }
             } else {
-                // open the nodes the block has made reachable, then merge its edges into their keys; the literal edge of the
-                // block's last node goes the same way
+                // the nodes the block has made reachable: its edges that end beyond it become their keys (merged with what earlier
+                // blocks left for the nodes that were open already); the literal edge of the block's last node goes the same way
                 const uint32_t new_end = blk_end;
-                for (uint32_t t = end_open + 1 + tid; t <= new_end; t += kParserThreads) L()->mprev[t & 511u] = kKeyNone;
-                xw::block_sync();
                 for (uint32_t t = b0 + nb + tid; t <= new_end; t += kParserThreads) {
-                    const unsigned long long kc = L()->mcur[lbuf][t & 511u];
-                    if (kc < L()->mprev[t & 511u]) L()->mprev[t & 511u] = kc;
+                    unsigned long long k = L()->mcur[lbuf][t & 511u];
+                    if (t <= end_open) { const unsigned long long kp = L()->mprev[t & 511u]; if (kp < k) k = kp; }
+                    if (t == b0 + nb) {
+                        const unsigned long long kl = ((unsigned long long)(L()->sh[11] + L()->sh[10]) << 32) | ((b0 + nb - 1) << 8) | kRankLit;
+                        if (kl < k) k = kl;                         // (equal cost: the smaller source wins, :1492 strict)
+                        L()->sh[9] = L()->sh[6];
+                    }
+                    L()->mprev[t & 511u] = k;
                 }
-                xw::block_sync();
-                if (tid == 0) {
-                    const uint32_t last = b0 + nb - 1;
-                    const unsigned long long kl = ((unsigned long long)(L()->sh[11] + L()->sh[10]) << 32) | (last << 8) | kRankLit;
-                    if (kl < L()->mprev[(last + 1) & 511u]) L()->mprev[(last + 1) & 511u] = kl;     // (equal cost: the smaller source wins, :1492 strict)
-                    L()->sh[9] = L()->sh[6];
-                    if (new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
-                }
+                if (tid == 0 && new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
                 if (new_end > end_open) end_open = new_end;
                 end_p = new_end;
                 b0 += nb;
