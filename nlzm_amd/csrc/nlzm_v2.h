@@ -30,8 +30,8 @@ constexpr uint32_t kFtRing = 1u << 14;          // finder -> table: positions in
 constexpr uint32_t kFtStride = 16;              // words per position
 constexpr uint32_t kTpRing = 1u << 13;          // table -> parser
 constexpr uint32_t kMaxEdges = 32;              // sampled lengths per position (:1558-1560: at most 32, at max_len 33)
-constexpr uint32_t kTpStride = 2 + 2 * kMaxEdges + 2;   // header (2), edges (distance, attributes), the mask of samples with a new distance (2)
-constexpr uint32_t kTpUniq = 2 + 2 * kMaxEdges;
+constexpr uint32_t kTpStride = 2 + 2 + 2 * kMaxEdges;   // header (2), the mask of samples with a new distance (2), edges (distance, attributes)
+constexpr uint32_t kTpUniq = 2, kTpEdges = 4;           // (header + mask, and every two edges, are ONE 16-byte store of the table stage)
 constexpr uint32_t kFrontMax = 264;             // entries of a front (one per length at most)
 constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the front ring (end, distance)
 
@@ -44,7 +44,8 @@ constexpr uint32_t kFtBt = 8u, kFtTop = 16u;
 // table -> parser record:
 //   w0        edges (bits 0..5) | input byte << 8 | table length (mt.max_len) << 16
 //   w1        entries of the front in the front ring
-//   w2..      per sampled length: distance, length | length value << 9 | distance slot << 18 | extra bits << 24 | valid << 31
+//   w2, w3    the mask of sampled lengths that bring a new distance
+//   w4..      per sampled length: distance, length | length value << 9 | distance slot << 18 | extra bits << 24 | valid << 31
 struct Hx {                                     // progress words, one 128-byte line each
     alignas(128) uint32_t f_pos;                // finder: records of positions < f_pos are written
     alignas(128) uint32_t t_pos;                // table: records of positions < t_pos are consumed
@@ -541,7 +542,7 @@ struct Finder {
             st[0] = w0; st[1] = a;
             uint32_t *dst = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
 #pragma unroll
-            for (int k = 0; k < 8; k++) xw::st_agent64((unsigned long long *)(dst + 2 * k), (unsigned long long)st[2 * k] | ((unsigned long long)st[2 * k + 1] << 32));
+            for (int k = 0; k < 4; k++) xw::st_agent128(dst + 4 * k, st[4 * k], st[4 * k + 1], st[4 * k + 2], st[4 * k + 3]);
         }
         xw::drain();
         // ---- state after lane m - 1
@@ -809,23 +810,26 @@ struct Table {
             step += step == 0;
             uint32_t j = 0;
             unsigned long long kj = f[0], kn = fn > 1 ? f[1] : 0;
+            unsigned long long held = 0;                        // the edge before, until it goes out with its neighbour
             for (uint32_t tl = max_len; tl >= kMatchMin; tl -= umin(tl, step)) {
                 while (j + 1 < fn && fr_end(kn) >= a + tl) { j++; kj = kn; kn = j + 1 < fn ? f[j + 1] : 0; }   // the entry with the smallest end >= a + tl
                 const uint32_t d = fr_dist(kj), mm = match_min(d);
                 uint32_t nx, ex;
                 const uint32_t slot = dist_slot(d - 1, nx, ex);
                 const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
-                xw::st_agent64((unsigned long long *)(rec + 2 + 2 * ne),
-                               (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32));
+                const uint32_t at = tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31);
+                if (ne & 1u) xw::st_agent128(rec + kTpEdges + 2 * (ne - 1), (uint32_t)held, (uint32_t)(held >> 32), d, at);
+                else held = (unsigned long long)d | ((unsigned long long)at << 32);
                 if (valid && d != dprev) uniq |= 1u << ne;      // the valid samples that bring a distance the one before did not have
                 if (valid) dprev = d;
                 ne++;
             }
+            if (ne & 1u) xw::st_agent64((unsigned long long *)(rec + kTpEdges + 2 * (ne - 1)), held);
         }
-        xw::st_agent64((unsigned long long *)rec, (unsigned long long)(ne | (lit << 8) | (mt_max << 16)) | ((unsigned long long)fn << 32));
-        xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
-        for (uint32_t k = 0; k < fn; k++)
-            xw::st_agent64((unsigned long long *)(fo + 2 * k), (unsigned long long)(fr_end(f[k]) - a) | ((unsigned long long)fr_dist(f[k]) << 32));
+        xw::st_agent128(rec, ne | (lit << 8) | (mt_max << 16), fn, uniq, 0u);
+        for (uint32_t k = 0; k + 1 < fn; k += 2)
+            xw::st_agent128(fo + 2 * k, fr_end(f[k]) - a, fr_dist(f[k]), fr_end(f[k + 1]) - a, fr_dist(f[k + 1]));
+        if (fn & 1u) xw::st_agent64((unsigned long long *)(fo + 2 * (fn - 1)), (unsigned long long)(fr_end(f[fn - 1]) - a) | ((unsigned long long)fr_dist(f[fn - 1]) << 32));
     }
 
     XW_FN void capture(uint32_t a, const unsigned long long *f, uint32_t fn);
@@ -1355,7 +1359,7 @@ struct Parser {
         uint32_t lim = lo + kStagePos;
         if ((int32_t)(t_out_seen - lim) < 0) lim = t_out_seen;
         const uint32_t n = (int32_t)(lim - st_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - st_req) : 0u;
-        const uint32_t wsrc = wi == kStageQ - 1 ? kTpUniq / 2 : wi;
+        const uint32_t wsrc = wi == 0 ? 0u : (wi == kStageQ - 1 ? kTpUniq / 2 : kTpEdges / 2 + wi - 1);   // (staged: header, sixteen edges, mask)
 #pragma unroll
         for (uint32_t u = 0; u < kPumpLoads; u++) {
             const uint32_t rr = kPumpRecs * u + ri;
@@ -1421,7 +1425,7 @@ struct Parser {
             valid = tl >= mm ? 1u : 0u;
             const uint32_t lv = valid ? tl - mm : 0u;
             const unsigned long long e = (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32);
-            xw::st_agent64((unsigned long long *)(rec + 2 + 2 * k), e);
+            xw::st_agent64((unsigned long long *)(rec + kTpEdges + 2 * k), e);
             if (k < kStageEdges) L()->stage[(a & (kStagePos - 1)) * kStageQ + 1 + k] = e;
         }
         // the valid samples that bring a distance the valid one before did not have (as the table stage lists them)
@@ -1645,7 +1649,7 @@ struct Parser {
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                     const uint32_t k = edge_of(w, j);
-                    er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + 2 + 2 * k))) : 0ull;
+                    er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < kEdgesPerWave; j++) {
@@ -1668,7 +1672,7 @@ struct Parser {
 #pragma unroll
                 for (uint32_t z = 0; z < 8; z++) {
                     const uint32_t k = um ? (uint32_t)__builtin_ctz(um) : 0u;
-                    dd[z] = um ? (k < kStageEdges ? (uint32_t)srec[1 + k] : xw::ld_agent(rec + 2 + 2 * k)) : 0u;
+                    dd[z] = um ? (k < kStageEdges ? (uint32_t)srec[1 + k] : xw::ld_agent(rec + kTpEdges + 2 * k)) : 0u;
                     um &= um - 1;
                 }
             }

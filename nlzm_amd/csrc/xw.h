@@ -98,6 +98,15 @@ XW_FN void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC
 XW_FN uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void st_agent64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sixteen bytes (16-byte aligned) in ONE write-through store: lands whole, and costs what a plain store does where four 4-byte
+// sc1 stores are four fabric writes.  (s_nop: the data registers of a store of more than eight bytes may not be written in the
+// cycle after it -- a hazard the compiler resolves for its own stores, not for this one.)
+XW_FN void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 v = { a, b, c, d };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"((__attribute__((address_space(1))) uint32_t *)p), "v"(v) : "memory");
+}
 XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // *p = v if *p == expect; returns what was there
@@ -227,6 +236,7 @@ inline void st_agent(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t ld_agent(const uint32_t *p) { return *(volatile const uint32_t *)p; }
 inline void st_agent64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline unsigned long long ld_agent64(const unsigned long long *p) { return *(volatile const unsigned long long *)p; }
+inline void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
 inline uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v) { const uint32_t o = *p; if (o == expect) *p = v; return o; }
