@@ -153,6 +153,17 @@ int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks
 int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req,
                              uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
 
+/* ---- independent blocks on several GPUs of one node ------------------------ */
+/* devices[0..ndev): HIP device ordinals, each listed once.  The input is cut into ndev * blocks_per_dev blocks exactly as
+ * nlzm_hip_compress_blocks cuts it for that many blocks (the reference side: one encode_file call per byte range,
+ * NLZM.cpp:1711); device i compresses blocks [i*blocks_per_dev, (i+1)*blocks_per_dev) in block mode on a host thread and a
+ * device context of its own (nlzm_hip_init is not needed for it, and the process-wide context is left as it was).  No GPU
+ * talks to another while compressing; the streams are then gathered onto devices[0], GPU to GPU (over xGMI where the
+ * devices are linked), and copied out in block order.  block_len: ndev * blocks_per_dev entries (may be NULL). */
+int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t blocks_per_dev,
+                                   const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
+                                   uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
+
 /* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
 /* key: "workers" (0 = BT4 inside the master workgroup, 1 = per-head worker
  * lanes, default 1), "batch_chunks" (chunks per persistent launch). */

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nlzm_hip_stream_step", "nlzm_hip_stream_finish", "nlzm_hip_get_stats", "nlzm_hip_get_timing",
     "nlzm_hip_rans_frames", "nlzm_hip_find_matches", "nlzm_hip_parse_emit", "nlzm_hip_set_option",
     "nlzm_hip_blocks_begin", "nlzm_hip_blocks_step", "nlzm_hip_blocks_finish", "nlzm_hip_blocks_abandon",
-    "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks",
+    "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks", "nlzm_hip_compress_blocks_multi",
 ]
 
 
@@ -102,6 +102,8 @@ def load_library() -> C.CDLL:
     lib.nlzm_hip_blocks_finish.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p]
     lib.nlzm_hip_blocks_abandon.restype = None
     lib.nlzm_hip_compress_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
+    lib.nlzm_hip_compress_blocks_multi.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                   C.c_void_p, C.c_uint64, u64p, u64p]
     lib.nlzm_hip_compress_blocks_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
     _lib = lib
     return lib
@@ -154,6 +156,28 @@ def compress_blocks(data, nblocks: int, hist_bits: int = 22) -> list[bytes]:
     lens = (C.c_uint64 * nblocks)()
     out_len = C.c_uint64(0)
     _chk(lib.nlzm_hip_compress_blocks(src.ctypes.data if n else None, n, nblocks, hist_bits, dst.ctypes.data, cap, lens, C.byref(out_len)))
+    out, pos = [], 0
+    for i in range(nblocks):
+        out.append(dst[pos: pos + int(lens[i])].tobytes())
+        pos += int(lens[i])
+    assert pos == out_len.value
+    return out
+
+
+def compress_blocks_multi(data, devices: list[int], blocks_per_dev: int, hist_bits: int = 22) -> list[bytes]:
+    """len(devices) * blocks_per_dev independent streams, blocks_per_dev of them in flight on each listed GPU of this node
+    (one host thread per GPU inside the library, no traffic between the GPUs but the final gather onto devices[0])."""
+    lib = load_library()
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    n = int(src.size)
+    nblocks = len(devices) * blocks_per_dev
+    cap = int(lib.nlzm_hip_compress_bound(n)) + nblocks * (16 + 131072)
+    dst = np.empty(cap, dtype=np.uint8)
+    lens = (C.c_uint64 * nblocks)()
+    out_len = C.c_uint64(0)
+    devs = (C.c_int * len(devices))(*devices)
+    _chk(lib.nlzm_hip_compress_blocks_multi(devs, len(devices), blocks_per_dev, src.ctypes.data if n else None, n, hist_bits,
+                                            dst.ctypes.data, cap, lens, C.byref(out_len)))
     out, pos = [], 0
     for i in range(nblocks):
         out.append(dst[pos: pos + int(lens[i])].tobytes())

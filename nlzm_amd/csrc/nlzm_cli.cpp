@@ -225,6 +225,7 @@ int main(int argc, char **argv)
     crc_init();
     uint32_t hist_bits = 22;                                                      // :2071
     uint32_t nblocks = 1;                           // -blocks:k (not in the reference): k independent streams, back to back
+    uint32_t ngpus = 0;                             // -gpus:g (not in the reference): the blocks on g GPUs of this node, -blocks:k on each
     while (argc >= 2 && *argv[1] == '-') {
         char *arg = argv[1];
         argv++; argc--;
@@ -238,6 +239,10 @@ int main(int argc, char **argv)
             const int v = atoi(arg + 7);
             nblocks = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
             printf("Blocks: %d\n", nblocks);
+        } else if (!strncmp(arg, "gpus:", 5)) {
+            const int v = atoi(arg + 5);
+            ngpus = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+            printf("GPUs: %d\n", ngpus);
         } else {
             printf("Unrecognized flag %s\n", arg);
             return -1;
@@ -250,7 +255,8 @@ int main(int argc, char **argv)
         if (!slurp(argv[2], in)) { printf("Error: %s file does not exist\n", argv[2]); return -1; }
         FILE *fout = fopen(argv[3], "wb");
         if (!fout) { printf("Error: %s file does not exist\n", argv[3]); return -1; }
-        if (nlzm_hip_init(0)) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
+        if (!ngpus && nlzm_hip_init(0)) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
+        const uint32_t nstreams = ngpus ? ngpus * nblocks : nblocks;
         uint32_t hb, fb, cs, feed;
         nlzm_hip_geometry(in.size(), hist_bits, &hb, &fb, &cs, &feed);
         {   // the reference's summary (:1755-1759): sizes of its own structures for this window
@@ -262,17 +268,20 @@ int main(int argc, char **argv)
             printf("Frame: %d KB\n", (int)(((1u << fb) + 1023) >> 10));
             printf("Dictionary search: %d KB\n", (int)((mf + 1023) >> 10));
         }
-        if (nblocks > 1)
-            printf("Note: -blocks:%u writes %u independent streams back to back; this program's d/t read them, the reference's d "
-                   "stops after the first\n", nblocks, nblocks);
+        if (nstreams > 1)
+            printf("Note: %u independent streams are written back to back; this program's d/t read them, the reference's d "
+                   "stops after the first\n", nstreams);
         printf("Working...\r");
-        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nblocks * (16 + 131072));
+        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nstreams * (16 + 131072));
         uint64_t out_n = 0;
         const clock_t t0 = clock();
         struct timespec w0, w1;
         clock_gettime(CLOCK_MONOTONIC, &w0);
-        std::vector<uint64_t> blen(nblocks);
-        const int rc = nblocks > 1 ? nlzm_hip_compress_blocks(in.data(), in.size(), nblocks, hist_bits, out.data(), out.size(), blen.data(), &out_n)
+        std::vector<uint64_t> blen(nstreams);
+        std::vector<int> devs;
+        for (uint32_t d = 0; d < ngpus; d++) devs.push_back((int)d);
+        const int rc = ngpus ? nlzm_hip_compress_blocks_multi(devs.data(), ngpus, nblocks, in.data(), in.size(), hist_bits, out.data(), out.size(), blen.data(), &out_n)
+                     : nblocks > 1 ? nlzm_hip_compress_blocks(in.data(), in.size(), nblocks, hist_bits, out.data(), out.size(), blen.data(), &out_n)
                                    : nlzm_hip_compress(in.data(), in.size(), hist_bits, out.data(), out.size(), &out_n);
         clock_gettime(CLOCK_MONOTONIC, &w1);
         (void)t0;
@@ -299,6 +308,7 @@ int main(int argc, char **argv)
         // one stream (the reference's format), or several back to back (block mode): found by hopping over the frames,
         // decoded on a host thread each, written in order
         std::vector<Span> parts;
+        size_t cut_tail = 0;
         for (size_t pos = 0; pos < in.size();) {
             const Span rest{ in.data() + pos, in.size() - pos };
             const size_t len = stream_length(rest);
@@ -306,8 +316,11 @@ int main(int argc, char **argv)
                 // what follows is not a stream: the reference stops at the first terminator (:646-648) and so do we;
                 // a container that is cut off inside its first stream is malformed
                 if (parts.empty()) break;
-                if (rest.n >= 4 && rest.p[0] == 0 && (rest.p[1] >= 10 && rest.p[1] <= 28)) { parts.clear(); break; }   // looks like a cut-off block
-                printf("Note: %zu bytes after the last stream ignored\n", rest.n);
+                // a further stream header (:1915-1921: hist_bits, frame_bits, both big-endian 16-bit) with a frame that is cut off:
+                // the complete streams are decoded and written, and the exit status says that the container was cut
+                const bool header = rest.n >= 4 && rest.p[0] == 0 && rest.p[1] >= 10 && rest.p[1] <= 28 && rest.p[2] == 0 && rest.p[3] >= 12 && rest.p[3] <= 20;
+                if (header) cut_tail = rest.n;
+                else printf("Note: %zu bytes after the last stream ignored\n", rest.n);
                 break;
             }
             parts.push_back(Span{ rest.p, len });
@@ -333,6 +346,7 @@ int main(int argc, char **argv)
         if (fout) { fwrite(out.data(), 1, out.size(), fout); fclose(fout); }
         printf("Working... %" PRIu64 " -> %" PRIu64 "\n", (uint64_t)in.size(), (uint64_t)out.size());
         printf("Done (output CRC32 %X, %.2f sec)\n", crc_calc(out.data(), out.size(), 0), (clock() - t0) / (double)CLOCKS_PER_SEC);
+        if (cut_tail) { printf("Error: the container is cut off inside block %zu (%zu bytes of it present); %zu complete blocks decoded\n", parts.size() + 1, cut_tail, parts.size()); return -2; }
     } else if (argc == 3 && cmd == 'h') {
         std::vector<uint8_t> in;
         if (!slurp(argv[2], in)) { printf("Error: %s file does not exist\n", argv[2]); return -1; }
@@ -345,7 +359,8 @@ int main(int argc, char **argv)
                "\th [input] - Calculate CRC32 for input file\n"
                "Flags:\n"
                "\t-window:bits = Maximum window size in bits, default 22 (4 MB), min 15, max 28 (32 KB to 256 MB)\n"
-               "\t-blocks:k = (this build) compress k independent blocks at once; d/t read the streams back to back\n");
+               "\t-blocks:k = (this build) compress k independent blocks at once; d/t read the streams back to back\n"
+               "\t-gpus:g = (this build) the blocks on GPUs 0..g-1 of this node, -blocks:k of them on each\n");
     }
     return 0;
 }

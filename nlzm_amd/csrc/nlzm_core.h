@@ -140,7 +140,7 @@ struct Globals {
     uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
     const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
     const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
-    const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size] positions grouped by bin, ascending
+    const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size][2] positions grouped by bin, ascending: position, BT4 head | unc << 31
     uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)
@@ -308,33 +308,44 @@ struct ResultSink {
     }
 };
 
+// what a worker lane's call touches (a view of Geom / Globals: the worker role holds these as values of its own)
+struct BtView {
+    const uint8_t *in;
+    uint32_t *heads, *tree, *ready, *pairs;
+    uint32_t batch_a0, bt_shift, wmask, tmask;
+};
+NLZM_HD BtView bt_view(const Geom &g, const Globals &G)
+{
+    return BtView{ G.in, G.bt_heads, G.bt_tree, G.bt_ready, G.bt_pairs, G.batch_a0, g.bt_shift, g.wmask, g.bt_tmask };
+}
+
 // the dry run of an `unc` position with its stores noted down by `st`
 template <class IO, class St>
-NLZM_HD void worker_bt_dry(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, unsigned long long &n_tests,
-                           unsigned long long &cmp_bytes, St &st)
+NLZM_HD void worker_bt_dry(const BtView &B, uint32_t a, uint32_t max_len, unsigned long long &n_tests,
+                           unsigned long long &cmp_bytes, St &st, uint32_t head = kNone /* the position's BT4 head, if the caller has it */)
 {
     LaneCmp cmp{ &cmp_bytes };
-    const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ G.bt_pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    const unsigned long long bi = a - B.batch_a0;
+    ResultSink<IO> sink{ B.pairs + bi * (2 * kBtMaxPairs), 0, 1 };
     uint32_t tests = 0;
-    const uint32_t h4 = hash4(load32u(G.in + a));
-    bt_find_and_update_st(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests, st);
+    const uint32_t h4 = head == kNone ? hash4(load32u(B.in + a)) : head << B.bt_shift;     // (only h4 >> bt_shift is used)
+    bt_find_and_update_st(B.heads, B.tree, B.bt_shift, B.wmask, B.tmask, B.in, a, h4, max_len, cmp, sink, tests, st);
     n_tests += tests;
-    sink.publish(G.bt_ready + bi * kBtRec, tests);
+    sink.publish(B.ready + bi * kBtRec, tests);
 }
 
 template <class IO, bool kWrite>
-NLZM_HD void worker_bt_call(const Geom &g, const Globals &G, uint32_t a, uint32_t max_len, bool publish,
-                            unsigned long long &n_tests, unsigned long long &cmp_bytes)
+NLZM_HD void worker_bt_call(const BtView &B, uint32_t a, uint32_t max_len, bool publish,
+                            unsigned long long &n_tests, unsigned long long &cmp_bytes, uint32_t head = kNone)
 {
     LaneCmp cmp{ &cmp_bytes };
-    const unsigned long long bi = a - G.batch_a0;
-    ResultSink<IO> sink{ publish ? G.bt_pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
+    const unsigned long long bi = a - B.batch_a0;
+    ResultSink<IO> sink{ publish ? B.pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
     uint32_t tests = 0;
-    const uint32_t h4 = hash4(load32u(G.in + a));
-    bt_find_and_update<kWrite>(G.bt_heads, G.bt_tree, g.bt_shift, g.wmask, g.bt_tmask, G.in, a, h4, max_len, cmp, sink, tests);
+    const uint32_t h4 = head == kNone ? hash4(load32u(B.in + a)) : head << B.bt_shift;
+    bt_find_and_update<kWrite>(B.heads, B.tree, B.bt_shift, B.wmask, B.tmask, B.in, a, h4, max_len, cmp, sink, tests);
     n_tests += tests;
-    if (publish) sink.publish(G.bt_ready + bi * kBtRec, tests);
+    if (publish) sink.publish(B.ready + bi * kBtRec, tests);
 }
 
 }  // namespace nlzm

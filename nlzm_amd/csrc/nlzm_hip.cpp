@@ -35,7 +35,7 @@ void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t wo
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
-                uint32_t *pos, hipStream_t st);
+                uint32_t *pos, const uint8_t *unc, uint32_t batch_a0, hipStream_t st);
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
                  FrameMeta *fmeta, uint32_t *scratch, unsigned long long scratch_stride, uint8_t *out,
                  unsigned long long out_stride, uint32_t out_cap, uint32_t nframes, hipStream_t st);
@@ -129,7 +129,41 @@ struct Ctx {
     unsigned long long last_dry_runs = 0, last_flag_waits = 0;
 };
 
-Ctx g_ctx;                  // the context behind the single-stream entry points
+struct BlockJob {
+    Ctx c;
+    uint64_t lo = 0, n = 0, len = 0, bound = 0;
+    uint8_t *d_out = nullptr;
+    int rc = 0;
+};
+
+// Everything the entry points keep per device: the single-stream context and the open block set.  The process-wide one serves
+// the one-device API (nlzm_hip_init picks its device); a multi-device call gives each of its per-device host threads one
+// of its own and points `t_dev` at it, so that the same code runs on every device at once.
+struct DevState {
+    Ctx ctx;                                        // the context behind the single-stream entry points
+    std::vector<BlockJob> jobs;                     // the open block set (nlzm_hip_blocks_begin .. _finish)
+    std::vector<hipStream_t> group_st;              // one HIP stream and an event pair per shared launch of a round
+    std::vector<std::array<hipEvent_t, 2>> group_ev;
+    void *pack_host = nullptr, *pack_dev = nullptr; // the streams' launch arguments of a round: pinned host copy, device copy
+    uint64_t blocks_n = 0;
+    const uint8_t *blocks_src = nullptr;
+    uint32_t blocks_hist = 0;
+    int64_t blocks_wb = 0;
+    uint64_t blocks_per = 0;                        // bytes per block when the caller fixes the partition (0: ceil(n / nblocks))
+};
+DevState g_dev0;
+thread_local DevState *t_dev = nullptr;
+inline DevState &cur() { return t_dev ? *t_dev : g_dev0; }
+#define g_ctx (cur().ctx)
+#define g_jobs (cur().jobs)
+#define g_group_st (cur().group_st)
+#define g_group_ev (cur().group_ev)
+#define g_pack_host (cur().pack_host)
+#define g_pack_dev (cur().pack_dev)
+#define g_blocks_n (cur().blocks_n)
+#define g_blocks_src (cur().blocks_src)
+#define g_blocks_hist (cur().blocks_hist)
+#define g_blocks_wb (cur().blocks_wb)
 
 void free_stream_buffers(Ctx &C)
 {
@@ -282,7 +316,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMalloc(&C.abort_word, 4));
         HIPCHK(hipMalloc(&C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4));
         HIPCHK(hipMalloc(&C.bin_cur, (size_t)C.batch * C.nheads * 4));
-        HIPCHK(hipMalloc(&C.bin_pos, bpos * 4));
+        HIPCHK(hipMalloc(&C.bin_pos, bpos * 8));
         HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
         HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
     }
@@ -347,7 +381,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
         launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
                          C.pf_c1, C.unc, C.st);
-        launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.st);
+        launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
     }
     {   // progress words of the stages: everything before the launch's first position is done
         v2::Hx &h = C.hx_host;          // (lives until the copy has been made)
@@ -542,9 +576,10 @@ int stream_finish(Ctx &C, uint64_t *dst_len)
 
 extern "C" {
 
-int nlzm_hip_init(int device)
+static void dev_shutdown(DevState &D);
+static int dev_init(DevState &D, int device)
 {
-    Ctx &C = g_ctx;
+    Ctx &C = D.ctx;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return set_err(NLZM_HIP_E_NODEVICE, "no HIP device (%s)", hipGetErrorString(e));
@@ -555,7 +590,7 @@ int nlzm_hip_init(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(NLZM_HIP_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     if (C.inited && C.device == device) return 0;
-    if (C.inited) nlzm_hip_shutdown();
+    if (C.inited) dev_shutdown(D);
     C.device = device;
     C.cu_count = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking));
@@ -564,11 +599,16 @@ int nlzm_hip_init(int device)
     return 0;
 }
 
-void nlzm_hip_shutdown(void)
+int nlzm_hip_init(int device) { return dev_init(cur(), device); }
+
+static void dev_shutdown(DevState &D)
 {
-    Ctx &C = g_ctx;
+    Ctx &C = D.ctx;
     if (!C.inited) return;
+    DevState *keep = t_dev;
+    t_dev = &D;
     blocks_close();
+    t_dev = keep;
     free_stream_buffers(C);
     if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
     if (C.cap_used) { (void)hipFree(C.cap_used); C.cap_used = nullptr; }
@@ -576,6 +616,7 @@ void nlzm_hip_shutdown(void)
     if (C.st) { (void)hipStreamDestroy(C.st); C.st = nullptr; }
     C.inited = false;
 }
+void nlzm_hip_shutdown(void) { dev_shutdown(cur()); }
 
 const char *nlzm_hip_last_error(void) { return g_err; }
 
@@ -784,13 +825,6 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req, 
 // ---- independent blocks --------------------------------------------------------------
 namespace {
 
-struct BlockJob {
-    Ctx c;
-    uint64_t lo = 0, n = 0, len = 0, bound = 0;
-    uint8_t *d_out = nullptr;
-    int rc = 0;
-};
-
 int block_ctx_init(Ctx &c, int device, int64_t worker_blocks, int64_t batch)
 {
     c.device = device;
@@ -811,15 +845,6 @@ void block_ctx_destroy(Ctx &c)
 }  // namespace
 
 namespace {
-std::vector<BlockJob> g_jobs;       // the open block set (nlzm_hip_blocks_begin .. _end)
-std::vector<hipStream_t> g_group_st;             // one HIP stream and an event pair per shared launch of a round
-std::vector<std::array<hipEvent_t, 2>> g_group_ev;
-void *g_pack_host = nullptr, *g_pack_dev = nullptr;     // the streams' launch arguments of a round: pinned host copy, device copy
-uint64_t g_blocks_n = 0;
-const uint8_t *g_blocks_src = nullptr;
-uint32_t g_blocks_hist = 0;
-int64_t g_blocks_wb = 0;
-
 void blocks_close()
 {
     for (auto &j : g_jobs) { if (j.d_out) (void)hipFree(j.d_out); j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
@@ -836,10 +861,12 @@ void blocks_close()
 template <class F>
 void for_blocks(uint32_t conc, F f)
 {
-    const int device = g_ctx.device;
+    DevState &D = cur();
+    const int device = D.ctx.device;
     std::mutex mu;
     uint32_t next_block = 0;
     auto worker = [&]() {
+        t_dev = &D;
         (void)hipSetDevice(device);
         for (;;) {
             uint32_t i;
@@ -858,6 +885,8 @@ extern "C" {
 int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req)
 {
     Ctx &C = g_ctx;
+    const uint64_t per_fixed = cur().blocks_per;    // (a multi-device call fixes the partition; cleared here)
+    cur().blocks_per = 0;
     if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
     if (!nblocks || nblocks > 64) return set_err(NLZM_HIP_E_ARG, "nblocks out of range");
     blocks_close();
@@ -880,7 +909,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double per_stream = 0.85 * (double)free_b / nblocks;
         Geom g0;
-        make_geom((n + nblocks - 1) / nblocks, hist_bits_req, g0);
+        make_geom(per_fixed ? per_fixed : (n + nblocks - 1) / nblocks, hist_bits_req, g0);
         const double fixed = 8.0 * ((double)g0.wmask + 1) * 2 + 4.0 * (double)g0.n + 5e7;     // BT4 tree (widened), RK hashes, the rest
         double left = per_stream - fixed;
         if (left < 2e8) return set_err(NLZM_HIP_E_NOMEM, "%u streams of %llu bytes at -window:%u do not fit %.1f GB of free memory", nblocks,
@@ -891,7 +920,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         if (fit < 1) return set_err(NLZM_HIP_E_NOMEM, "%u streams do not fit the device memory", nblocks);
         if (batch > fit) batch = fit;
     }
-    const uint64_t per = (n + nblocks - 1) / nblocks;              // block i = [i*per, min(n, (i+1)*per))
+    const uint64_t per = per_fixed ? per_fixed : (n + nblocks - 1) / nblocks;     // block i = [i*per, min(n, (i+1)*per))
     g_jobs.resize(nblocks);
     for (uint32_t i = 0; i < nblocks; i++) {
         g_jobs[i].lo = (uint64_t)i * per < n ? (uint64_t)i * per : n;
@@ -1085,6 +1114,98 @@ int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, u
     if (!rc && hipMemcpy(dst, d_out, len, hipMemcpyDeviceToHost) != hipSuccess) rc = set_err(NLZM_HIP_E_NODEVICE, "copy back failed");
     (void)hipFree(d_in); (void)hipFree(d_out);
     if (!rc) *dst_len = len;
+    return rc;
+}
+
+// ---- independent blocks on several GPUs of one node -------------------------------------------------
+// One host thread and one device state per GPU; device i compresses blocks [i*m, (i+1)*m) of the n-byte input's partition into
+// ndev*m blocks (the same byte ranges nlzm_hip_compress_blocks uses for that many blocks) in block mode; there is no traffic
+// between the GPUs while they compress.  The only exchange is the final gather of the streams onto the first device of the
+// list, GPU to GPU (hipMemcpyPeerAsync: over xGMI where the devices are linked), from where the artifact goes to the host.
+int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t blocks_per_dev, const uint8_t *src, uint64_t n,
+                                   uint32_t hist_bits_req, uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len)
+{
+    if (!devices || !ndev || !blocks_per_dev || (!src && n) || !dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
+    if (ndev > 64) return set_err(NLZM_HIP_E_ARG, "more than 64 devices");
+    for (uint32_t i = 0; i < ndev; i++)
+        for (uint32_t k = 0; k < i; k++)
+            if (devices[i] == devices[k]) return set_err(NLZM_HIP_E_ARG, "device %d is listed twice", devices[i]);
+    const uint64_t nb_total = (uint64_t)ndev * blocks_per_dev;
+    const uint64_t per = n ? (n + nb_total - 1) / nb_total : 1;
+    struct Part {
+        DevState D;
+        int device = 0, rc = 0;
+        uint64_t lo = 0, n = 0, bound = 0, len = 0;
+        uint8_t *d_in = nullptr, *d_out = nullptr;
+        std::vector<uint64_t> blens;
+        char msg[sizeof g_err] = "";
+    };
+    std::vector<Part> parts(ndev);
+    auto run_part = [&](uint32_t i) {
+        Part &P = parts[i];
+        t_dev = &P.D;
+        P.device = devices[i];
+        P.lo = (uint64_t)i * blocks_per_dev * per < n ? (uint64_t)i * blocks_per_dev * per : n;
+        const uint64_t hi = (uint64_t)(i + 1) * blocks_per_dev * per < n ? (uint64_t)(i + 1) * blocks_per_dev * per : n;
+        P.n = hi - P.lo;
+        P.bound = nlzm_hip_compress_bound(P.n) + (uint64_t)blocks_per_dev * (16 + 131072);
+        P.blens.assign(blocks_per_dev, 0);
+        P.rc = [&]() -> int {
+            int rc = dev_init(P.D, P.device);
+            if (rc) return rc;
+            HIPCHK(hipMalloc(&P.d_in, P.n + 512));
+            HIPCHK(hipMalloc(&P.d_out, P.bound));
+            HIPCHK(hipMemset(P.d_in + P.n, 0, 512));
+            if (P.n) HIPCHK(hipMemcpy(P.d_in, src + P.lo, P.n, hipMemcpyHostToDevice));
+            P.D.blocks_per = per;
+            return nlzm_hip_compress_blocks_dev(P.d_in, P.n, blocks_per_dev, hist_bits_req, P.d_out, P.bound, P.blens.data(), &P.len);
+        }();
+        if (P.rc) { std::lock_guard<std::mutex> lk(g_err_mu); snprintf(P.msg, sizeof P.msg, "device %d: %.*s", P.device, (int)sizeof P.msg - 32, g_err); }
+        t_dev = nullptr;
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < ndev; i++) th.emplace_back(run_part, i);
+        for (auto &t : th) t.join();
+    }
+    int rc = 0;
+    uint64_t total = 0;
+    for (auto &P : parts) { if (P.rc && !rc) { rc = P.rc; std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, P.msg, sizeof g_err); } total += P.len; }
+    if (!rc && total > dst_cap) rc = set_err(NLZM_HIP_E_CAPACITY, "streams are %llu bytes, dst_cap %llu", (unsigned long long)total, (unsigned long long)dst_cap);
+    if (!rc) {
+        // the gather: every device's streams onto the first one, in block order, then one copy to the host
+        const int root = parts[0].device;
+        uint8_t *d_all = nullptr;
+        rc = [&]() -> int {
+            HIPCHK(hipSetDevice(root));
+            if (ndev == 1) { HIPCHK(hipMemcpy(dst, parts[0].d_out, total, hipMemcpyDeviceToHost)); return 0; }
+            HIPCHK(hipMalloc(&d_all, total ? total : 1));
+            uint64_t off = 0;
+            for (auto &P : parts) {
+                if (P.len) HIPCHK(hipMemcpyPeerAsync(d_all + off, root, P.d_out, P.device, P.len, nullptr));
+                off += P.len;
+            }
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(dst, d_all, total, hipMemcpyDeviceToHost));
+            return 0;
+        }();
+        if (d_all) (void)hipFree(d_all);
+        if (!rc) {
+            if (block_len) for (uint32_t i = 0; i < ndev; i++) for (uint32_t k = 0; k < blocks_per_dev; k++) block_len[(uint64_t)i * blocks_per_dev + k] = parts[i].blens[k];
+            *dst_len = total;
+        }
+    }
+    // the job's counters (nlzm_hip_get_stats of the process-wide context reports them) and the clean-up, device by device
+    memset(&g_dev0.ctx.stats, 0, sizeof g_dev0.ctx.stats);
+    for (auto &P : parts) {
+        uint64_t *d = (uint64_t *)&g_dev0.ctx.stats; const uint64_t *q = (const uint64_t *)&P.D.ctx.stats;
+        for (size_t k = 0; k < sizeof(nlzm_hip_stats) / 8; k++) d[k] += q[k];
+        (void)hipSetDevice(P.device);
+        if (P.d_in) (void)hipFree(P.d_in);
+        if (P.d_out) (void)hipFree(P.d_out);
+        dev_shutdown(P.D);
+    }
+    if (g_dev0.ctx.inited) (void)hipSetDevice(g_dev0.ctx.device);
     return rc;
 }
 

@@ -148,12 +148,15 @@ __global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long lon
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ in, Geom g, uint32_t c0,
                                                    uint32_t nheads /* = bins */, uint32_t *__restrict__ off_all,
-                                                   uint32_t *__restrict__ cur_all, uint32_t *__restrict__ pos_all)
+                                                   uint32_t *__restrict__ cur_all, uint32_t *__restrict__ pos_all,
+                                                   const uint8_t *__restrict__ unc, uint32_t batch_a0)
 {
     const uint32_t ci = c0 + blockIdx.x;
     uint32_t *off = off_all + (unsigned long long)blockIdx.x * (nheads + 1);
     uint32_t *cur = cur_all + (unsigned long long)blockIdx.x * nheads;
-    uint32_t *pos = pos_all + (unsigned long long)blockIdx.x * g.chunk_size;
+    // an entry: the position, and its BT4 head with the pre-filter's mark in bit 31 (what a worker lane needs to start the call:
+    // one load instead of a chain of three)
+    uint32_t *pos = pos_all + (unsigned long long)blockIdx.x * g.chunk_size * 2;
     const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
     const unsigned long long remain = g.n - chunk_abs;
     const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     for (uint32_t t0 = 0; t0 < n_ok; t0 += 1024) {
         const uint32_t p = t0 + threadIdx.x;
         const bool ok = p < n_ok;
-        const uint32_t h = ok ? (hash4(load32u(base + p)) >> g.bt_shift) % nheads : kNone;
+        const uint32_t hfull = ok ? hash4(load32u(base + p)) >> g.bt_shift : 0u;
+        const uint32_t h = ok ? hfull % nheads : kNone;
         heads_t[threadIdx.x] = h;
         __syncthreads();
         uint32_t at = 0, after = 1;
@@ -198,7 +202,9 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
                 after += (o == h) & (t > threadIdx.x);
             }
             at = cur[h] + before;
-            pos[at] = (uint32_t)chunk_abs + p;
+            const uint32_t a = (uint32_t)chunk_abs + p;
+            pos[2 * at] = a;
+            pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u);
         }
         __syncthreads();
         if (ok && !after) cur[h] = at + 1;
@@ -263,8 +269,19 @@ struct StoreLog {
 template <class LB>
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
-    const uint32_t nl = wblocks * blockDim.x;
     const uint32_t gl = wblock * blockDim.x + threadIdx.x;
+    // What a descent touches, as values of this role (made opaque): left as kernel arguments, the compiler re-loads them
+    // from the argument segment inside the test loop -- two 64-byte scalar loads and their waits per test -- rather than keep them.
+    unsigned long long p0 = (unsigned long long)G.in, p1 = (unsigned long long)G.bt_heads, p2 = (unsigned long long)G.bt_tree,
+                       p3 = (unsigned long long)G.bt_ready, p4 = (unsigned long long)G.bt_pairs;
+    uint32_t q0 = G.batch_a0, q1 = g.bt_shift, q2 = g.wmask, q3 = g.bt_tmask;
+    asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2), "+s"(p3), "+s"(p4));
+    asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
+    // (re-typed as global pointers: accesses through pointers of unknown kind would be flat ones)
+#define NLZM_AS_GLOBAL(T, x) ((T *)(__attribute__((address_space(1))) T *)(x))
+    const BtView B{ NLZM_AS_GLOBAL(const uint8_t, p0), NLZM_AS_GLOBAL(uint32_t, p1), NLZM_AS_GLOBAL(uint32_t, p2), NLZM_AS_GLOBAL(uint32_t, p3),
+                    NLZM_AS_GLOBAL(uint32_t, p4), q0, q1, q2, q3 };
+#undef NLZM_AS_GLOBAL
     // Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it,
     // so the position a lane may block on is always its smallest unprocessed one.
     bool active = gl < G.nheads;
@@ -295,29 +312,32 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                     }
                 }
                 if (active) {
-                    const uint32_t *pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size;
+                    const uint32_t *pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size * 2;
                     if (i0 >= e0) { c++; loaded = false; }
                     else {
-                        a = pos[i0++];
+                        const unsigned long long pe = *(const unsigned long long *)(pos + 2 * i0);
+                        i0++;
+                        a = (uint32_t)pe;
+                        const uint32_t hidx = (uint32_t)(pe >> 32) & 0x7FFFFFFFu;
                         max_len = umin(la_end - a, kMatchMax);
-                        if (G.unc[a - G.batch_a0]) {
+                        if (pe >> 63) {
                             // whether this call happens is decided by the master.  If the decision is in already (the
                             // master is ahead of this lane, as it is inside nice regions where 7 of 8 calls are
                             // skipped, :1529), act on it; otherwise its MATCHES do not depend on the decision: report
                             // them now from a dry run, insert once the decision is in
                             const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
                             if (f == kFlagCall) {
-                                worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
+                                worker_bt_call<LaneIO, true>(B, a, max_len, true, n_tests, n_cmp, hidx);
                                 n_calls++;
                             } else if (f != kFlagSkip) {
                                 slog.n = 0; slog.full = false; dry_t = 0; dry_c = 0;
-                                worker_bt_dry<LaneIO>(g, G, a, max_len, dry_t, dry_c, slog);
+                                worker_bt_dry<LaneIO>(B, a, max_len, dry_t, dry_c, slog, hidx);
                                 n_dry++;
                                 stage = 1; t_wait0 = 0; idle = 0;
                             }
                         } else {
                             const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
-                            worker_bt_call<LaneIO, true>(g, G, a, max_len, true, n_tests, n_cmp);
+                            worker_bt_call<LaneIO, true>(B, a, max_len, true, n_tests, n_cmp, hidx);
                             n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
                             n_calls++;
 #ifdef NLZM_LEAD_DIAG
@@ -336,7 +356,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                 if (f == kFlagCall) {
                     // the call happens: what the dry run noted is exactly what it writes
                     if (!slog.full) { slog.replay(G.bt_heads, G.bt_tree); n_tests += dry_t; n_cmp += dry_c; }
-                    else worker_bt_call<LaneIO, true>(g, G, a, max_len, false, n_tests, n_cmp);
+                    else worker_bt_call<LaneIO, true>(B, a, max_len, false, n_tests, n_cmp);
                     n_calls++;
                     stage = 0;
                 } else if (f == kFlagSkip) {
@@ -560,10 +580,10 @@ void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint
 }
 
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
-                uint32_t *pos, hipStream_t st)
+                uint32_t *pos, const uint8_t *unc, uint32_t batch_a0, hipStream_t st)
 {
     if (!nchunks) return;
-    hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos);
+    hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos, unc, batch_a0);
 }
 
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,

@@ -123,14 +123,14 @@ struct SimWorkers {
         unsigned long long dt = 0, dc = 0;
         if (G->unc[a - G->batch_a0]) {
             if (!published[a - G->batch_a0]) {
-                worker_bt_call<HostIO, false>(g, *G, a, max_len, true, dt, dc);
+                worker_bt_call<HostIO, false>(bt_view(g, *G), a, max_len, true, dt, dc);
                 published[a - G->batch_a0] = 1; dry++;
             }
             const uint32_t f = G->bt_flag[a - G->batch_a0];
             if (f == 0) { if (final_flush) { printf("sim: flag of uncertain position %u never published\n", a); exit(1); } return; }
-            if (f == kFlagCall) { worker_bt_call<HostIO, true>(g, *G, a, max_len, false, tests, cmp); calls++; }
+            if (f == kFlagCall) { worker_bt_call<HostIO, true>(bt_view(g, *G), a, max_len, false, tests, cmp); calls++; }
         } else {
-            worker_bt_call<HostIO, true>(g, *G, a, max_len, true, tests, cmp);
+            worker_bt_call<HostIO, true>(bt_view(g, *G), a, max_len, true, tests, cmp);
             published[a - G->batch_a0] = 1; calls++;
         }
         next[h]++;

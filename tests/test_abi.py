@@ -110,8 +110,20 @@ def test_cli_decodes_streams_back_to_back(tmp_path, lib):
     r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(f), str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and f"Blocks: {k}" in r.stdout, r.stdout
     assert out.read_bytes() == data.tobytes()
-    # a cut-off container is refused
+    # a container cut off inside its last block: the complete blocks are decoded and written, the exit status says it was cut
     f.write_bytes(b"".join(streams)[:-3])
+    out2 = tmp_path / "o2.bin"
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(f), str(out2)], capture_output=True, text=True)
+    assert r.returncode not in (0, 255) and "cut off inside block 5" in r.stdout and f"Blocks: {k - 1}" in r.stdout, r.stdout
+    lo4, _ = shard.block_range(data.size, k, k - 1)
+    assert out2.read_bytes() == data.tobytes()[:lo4]
+    # a valid stream followed by bytes that are no stream header: decoded as the reference would (it stops at the first
+    # terminator, NLZM.cpp:646-648), with a note
+    f.write_bytes(streams[0] + b"\x00\x13\x07garbage")
+    r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(f)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ignored" in r.stdout, r.stdout
+    # cut inside the FIRST stream: nothing to decode
+    f.write_bytes(streams[0][:-9])
     r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(f)], capture_output=True, text=True)
     assert r.returncode != 0 and "malformed" in r.stdout
 

@@ -194,6 +194,33 @@ def test_cli_block_mode_round_trip(gpu, tmp_path):
     assert r.returncode == 0 and back.read_bytes() == data.tobytes()
 
 
+def test_multi_device_entry(gpu):
+    """nlzm_hip_compress_blocks_multi with the devices this box has (the GPU box has one: the per-device host thread, the
+    device context of its own, the fixed partition and the gather are what is exercised; more than one GPU only ever runs in
+    the driver's scaling run).  k devices x m blocks = the partition of compress_blocks with k*m blocks, every stream the
+    oracle's for its byte range; the process-wide context is untouched by the call."""
+    import torch
+    from nlzm_amd import shard
+    ndev = torch.cuda.device_count()
+    data = corpus.mixed(1_200_000, corpus.SEED + 17)
+    before = gpu.compress(data[:100_000], 17)
+    for devs, m in (([0], 6), (list(range(ndev)), 3)):
+        got = gpu.compress_blocks_multi(data, devs, m, 19)
+        k = len(devs) * m
+        assert len(got) == k
+        for i, stream in enumerate(got):
+            lo, hi = shard.block_range(data.size, k, i)
+            assert stream == oracle_py.compress(data[lo:hi], 19), (devs, m, i)
+    # a ragged tail: the last device's range is shorter than the others' (3 x 5 blocks of 7 bytes over 100 bytes would leave
+    # blocks empty; here 1 device x 5 blocks over 23 bytes)
+    tiny = corpus.syn_text(23, corpus.SEED + 3)
+    got = gpu.compress_blocks_multi(tiny, [0], 5, 17)
+    for i, stream in enumerate(got):
+        lo, hi = shard.block_range(23, 5, i)
+        assert stream == oracle_py.compress(tiny[lo:hi], 17)
+    assert gpu.compress(data[:100_000], 17) == before
+
+
 def test_blocks_of_a_sharded_run(gpu):
     """k-way split: each block is an independent stream identical to the oracle's."""
     from nlzm_amd import shard
