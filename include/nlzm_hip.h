@@ -153,6 +153,19 @@ int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks
 int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req,
                              uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
 
+/* ---- streaming host input and output ---------------------- */
+/* The reference reads its input and writes its frames as it goes (NLZM.cpp:1774-1778, :1853, :1870-1885).  Here the
+ * caller announces the input's length, hands the bytes over in pieces, in order (any piece size; a piece travels through
+ * pinned staging buffers on a copy stream while the chunks whose input has arrived are being compressed), and takes the
+ * stream back in pieces (whole frames, as they are finished).  The host side never holds more than a piece; the input stays
+ * whole in HBM (matches reach back a window).  feed_finish after the last piece, feed_output until it gives 0 bytes,
+ * feed_end to release the buffers.  A call that fails has ended the feed. */
+int nlzm_hip_feed_begin(uint64_t n, uint32_t hist_bits_req);
+int nlzm_hip_feed(const uint8_t *piece, uint64_t len);
+int nlzm_hip_feed_output(uint8_t *dst, uint64_t cap, uint64_t *len);
+int nlzm_hip_feed_finish(void);
+void nlzm_hip_feed_end(void);
+
 /* ---- independent blocks on several GPUs of one node ------------------------ */
 /* devices[0..ndev): HIP device ordinals, each listed once.  The input is cut into ndev * blocks_per_dev blocks exactly as
  * nlzm_hip_compress_blocks cuts it for that many blocks (the reference side: one encode_file call per byte range,

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "nlzm_hip_rans_frames", "nlzm_hip_find_matches", "nlzm_hip_parse_emit", "nlzm_hip_set_option",
     "nlzm_hip_blocks_begin", "nlzm_hip_blocks_step", "nlzm_hip_blocks_finish", "nlzm_hip_blocks_abandon",
     "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks", "nlzm_hip_compress_blocks_multi",
+    "nlzm_hip_feed_begin", "nlzm_hip_feed", "nlzm_hip_feed_output", "nlzm_hip_feed_finish", "nlzm_hip_feed_end",
 ]
 
 
@@ -102,6 +103,10 @@ def load_library() -> C.CDLL:
     lib.nlzm_hip_blocks_finish.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p]
     lib.nlzm_hip_blocks_abandon.restype = None
     lib.nlzm_hip_compress_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
+    lib.nlzm_hip_feed_begin.argtypes = [C.c_uint64, C.c_uint32]
+    lib.nlzm_hip_feed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.nlzm_hip_feed_output.argtypes = [C.c_void_p, C.c_uint64, u64p]
+    lib.nlzm_hip_feed_end.restype = None
     lib.nlzm_hip_compress_blocks_multi.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
                                                    C.c_void_p, C.c_uint64, u64p, u64p]
     lib.nlzm_hip_compress_blocks_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p, u64p]
@@ -162,6 +167,36 @@ def compress_blocks(data, nblocks: int, hist_bits: int = 22) -> list[bytes]:
         pos += int(lens[i])
     assert pos == out_len.value
     return out
+
+
+def compress_fed(data, hist_bits: int = 22, piece: int = 1 << 20) -> bytes:
+    """The streaming form of compress(): the input handed over `piece` bytes at a time (pinned staging, uploads overlapped
+    with the launches), the stream taken back as its frames are finished (NLZM.cpp:1774-1778, :1853, :1870-1885)."""
+    lib = load_library()
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    n = int(src.size)
+    _chk(lib.nlzm_hip_feed_begin(n, hist_bits))
+    buf = np.empty(1 << 20, dtype=np.uint8)
+    got = C.c_uint64(0)
+    out = []
+
+    def drain():
+        while True:
+            _chk(lib.nlzm_hip_feed_output(buf.ctypes.data, buf.size, C.byref(got)))
+            if not got.value:
+                return
+            out.append(buf[: got.value].tobytes())
+
+    try:
+        for lo in range(0, n, piece):
+            m = min(piece, n - lo)
+            _chk(lib.nlzm_hip_feed(src[lo:].ctypes.data, m))
+            drain()
+        _chk(lib.nlzm_hip_feed_finish())
+        drain()
+    finally:
+        lib.nlzm_hip_feed_end()
+    return b"".join(out)
 
 
 def compress_blocks_multi(data, devices: list[int], blocks_per_dev: int, hist_bits: int = 22) -> list[bytes]:

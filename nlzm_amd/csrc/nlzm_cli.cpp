@@ -251,14 +251,26 @@ int main(int argc, char **argv)
     const int cmd = argc >= 2 ? (argv[1][0] | 0x20) : 0;
     if (argc == 4 && cmd == 'c') {
         if (FILE *probe = fopen(argv[3], "rb")) { printf("Error: %s already exists\n", argv[3]); fclose(probe); return -1; }
+        const bool one_stream = !ngpus && nblocks == 1;
         std::vector<uint8_t> in;
-        if (!slurp(argv[2], in)) { printf("Error: %s file does not exist\n", argv[2]); return -1; }
+        FILE *fin = nullptr;
+        uint64_t in_size = 0;
+        if (one_stream) {       // read, uploaded and compressed piece by piece (nlzm_hip_feed_*): the file is never whole in host memory
+            fin = fopen(argv[2], "rb");
+            if (!fin) { printf("Error: %s file does not exist\n", argv[2]); return -1; }
+            fseeko(fin, 0, SEEK_END);
+            in_size = (uint64_t)ftello(fin);
+            fseeko(fin, 0, SEEK_SET);
+        } else {
+            if (!slurp(argv[2], in)) { printf("Error: %s file does not exist\n", argv[2]); return -1; }
+            in_size = in.size();
+        }
         FILE *fout = fopen(argv[3], "wb");
-        if (!fout) { printf("Error: %s file does not exist\n", argv[3]); return -1; }
+        if (!fout) { printf("Error: %s file does not exist\n", argv[3]); if (fin) fclose(fin); return -1; }
         if (!ngpus && nlzm_hip_init(0)) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
         const uint32_t nstreams = ngpus ? ngpus * nblocks : nblocks;
         uint32_t hb, fb, cs, feed;
-        nlzm_hip_geometry(in.size(), hist_bits, &hb, &fb, &cs, &feed);
+        nlzm_hip_geometry(in_size, hist_bits, &hb, &fb, &cs, &feed);
         {   // the reference's summary (:1755-1759): sizes of its own structures for this window
             const uint32_t c1 = hb < 15 ? 15 : (hb > 17 ? 17 : hb), c2 = hb < 16 ? 16 : (hb > 20 ? 20 : hb), c3 = hb < 16 ? 16 : (hb > 22 ? 22 : hb);
             const uint64_t mf = (4ull << 12) + (8ull << (12 + c1 - 15)) + (4ull << (13 + c2 - 16)) + (8ull << hb) + (4ull << (15 + c3 - 16));
@@ -272,11 +284,44 @@ int main(int argc, char **argv)
             printf("Note: %u independent streams are written back to back; this program's d/t read them, the reference's d "
                    "stops after the first\n", nstreams);
         printf("Working...\r");
-        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nstreams * (16 + 131072));
         uint64_t out_n = 0;
         const clock_t t0 = clock();
         struct timespec w0, w1;
         clock_gettime(CLOCK_MONOTONIC, &w0);
+        if (one_stream) {
+            // the reference's loop in big steps: read a piece, hand it over, write the frames that are finished (:1774-1778, :1853, :1870-1885)
+            std::vector<uint8_t> piece(16u << 20), obuf(16u << 20);
+            uint32_t crc = 0;
+            int rc = nlzm_hip_feed_begin(in_size, hist_bits);
+            auto drain = [&]() {
+                for (uint64_t got = 1; !rc && got;) {
+                    rc = nlzm_hip_feed_output(obuf.data(), obuf.size(), &got);
+                    if (!rc && got) { fwrite(obuf.data(), 1, (size_t)got, fout); out_n += got; }
+                }
+            };
+            for (uint64_t done = 0; !rc && done < in_size;) {
+                const size_t m = (size_t)(in_size - done < piece.size() ? in_size - done : piece.size());
+                if (fread(piece.data(), 1, m, fin) != m) { printf("Error: %s could not be read\n", argv[2]); rc = -1; break; }
+                crc = crc_calc(piece.data(), m, crc);
+                rc = nlzm_hip_feed(piece.data(), m);
+                done += m;
+                drain();
+                printf("Working... %" PRIu64 " -> %" PRIu64 "\r", done, out_n);
+                fflush(stdout);
+            }
+            if (!rc) rc = nlzm_hip_feed_finish();
+            drain();
+            nlzm_hip_feed_end();
+            fclose(fin);
+            clock_gettime(CLOCK_MONOTONIC, &w1);
+            if (rc) { if (rc != -1) printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
+            fclose(fout);
+            printf("Working... %" PRIu64 " -> %" PRIu64 "\n", in_size, out_n);
+            printf("Done (input CRC32 %X, %.2f sec)\n", crc, (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec));
+            nlzm_hip_shutdown();
+            return 0;
+        }
+        std::vector<uint8_t> out(nlzm_hip_compress_bound(in.size()) + (size_t)nstreams * (16 + 131072));
         std::vector<uint64_t> blen(nstreams);
         std::vector<int> devs;
         for (uint32_t d = 0; d < ngpus; d++) devs.push_back((int)d);

@@ -150,7 +150,18 @@ struct DevState {
     uint32_t blocks_hist = 0;
     int64_t blocks_wb = 0;
     uint64_t blocks_per = 0;                        // bytes per block when the caller fixes the partition (0: ceil(n / nblocks))
+    // streaming host input (nlzm_hip_feed_*): two pinned staging buffers on a copy stream of their own
+    struct Feed {
+        bool open = false;
+        uint64_t n = 0, fed = 0, arrived = 0, taken = 0;    // input bytes handed over / known to be in HBM; output bytes handed back
+        uint8_t *pin[2] = { nullptr, nullptr };
+        hipEvent_t ev[2] = { nullptr, nullptr };
+        uint64_t end_of[2] = { 0, 0 };                      // input offset a staging buffer's last upload ends at
+        hipStream_t st = nullptr;
+        uint32_t next = 0;
+    } feed;
 };
+constexpr uint64_t kFeedPiece = 32ull << 20;        // bytes per staging buffer
 DevState g_dev0;
 thread_local DevState *t_dev = nullptr;
 inline DevState &cur() { return t_dev ? *t_dev : g_dev0; }
@@ -609,6 +620,8 @@ static void dev_shutdown(DevState &D)
     t_dev = &D;
     blocks_close();
     t_dev = keep;
+    if (D.feed.pin[0] || D.feed.st) { for (int k = 0; k < 2; k++) { if (D.feed.pin[k]) (void)hipHostFree(D.feed.pin[k]); if (D.feed.ev[k]) (void)hipEventDestroy(D.feed.ev[k]); }
+                                      if (D.feed.st) (void)hipStreamDestroy(D.feed.st); D.feed = DevState::Feed{}; }
     free_stream_buffers(C);
     if (C.cap_words) { (void)hipFree(C.cap_words); C.cap_words = nullptr; }
     if (C.cap_used) { (void)hipFree(C.cap_used); C.cap_used = nullptr; }
@@ -1116,6 +1129,116 @@ int nlzm_hip_compress_blocks(const uint8_t *src, uint64_t n, uint32_t nblocks, u
     if (!rc) *dst_len = len;
     return rc;
 }
+
+// ---- streaming host input (the reference reads and writes as it goes: NLZM.cpp:1774-1778, :1853, :1870-1885) ----
+// The caller hands the input over in pieces, in order, and takes the stream back in pieces.  A piece goes through one of
+// two pinned staging buffers onto a copy stream; while it travels, the chunks whose input has arrived are compressed, so
+// host reads, uploads and kernels overlap and the host never holds more than a piece (the input stays whole in HBM:
+// matches reach back a window).
+static void feed_close(DevState &D)
+{
+    DevState::Feed &F = D.feed;
+    for (int k = 0; k < 2; k++) { if (F.pin[k]) (void)hipHostFree(F.pin[k]); if (F.ev[k]) (void)hipEventDestroy(F.ev[k]); F.pin[k] = nullptr; F.ev[k] = nullptr; }
+    if (F.st) (void)hipStreamDestroy(F.st);
+    F = DevState::Feed{};
+}
+// chunks whose input (with the lookahead the launch's kernels read) lies below `arrived`
+static uint32_t feed_chunks_ready(const Geom &g, uint64_t arrived)
+{
+    if (arrived >= g.n) return g.nchunks;
+    const uint64_t slack = (uint64_t)g.feed - g.chunk_size + 1024;      // lookahead of the last chunk + RK256 / pre-filter windows
+    if (arrived < slack + g.chunk_size) return 0;
+    return (uint32_t)((arrived - slack) / g.chunk_size);
+}
+static int feed_run(DevState &D)
+{
+    Ctx &C = D.ctx;
+    const uint32_t ready = feed_chunks_ready(C.g, D.feed.arrived);
+    if (ready > C.next_chunk) return stream_step(C, ready - C.next_chunk, nullptr, nullptr, nullptr);
+    return 0;
+}
+
+int nlzm_hip_feed_begin(uint64_t n, uint32_t hist_bits_req)
+{
+    DevState &D = cur();
+    Ctx &C = D.ctx;
+    if (!C.inited) return set_err(NLZM_HIP_E_NODEVICE, "nlzm_hip_init() has not succeeded");
+    if (n >= 0xFFFF0000ull) return set_err(NLZM_HIP_E_TOOBIG, "input too large");
+    feed_close(D);
+    if (C.own_in) { (void)hipFree(C.own_in); C.own_in = nullptr; }
+    if (C.own_dst) { (void)hipFree(C.own_dst); C.own_dst = nullptr; }
+    const uint64_t bound = nlzm_hip_compress_bound(n);
+    HIPCHK(hipMalloc(&C.own_in, n + 512));
+    HIPCHK(hipMalloc(&C.own_dst, bound));
+    HIPCHK(hipMemsetAsync(C.own_in + n, 0, 512, C.st));
+    int rc = stream_begin(C, C.own_in, n, hist_bits_req, C.own_dst, bound);
+    if (rc) return rc;
+    DevState::Feed &F = D.feed;
+    rc = [&]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&F.st, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { HIPCHK(hipHostMalloc((void **)&F.pin[k], kFeedPiece, hipHostMallocDefault)); HIPCHK(hipEventCreate(&F.ev[k])); }
+        return 0;
+    }();
+    if (rc) { feed_close(D); return rc; }
+    F.open = true; F.n = n;
+    return 0;
+}
+
+int nlzm_hip_feed(const uint8_t *piece, uint64_t len)
+{
+    DevState &D = cur();
+    DevState::Feed &F = D.feed;
+    if (!F.open) return set_err(NLZM_HIP_E_ARG, "no open feed");
+    if ((!piece && len) || F.fed + len > F.n) return set_err(NLZM_HIP_E_ARG, "feed of %llu bytes at %llu exceeds the %llu announced", (unsigned long long)len,
+                                                             (unsigned long long)F.fed, (unsigned long long)F.n);
+    while (len) {
+        const uint32_t k = F.next;
+        const uint64_t m = len < kFeedPiece ? len : kFeedPiece;
+        // the staging buffer is free once its last upload has landed; what landed is input the kernels may read
+        HIPCHK(hipEventSynchronize(F.ev[k]));
+        if (F.end_of[k] > F.arrived) F.arrived = F.end_of[k];
+        memcpy(F.pin[k], piece, m);
+        HIPCHK(hipMemcpyAsync(D.ctx.own_in + F.fed, F.pin[k], m, hipMemcpyHostToDevice, F.st));
+        HIPCHK(hipEventRecord(F.ev[k], F.st));
+        F.fed += m; F.end_of[k] = F.fed; F.next = k ^ 1u;
+        piece += m; len -= m;
+        // (this piece is on its way: meanwhile, the chunks whose input is there)
+        const int rc = feed_run(D);
+        if (rc) { feed_close(D); return rc; }
+    }
+    return 0;
+}
+
+// the bytes of the stream produced since the last call (whole frames); *len = 0: nothing new
+int nlzm_hip_feed_output(uint8_t *dst, uint64_t cap, uint64_t *len)
+{
+    DevState &D = cur();
+    DevState::Feed &F = D.feed;
+    if (!F.open) return set_err(NLZM_HIP_E_ARG, "no open feed");
+    if (!dst || !len) return set_err(NLZM_HIP_E_ARG, "null argument");
+    const uint64_t have = D.ctx.out_pos - F.taken, m = have < cap ? have : cap;
+    if (m) HIPCHK(hipMemcpy(dst, D.ctx.own_dst + F.taken, m, hipMemcpyDeviceToHost));
+    F.taken += m;
+    *len = m;
+    return 0;
+}
+
+// after the last piece: the remaining chunks and the terminator; then nlzm_hip_feed_output until it returns 0 bytes, then
+// nlzm_hip_feed_end
+int nlzm_hip_feed_finish(void)
+{
+    DevState &D = cur();
+    DevState::Feed &F = D.feed;
+    if (!F.open) return set_err(NLZM_HIP_E_ARG, "no open feed");
+    if (F.fed != F.n) { const unsigned long long a = F.fed, b = F.n; feed_close(D); return set_err(NLZM_HIP_E_ARG, "%llu of %llu input bytes were fed", a, b); }
+    HIPCHK(hipStreamSynchronize(F.st));
+    F.arrived = F.n;
+    int rc = feed_run(D);
+    if (!rc) { uint64_t total = 0; rc = stream_finish(D.ctx, &total); }
+    if (rc) feed_close(D);
+    return rc;
+}
+void nlzm_hip_feed_end(void) { feed_close(cur()); }
 
 // ---- independent blocks on several GPUs of one node -------------------------------------------------
 // One host thread and one device state per GPU; device i compresses blocks [i*m, (i+1)*m) of the n-byte input's partition into

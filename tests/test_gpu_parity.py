@@ -194,6 +194,18 @@ def test_cli_block_mode_round_trip(gpu, tmp_path):
     assert r.returncode == 0 and back.read_bytes() == data.tobytes()
 
 
+def test_streaming_feed(gpu):
+    """nlzm_hip_feed_*: the input handed over in pieces (ragged sizes, smaller and larger than a chunk, larger than a staging
+    buffer), uploads overlapped with the launches, the stream taken back as frames finish -- the same bytes as the one-shot
+    call, the empty input included."""
+    data = corpus.mixed(2_500_000, corpus.SEED + 31)
+    want = gpu.compress(data, 18)
+    for piece in (7_001, 122_368, 1 << 20, 40 << 20):
+        assert gpu.compress_fed(data, 18, piece) == want, piece
+    assert gpu.compress_fed(data[:0], 22) == oracle_py.compress(data[:0], 22)
+    assert gpu.compress(data, 18) == want            # (the one-shot entry still works after a feed)
+
+
 def test_multi_device_entry(gpu):
     """nlzm_hip_compress_blocks_multi with the devices this box has (the GPU box has one: the per-device host thread, the
     device context of its own, the fixed partition and the gather are what is exercised; more than one GPU only ever runs in
