@@ -142,6 +142,7 @@ struct Globals {
     const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
     const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size][2] positions grouped by bin, ascending: position, BT4 head | unc << 31
     uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
+    uint32_t wthreads;          // lanes of a worker block that take bins (the first so many of its 512 threads)
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)
     WorkerCounters *wcnt;

@@ -81,6 +81,9 @@ struct Ctx {
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
     int64_t opt_worker_blocks = 240;        // + the three stage blocks: below the 256 CUs, one 512-thread block per CU
+    int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (a stream's 240 worker CUs are there for latency, not for lanes: with
+                                            // two of a CU's eight waves walking trees a test takes less time than with all eight, and a lane with four heads
+                                            // is not busier than one with one -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
     int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
     int cu_count = 0;
 
@@ -295,7 +298,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         if (C.opt_worker_blocks > room) C.opt_worker_blocks = room;
     }
     {   // one bin per worker lane (or per head when there are fewer heads than lanes)
-        const unsigned long long lanes = (unsigned long long)(C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks) * 512;
+        const unsigned long long lanes = (unsigned long long)(C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks) * (unsigned long long)C.opt_worker_threads;
         if (lanes < C.nheads) C.nheads = (uint32_t)lanes;
     }
     if (C.workers) {
@@ -384,7 +387,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
     if (C.workers) {
         const unsigned long long cnt = a1 - a0;
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
-        G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads;
+        G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads; G.wthreads = (uint32_t)C.opt_worker_threads;
         G.abort_word = C.abort_word; G.wcnt = C.wcnt;
         HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4 * kBtRec, C.st));
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
@@ -737,6 +740,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
+    if (!strcmp(key, "worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "worker_threads out of range"); C.opt_worker_threads = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
 }
@@ -841,7 +845,7 @@ namespace {
 int block_ctx_init(Ctx &c, int device, int64_t worker_blocks, int64_t batch)
 {
     c.device = device;
-    c.opt_workers = 1; c.opt_worker_blocks = worker_blocks; c.opt_batch = batch;
+    c.opt_workers = 1; c.opt_worker_blocks = worker_blocks; c.opt_batch = batch; c.opt_worker_threads = 512;        // (block mode: a stream has few worker CUs, every lane of them takes bins)
     HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
     c.inited = true;

@@ -266,10 +266,75 @@ struct StoreLog {
     }
 };
 
+// MatchFinderBT::FindAndUpdate (:978-1022) as the worker lanes run it: the same steps as bt_find_and_update_st
+// (nlzm_core.h, which the host-side checks use), written for the lane -- the node's pair is ONE 8-byte load requested
+// together with the bytes to compare, what a step changes is chosen by selects, and only a record-setter (about one test in
+// four) takes a branch.  A hot head's lane is a chain of such steps, one memory round trip each; the instructions around
+// the round trip were as long as the round trip itself.
+template <class St>
+__device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st, ResultSink<LaneIO> &sink,
+                                           uint32_t &tests_out, unsigned long long &cmp_bytes)
+{
+    const uint8_t *pa = B.in + a;
+    uint32_t sp = B.heads[hidx];
+    st.head(B.heads, hidx, a);                                      // :983-984
+    uint32_t pend_l = (a & B.tmask) << 1, pend_r = pend_l + 1, len_l = 0, len_r = 0, tests = 0;
+    unsigned long long cb = 0;
+    while (sp != kNone && a > sp && a - sp <= B.wmask && tests < 256) {    // :989 (256 tests at most, :777, :988)
+        tests++;
+        const uint32_t pair = (sp & B.tmask) << 1;
+        const unsigned long long pp = *(const unsigned long long *)(B.tree + pair);     // left, right
+        const uint8_t *ps = B.in + sp;
+        const uint32_t init = umin(len_l, len_r);                   // :993
+        // RingDictionary::MatchLengthSigned (:854-877): common prefix from `init`, at most max_len; sign = which side is smaller
+        uint32_t l = init, sign = 0;
+        bool full = true;
+        while (l < max_len) {
+            const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
+            if (d) {
+                const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                if (l + nb < max_len) { l += nb; full = false; sign = (uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF)); }
+                break;
+            }
+            l += 8;
+        }
+        if (full) l = max_len;
+        cb += (l - init) + (full ? 0u : 1u);
+        const uint32_t pl = (uint32_t)pp, pr = (uint32_t)(pp >> 32), d = a - sp;
+        if (l >= match_min(d) && l > sink.best) sink(d, l);         // :996-998; only record-setters change the table
+        if (full) {                                                 // :1000-1004
+            st.link(B.tree, pend_l, pl); st.link(B.tree, pend_r, pr);
+            tests_out = tests; cmp_bytes += cb;
+            return;
+        }
+        // :1006-1017 as selects
+        const bool right = sign != 0;
+        st.link(B.tree, right ? pend_l : pend_r, sp);
+        pend_l = right ? pair + 1 : pend_l; pend_r = right ? pend_r : pair;
+        len_r = right ? l : len_r; len_l = right ? len_l : l;
+        sp = right ? pr : pl;
+    }
+    st.link(B.tree, pend_r, kNone); st.link(B.tree, pend_l, kNone);    // :1020-1021
+    tests_out = tests; cmp_bytes += cb;
+}
+// one call for position a with BT4 head hidx: stores at once (St = StoreNow) or noted down (a dry run), result published
+template <class St>
+__device__ __forceinline__ void worker_call(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st,
+                                            unsigned long long &n_tests, unsigned long long &cmp_bytes)
+{
+    const unsigned long long bi = a - B.batch_a0;
+    ResultSink<LaneIO> sink{ B.pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    uint32_t tests = 0;
+    bt_descent(B, a, hidx, max_len, st, sink, tests, cmp_bytes);
+    n_tests += tests;
+    sink.publish(B.ready + bi * kBtRec, tests);
+}
+
 template <class LB>
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
-    const uint32_t gl = wblock * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= G.wthreads) return;
+    const uint32_t gl = wblock * G.wthreads + threadIdx.x;
     // What a descent touches, as values of this role (made opaque): left as kernel arguments, the compiler re-loads them
     // from the argument segment inside the test loop -- two 64-byte scalar loads and their waits per test -- rather than keep them.
     unsigned long long p0 = (unsigned long long)G.in, p1 = (unsigned long long)G.bt_heads, p2 = (unsigned long long)G.bt_tree,
@@ -327,17 +392,17 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             // them now from a dry run, insert once the decision is in
                             const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
                             if (f == kFlagCall) {
-                                worker_bt_call<LaneIO, true>(B, a, max_len, true, n_tests, n_cmp, hidx);
+                                { StoreNow now; worker_call(B, a, hidx, max_len, now, n_tests, n_cmp); }
                                 n_calls++;
                             } else if (f != kFlagSkip) {
                                 slog.n = 0; slog.full = false; dry_t = 0; dry_c = 0;
-                                worker_bt_dry<LaneIO>(B, a, max_len, dry_t, dry_c, slog, hidx);
+                                worker_call(B, a, hidx, max_len, slog, dry_t, dry_c);
                                 n_dry++;
                                 stage = 1; t_wait0 = 0; idle = 0;
                             }
                         } else {
                             const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
-                            worker_bt_call<LaneIO, true>(B, a, max_len, true, n_tests, n_cmp, hidx);
+                            { StoreNow now; worker_call(B, a, hidx, max_len, now, n_tests, n_cmp); }
                             n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
                             n_calls++;
 #ifdef NLZM_LEAD_DIAG
