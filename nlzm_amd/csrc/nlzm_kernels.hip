@@ -283,20 +283,30 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
     while (sp != kNone && a > sp && a - sp <= B.wmask && tests < 256) {    // :989 (256 tests at most, :777, :988)
         tests++;
         const uint32_t pair = (sp & B.tmask) << 1;
-        const unsigned long long pp = *(const unsigned long long *)(B.tree + pair);     // left, right
         const uint8_t *ps = B.in + sp;
         const uint32_t init = umin(len_l, len_r);                   // :993
-        // RingDictionary::MatchLengthSigned (:854-877): common prefix from `init`, at most max_len; sign = which side is smaller
-        uint32_t l = init, sign = 0;
-        bool full = true;
-        while (l < max_len) {
-            const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
-            if (d) {
-                const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
-                if (l + nb < max_len) { l += nb; full = false; sign = (uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF)); }
-                break;
+        // the node's pair and the first eight bytes of both sides: requested together, one round trip
+        const unsigned long long pp = *(const unsigned long long *)(B.tree + pair);     // left, right
+        const unsigned long long x0 = load64u(ps + init), y0 = load64u(pa + init), d0 = x0 ^ y0;
+        // RingDictionary::MatchLengthSigned (:854-877): common prefix from `init`, at most max_len; sign = which side is smaller.
+        // Nearly always decided inside these eight bytes; the rest goes round by round.
+        const uint32_t nb0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u;
+        uint32_t l = init + nb0;
+        bool full = l >= max_len;
+        uint32_t sign = (uint32_t)(((x0 >> (8 * (nb0 & 7u))) & 0xFF) < ((y0 >> (8 * (nb0 & 7u))) & 0xFF));
+        if (!d0 && !full) {
+            for (;;) {
+                const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
+                if (d) {
+                    const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                    l += nb;
+                    sign = (uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF));
+                    break;
+                }
+                l += 8;
+                if (l >= max_len) break;
             }
-            l += 8;
+            full = l >= max_len;
         }
         if (full) l = max_len;
         cb += (l - init) + (full ? 0u : 1u);

@@ -50,8 +50,7 @@ def test_full_size_configs(gpu, name):
     """BASELINE configs 1, 3, 5 and 4 at full size against the REFERENCE's own stream (tests/golden/full.json, made by
     oracle/make_golden_full.py from the compiled reference):
       text_100m_w24   100,000,000 B at -window:24 -- cfg 1's workload: five rebases at 128 KiB frames (NLZM.cpp:1786-1792)
-      text_100m_w26   100,000,000 B at -window:26 -- no rebase, the last ~33 MB in the p >= W masking regime of HT/RK;
-                      compressed TWICE: the stream must not depend on the timing of the stages (round 2 had such a fault)
+      text_100m_w26   100,000,000 B at -window:26 -- no rebase, the last ~33 MB in the p >= W masking regime of HT/RK
       block_125m_w28  one 125,000,000-B block at -window:28 -- the header must read 27 (NLZM.cpp:1716-1718)
       text_1g_w28     the whole 1,000,000,000-B stream at -window:28 -- rebases near 537 MB and 805 MB"""
     full = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "full.json")))["cases"]}
@@ -65,10 +64,6 @@ def test_full_size_configs(gpu, name):
     st = gpu.stats()
     assert st["positions"] == data.size
     assert st["shifts"] == {"text_100m_w24": 4, "text_100m_w26": 0, "block_125m_w28": 0, "text_1g_w28": 2}[name]
-    if name == "text_100m_w26":
-        again = gpu.compress(data, case[4])
-        assert hashlib.sha256(again).hexdigest() == g["stream_sha256"], "second run of the same input differs"
-        assert gpu.stats() == st
 
 
 def test_blocks_at_bench_geometry(gpu):
@@ -149,6 +144,11 @@ def test_large_window_properties(gpu):
     st = gpu.stats()
     assert st["positions"] == data.size and st["frames"] == -(-data.size // 122368)
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(oracle_py.compress(data, 28)).hexdigest()
+    # the same input again, twice: the stream and every counter must not depend on how the stages' timing falls (round 2 had
+    # such a fault on large inputs: four different sizes for one input)
+    for _ in range(2):
+        assert gpu.compress(data, 28) == got, "another run of the same input differs"
+        assert gpu.stats() == st
 
 
 @pytest.mark.parametrize("nblocks,hb", [(4, 20), (8, 16), (16, 22), (40, 18), (64, 17)])
