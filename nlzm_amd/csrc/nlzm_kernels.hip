@@ -24,7 +24,7 @@ namespace nlzm {
 constexpr uint32_t kLogCap = 24;                    // stores a worker lane notes down during a dry run
 union V2Lds {
     v2::FLds f; v2::TLds t; v2::PLds p;
-    uint32_t wlog[512 * kLogCap * 2];
+    uint32_t wlog[512 * kLogCap * 2 + 512 * 8];     // worker lanes: the store logs of dry runs, then eight words of record-setters per lane
 };
 __shared__ V2Lds g_v2_lds;
 }  // namespace nlzm
@@ -271,8 +271,32 @@ struct StoreLog {
 // together with the bytes to compare, what a step changes is chosen by selects, and only a record-setter (about one test in
 // four) takes a branch.  A hot head's lane is a chain of such steps, one memory round trip each; the instructions around
 // the round trip were as long as the round trip itself.
+// The record-setters of a descent on their way to the record: the first four in LDS (eight words per lane, behind the
+// store logs: a register each would be carried, and copied, through every step of the descent), the rest in bt_pairs.
+struct LaneSink {
+    uint32_t *slot;         // LDS: this lane's eight words
+    uint32_t *pairs;        // bt_pairs of the position
+    uint32_t count = 0, best = 1, best_d = 0;
+    __device__ __forceinline__ void operator()(uint32_t d, uint32_t l)
+    {
+        best = l; best_d = d;
+        if (count < 4) { slot[2 * count] = d; slot[2 * count + 1] = l; }
+        else { LaneIO::st_agent(pairs + 2 * count, d); LaneIO::st_agent(pairs + 2 * count + 1, l); }
+        count++;
+    }
+    __device__ __forceinline__ void publish(uint32_t *rec, uint32_t tests) const
+    {
+        if (count > 4) LaneIO::drain();
+        const uint32_t d0 = count > 0 ? slot[0] : 0u, l0 = count > 0 ? slot[1] : 0u, d1 = count > 1 ? slot[2] : 0u, l1 = count > 1 ? slot[3] : 0u;
+        const uint32_t d2 = count > 2 ? slot[4] : 0u, l2 = count > 2 ? slot[5] : 0u, d3 = count > 3 ? slot[6] : 0u, l3 = count > 3 ? slot[7] : 0u;
+        LaneIO::st_quad(rec + 4, d0, l0, d1, kBtTag);
+        LaneIO::st_quad(rec + 8, l1, d2, l2, kBtTag);
+        LaneIO::st_quad(rec + 12, d3, l3, 0u, kBtTag);
+        LaneIO::st_quad(rec, kBtReady | (tests << 9) | count, best_d, count ? best : 0u, 0u);
+    }
+};
 template <class St>
-__device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st, ResultSink<LaneIO> &sink,
+__device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st, LaneSink &sink,
                                            uint32_t &tests_out, unsigned long long &cmp_bytes)
 {
     const uint8_t *pa = B.in + a;
@@ -333,7 +357,7 @@ __device__ __forceinline__ void worker_call(const BtView &B, uint32_t a, uint32_
                                             unsigned long long &n_tests, unsigned long long &cmp_bytes)
 {
     const unsigned long long bi = a - B.batch_a0;
-    ResultSink<LaneIO> sink{ B.pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    LaneSink sink{ (uint32_t *)&g_v2_lds + 512 * kLogCap * 2 + 8 * threadIdx.x, B.pairs + bi * (2 * kBtMaxPairs) };
     uint32_t tests = 0;
     bt_descent(B, a, hidx, max_len, st, sink, tests, cmp_bytes);
     n_tests += tests;
