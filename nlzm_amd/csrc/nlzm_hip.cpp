@@ -536,6 +536,9 @@ int refresh_stats(Ctx &C)
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "parser: waited for its record loader %llu times, the table stage %.0f positions ahead on average then\n", P.prof[26], (double)P.prof[27] / (double)(P.prof[26] ? P.prof[26] : 1));
+        if (P.prof[88]) fprintf(stderr, "finder sections (cycles/position, profile build): predict %.0f, own loads %.0f, HT rows %.0f, candidates + jobs %.0f, record + RK256 %.0f, "
+                                "BT4 results (wait included) %.0f, verify %.0f, commit %.0f\n", P.prof[88] / n, P.prof[89] / n, P.prof[90] / n, P.prof[91] / n, P.prof[92] / n,
+                                P.prof[93] / n, P.prof[94] / n, P.prof[95] / n);
         if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position, profile build): gather %.0f, scan %.0f, emit %.0f\n", P.prof[44] / n, P.prof[45] / n, P.prof[46] / n);
         if (P.prof[32]) {
             const double np = (double)(P.prof[13] ? P.prof[13] : 1);

@@ -166,6 +166,12 @@ struct Finder {
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long t_wait, t_wait_bt = 0, t_total;
     uint32_t n_late_unc = 0, n_late_other = 0;
+    unsigned long long t_f[8] = {};             // profile build: cycles per section of block()
+#ifdef NLZM_PROFILE
+    XW_FN unsigned long long ptick() const { return xw::tick(); }
+#else
+    XW_FN unsigned long long ptick() const { return 0; }
+#endif
 
     XW_FN void fail(uint32_t code, uint32_t pos, uint32_t site = 0, uint32_t x0 = 0, uint32_t x1 = 0)
     {
@@ -207,6 +213,7 @@ struct Finder {
         const unsigned long long closed_mask = xw::ballot(in_blk && s_active && !s_sliding);
         const uint32_t jc = closed_mask ? (uint32_t)__builtin_ctzll(closed_mask) : 64u;
 
+        const unsigned long long f0 = ptick();
         // ---- predicted finder calls (:1514, :1529) from the state the block starts with
         const uint32_t reach_pred = umax(reach, s_e);
         const bool nice_pred = in_blk && reach_pred >= a + kNice && reach_pred > a;
@@ -266,6 +273,7 @@ struct Finder {
             if (cm) cut_rk = (uint32_t)__builtin_ctzll(cm);
         }
 
+        const unsigned long long f1 = ptick();
         // ---- loads that the position alone addresses
         uint32_t v4 = 0;
         unsigned long long own0 = 0, own1 = 0;
@@ -275,6 +283,7 @@ struct Finder {
         const bool unc = in_blk && G.workers && G.unc[bi] != 0;
         const bool bt_call = call_full && avail >= 4 && G.workers;
 
+        const unsigned long long f2 = ptick();
         // ---- HT2 / HT3 rows as each calling lane finds them (:910-938): the tables in LDS, overwritten by what the
         // earlier calling lanes of the block store (bucket b: HT2[b] = E2; HT3[b+1] = HT3[b], HT3[b] = E3)
         const uint32_t h2 = hash4(v4 & 0xFFFFu), h3 = hash4(v4 & 0xFFFFFFu);     // :1516-1517
@@ -297,6 +306,7 @@ struct Finder {
             }
         }
 
+        const unsigned long long f3 = ptick();
         // ---- candidates (:922-925) and their first 16 bytes; what is longer goes to the job list
         uint32_t cd[4] = { 0, 0, 0, 0 };            // distance of candidate k: HT2, HT3 row 0, HT3 row 1, RK256; 0: none
         if (ht_call) {
@@ -381,6 +391,7 @@ struct Finder {
             for (int k = 0; k < 3; k++) if (cd[k] && cl[k] == kNone) cl[k] = L->job_len[i * 4 + k];
         }
 
+        const unsigned long long f4 = ptick();
         // ---- the record of this position: pairs of HT2 and HT3 (:917-933)
         uint32_t *st = L->stage + i * kFtStride;
         uint32_t np = 0, ec = 0, od = kNone, cmpb = 0;      // pairs, largest closed end, smallest open distance, bytes compared
@@ -439,6 +450,7 @@ struct Finder {
             }
         }
 
+        const unsigned long long f5 = ptick();
         // ---- BT4: the worker lanes' result (longest record-setter in the record's words 9, 10).
         // A worker lane walks its bin in position order and, at an `unc` position, waits for this stage's decision before
         // it goes on: the result of a later position of the same bin cannot arrive before this block is committed.
@@ -498,6 +510,7 @@ struct Finder {
             t_wait += xw::tick() - tw; t_wait_bt += xw::tick() - tw;
         }
 
+        const unsigned long long f6 = ptick();
         // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
         const uint32_t pm = xw::scan_max(in_blk ? ec : 0u);                     // inclusive prefix max of the closed ends
         uint32_t before = umax(xw::lane_below(pm, 0u), reach);
@@ -523,6 +536,7 @@ struct Finder {
         // a position that the pre-filter promised to be a BT4 position must not be nice
         if (xw::any(fin && nice_real && !unc && avail >= 4 && G.workers)) { fail(kErrV2Promise, a0, 8); return 1; }
 
+        const unsigned long long f7 = ptick();
         // ---- commit
         // HT rows in position order (the last writer of a row wins)
         for (unsigned long long mm = htm & ((m < 64 ? (1ull << m) : 0ull) - 1ull); mm; mm &= mm - 1) {
@@ -576,6 +590,10 @@ struct Finder {
         }
         if (i == 0) xw::st_agent(&V.hx->f_pos, a0 + m);
         xw::trace(2, a0, n, m, reach, s_active, s_d, s_end);
+        {
+            const unsigned long long f8 = ptick();
+            t_f[0] += f1 - f0; t_f[1] += f2 - f1; t_f[2] += f3 - f2; t_f[3] += f4 - f3; t_f[4] += f5 - f4; t_f[5] += f6 - f5; t_f[6] += f7 - f6; t_f[7] += f8 - f7;
+        }
         return m;
     }
 
@@ -650,6 +668,9 @@ struct Finder {
             xw::atomic_add64_agent(&pr[12], n_cut5);
             xw::atomic_add64_agent(&pr[16], t_wait); xw::atomic_add64_agent(&pr[17], xw::tick() - t_start); xw::atomic_add64_agent(&pr[25], t_wait_bt);
             xw::atomic_add64_agent(&pr[28], n_late_unc); xw::atomic_add64_agent(&pr[29], n_late_other);
+#ifdef NLZM_PROFILE
+            for (int z = 0; z < 8; z++) xw::atomic_add64_agent(&pr[88 + z], t_f[z]);
+#endif
             if (err || xw::ld_agent(&V.hx->err)) {                  // where this stage was when it left
                 uint32_t *d = V.hx->dbg[0];
                 xw::st_agent(d + 0, dbg_a); xw::st_agent(d + 1, reach); xw::st_agent(d + 2, s_active); xw::st_agent(d + 3, s_d);
