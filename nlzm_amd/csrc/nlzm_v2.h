@@ -147,6 +147,7 @@ struct FLds {
     uint32_t job[64 * 3 * 4];                   // byte compares longer than the lanes' own first look: lane | cand << 8, distance, cap
     uint32_t job_len[64 * 4];
     uint32_t njobs;
+    uint32_t last[8192];                        // scratch of a block: the last lane of a bucket class (HT2: bucket; HT3: 4096 + bucket % 4096), + 1
     Counters cnt;
 };
 
@@ -293,9 +294,22 @@ struct Finder {
         uint32_t row2 = 0, r0 = 0, r1 = 0;
         if (ht_call) { row2 = L->ht2[i2]; r0 = L->ht3[i3]; r1 = L->ht3[i3 + 1]; }
         const unsigned long long htm = xw::ballot(ht_call);
-        for (unsigned long long mm = htm; mm; mm &= mm - 1) {
+        // Only a lane that has a LATER calling lane on one of its rows (HT2: the same bucket; HT3: buckets b-1, b, b+1, for the
+        // overlap) matters to anybody else -- a few of the 64.  Found without comparing all pairs: every calling lane marks its
+        // bucket class with its number (LDS max), then looks whether a higher number stands on a class it touches.  Classes
+        // are buckets modulo 4096: a false neighbour only sends a lane through the ordered path for nothing.
+        bool later = false;
+        {
+            uint32_t *last = L->last;
+            if (ht_call) { xw::lds_max(&last[i2], i + 1); xw::lds_max(&last[4096 + (i3 & 4095u)], i + 1); }
+            xw::wave_sync();
+            if (ht_call) later = last[i2] > i + 1 || last[4096 + (i3 & 4095u)] > i + 1 || last[4096 + ((i3 + 1) & 4095u)] > i + 1 || last[4096 + ((i3 - 1) & 4095u)] > i + 1;
+            xw::wave_sync();
+            if (ht_call) { last[i2] = 0; last[4096 + (i3 & 4095u)] = 0; }
+        }
+        const unsigned long long dep = xw::ballot(later);                       // (lanes whose rows a later lane sees or overwrites)
+        for (unsigned long long mm = dep; mm; mm &= mm - 1) {
             const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-            if (!(htm >> j >> 1)) break;                                        // no calling lane after j
             const uint32_t b2 = xw::readlane(i2, j), b3 = xw::readlane(i3, j);
             const uint32_t x2 = xw::readlane(e2, j), x3 = xw::readlane(e3, j), y0 = xw::readlane(r0, j);
             if (ht_call && i > j) {
@@ -538,12 +552,15 @@ struct Finder {
 
         const unsigned long long f7 = ptick();
         // ---- commit
-        // HT rows in position order (the last writer of a row wins)
-        for (unsigned long long mm = htm & ((m < 64 ? (1ull << m) : 0ull) - 1ull); mm; mm &= mm - 1) {
+        // HT rows in position order (the last writer of a row wins): the lanes with a later lane on their rows one after the
+        // other, then all the others at once (no two of them touch the same row, and nobody after them touches theirs)
+        for (unsigned long long mm = dep & htm & ((m < 64 ? (1ull << m) : 0ull) - 1ull); mm; mm &= mm - 1) {
             const uint32_t j = (uint32_t)__builtin_ctzll(mm);
             if (i == j) { L->ht2[i2] = e2; L->ht3[i3] = e3; L->ht3[i3 + 1] = r0; }
             xw::wave_sync();
         }
+        if (ht_call && i < m && !later) { L->ht2[i2] = e2; L->ht3[i3] = e3; L->ht3[i3 + 1] = r0; }
+        xw::wave_sync();
         if (fin && unc && avail >= 4) xw::st_agent(G.bt_flag + bi, nice_real ? kFlagSkip : kFlagCall);
         if (fin && rk_call && (q & 255u) == 0) G.rk_table[rkh >> g.rk_shift] = q | (rkh << g.wbits);
         // the record
@@ -558,8 +575,7 @@ struct Finder {
 #pragma unroll
             for (int k = 0; k < 4; k++) xw::st_agent128(dst + 4 * k, st[4 * k], st[4 * k + 1], st[4 * k + 2], st[4 * k + 3]);
         }
-        xw::drain();
-        // ---- state after lane m - 1
+        // ---- state after lane m - 1 (the record's stores travel meanwhile: drained before the progress word below)
         {
             const uint32_t last = m - 1;
             const uint32_t pm_last = xw::readlane(pm, last);
@@ -588,6 +604,7 @@ struct Finder {
             for (uint32_t d = 32; d; d >>= 1) c += xw::shfl(c, i ^ d);
             n_cmp += xw::readfirst(c);
         }
+        xw::drain();
         if (i == 0) xw::st_agent(&V.hx->f_pos, a0 + m);
         xw::trace(2, a0, n, m, reach, s_active, s_d, s_end);
         {
@@ -604,6 +621,7 @@ struct Finder {
         StateV2 *S = (StateV2 *)V.state;
         const uint32_t i = xw::lane();
         const uint32_t ht3_rows = (1u << (32 - g.ht3_shift)) + 1;
+        for (uint32_t k = i; k < 8192; k += 64) L->last[k] = 0;
         for (uint32_t k = i; k < 4096; k += 64) L->ht2[k] = G.ht2[k];
         for (uint32_t k = i; k < ht3_rows; k += 64) L->ht3[k] = G.ht3[k];
         base = xw::readfirst((uint32_t)P->reb_base);

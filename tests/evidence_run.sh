@@ -1,15 +1,18 @@
 #!/bin/bash
-# Round evidence, run on the GPU box through gpurun:  bash tests/evidence_run.sh r02
-# (parity suite, bench line, stage accounting of two configurations, then the rocprofv3 passes of tests/prof_run.sh)
-R=${1:-r02}
+# Round evidence, run on the GPU box through gpurun:  bash tests/evidence_run.sh r03
+# (stage accounting of three configurations, the profile build's per-section numbers, block mode; then the rocprofv3 passes
+#  of tests/prof_run.sh.  The parity suite and the whole-stream bench line are separate calls: they take 12 and 10 minutes.)
+R=${1:-r03}
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/${R}_pytest_gpu.log 2>&1; tail -2 gpurun_out/${R}_pytest_gpu.log
-python bench.py > gpurun_out/${R}_bench.log 2>&1; tail -1 gpurun_out/${R}_bench.log | cut -c1-200
 {
-  echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1   (3 MB of text, -window:20)"
+  echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1   (3 MB of text, -window:20; product library)"
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1 2>&1
-  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 8e6 28 1   (8 MB of text, -window:28 -> 23)"
-  NLZM_WAIT_PRINT=1 python tests/gpu_one.py 8e6 28 1 2>&1
+  echo; echo "# the same with the profile build (nlzm_amd/libnlzm_hip_prof.so: per-section cycle counters; slower by the counters)"
+  NLZM_LIB=nlzm_amd/libnlzm_hip_prof.so NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1 2>&1
+  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 20e6 28 1   (20 MB of text, -window:28 -> 25)"
+  NLZM_WAIT_PRINT=1 python tests/gpu_one.py 20e6 28 1 2>&1
+  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1   (300 MB of text, -window:28: depth)"
+  NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1 2>&1
   echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_blocks.py 8 20 32   (32 independent blocks of 8 MB in flight)"
   NLZM_WAIT_PRINT=1 python tests/gpu_blocks.py 8 20 32 2>&1 | grep -v "^cycles\|^finder\|^table\|^worker\|^parser" 
 } > gpurun_out/${R}_wave_accounting.txt
