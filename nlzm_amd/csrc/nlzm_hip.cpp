@@ -566,8 +566,9 @@ int refresh_stats(Ctx &C)
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
         if (getenv("NLZM_WAIT_PRINT") && wc.lead[0] + wc.lead[1] + wc.lead[2] + wc.lead[3] + wc.lead[4] + wc.lead[5])
-            fprintf(stderr, "non-unc calls by lead over the master's batch start when done: behind %llu, <64 %llu, <256 %llu, <4096 %llu, <65536 %llu, more %llu\n",
-                    wc.lead[0], wc.lead[1], wc.lead[2], wc.lead[3], wc.lead[4], wc.lead[5]);
+            fprintf(stderr, "non-unc calls that end with the finder less than 64 positions away: first call after a wait for a decision, same head %llu, other head %llu; "
+                            "2nd..4th call after a wait %llu; others %llu (tests of all these %llu) | calls that end further ahead %llu\n",
+                    wc.lead[0], wc.lead[1], wc.lead[2], wc.lead[3], wc.lead[5], wc.lead[4]);
         if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));

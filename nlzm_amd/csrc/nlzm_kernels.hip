@@ -394,6 +394,14 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0, prog_seen = 0;
     bool fail = false;
+#ifdef NLZM_LEAD_DIAG
+    uint32_t since_wait = 0, wait_head = 0, cur_wait_head = 0; bool waited_ever = false;
+#define NLZM_DIAG_WAIT_BEGIN cur_wait_head = hidx;
+#define NLZM_DIAG_WAIT_END if (idle) { since_wait = 0; wait_head = cur_wait_head; waited_ever = true; }
+#else
+#define NLZM_DIAG_WAIT_BEGIN
+#define NLZM_DIAG_WAIT_END
+#endif
 
     while (__any(active)) {
         bool waiting = false;
@@ -433,6 +441,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                                 worker_call(B, a, hidx, max_len, slog, dry_t, dry_c);
                                 n_dry++;
                                 stage = 1; t_wait0 = 0; idle = 0;
+                                NLZM_DIAG_WAIT_BEGIN
                             }
                         } else {
                             const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
@@ -440,11 +449,13 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
                             n_calls++;
 #ifdef NLZM_LEAD_DIAG
-                            {   // where is the master (start of its look-ahead batch) now that this call is done?
-                                const uint32_t mp = LaneIO::ld_agent((const uint32_t *)&G.persist->prof[31]);
+                            {   // where is the finder now that this call is done, and what had this lane done just before?
+                                const uint32_t mp = LaneIO::ld_agent(G.progress);
                                 const int lead = (int)(a - mp);
-                                const int k = lead < 0 ? 0 : (lead < 64 ? 1 : (lead < 256 ? 2 : (lead < 4096 ? 3 : (lead < 65536 ? 4 : 5))));
+                                since_wait++;
+                                const int k = lead >= 64 ? 4 : (!waited_ever ? 3 : (since_wait == 1 ? (hidx == wait_head ? 0 : 1) : (since_wait <= 4 ? 2 : 3)));
                                 atomicAdd(&G.wcnt->lead[k], 1ull);
+                                if (lead < 64) atomicAdd(&G.wcnt->lead[5], n_tests - k0);
                             }
 #endif
                         }
@@ -458,8 +469,10 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                     else worker_bt_call<LaneIO, true>(B, a, max_len, false, n_tests, n_cmp);
                     n_calls++;
                     stage = 0;
+                    NLZM_DIAG_WAIT_END
                 } else if (f == kFlagSkip) {
                     stage = 0;
+                    NLZM_DIAG_WAIT_END
                 } else {
                     waiting = true;
                     n_wait++;
