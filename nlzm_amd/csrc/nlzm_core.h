@@ -116,6 +116,7 @@ struct WorkerCounters {
     unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
     unsigned long long lead[6];                     // NLZM_LEAD_DIAG: calls by how far ahead of the master they ended
     unsigned long long stuck_lanes, stuck_pos_inv;  // lanes that left while waiting for a decision (a launch that failed); ~(smallest such position)
+    unsigned long long spec_calls, spec_good;       // decisions "skip" that took calls back; calls behind the skipped position that were made again
 };
 
 // Everything the master needs from HBM.
@@ -143,6 +144,7 @@ struct Globals {
     const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size][2] positions grouped by bin, ascending: position, BT4 head | unc << 31
     uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
     uint32_t wthreads;          // lanes of a worker block that take bins (the first so many of its 512 threads)
+    uint32_t *bt_undo;          // [lane][calls with their fate open][kUndoCap]: slot and replaced value of every store of such a call
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)
     WorkerCounters *wcnt;

@@ -34,6 +34,7 @@ void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals
 void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
+unsigned long long worker_undo_bytes_per_lane();
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
                 uint32_t *pos, const uint8_t *unc, uint32_t batch_a0, hipStream_t st);
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
@@ -110,7 +111,7 @@ struct Ctx {
     uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
     uint32_t t_bits = 0, m_bits = 0, nheads = 0;
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
-    uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr;
+    uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr, *bt_undo = nullptr;
     WorkerCounters *wcnt = nullptr;
     // three-stage pipeline (nlzm_v2.h): hand-off rings, progress words, stage state
     uint32_t *v2_ft = nullptr, *v2_tp = nullptr, *v2_tf = nullptr, *v2_state = nullptr;
@@ -183,12 +184,12 @@ void free_stream_buffers(Ctx &C)
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
-                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt,
+                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo,
                      C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
-    C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = nullptr; C.wcnt = nullptr;
+    C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
     C.persist = nullptr; C.syms = C.scratch = nullptr; C.bits = C.frames = nullptr; C.fmeta = nullptr;
     C.dst_off = nullptr; C.own_in = C.own_dst = nullptr;
@@ -333,6 +334,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMalloc(&C.bin_pos, bpos * 8));
         HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
         HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
+        HIPCHK(hipMalloc(&C.bt_undo, (size_t)C.nheads * worker_undo_bytes_per_lane()));     // (6 KB per lane)
     }
 
     // hand-off between the finder, table and parser stages
@@ -388,7 +390,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         const unsigned long long cnt = a1 - a0;
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
         G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads; G.wthreads = (uint32_t)C.opt_worker_threads;
-        G.abort_word = C.abort_word; G.wcnt = C.wcnt;
+        G.abort_word = C.abort_word; G.wcnt = C.wcnt; G.bt_undo = C.bt_undo;
         HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4 * kBtRec, C.st));
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
         HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
@@ -569,6 +571,9 @@ int refresh_stats(Ctx &C)
             fprintf(stderr, "non-unc calls that end with the finder less than 64 positions away: first call after a wait for a decision, same head %llu, other head %llu; "
                             "2nd..4th call after a wait %llu; others %llu (tests of all these %llu) | calls that end further ahead %llu\n",
                     wc.lead[0], wc.lead[1], wc.lead[2], wc.lead[3], wc.lead[5], wc.lead[4]);
+        if (getenv("NLZM_WAIT_PRINT"))
+            fprintf(stderr, "worker lanes: %llu calls made with their fate open (at and behind a position not decided yet), %llu decisions that took calls back, %llu calls made again for it\n",
+                    wc.dry_runs, wc.spec_calls, wc.spec_good);
         if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));

@@ -21,10 +21,11 @@ namespace nlzm {
 
 // LDS image of the three-stage pipeline (nlzm_v2.h): every block of pipeline2_kernel has ONE role, so the roles share
 // the bytes.  A file-scope __shared__ object: every access is a ds_* instruction.
-constexpr uint32_t kLogCap = 24;                    // stores a worker lane notes down during a dry run
+constexpr uint32_t kAhead = 3;                      // calls a worker lane may have made whose fate is not decided yet
+constexpr uint32_t kEntryWords = 16;                // LDS words per such call: eight of record-setters, eight of bookkeeping
 union V2Lds {
     v2::FLds f; v2::TLds t; v2::PLds p;
-    uint32_t wlog[512 * kLogCap * 2 + 512 * 8];     // worker lanes: the store logs of dry runs, then eight words of record-setters per lane
+    uint32_t wq[512 * kAhead * kEntryWords];        // worker lanes: word w of call e of thread t at (e * 16 + w) * 512 + t
 };
 __shared__ V2Lds g_v2_lds;
 }  // namespace nlzm
@@ -240,70 +241,50 @@ struct LaneIO {
     }
 };
 
-// The stores of a dry run, noted in LDS (a worker block does not use the master's LDS image): kLogCap (address, value)
-// pairs per lane, interleaved by lane so that a wave's k-th entries sit in different banks.
-struct LogInV2 { static __device__ __forceinline__ uint32_t *base() { return (uint32_t *)&g_v2_lds; } };
-template <class LB>
-struct StoreLog {
-    uint32_t n;
-    bool full;
-    // entry k of this lane: target (index into tree[], or 0x80000000 | index into heads[]) and value
-    __device__ __forceinline__ static uint32_t *slot(uint32_t k) { return LB::base() + 2 * (k * 512 + threadIdx.x); }
-    __device__ __forceinline__ void put(uint32_t t, uint32_t v)
-    {
-        if (n < kLogCap) { uint32_t *e = slot(n); e[0] = t; e[1] = v; n++; }
-        else full = true;
-    }
-    __device__ __forceinline__ void head(uint32_t *, uint32_t i, uint32_t v) { put(0x80000000u | i, v); }
-    __device__ __forceinline__ void link(uint32_t *, uint32_t i, uint32_t v) { put(i, v); }
-    __device__ __forceinline__ void replay(uint32_t *heads, uint32_t *tree) const
-    {
-        for (uint32_t k = 0; k < n; k++) {
-            const uint32_t *e = slot(k);
-            const uint32_t t = e[0];
-            if (t >> 31) heads[t & 0x7FFFFFFFu] = e[1]; else tree[t] = e[1];
-        }
-    }
-};
-
 // MatchFinderBT::FindAndUpdate (:978-1022) as the worker lanes run it: the same steps as bt_find_and_update_st
 // (nlzm_core.h, which the host-side checks use), written for the lane -- the node's pair is ONE 8-byte load requested
 // together with the bytes to compare, what a step changes is chosen by selects, and only a record-setter (about one test in
 // four) takes a branch.  A hot head's lane is a chain of such steps, one memory round trip each; the instructions around
 // the round trip were as long as the round trip itself.
-// The record-setters of a descent on their way to the record: the first four in LDS (eight words per lane, behind the
-// store logs: a register each would be carried, and copied, through every step of the descent), the rest in bt_pairs.
+//
+// The record-setters of a descent on their way to the record: the first four in LDS (a register each would be carried, and
+// copied, through every step of the descent), the rest in bt_pairs.
 struct LaneSink {
-    uint32_t *slot;         // LDS: this lane's eight words
+    uint32_t *slot;         // LDS: this call's eight words (stride 512: the lanes' words interleave)
     uint32_t *pairs;        // bt_pairs of the position
     uint32_t count = 0, best = 1, best_d = 0;
     __device__ __forceinline__ void operator()(uint32_t d, uint32_t l)
     {
         best = l; best_d = d;
-        if (count < 4) { slot[2 * count] = d; slot[2 * count + 1] = l; }
+        if (count < 4) { slot[(2 * count) * 512] = d; slot[(2 * count + 1) * 512] = l; }
         else { LaneIO::st_agent(pairs + 2 * count, d); LaneIO::st_agent(pairs + 2 * count + 1, l); }
         count++;
     }
     __device__ __forceinline__ void publish(uint32_t *rec, uint32_t tests) const
     {
         if (count > 4) LaneIO::drain();
-        const uint32_t d0 = count > 0 ? slot[0] : 0u, l0 = count > 0 ? slot[1] : 0u, d1 = count > 1 ? slot[2] : 0u, l1 = count > 1 ? slot[3] : 0u;
-        const uint32_t d2 = count > 2 ? slot[4] : 0u, l2 = count > 2 ? slot[5] : 0u, d3 = count > 3 ? slot[6] : 0u, l3 = count > 3 ? slot[7] : 0u;
+        const uint32_t d0 = count > 0 ? slot[0] : 0u, l0 = count > 0 ? slot[512] : 0u, d1 = count > 1 ? slot[2 * 512] : 0u, l1 = count > 1 ? slot[3 * 512] : 0u;
+        const uint32_t d2 = count > 2 ? slot[4 * 512] : 0u, l2 = count > 2 ? slot[5 * 512] : 0u, d3 = count > 3 ? slot[6 * 512] : 0u, l3 = count > 3 ? slot[7 * 512] : 0u;
         LaneIO::st_quad(rec + 4, d0, l0, d1, kBtTag);
         LaneIO::st_quad(rec + 8, l1, d2, l2, kBtTag);
         LaneIO::st_quad(rec + 12, d3, l3, 0u, kBtTag);
         LaneIO::st_quad(rec, kBtReady | (tests << 9) | count, best_d, count ? best : 0u, 0u);
     }
 };
-template <class St>
-__device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st, LaneSink &sink,
-                                           uint32_t &tests_out, unsigned long long &cmp_bytes)
+// `keep`: the call is made before it is known whether it happens (see worker_role) -- every store also notes, in `undo`,
+// the slot and the value it replaces (a slot is assigned once per call, :1006-1017, so the old value is the child the call
+// went on to when it took the slot), at most 1 + 256 + 2 entries.
+constexpr uint32_t kUndoCap = 260;
+__device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, bool keep, uint32_t *undo,
+                                           uint32_t &n_undo, LaneSink &sink, uint32_t &tests_out, uint32_t &cmp_out)
 {
     const uint8_t *pa = B.in + a;
     uint32_t sp = B.heads[hidx];
-    st.head(B.heads, hidx, a);                                      // :983-984
-    uint32_t pend_l = (a & B.tmask) << 1, pend_r = pend_l + 1, len_l = 0, len_r = 0, tests = 0;
-    unsigned long long cb = 0;
+    uint32_t nu = 0;
+    if (keep) { *(unsigned long long *)undo = (0x80000000u | hidx) | ((unsigned long long)sp << 32); nu = 1; }
+    B.heads[hidx] = a;                                              // :983-984
+    uint32_t pend_l = (a & B.tmask) << 1, pend_r = pend_l + 1, len_l = 0, len_r = 0, tests = 0, cb = 0;
+    uint32_t old_l = kNone, old_r = kNone;                          // (the new node's own slots: what they held belongs to no tree)
     while (sp != kNone && a > sp && a - sp <= B.wmask && tests < 256) {    // :989 (256 tests at most, :777, :988)
         tests++;
         const uint32_t pair = (sp & B.tmask) << 1;
@@ -337,34 +318,45 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
         const uint32_t pl = (uint32_t)pp, pr = (uint32_t)(pp >> 32), d = a - sp;
         if (l >= match_min(d) && l > sink.best) sink(d, l);         // :996-998; only record-setters change the table
         if (full) {                                                 // :1000-1004
-            st.link(B.tree, pend_l, pl); st.link(B.tree, pend_r, pr);
-            tests_out = tests; cmp_bytes += cb;
+            B.tree[pend_l] = pl; B.tree[pend_r] = pr;
+            if (keep) {
+                *(unsigned long long *)(undo + 2 * nu) = pend_l | ((unsigned long long)old_l << 32);
+                *(unsigned long long *)(undo + 2 * nu + 2) = pend_r | ((unsigned long long)old_r << 32);
+                nu += 2;
+            }
+            tests_out = tests; cmp_out = cb; n_undo = nu;
             return;
         }
         // :1006-1017 as selects
         const bool right = sign != 0;
-        st.link(B.tree, right ? pend_l : pend_r, sp);
+        const uint32_t slot = right ? pend_l : pend_r;
+        B.tree[slot] = sp;
+        if (keep) { *(unsigned long long *)(undo + 2 * nu) = slot | ((unsigned long long)(right ? old_l : old_r) << 32); nu++; }
         pend_l = right ? pair + 1 : pend_l; pend_r = right ? pend_r : pair;
+        old_l = right ? pr : old_l; old_r = right ? old_r : pl;
         len_r = right ? l : len_r; len_l = right ? len_l : l;
         sp = right ? pr : pl;
     }
-    st.link(B.tree, pend_r, kNone); st.link(B.tree, pend_l, kNone);    // :1020-1021
-    tests_out = tests; cmp_bytes += cb;
-}
-// one call for position a with BT4 head hidx: stores at once (St = StoreNow) or noted down (a dry run), result published
-template <class St>
-__device__ __forceinline__ void worker_call(const BtView &B, uint32_t a, uint32_t hidx, uint32_t max_len, St &st,
-                                            unsigned long long &n_tests, unsigned long long &cmp_bytes)
-{
-    const unsigned long long bi = a - B.batch_a0;
-    LaneSink sink{ (uint32_t *)&g_v2_lds + 512 * kLogCap * 2 + 8 * threadIdx.x, B.pairs + bi * (2 * kBtMaxPairs) };
-    uint32_t tests = 0;
-    bt_descent(B, a, hidx, max_len, st, sink, tests, cmp_bytes);
-    n_tests += tests;
-    sink.publish(B.ready + bi * kBtRec, tests);
+    B.tree[pend_r] = kNone; B.tree[pend_l] = kNone;                 // :1020-1021
+    if (keep) {
+        *(unsigned long long *)(undo + 2 * nu) = pend_r | ((unsigned long long)old_r << 32);
+        *(unsigned long long *)(undo + 2 * nu + 2) = pend_l | ((unsigned long long)old_l << 32);
+        nu += 2;
+    }
+    tests_out = tests; cmp_out = cb; n_undo = nu;
 }
 
-template <class LB>
+// A worker lane.  Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it.
+//
+// Whether BT4 runs at a position the pre-filter marked is the finder stage's decision, and the lane is usually there first.
+// It does not wait: it makes the call (nearly four of five such decisions are "call": the positions that are skipped lie in
+// nice regions, where the finder stage runs ahead of the lanes), noting what every store replaced, and goes on with the
+// next positions of its bin on top of it -- up to kAhead calls whose fate is open.  The first of them is an undecided
+// position; its RESULT does not depend on its own decision and goes out at once.  The results of the calls behind it do
+// (their trees contain it), so they are held back: the finder stage never sees a result that a decision could still
+// change.  When the decision is "call" the held results go out as they are.  When it is "skip" every store of these calls
+// is taken back, latest first, and the lane goes on from the position behind the skipped one.
+// Per call, in LDS (interleaved by thread): the first four record-setters and what the lane needs to publish or drop it.
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
     if (threadIdx.x >= G.wthreads) return;
@@ -380,35 +372,68 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
 #define NLZM_AS_GLOBAL(T, x) ((T *)(__attribute__((address_space(1))) T *)(x))
     const BtView B{ NLZM_AS_GLOBAL(const uint8_t, p0), NLZM_AS_GLOBAL(uint32_t, p1), NLZM_AS_GLOBAL(uint32_t, p2), NLZM_AS_GLOBAL(uint32_t, p3),
                     NLZM_AS_GLOBAL(uint32_t, p4), q0, q1, q2, q3 };
+    uint32_t *const undo_base = NLZM_AS_GLOBAL(uint32_t, (unsigned long long)G.bt_undo) + (unsigned long long)gl * (kAhead * kUndoCap * 2);
 #undef NLZM_AS_GLOBAL
-    // Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it,
-    // so the position a lane may block on is always its smallest unprocessed one.
     bool active = gl < G.nheads;
     uint32_t c = c0;
     bool loaded = false;
     uint32_t i0 = 0, e0 = 0;
     uint32_t la_end = 0;            // absolute end of the chunk's lookahead
-    uint32_t stage = 0, a = 0, max_len = 0;
-    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_dry = 0, n_wait = 0, dry_t = 0, dry_c = 0, n_cyc = 0, n_cyc_tests = 0;
-    StoreLog<LB> slog{ 0, false };
+    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_open = 0, n_wait = 0, n_cyc = 0, n_cyc_tests = 0, n_back = 0, n_redo = 0;
+    // the calls whose fate is open: a ring of kAhead entries, `first` the oldest (an undecided position), `nq` of them
+    uint32_t first = 0, nq = 0, head_a = 0;
+    uint32_t *const my = (uint32_t *)&g_v2_lds + threadIdx.x;
+    enum : uint32_t { kWa = 8, kWtests = 9, kWcmp = 10, kWcount = 11, kWbest = 12, kWbestd = 13, kWundo = 14, kWinfo = 15 };   // (info: marked | bin index << 1)
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0, prog_seen = 0;
     bool fail = false;
-#ifdef NLZM_LEAD_DIAG
-    uint32_t since_wait = 0, wait_head = 0, cur_wait_head = 0; bool waited_ever = false;
-#define NLZM_DIAG_WAIT_BEGIN cur_wait_head = hidx;
-#define NLZM_DIAG_WAIT_END if (idle) { since_wait = 0; wait_head = cur_wait_head; waited_ever = true; }
-#else
-#define NLZM_DIAG_WAIT_BEGIN
-#define NLZM_DIAG_WAIT_END
-#endif
 
     while (__any(active)) {
         bool waiting = false;
+        uint32_t job = 0, ja = 0, jh = 0, jlen = 0, jinfo = 0;      // job 1: a call that stands; 2: one whose fate is open
         if (active) {
-            if (stage == 0) {
+            // ---- the oldest open call: is its decision in?
+            if (nq) {
+                const uint32_t f = LaneIO::ld_agent(G.bt_flag + (head_a - G.batch_a0));
+                if (f == kFlagCall) {
+                    // it stands; so do the calls behind it up to the next undecided position, whose results go out now
+                    for (uint32_t k = 0; k < kAhead; k++) {
+                        uint32_t *e = my + (first * kEntryWords) * 512;
+                        n_calls++; n_tests += e[kWtests * 512]; n_cmp += e[kWcmp * 512];
+                        first = first + 1 == kAhead ? 0u : first + 1; nq--;
+                        if (!nq) break;
+                        e = my + (first * kEntryWords) * 512;
+                        const uint32_t ea = e[kWa * 512];
+                        LaneSink sk{ e, B.pairs + (unsigned long long)(ea - B.batch_a0) * (2 * kBtMaxPairs), e[kWcount * 512], e[kWbest * 512], e[kWbestd * 512] };
+                        sk.publish(B.ready + (unsigned long long)(ea - B.batch_a0) * kBtRec, e[kWtests * 512]);
+                        if (e[kWinfo * 512] & 1u) {                 // a marked position: the new oldest, unless its decision is in too
+                            head_a = ea;
+                            if (LaneIO::ld_agent(G.bt_flag + (ea - G.batch_a0)) != kFlagCall) break;     // (skip: taken back in the next round)
+                        }
+                    }
+                } else if (f == kFlagSkip) {
+                    // it does not happen: every store of the open calls is taken back, latest first; the lane goes on behind it
+                    uint32_t resume = i0;
+                    for (uint32_t k = nq; k-- > 0;) {
+                        const uint32_t slot = first + k >= kAhead ? first + k - kAhead : first + k;
+                        const uint32_t *e = my + (slot * kEntryWords) * 512;
+                        const uint32_t *u = undo_base + slot * (kUndoCap * 2);
+                        for (uint32_t j = e[kWundo * 512]; j-- > 0;) {
+                            const unsigned long long w = *(const unsigned long long *)(u + 2 * j);
+                            const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
+                            if (t >> 31) B.heads[t & 0x7FFFFFFFu] = v; else B.tree[t] = v;
+                        }
+                        if (k == 1) resume = e[kWinfo * 512] >> 1;  // (the entry behind the skipped one: made again)
+                        if (k) n_redo++;
+                    }
+                    n_back++;
+                    i0 = resume; nq = 0;
+                }
+            }
+            // ---- the next position of the bin
+            if (nq < kAhead) {
                 if (!loaded) {
-                    if (c >= c1) active = false;
+                    if (c >= c1) { if (!nq) active = false; }
                     else {
                         const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
                         i0 = off[gl]; e0 = off[gl + 1];
@@ -418,93 +443,75 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                         loaded = true;
                     }
                 }
-                if (active) {
+                if (active && loaded) {
                     const uint32_t *pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size * 2;
-                    if (i0 >= e0) { c++; loaded = false; }
+                    if (i0 >= e0) { if (!nq) { c++; loaded = false; } }      // (open calls: the chunk is left when they are settled)
                     else {
                         const unsigned long long pe = *(const unsigned long long *)(pos + 2 * i0);
+                        ja = (uint32_t)pe; jh = (uint32_t)(pe >> 32) & 0x7FFFFFFFu; jlen = umin(la_end - ja, kMatchMax);
+                        jinfo = (i0 << 1) | (uint32_t)(pe >> 63);
                         i0++;
-                        a = (uint32_t)pe;
-                        const uint32_t hidx = (uint32_t)(pe >> 32) & 0x7FFFFFFFu;
-                        max_len = umin(la_end - a, kMatchMax);
                         if (pe >> 63) {
-                            // whether this call happens is decided by the master.  If the decision is in already (the
-                            // master is ahead of this lane, as it is inside nice regions where 7 of 8 calls are
-                            // skipped, :1529), act on it; otherwise its MATCHES do not depend on the decision: report
-                            // them now from a dry run, insert once the decision is in
-                            const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
-                            if (f == kFlagCall) {
-                                { StoreNow now; worker_call(B, a, hidx, max_len, now, n_tests, n_cmp); }
-                                n_calls++;
-                            } else if (f != kFlagSkip) {
-                                slog.n = 0; slog.full = false; dry_t = 0; dry_c = 0;
-                                worker_call(B, a, hidx, max_len, slog, dry_t, dry_c);
-                                n_dry++;
-                                stage = 1; t_wait0 = 0; idle = 0;
-                                NLZM_DIAG_WAIT_BEGIN
-                            }
-                        } else {
-                            const unsigned long long t0 = __builtin_readcyclecounter(), k0 = n_tests;
-                            { StoreNow now; worker_call(B, a, hidx, max_len, now, n_tests, n_cmp); }
-                            n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += n_tests - k0;
-                            n_calls++;
-#ifdef NLZM_LEAD_DIAG
-                            {   // where is the finder now that this call is done, and what had this lane done just before?
-                                const uint32_t mp = LaneIO::ld_agent(G.progress);
-                                const int lead = (int)(a - mp);
-                                since_wait++;
-                                const int k = lead >= 64 ? 4 : (!waited_ever ? 3 : (since_wait == 1 ? (hidx == wait_head ? 0 : 1) : (since_wait <= 4 ? 2 : 3)));
-                                atomicAdd(&G.wcnt->lead[k], 1ull);
-                                if (lead < 64) atomicAdd(&G.wcnt->lead[5], n_tests - k0);
-                            }
-#endif
-                        }
-                    }
-                }
-            } else {
-                const uint32_t f = LaneIO::ld_agent(G.bt_flag + (a - G.batch_a0));
-                if (f == kFlagCall) {
-                    // the call happens: what the dry run noted is exactly what it writes
-                    if (!slog.full) { slog.replay(G.bt_heads, G.bt_tree); n_tests += dry_t; n_cmp += dry_c; }
-                    else worker_bt_call<LaneIO, true>(B, a, max_len, false, n_tests, n_cmp);
-                    n_calls++;
-                    stage = 0;
-                    NLZM_DIAG_WAIT_END
-                } else if (f == kFlagSkip) {
-                    stage = 0;
-                    NLZM_DIAG_WAIT_END
-                } else {
-                    waiting = true;
-                    n_wait++;
-                    if ((++idle & 1023u) == 0) {
-                        if (LaneIO::ld_agent(G.abort_word)) active = false;
-                        // give up only when the finder stage itself has not moved for 30 s (a lane that is far ahead of it
-                        // waits as long as the launch takes)
-                        const unsigned long long now = wall_clock64();
-                        const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
-                        if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
-                        else if (now - t_wait0 > 3000000000ull) { fail = true; }
+                            // a marked position.  Decision in already (the finder stage is ahead of this lane, as it is inside nice
+                            // regions, :1529): act on it; otherwise the call is made with its fate open
+                            const uint32_t f = LaneIO::ld_agent(G.bt_flag + (ja - G.batch_a0));
+                            job = f == kFlagSkip ? 0u : ((f == kFlagCall && !nq) ? 1u : 2u);
+                        } else job = nq ? 2u : 1u;
                     }
                 }
             }
-            if (fail) { LaneIO::st_agent(G.abort_word, 2u); active = false; }
+            if (!job && nq) {
+                waiting = true;
+                n_wait++;
+                if ((++idle & 1023u) == 0) {
+                    if (LaneIO::ld_agent(G.abort_word)) active = false;
+                    // give up only when the finder stage itself has not moved for 30 s (a lane that is far ahead of it
+                    // waits as long as the launch takes)
+                    const unsigned long long now = wall_clock64();
+                    const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
+                    if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
+                    else if (now - t_wait0 > 3000000000ull) { fail = true; }
+                }
+            }
+            if (fail) { LaneIO::st_agent(G.abort_word, 2u); active = false; job = 0; }
+        }
+        if (job) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            const unsigned long long bi = ja - B.batch_a0;
+            const uint32_t slot = first + nq >= kAhead ? first + nq - kAhead : first + nq;     // (job 1: nq = 0, any slot will do)
+            uint32_t *e = my + (slot * kEntryWords) * 512;
+            LaneSink sink{ e, B.pairs + bi * (2 * kBtMaxPairs) };
+            uint32_t tests = 0, cmpb = 0, nu = 0;
+            bt_descent(B, ja, jh, jlen, job == 2, undo_base + slot * (kUndoCap * 2), nu, sink, tests, cmpb);
+            if (job == 1) {
+                sink.publish(B.ready + bi * kBtRec, tests);
+                n_calls++; n_tests += tests; n_cmp += cmpb;
+                n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += tests;
+            } else {
+                if (!nq) { sink.publish(B.ready + bi * kBtRec, tests); head_a = ja; t_wait0 = 0; idle = 0; }    // (the oldest: its result stands whatever is decided)
+                e[kWa * 512] = ja; e[kWtests * 512] = tests; e[kWcmp * 512] = cmpb; e[kWcount * 512] = sink.count;
+                e[kWbest * 512] = sink.best; e[kWbestd * 512] = sink.best_d; e[kWundo * 512] = nu; e[kWinfo * 512] = jinfo;
+                nq++; n_open++;
+            }
         }
         if (!__any(active && !waiting)) __builtin_amdgcn_s_sleep(8);
     }
-    if (stage == 1) {       // left while waiting for a decision: the launch failed; say where (error report)
+    if (nq) {               // left with calls open: the launch failed; say where (error report)
         atomicAdd(&G.wcnt->stuck_lanes, 1ull);
-        atomicMax(&G.wcnt->stuck_pos_inv, (unsigned long long)(uint32_t)~a);
+        atomicMax(&G.wcnt->stuck_pos_inv, (unsigned long long)(uint32_t)~head_a);
     }
     // counters: one atomic per wave
     for (int m = 32; m >= 1; m >>= 1) {
         n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
-        n_dry += __shfl_xor(n_dry, m, 64); n_wait += __shfl_xor(n_wait, m, 64);
+        n_open += __shfl_xor(n_open, m, 64); n_wait += __shfl_xor(n_wait, m, 64);
         n_cyc += __shfl_xor(n_cyc, m, 64); n_cyc_tests += __shfl_xor(n_cyc_tests, m, 64);
+        n_back += __shfl_xor(n_back, m, 64); n_redo += __shfl_xor(n_redo, m, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
-        atomicAdd(&G.wcnt->dry_runs, n_dry); atomicAdd(&G.wcnt->flag_waits, n_wait);
+        atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->flag_waits, n_wait);
         atomicAdd(&G.wcnt->call_cycles, n_cyc); atomicAdd(&G.wcnt->call_tests, n_cyc_tests);
+        atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
     }
 }
 
@@ -525,7 +532,7 @@ __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G,
         else if (local_block == 1) { v2::Table r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
     } else {
-        worker_role<LogInV2>(g, G, c0, c1, wblocks, local_block - kV2Roles);
+        worker_role(g, G, c0, c1, wblocks, local_block - kV2Roles);
     }
 }
 __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::GlobalsV2 V, uint32_t c0, uint32_t c1)
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args 
     NLZM_GLOBAL_PTR(a.G.bt_heads); NLZM_GLOBAL_PTR(a.G.bt_tree); NLZM_GLOBAL_PTR(a.G.persist); NLZM_GLOBAL_PTR(a.G.syms); NLZM_GLOBAL_PTR(a.G.bits);
     NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs);
     NLZM_GLOBAL_PTR(a.G.bt_flag); NLZM_GLOBAL_PTR(a.G.unc); NLZM_GLOBAL_PTR(a.G.bin_off); NLZM_GLOBAL_PTR(a.G.bin_pos); NLZM_GLOBAL_PTR(a.G.abort_word);
-    NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt);
+    NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt); NLZM_GLOBAL_PTR(a.G.bt_undo);
     NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state);
 #undef NLZM_GLOBAL_PTR
     pipeline2_roles(a.g, a.G, a.V, a.c0, a.c1, local, bps - kV2Roles);
@@ -697,6 +704,8 @@ void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks,
     if (!nchunks) return;
     hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos, unc, batch_a0);
 }
+
+unsigned long long worker_undo_bytes_per_lane() { return (unsigned long long)kAhead * kUndoCap * 8; }
 
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
                  FrameMeta *fmeta, uint32_t *scratch, unsigned long long scratch_stride, uint8_t *out,
