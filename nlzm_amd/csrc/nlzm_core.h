@@ -116,6 +116,7 @@ struct WorkerCounters {
     unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
     unsigned long long lead[6];                     // NLZM_LEAD_DIAG: calls by how far ahead of the master they ended
     unsigned long long stuck_lanes, stuck_pos_inv;  // lanes that left while waiting for a decision (a launch that failed); ~(smallest such position)
+    unsigned long long hot_bins, hot_calls;         // hot bins over all launches; calls made by their waves
     unsigned long long spec_calls, spec_good;       // decisions "skip" that took calls back; calls behind the skipped position that were made again
 };
 
@@ -144,6 +145,9 @@ struct Globals {
     const uint32_t *bin_pos;    // [chunk - chunk0][chunk_size][2] positions grouped by bin, ascending: position, BT4 head | unc << 31
     uint32_t nheads;            // bins = min(BT4 heads, worker lanes); head h belongs to bin h % bins
     uint32_t wthreads;          // lanes of a worker block that take bins (the first so many of its 512 threads)
+    const uint32_t *hot_of_bin; // [nheads] nonzero: the bin has a wave of its own (hot_select_kernel); null: no such waves
+    const uint32_t *hot_list;   // [0]: hot bins of this launch, [1 + k]: the k-th of them
+    unsigned long long *hot_undo;   // [hot bin index][lane][kUndoCap]: the notes of the calls of a hot bin's wave
     uint32_t *bt_undo;          // [lane][calls with their fate open][kUndoCap]: slot and replaced value of every store of such a call
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)

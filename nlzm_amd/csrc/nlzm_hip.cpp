@@ -35,6 +35,9 @@ void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t wo
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 unsigned long long worker_undo_bytes_per_lane();
+unsigned long long worker_hot_undo_bytes_per_wave();
+void launch_hot_select(const uint32_t *off, uint32_t nchunks, uint32_t nheads, uint32_t hmax, uint32_t min_count, uint32_t *hot_of_bin,
+                       uint32_t *hot_list, WorkerCounters *wcnt, hipStream_t st);
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,
                 uint32_t *pos, const uint8_t *unc, uint32_t batch_a0, hipStream_t st);
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,
@@ -85,6 +88,8 @@ struct Ctx {
     int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (a stream's 240 worker CUs are there for latency, not for lanes: with
                                             // two of a CU's eight waves walking trees a test takes less time than with all eight, and a lane with four heads
                                             // is not busier than one with one -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
+    int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
+    int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
     int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
     int cu_count = 0;
 
@@ -111,7 +116,9 @@ struct Ctx {
     uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
     uint32_t t_bits = 0, m_bits = 0, nheads = 0;
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
-    uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr, *bt_undo = nullptr;
+    uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr, *bt_undo = nullptr, *hot_of_bin = nullptr, *hot_list = nullptr;
+    unsigned long long *hot_undo = nullptr;
+    uint32_t hot_max = 0;
     WorkerCounters *wcnt = nullptr;
     // three-stage pipeline (nlzm_v2.h): hand-off rings, progress words, stage state
     uint32_t *v2_ft = nullptr, *v2_tp = nullptr, *v2_tf = nullptr, *v2_state = nullptr;
@@ -184,12 +191,12 @@ void free_stream_buffers(Ctx &C)
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
-                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo,
+                     C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo, C.hot_of_bin, C.hot_list, C.hot_undo,
                      C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
-    C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = nullptr; C.wcnt = nullptr;
+    C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = C.hot_of_bin = C.hot_list = nullptr; C.hot_undo = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
     C.persist = nullptr; C.syms = C.scratch = nullptr; C.bits = C.frames = nullptr; C.fmeta = nullptr;
     C.dst_off = nullptr; C.own_in = C.own_dst = nullptr;
@@ -335,6 +342,19 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
         HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
         HIPCHK(hipMalloc(&C.bt_undo, (size_t)C.nheads * worker_undo_bytes_per_lane()));     // (6 KB per lane)
+        {   // hot bins: the waves of a worker block behind its bin-taking lanes (none in block mode, where every lane takes bins)
+            int64_t hw = C.opt_hot_waves;
+            if (const char *e = getenv("NLZM_HOT_WAVES")) hw = atoll(e);            // (experiments)
+            if (const char *e = getenv("NLZM_HOT_MIN")) C.opt_hot_min = atoll(e);
+            const int64_t spare = (512 - C.opt_worker_threads) / 64;
+            if (hw > spare) hw = spare;
+            C.hot_max = hw > 0 ? (uint32_t)(hw * C.opt_worker_blocks) : 0u;
+            if (C.hot_max) {
+                HIPCHK(hipMalloc(&C.hot_of_bin, (size_t)C.nheads * 4));
+                HIPCHK(hipMalloc(&C.hot_list, ((size_t)C.hot_max + 1) * 4));
+                HIPCHK(hipMalloc(&C.hot_undo, (size_t)C.hot_max * worker_hot_undo_bytes_per_wave()));
+            }
+        }
     }
 
     // hand-off between the finder, table and parser stages
@@ -398,6 +418,10 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
                          C.pf_c1, C.unc, C.st);
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
+        if (C.hot_max) {
+            launch_hot_select(C.bin_off, nb, C.nheads, C.hot_max, (uint32_t)C.opt_hot_min, C.hot_of_bin, C.hot_list, C.wcnt, C.st);
+            G.hot_of_bin = C.hot_of_bin; G.hot_list = C.hot_list; G.hot_undo = C.hot_undo;
+        }
     }
     {   // progress words of the stages: everything before the launch's first position is done
         v2::Hx &h = C.hx_host;          // (lives until the copy has been made)
@@ -574,6 +598,8 @@ int refresh_stats(Ctx &C)
         if (getenv("NLZM_WAIT_PRINT"))
             fprintf(stderr, "worker lanes: %llu calls made with their fate open (at and behind a position not decided yet), %llu decisions that took calls back, %llu calls made again for it\n",
                     wc.dry_runs, wc.spec_calls, wc.spec_good);
+        if (getenv("NLZM_WAIT_PRINT") && C.hot_max)
+            fprintf(stderr, "hot bins (a wave each): %llu over all launches, %llu of %llu calls made by their waves\n", wc.hot_bins, wc.hot_calls, wc.bt_calls);
         if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));
@@ -749,6 +775,8 @@ int nlzm_hip_set_option(const char *key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
+    if (!strcmp(key, "hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "hot_waves out of range"); C.opt_hot_waves = value; return 0; }
+    if (!strcmp(key, "hot_min")) { if (value < 1 || value > (1 << 30)) return set_err(NLZM_HIP_E_ARG, "hot_min out of range"); C.opt_hot_min = value; return 0; }
     if (!strcmp(key, "worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "worker_threads out of range"); C.opt_worker_threads = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);

@@ -215,6 +215,54 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
 }
 
 // ---------------------------------------------------------------------------
+// hot bins of a launch: the bins with the most positions, at most `hmax` of them and none below `min_count` -- each gets a
+// wave of its own (worker_role_hot).  One workgroup: totals per bin, a histogram of their binary logarithms, the smallest
+// power of two as threshold that leaves no more than hmax bins, then the list.
+//   hot_of_bin[b]  0, or 1 + the bin's index in the list        hot_list[0] = bins in the list, hot_list[1 + k] = the k-th
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hot_select_kernel(const uint32_t *__restrict__ off_all, uint32_t nchunks, uint32_t nheads,
+                                                          uint32_t hmax, uint32_t min_count, uint32_t *__restrict__ hot_of_bin,
+                                                          uint32_t *__restrict__ hot_list, WorkerCounters *__restrict__ wcnt)
+{
+    __shared__ uint32_t hist[32];
+    __shared__ uint32_t thr_s, n_s;
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_s = 0;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nheads; b += 1024) {
+        uint32_t tot = 0;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t *off = off_all + (unsigned long long)c * (nheads + 1);
+            tot += off[b + 1] - off[b];
+        }
+        hot_of_bin[b] = tot;
+        if (tot >= min_count && tot) atomicAdd(&hist[31 - __builtin_clz(tot)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0, k = 32;
+        for (int j = 31; j >= 0; j--) {
+            if (acc + hist[j] > hmax) break;
+            acc += hist[j]; k = (uint32_t)j;
+        }
+        thr_s = k >= 32 ? 0xFFFFFFFFu : umax(min_count, 1u << k);
+    }
+    __syncthreads();
+    const uint32_t thr = thr_s;
+    for (uint32_t b = threadIdx.x; b < nheads; b += 1024) {
+        const uint32_t tot = hot_of_bin[b];
+        uint32_t v = 0;
+        if (tot >= thr) {
+            const uint32_t idx = atomicAdd(&n_s, 1u);
+            if (idx < hmax) { hot_list[1 + idx] = b; v = idx + 1; }
+        }
+        hot_of_bin[b] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { hot_list[0] = umin(n_s, hmax); atomicAdd(&wcnt->hot_bins, (unsigned long long)umin(n_s, hmax)); }
+}
+
+// ---------------------------------------------------------------------------
 // worker lanes: BT4, one serial worker per hash head (trees of different heads are
 // disjoint: slot (p & mask)*2 is written by p's own insertion and re-linked only by
 // later positions of the same head, NLZM.cpp:979-1021).
@@ -348,6 +396,264 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
     tests_out = tests; cmp_out = cb; n_undo = nu;
 }
 
+// ---------------------------------------------------------------------------
+// A hot bin -- the bin of a frequent 4-byte head of the text -- is a serial chain of calls that one lane cannot keep up with
+// at depth: such a bin gets a WAVE.  Its lanes run consecutive calls of the bin at the same time, each
+// trailing the calls before it down the tree, with exactly the results of the serial order:
+//  * During a call every slot of the tree is assigned at most once (:1006-1017: the slot a call holds as pend_l / pend_r is
+//    written when the call turns that way again, or at its end), and a call reads a slot only on its way down.  A call
+//    marks the slot it takes as pending (kPending in the slot itself, before the store that makes the slot's node
+//    reachable); a call that needs a pending slot repeats the step.  A later call can reach a node of an earlier call's
+//    path only through a slot that call has assigned, i.e. after it has left the node, and can enter only the side the
+//    earlier call did not take: it never overtakes, the earliest call in flight never meets a mark, the wave always moves.
+//    All lanes are lanes of ONE wave: its memory operations are issued in program order (loads at the top of a step,
+//    stores at its end), which orders a mark before the store that exposes it and both before the next step's loads.
+//  * Calls start one per step, in the bin's order (a call starts by reading its head and storing itself there).
+//  * An undecided position does not stop the wave: as in the lanes' role its decision is assumed (skip if the position
+//    before is marked too, call otherwise), the results of the calls behind it are held back until the decision, and every
+//    store notes (slot, value it replaced) in the lane's list.  A decision as assumed releases what was held.  Otherwise the
+//    wave stops starting calls, lets the calls in flight finish, takes the stores of every call behind the position
+//    back, latest first, takes back or makes the position's own, and goes on behind it.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kPending = 0xFFFFFFFEu;      // (no position: stream_begin refuses inputs of 0xFFFF0000 bytes and more)
+__device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t bin, uint32_t hot_index)
+{
+    unsigned long long p0 = (unsigned long long)G.in, p1 = (unsigned long long)G.bt_heads, p2 = (unsigned long long)G.bt_tree,
+                       p3 = (unsigned long long)G.bt_ready, p4 = (unsigned long long)G.bt_pairs, p5 = (unsigned long long)G.bt_flag,
+                       p6 = (unsigned long long)G.hot_undo;
+    uint32_t q0 = G.batch_a0, q2 = g.wmask, q3 = g.bt_tmask;
+    asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2), "+s"(p3), "+s"(p4), "+s"(p5), "+s"(p6));
+    asm volatile("" : "+s"(q0), "+s"(q2), "+s"(q3));
+#define NLZM_AS_GLOBAL(T, x) ((T *)(__attribute__((address_space(1))) T *)(x))
+    const uint8_t *in = NLZM_AS_GLOBAL(const uint8_t, p0);
+    uint32_t *heads = NLZM_AS_GLOBAL(uint32_t, p1), *tree = NLZM_AS_GLOBAL(uint32_t, p2), *ready = NLZM_AS_GLOBAL(uint32_t, p3);
+    uint32_t *pairs = NLZM_AS_GLOBAL(uint32_t, p4);
+    const uint32_t *flags = NLZM_AS_GLOBAL(const uint32_t, p5);
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long *const undo = NLZM_AS_GLOBAL(unsigned long long, p6) + ((unsigned long long)hot_index * 64 + lane) * kUndoCap;
+#undef NLZM_AS_GLOBAL
+    const uint32_t batch_a0 = q0, wmask = q2, tmask = q3;
+    enum : uint32_t { kIdle = 0, kStart = 1, kRun = 2, kHeld = 3 };
+    // the bin's entries, in order (wave-uniform)
+    uint32_t c = c0, i0 = 0, e0 = 0, la_end = 0, seq_next = 1;
+    const uint32_t *pos = G.bin_pos;
+    bool loaded = false, more = true, have_pe = false, rec = false;
+    unsigned long long pe = 0;
+    // the lane's call
+    uint32_t st = kIdle, a = 0, hidx = 0, max_len = 0, sp = kNone, pend_l = 0, pend_r = 0, len_l = 0, len_r = 0, tests = 0, cb = 0;
+    uint32_t seq = 0, binidx = 0, nu = 0;
+    bool marked = false, und = false, dry = false, published = false, wrong = false, risky = false;
+    bool last_skip = false;         // (wave-uniform) the bin's latest decision was "skip"
+    LaneSink sink{ (uint32_t *)&g_v2_lds + threadIdx.x, nullptr };
+    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_open = 0, n_back = 0, n_redo = 0;
+    unsigned long long t_wait0 = 0;
+    uint32_t idle = 0, prog_seen = 0, steps = 0;
+    bool fail = false;
+
+    for (;;) {
+        // ---- the oldest undecided position in flight; a wrong assumption
+        uint32_t oseq = 0xFFFFFFFFu;
+        for (unsigned long long m = __ballot(und); m; m &= m - 1) oseq = umin(oseq, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
+        uint32_t rseq = 0xFFFFFFFFu;
+        for (unsigned long long m = __ballot(wrong); m; m &= m - 1) rseq = umin(rseq, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
+        if (rseq != 0xFFFFFFFFu) rec = true;
+        if (rec && !__any(st == kStart || st == kRun)) {
+            // every call in flight has ended: the stores of the calls behind the position are taken back, latest first, then
+            // the position's own are taken back ("skip") or made ("call"); the bin goes on behind it
+            for (;;) {
+                uint32_t smax = 0;
+                for (unsigned long long m = __ballot(st == kHeld && seq > rseq); m; m &= m - 1)
+                    smax = umax(smax, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
+                if (!smax) break;
+                if (st == kHeld && seq == smax) {
+                    if (!dry) for (uint32_t j = nu; j-- > 0;) {
+                        const unsigned long long w = undo[j];
+                        const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
+                        if (t >> 31) heads[t & 0x7FFFFFFFu] = v; else tree[t] = v;
+                    }
+                    st = kIdle; und = false; wrong = false; n_redo++;
+                }
+            }
+            uint32_t resume = 0;
+            if (st == kHeld && seq == rseq) {
+                for (uint32_t j = nu; j-- > 0;) {                   // (made with its stores: the values they replaced; without: the values they write)
+                    const unsigned long long w = undo[j];
+                    const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
+                    if (t >> 31) heads[t & 0x7FFFFFFFu] = v; else tree[t] = v;
+                }
+                if (dry) { n_calls++; n_tests += tests; n_cmp += cb; }
+                st = kIdle; und = false; wrong = false; n_back++;
+                resume = binidx + 1;
+            }
+            for (unsigned long long m = __ballot(resume != 0); m; m &= m - 1) i0 = (uint32_t)__builtin_amdgcn_readlane((int)resume, (int)__builtin_ctzll(m));
+            have_pe = false; more = true;
+            rec = false;
+            continue;
+        }
+        // ---- one call starts per step, on the first free lane (not while a wrong assumption is being undone)
+        uint32_t start_lane = 64;
+        const unsigned long long free_m = __ballot(st == kIdle);
+        // (A call made without its stores does not hold later calls back -- they could overtake it and change what it has yet
+        //  to read: nothing starts until it has ended.)
+        // (An undecided position assumed to be skipped although the bin's last decision was "call" is wrong one time in eight,
+        //  and a wrong assumption costs every call behind it: nothing starts behind such a position until it is decided.)
+        const bool dry_on_its_way = __any((st == kStart || st == kRun) && dry) || __any(und && risky);
+        if (!rec && !dry_on_its_way && have_pe && free_m) { start_lane = (uint32_t)__builtin_ctzll(free_m); have_pe = false; }
+        if (lane == start_lane) {
+            a = (uint32_t)pe; hidx = (uint32_t)(pe >> 32) & 0x3FFFFFFFu;
+            max_len = umin(la_end - a, kMatchMax);
+            marked = (pe >> 63) != 0; dry = (pe >> 62) == 3u;           // (without stores: if it turns out to be undecided)
+            seq = seq_next; binidx = i0 - 1;
+            st = kStart;
+        }
+        if (start_lane < 64) seq_next++;
+        // ---- the next entry of the bin (requested a step ahead of its use); the chunk is left when no call is in flight
+        if (!have_pe && more && !rec) {
+            for (;;) {
+                if (!loaded) {
+                    if (c >= c1) { more = false; break; }
+                    const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
+                    i0 = off[bin]; e0 = off[bin + 1];
+                    const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
+                    const unsigned long long remain = g.n - chunk_abs;
+                    la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
+                    pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size * 2;
+                    loaded = true;
+                }
+                if (i0 < e0) { pe = *(const unsigned long long *)(pos + 2 * i0); i0++; have_pe = true; break; }
+                if (__any(st != kIdle)) break;                      // (a wrong assumption would bring the bin back into this chunk)
+                c++; loaded = false;
+            }
+        }
+        // ---- loads of this step
+        uint32_t v_word = 0, v_flag = 0;
+        unsigned long long pp = 0, x0 = 0, y0 = 0;
+        bool fin_now = false;
+        uint32_t fin_l = kNone, fin_r = kNone;
+        if (st == kRun && !(sp != kNone && a > sp && a - sp <= wmask && tests < 256)) fin_now = true;   // :989, :1020-1021
+        const uint32_t pair = (sp & tmask) << 1, init = umin(len_l, len_r);
+        if ((st == kStart && marked) || und) v_flag = LaneIO::ld_agent(flags + (a - batch_a0));
+        if (st == kStart) v_word = heads[hidx];
+        else if (st == kRun && !fin_now) {
+            pp = *(const unsigned long long *)(tree + pair);
+            x0 = load64u(in + sp + init); y0 = load64u(in + a + init);
+        }
+        // ---- what they say
+        {
+            const bool decided = und && !wrong && (v_flag == kFlagCall || v_flag == kFlagSkip);
+            if (decided) {
+                if ((v_flag == kFlagSkip) == dry) und = false;      // as assumed
+                else wrong = true;                                  // (und stays: nothing behind it is released)
+            }
+            if (__any(decided)) last_skip = __any(decided && v_flag == kFlagSkip);
+        }
+        if (st == kStart) {
+            bool go = true;
+            if (marked) {
+                if (v_flag == kFlagSkip) { st = kIdle; go = false; }        // decided already: it does not happen
+                else if (v_flag == kFlagCall) dry = false;                  // decided already: it happens
+                else { und = true; risky = dry && !last_skip; n_open++; t_wait0 = 0; idle = 0; }       // its fate is open: assumed (dry as set at the start)
+            } else dry = false;
+            if (go) {
+                sp = v_word;                                        // :983
+                pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0;
+                sink.count = 0; sink.best = 1; sink.best_d = 0; sink.pairs = pairs + (unsigned long long)(a - batch_a0) * (2 * kBtMaxPairs);
+                published = false;
+                undo[0] = (0x80000000u | hidx) | ((unsigned long long)(dry ? a : sp) << 32);
+                nu = 1;
+                if (!dry) {
+                    *(unsigned long long *)(tree + pend_l) = ((unsigned long long)kPending << 32) | kPending;   // the new node's two slots: taken
+                    heads[hidx] = a;                                // :984
+                }
+                st = kRun;
+            }
+        } else if (st == kRun && !fin_now) {
+            const unsigned long long d0 = x0 ^ y0;
+            const uint32_t nb0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u;
+            uint32_t l = init + nb0;
+            bool full = l >= max_len;
+            uint32_t sign = (uint32_t)(((x0 >> (8 * (nb0 & 7u))) & 0xFF) < ((y0 >> (8 * (nb0 & 7u))) & 0xFF));
+            const uint32_t pl = (uint32_t)pp, pr = (uint32_t)(pp >> 32);
+            if (!d0 && !full) {
+                const uint8_t *ps = in + sp, *pa = in + a;
+                for (;;) {
+                    const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
+                    if (d) {
+                        const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
+                        l += nb;
+                        sign = (uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF));
+                        break;
+                    }
+                    l += 8;
+                    if (l >= max_len) break;
+                }
+                full = l >= max_len;
+            }
+            if (full) l = max_len;
+            const bool right = sign != 0;
+            // the slot(s) this step reads on: still held by an earlier call -> the step is repeated
+            const bool held = full ? (pl == kPending || pr == kPending) : ((right ? pr : pl) == kPending);
+            if (!held) {
+                tests++;
+                cb += (l - init) + (full ? 0u : 1u);
+                const uint32_t d = a - sp;
+                if (l >= match_min(d) && l > sink.best) sink(d, l);         // :996-998
+                if (full) { fin_now = true; fin_l = pl; fin_r = pr; }       // :1000-1004
+                else {
+                    // :1006-1017.  The slot taken is marked before the store that makes its node reachable for later calls.
+                    const uint32_t slot = right ? pend_l : pend_r;
+                    if (!dry) {
+                        tree[right ? pair + 1 : pair] = kPending;
+                        tree[slot] = sp;
+                    }
+                    // noted -- with stores: the slot taken now and what it held; without: the store itself
+                    undo[nu] = dry ? (slot | ((unsigned long long)sp << 32)) : ((right ? pair + 1 : pair) | ((unsigned long long)(right ? pr : pl) << 32));
+                    nu++;
+                    pend_l = right ? pair + 1 : pend_l; pend_r = right ? pend_r : pair;
+                    len_r = right ? l : len_r; len_l = right ? len_l : l;
+                    sp = right ? pr : pl;
+                }
+            }
+        }
+        if (fin_now) {
+            if (!dry) { tree[pend_l] = fin_l; tree[pend_r] = fin_r; }
+            else { undo[nu] = pend_l | ((unsigned long long)fin_l << 32); undo[nu + 1] = pend_r | ((unsigned long long)fin_r << 32); nu += 2; }
+            st = kHeld;
+        }
+        // ---- a call that has ended: its result goes out when no undecided position stands before it
+        if (st == kHeld && !wrong) {
+            if (!published && seq <= oseq) { sink.publish(ready + (unsigned long long)(a - batch_a0) * kBtRec, tests); published = true; }
+            if (published && !und && seq <= oseq) {
+                if (!dry) { n_calls++; n_tests += tests; n_cmp += cb; }
+                st = kIdle;
+            }
+        }
+        // ---- watchdogs (a position whose decision does not come; a launch that failed elsewhere)
+        if (und && (++idle & 4095u) == 0) {
+            const unsigned long long now = wall_clock64();
+            const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
+            if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
+            else if (now - t_wait0 > 3000000000ull) fail = true;
+        }
+        if (__any(fail)) { if (lane == 0) LaneIO::st_agent(G.abort_word, 2u); break; }
+        if ((++steps & 0x3FFFu) == 0 && __any(LaneIO::ld_agent(G.abort_word) != 0)) break;
+        if (!more && !have_pe && !rec && !__any(st != kIdle)) break;
+    }
+    if (st != kIdle) {
+        atomicAdd(&G.wcnt->stuck_lanes, 1ull);
+        atomicMax(&G.wcnt->stuck_pos_inv, (unsigned long long)(uint32_t)~a);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
+        n_open += __shfl_xor(n_open, m, 64); n_back += __shfl_xor(n_back, m, 64); n_redo += __shfl_xor(n_redo, m, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
+        atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
+        atomicAdd(&G.wcnt->hot_calls, n_calls);
+    }
+}
+
 // A worker lane.  Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it.
 //
 // Whether BT4 runs at a position the pre-filter marked is the finder stage's decision, and the lane is usually there first.
@@ -363,7 +669,14 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
 // Per call, in LDS (interleaved by thread): the first four record-setters and what the lane needs to publish or drop it.
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
-    if (threadIdx.x >= G.wthreads) return;
+    if (threadIdx.x >= G.wthreads) {
+        // the waves behind the bin-taking lanes: one hot bin each (hot bin k: wave k / wblocks of worker block k % wblocks)
+        if (!G.hot_list) return;
+        const uint32_t k = ((threadIdx.x - G.wthreads) >> 6) * wblocks + wblock;
+        if (k >= G.hot_list[0]) return;
+        worker_role_hot(g, G, c0, c1, G.hot_list[1 + k], k);
+        return;
+    }
     const uint32_t gl = wblock * G.wthreads + threadIdx.x;
     // What a descent touches, as values of this role (made opaque): left as kernel arguments, the compiler re-loads them
     // from the argument segment inside the test loop -- two 64-byte scalar loads and their waits per test -- rather than keep them.
@@ -378,7 +691,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                     NLZM_AS_GLOBAL(uint32_t, p4), q0, q1, q2, q3 };
     uint32_t *const undo_base = NLZM_AS_GLOBAL(uint32_t, (unsigned long long)G.bt_undo) + (unsigned long long)gl * (kAhead * kUndoCap * 2);
 #undef NLZM_AS_GLOBAL
-    bool active = gl < G.nheads;
+    bool active = gl < G.nheads && !(G.hot_of_bin && G.hot_of_bin[gl < G.nheads ? gl : 0]);        // (a hot bin has a wave of its own)
     uint32_t c = c0;
     bool loaded = false;
     uint32_t i0 = 0, e0 = 0;
@@ -567,7 +880,7 @@ __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args 
     NLZM_GLOBAL_PTR(a.G.bt_heads); NLZM_GLOBAL_PTR(a.G.bt_tree); NLZM_GLOBAL_PTR(a.G.persist); NLZM_GLOBAL_PTR(a.G.syms); NLZM_GLOBAL_PTR(a.G.bits);
     NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs);
     NLZM_GLOBAL_PTR(a.G.bt_flag); NLZM_GLOBAL_PTR(a.G.unc); NLZM_GLOBAL_PTR(a.G.bin_off); NLZM_GLOBAL_PTR(a.G.bin_pos); NLZM_GLOBAL_PTR(a.G.abort_word);
-    NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt); NLZM_GLOBAL_PTR(a.G.bt_undo);
+    NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt); NLZM_GLOBAL_PTR(a.G.bt_undo); NLZM_GLOBAL_PTR(a.G.hot_of_bin); NLZM_GLOBAL_PTR(a.G.hot_list); NLZM_GLOBAL_PTR(a.G.hot_undo);
     NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state);
 #undef NLZM_GLOBAL_PTR
     pipeline2_roles(a.g, a.G, a.V, a.c0, a.c1, local, bps - kV2Roles);
@@ -717,6 +1030,13 @@ void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks,
     hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos, unc, batch_a0);
 }
 
+void launch_hot_select(const uint32_t *off, uint32_t nchunks, uint32_t nheads, uint32_t hmax, uint32_t min_count, uint32_t *hot_of_bin,
+                       uint32_t *hot_list, WorkerCounters *wcnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(hot_select_kernel, dim3(1), dim3(1024), 0, st, off, nchunks, nheads, hmax, min_count, hot_of_bin, hot_list, wcnt);
+}
+
+unsigned long long worker_hot_undo_bytes_per_wave() { return 64ull * kUndoCap * 8; }
 unsigned long long worker_undo_bytes_per_lane() { return (unsigned long long)kAhead * kUndoCap * 8; }
 
 void launch_rans(const uint32_t *syms, unsigned long long syms_stride, const uint8_t *bits, unsigned long long bits_stride,

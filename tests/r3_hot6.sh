@@ -1,0 +1,15 @@
+#!/bin/bash
+mkdir -p gpurun_out
+{
+NLZM_HOT_MIN=4 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_stream_bit_exact or test_find_matches or test_batching or large_window or cli_" 2>&1 | tail -3
+NLZM_HOT_MIN=64 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_stream_bit_exact" 2>&1 | tail -3
+for cfg in "0 4096" "2 4096" "2 1024" "2 16384"; do
+set -- $cfg
+echo "== hot waves $1 min $2"
+NLZM_HOT_WAVES=$1 NLZM_HOT_MIN=$2 NLZM_WAIT_PRINT=1 timeout 600 python tests/gpu_one.py 300e6 28 1 2>&1 | grep "^cycles\|^hot\|^worker lanes: [0-9]* calls\|^[0-9]"
+done
+echo "== 20 MB: hot waves 0 / 2"
+NLZM_HOT_WAVES=0 NLZM_WAIT_PRINT=1 timeout 600 python tests/gpu_one.py 20e6 28 1 2>&1 | grep "^cycles\|^[0-9]"
+NLZM_WAIT_PRINT=1 timeout 600 python tests/gpu_one.py 20e6 28 1 2>&1 | grep "^cycles\|^hot\|^[0-9]"
+} > gpurun_out/hot6.log 2>&1
+cat gpurun_out/hot6.log
