@@ -94,6 +94,27 @@ def test_batching_is_invisible(gpu):
     gpu.set_option("batch_chunks", 32)
 
 
+def test_worker_lanes_and_hot_bin_waves_are_invisible(gpu):
+    """How the BT4 calls are spread over lanes and waves must not change a byte or a counter (MatchFinderBT::FindAndUpdate,
+    NLZM.cpp:978-1022, is serial per hash head): a wave for nearly every bin (threshold forced down to 4 and 64 positions per
+    launch, so that its trailing descents, its held results and its take-backs run on small inputs), no such waves at all,
+    and other numbers of bin-taking lanes."""
+    data = corpus.syn_text(1_500_000, corpus.SEED + 33)
+    dups = corpus.dups(600_000, corpus.SEED + 34)
+    want = oracle_py.compress(data, 18, want_stats=True)
+    want_dups = oracle_py.compress(dups, 16)
+    try:
+        for hot_waves, hot_min, lanes in ((2, 4, 128), (6, 64, 64), (0, 8192, 128), (2, 8192, 256), (2, 4, 64)):
+            gpu.set_option("hot_waves", hot_waves); gpu.set_option("hot_min", hot_min); gpu.set_option("worker_threads", lanes)
+            assert gpu.compress(data, 18) == want[0], (hot_waves, hot_min, lanes)
+            st = gpu.stats()
+            for k in ("bt_calls", "bt_tests", "positions", "nice_positions", "segments"):
+                assert st[k] == want[1][k], (k, hot_waves, hot_min, lanes)
+            assert gpu.compress(dups, 16) == want_dups, (hot_waves, hot_min, lanes)
+    finally:
+        gpu.set_option("hot_waves", 2); gpu.set_option("hot_min", 8192); gpu.set_option("worker_threads", 128)
+
+
 def test_rans_frames_stage(gpu):
     """CodeFrame::Flush replacement (NLZM.cpp:590-640) on captured symbol/bit streams."""
     case = next(c for c in cases.CASES if c[0] == "mixed_1m_w20")
