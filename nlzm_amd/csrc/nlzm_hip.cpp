@@ -84,10 +84,12 @@ struct Ctx {
     // options
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
-    int64_t opt_worker_blocks = 240;        // + the three stage blocks: below the 256 CUs, one 512-thread block per CU
-    int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (a stream's 240 worker CUs are there for latency, not for lanes: with
-                                            // two of a CU's eight waves walking trees a test takes less time than with all eight, and a lane with four heads
-                                            // is not busier than one with one -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
+    int64_t opt_worker_blocks = 60;         // + the three stage blocks: a quarter of the 256 CUs, one 512-thread block per CU.  Measured (profiles/
+                                            // r03_worker_cu_sweep.log): 240 / 120 / 60 / 30 / 16 / 8 worker CUs give 3.71 / 3.72 / 3.72 / 3.70 / 3.70 / 3.63 MB/s
+                                            // at 150 MB depth and 240 / 60 / 32 the same at 20 MB and 300 MB -- the lanes are there for latency, and the hot
+                                            // bins have waves of their own; 60 leaves a margin and three quarters of the device to other streams
+    int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (with two of a CU's eight waves walking trees a test takes less
+                                            // time than with all eight -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
     int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
     int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
