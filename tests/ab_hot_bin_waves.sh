@@ -1,4 +1,6 @@
 #!/bin/bash
+# Same-box comparison behind profiles/r03_hot_bin_waves_ab.log (run through gpurun): parity with a wave on nearly every bin, then
+# 300 MB without the hot bins' waves (NLZM_HOT_WAVES=0) and with them at several thresholds (NLZM_HOT_MIN positions per launch).
 mkdir -p gpurun_out
 {
 NLZM_HOT_MIN=4 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_stream_bit_exact or test_find_matches or test_batching or large_window" 2>&1 | tail -3

@@ -1,4 +1,7 @@
 #!/bin/bash
+# Same-box comparison behind profiles/r03_worker_ab.log (run through gpurun): the worker lanes that wait for the finder's decisions
+# (nlzm_amd/libnlzm_hip_old.so: commit 443affa built with tests/build_variant.sh from a checkout of that commit) against the lanes
+# that assume them, at 300 MB.  (The NLZM_HOT_* settings of that day's build selected a variant that was dropped.)
 mkdir -p gpurun_out
 {
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_stream_bit_exact or test_find_matches or test_batching or large_window or cli_ or blocks_in_flight or ragged" 2>&1 | tail -3
