@@ -1683,26 +1683,13 @@ struct Parser {
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) { ed[j] = 0; ea[j] = 0; }
-            {
-                unsigned long long er[kEdgesPerWave];
+            // (requested here, used after the literal prices below: an edge beyond the sixteen that are staged comes from the ring
+            //  in HBM, and nearly every block has a node with one)
+            unsigned long long er[kEdgesPerWave];
 #pragma unroll
-                for (uint32_t j = 0; j < kEdgesPerWave; j++) {
-                    const uint32_t k = edge_of(w, j);
-                    er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < kEdgesPerWave; j++) {
-                    const uint32_t k = edge_of(w, j);
-                    if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
-                    const uint32_t at = (uint32_t)(er[j] >> 32);
-                    if (at >> 31) {
-                        const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-                        const uint32_t lp = L()->len_price[lv];
-                        const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
-                        ed[j] = (uint32_t)er[j];
-                        ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
-                    }
-                }
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                const uint32_t k = edge_of(w, j);
+                er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
             }
             const unsigned long long q3 = ptick();
             uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };            // the node's first eight distinct valid distances (probe waves)
@@ -1720,6 +1707,19 @@ struct Parser {
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
             const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
             if (w == 0 && i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                const uint32_t k = edge_of(w, j);
+                if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
+                const uint32_t at = (uint32_t)(er[j] >> 32);
+                if (at >> 31) {
+                    const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
+                    const uint32_t lp = L()->len_price[lv];
+                    const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
+                    ed[j] = (uint32_t)er[j];
+                    ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
+                }
+            }
             for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
             xw::block_sync();
             if (w == 0) acc(kAccSetup, xw::tick() - ts);
