@@ -186,6 +186,44 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     for (uint32_t h = lo; h < hi; h++) { const uint32_t v = off[h]; off[h] = run; cur[h] = run; run += v; }
     __syncthreads();
     // stable scatter, 1024 positions at a time
+    constexpr uint32_t kBinsInLds = 12288;
+    __shared__ uint32_t lcur[kBinsInLds];
+    if (nheads <= kBinsInLds) {
+        // The cursors live in LDS.  A wave ranks its 64 positions among those of the same bin (one round of ballots per distinct
+        // bin in the wave); the waves then take their places in the bins one after the other, which keeps a bin's positions
+        // ascending -- 16 short steps per 1024 positions instead of a 1024-step comparison loop per position.
+        for (uint32_t h = threadIdx.x; h < nheads; h += 1024) lcur[h] = off[h];
+        __syncthreads();
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        for (uint32_t t0 = 0; t0 < n_ok; t0 += 1024) {
+            const uint32_t p = t0 + threadIdx.x;
+            const bool ok = p < n_ok;
+            const uint32_t hfull = ok ? hash4(load32u(base + p)) >> g.bt_shift : 0u;
+            const uint32_t h = ok ? hfull % nheads : kNone;
+            uint32_t rank = 0, cnt = 0, lead = lane;
+            for (unsigned long long todo = __ballot(ok); todo;) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)l);
+                const unsigned long long m = __ballot(ok && h == v);
+                if (ok && h == v) { rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)); cnt = (uint32_t)__builtin_popcountll(m); lead = l; }
+                todo &= ~m;
+            }
+            uint32_t first = 0;
+            for (uint32_t w = 0; w < 16; w++) {
+                if (wave == w && ok && lead == lane) { first = lcur[h]; lcur[h] = first + cnt; }    // (one lane per bin: no two touch the same cursor)
+                __syncthreads();
+            }
+            first = (uint32_t)__shfl((int)first, (int)lead, 64);
+            if (ok) {
+                const uint32_t at = first + rank;
+                const uint32_t a = (uint32_t)chunk_abs + p;
+                pos[2 * at] = a;
+                pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u) | ((a > batch_a0 && unc[a - batch_a0 - 1]) ? 0x40000000u : 0u);
+            }
+        }
+        return;
+    }
+    // more bins than the LDS holds cursors for: the cursors in HBM, a position's rank among its 1024 by comparison
     for (uint32_t t0 = 0; t0 < n_ok; t0 += 1024) {
         const uint32_t p = t0 + threadIdx.x;
         const bool ok = p < n_ok;
