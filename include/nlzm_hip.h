@@ -178,8 +178,7 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
                                    uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
 
 /* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
-/* key: "workers" (0 = BT4 inside the master workgroup, 1 = per-head worker
- * lanes, default 1), "batch_chunks" (chunks per persistent launch), "worker_blocks" (worker CUs of a stream, default 60),
+/* key: "workers" (only 1: BT4 runs on per-head worker lanes), "batch_chunks" (chunks per persistent launch), "worker_blocks" (worker CUs of a stream, default 60),
  * "worker_threads" (bin-taking lanes per worker CU, 64..512, default 128), "hot_waves" (waves per worker CU that take a hot
  * BT4 bin each, 0..6, default 2), "hot_min" (positions per launch from which a bin counts as hot, default 8192).
  * None of them changes a byte of the output. */
