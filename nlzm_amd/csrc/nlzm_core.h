@@ -114,7 +114,6 @@ NLZM_HD uint32_t bt_rec_l(uint32_t k) { return k == 0 ? 5u : (k == 1 ? 8u : (k =
 struct WorkerCounters {
     unsigned long long bt_calls, bt_tests, cmp_bytes, dry_runs, flag_waits;
     unsigned long long call_cycles, call_tests;     // diagnostics: cycles / tests of the write-mode calls (per-lane clocks)
-    unsigned long long lead[6];                     // NLZM_LEAD_DIAG: calls by how far ahead of the master they ended
     unsigned long long stuck_lanes, stuck_pos_inv;  // lanes that left while waiting for a decision (a launch that failed); ~(smallest such position)
     unsigned long long hot_bins, hot_calls;         // hot bins over all launches; calls made by their waves
     unsigned long long spec_calls, spec_good;       // decisions "skip" that took calls back; calls behind the skipped position that were made again

@@ -593,10 +593,6 @@ int refresh_stats(Ctx &C)
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
-        if (getenv("NLZM_WAIT_PRINT") && wc.lead[0] + wc.lead[1] + wc.lead[2] + wc.lead[3] + wc.lead[4] + wc.lead[5])
-            fprintf(stderr, "non-unc calls that end with the finder less than 64 positions away: first call after a wait for a decision, same head %llu, other head %llu; "
-                            "2nd..4th call after a wait %llu; others %llu (tests of all these %llu) | calls that end further ahead %llu\n",
-                    wc.lead[0], wc.lead[1], wc.lead[2], wc.lead[3], wc.lead[5], wc.lead[4]);
         if (getenv("NLZM_WAIT_PRINT"))
             fprintf(stderr, "worker lanes: %llu calls made with their fate open (at and behind a position not decided yet), %llu decisions that took calls back, %llu calls made again for it\n",
                     wc.dry_runs, wc.spec_calls, wc.spec_good);
