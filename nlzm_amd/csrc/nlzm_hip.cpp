@@ -17,6 +17,7 @@
 #include <mutex>
 #include <thread>
 #include <chrono>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/nlzm_hip.h"
@@ -843,7 +844,22 @@ int nlzm_hip_find_matches(const uint8_t *src, uint64_t n, uint32_t hist_bits_req
     unsigned long long used = 0;
     if (!rc) {
         HIPCHK(hipMemcpy(&used, C.cap_used, 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(out_words, C.cap_words, used * 4, hipMemcpyDeviceToHost));
+        // (the table stage's waves finish positions out of order: the records {position, max_len, delta[2..max_len]} are put
+        //  into position order here)
+        std::vector<uint32_t> raw(used);
+        HIPCHK(hipMemcpy(raw.data(), C.cap_words, used * 4, hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint32_t, unsigned long long>> recs;      // position, offset
+        for (unsigned long long at = 0; at + 2 <= used;) {
+            recs.emplace_back(raw[at], at);
+            at += 2 + (raw[at + 1] >= 2 ? raw[at + 1] - 1 : 0);
+        }
+        std::sort(recs.begin(), recs.end());
+        unsigned long long o = 0;
+        for (const auto &r : recs) {
+            const unsigned long long len = 2 + (raw[r.second + 1] >= 2 ? raw[r.second + 1] - 1 : 0);
+            memcpy(out_words + o, raw.data() + r.second, len * 4);
+            o += len;
+        }
         *used_words = used;
     }
     (void)hipFree(C.cap_words); (void)hipFree(C.cap_used);

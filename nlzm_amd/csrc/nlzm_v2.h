@@ -33,7 +33,7 @@ constexpr uint32_t kMaxEdges = 32;              // sampled lengths per position 
 constexpr uint32_t kTpStride = 2 + 2 + 2 * kMaxEdges;   // header (2), the mask of samples with a new distance (2), edges (distance, attributes)
 constexpr uint32_t kTpUniq = 2, kTpEdges = 4;           // (header + mask, and every two edges, are ONE 16-byte store of the table stage)
 constexpr uint32_t kFrontMax = 264;             // entries of a front (one per length at most)
-constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the front ring (end, distance)
+constexpr uint32_t kTfStride = 5 * 64;          // words per position in the ring of dense tables: delta[l] at [l - 1]
 
 // finder -> table record:
 //   w0        number of pairs in w2.. (bits 0..2) | BT4 ran: take the worker record's list (bit 3) | top pair present (bit 4)
@@ -43,7 +43,7 @@ constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the fro
 constexpr uint32_t kFtBt = 8u, kFtTop = 16u;
 // table -> parser record:
 //   w0        edges (bits 0..5) | input byte << 8 | table length (mt.max_len) << 16
-//   w1        entries of the front in the front ring
+//   w1        (unused)
 //   w2, w3    the mask of sampled lengths that bring a new distance
 //   w4..      per sampled length: distance, length | length value << 9 | distance slot << 18 | extra bits << 24 | valid << 31
 struct Hx {                                     // progress words, one 128-byte line each
@@ -705,388 +705,382 @@ struct Finder {
 // =================================================================================================
 // The match table of a position (mt_carry as :1543 leaves it) is delta[l] = smallest distance of any match found at a
 // position q <= p that still has >= l bytes left at p (Update is an element-wise min, :835-852; CarryFrom shifts by
-// one, :823-833).  With e = q + length (the match's absolute end), delta[l] at p is the smallest distance among the
-// entries with e >= p + l: only the Pareto front over (e larger, distance smaller) matters, and dominance between two
-// entries does not depend on p.  So the front at p is the Pareto front of ALL pairs found at positions <= p, cut to
-// e >= p + 2 -- an associative merge, computed for the 64 positions of a block by a parallel prefix scan.
+// one, :823-833).  With e = q + length (the match's absolute end):
+//
+//     delta[l] at p  =  min { G[e'] : e' >= p + l },     G[e] = smallest distance of the matches that END exactly at e
+//
+// -- a match is a POINT in G (one LDS atomic min, whatever its length), moving to the next position costs nothing (G is
+// indexed by the absolute end), and the table of a position is a suffix minimum over the window e in (p, p + 264].
 // (The one entry whose end moves with p, the top entry while it keeps extending :1503-1512, arrives from the finder
-// stage as a fresh pair per position.)
-constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
+// stage as a fresh pair per position.)  The stage is a pipeline of its own, one workgroup:
+//
+//   loader   (wave 0)     the finder's records and the worker lanes' BT4 records of the positions to come, staged in LDS
+//                         (sixteen positions a step, the next step's loads in flight while this step's are written)
+//   updater  (wave 1)     position by position, the only serial part: lanes = the position's pairs (six of the finder's, its
+//                         top entry, four of the BT4 record; more than four record-setters, rare, from HBM): one atomic min into G,
+//                         the largest end so far (mt.max_len = that - p), then G's window copied into the position's row
+//                         -- the table as of THIS position, while the wave goes on to the next
+//   emitters (waves 2..7) a position each, in turn: suffix minimum of the row by DPP scans (lanes = lengths, 64 a chunk), the
+//                         dense table to the ring the parser re-lists from near a forced cut (:1545) and the stage test reads,
+//                         then the sampled lengths of :1558-1562 with the lanes as SAMPLES: distance, length value, distance
+//                         slot, extra bits, the mask of samples that bring a new distance; 16-byte stores.
+constexpr uint32_t kTW = 8;                     // waves of the stage
+constexpr uint32_t kTEmit = kTW - 2;            // emitters
+constexpr uint32_t kTRecRing = 64;              // positions whose records are staged
+constexpr uint32_t kTRowRing = 32;              // positions whose rows are in flight between the updater and the emitters
+constexpr uint32_t kTRowStride = 5 * 64;        // entries of a row: lengths 1 .. 264, in chunks of 64
+constexpr uint32_t kGRing = 512;
+constexpr uint32_t kTLoad = 16;                 // positions the loader requests a step
 
-#ifndef NLZM_KTW
-#define NLZM_KTW 3
-#endif
-constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn
-struct TWave {
-    unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
-    uint32_t recs[64 * kFtStride];              // the block's finder records
-    uint32_t overflow;
-};
 struct TLds {
-    TWave w[kTW];
-    unsigned long long carry[kFrontMax + 8];    // front after the last finished position
-    unsigned long long tmp[2 * kFrontMax + 300];
-    uint32_t carry_n;
-    uint32_t turn;                              // blocks are taken in turn: the wave whose sequence number this is cuts the next block
-    uint32_t cursor;                            // first position not yet in a block
-    uint32_t carry_seq;                         // ... and finished in that order: the block with this sequence number takes the carry
-    uint32_t stop;
+    uint32_t G[kGRing];                         // end e at [e & 511]
+    uint32_t row[kTRowRing * kTRowStride];      // position p, length l at [(p & 31) * 320 + l - 1]: G[p + l] as of position p
+    uint32_t frec[kTRecRing * kFtStride];       // finder records, position p at [(p & 63) * 16]
+    uint32_t brec[kTRecRing * kBtRec];          // BT4 records
+    uint32_t pinfo[kTRowRing], pa1[kTRowRing];  // mt.max_len | byte << 16; the chunk's last position + 1
+    uint32_t staged;                            // loader: records of positions below this are in LDS
+    uint32_t u_pos;                             // updater: rows of positions below this are written
+    uint32_t e_done[kTEmit];                    // emitter k: the next position it will write (its positions below are out)
+    uint32_t u_taken;                           // updater: records of positions below this are consumed
+    uint32_t stop;                              // nonzero: leave
 };
 
-NLZM_HD unsigned long long fr_key(uint32_t e, uint32_t d) { return ((unsigned long long)e << 32) | (0xFFFFFFFFu - d); }
-NLZM_HD uint32_t fr_end(unsigned long long k) { return (uint32_t)(k >> 32); }
-NLZM_HD uint32_t fr_dist(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
+NLZM_HD uint32_t tf_index(uint32_t l) { return l - 1; }     // dense table of a position in the ring: delta[l]
 
 struct Table {
     Geom g;
     Globals G;
     GlobalsV2 V;
     uint32_t err;
-    uint32_t p_pos_seen;
-    unsigned long long n_blocks, n_slow, t_wait;
-    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: gather, scan, carry + emit, wait for the carry
+    unsigned long long n_pos = 0, n_slow = 0, t_wait = 0;
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: updater work / wait, emitter work / wait
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
 #else
     XW_FN unsigned long long ptick() const { return 0; }
 #endif
+    XW_FN TLds *L() const { return xw::lds<TLds>(); }
 
-    // merge two fronts (each sorted by descending key, at most na / nb entries at pa / pb with stride 1) into out;
-    // entries of b that end before `low` are left out.  Returns the count, or kNone if it exceeds cap.
-    static XW_FN uint32_t merge(const unsigned long long *pa, uint32_t na, const unsigned long long *pb, uint32_t nb, uint32_t low,
-                                unsigned long long *out, uint32_t cap)
-    {
-        while (nb && fr_end(pb[nb - 1]) < low) nb--;            // (ends fall along the list: the expired ones are at its tail)
-        while (na && fr_end(pa[na - 1]) < low) na--;
-        uint32_t ia = 0, ib = 0, no = 0, dmin = kNone;
-        unsigned long long ka = na ? pa[0] : 0, kb = nb ? pb[0] : 0;
-        while (ia < na || ib < nb) {
-            const bool ta = ib >= nb || (ia < na && ka >= kb);
-            const unsigned long long k = ta ? ka : kb;
-            if (ta) { ia++; ka = ia < na ? pa[ia] : 0; } else { ib++; kb = ib < nb ? pb[ib] : 0; }
-            const uint32_t d = fr_dist(k);
-            if (d < dmin) {                                     // not dominated by an entry that ends at least as late
-                if (no >= cap) return kNone;
-                out[no++] = k; dmin = d;
-            }
-        }
-        return no;
-    }
-
-    // pairs of position a into a list (unsorted); returns the count or kNone (more than cap)
-    XW_FN uint32_t gather(uint32_t a, uint32_t cap_len, const uint32_t *rec, unsigned long long *out, uint32_t cap)
-    {
-        uint32_t n = 0;
-        const uint32_t w0 = rec[0], np = w0 & 7u;
-        for (uint32_t k = 0; k < np; k++) {
-            if (n >= cap) return kNone;
-            out[n++] = fr_key(a + rec[3 + 2 * k], rec[2 + 2 * k]);
-        }
-        if (w0 & kFtTop) { if (n >= cap) return kNone; out[n++] = fr_key(a + rec[15], rec[14]); }
-        if (w0 & kFtBt) {
-            // the worker lane's record: the record-setters of the descent, lengths and distances growing along the list
-            // (count and first four pairs in one 64-byte record: requested together)
-            const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
-            const uint32_t *br = G.bt_ready + bi * kBtRec;
-            // (the finder stage saw quad 0 before it wrote this position's record; quads 1..3 were stored before quad 0 and carry a tag:
-            //  looked at again in the rare case that one is not there yet)
-            uint32_t bw[16];
-            for (;;) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) bw[k] = xw::ld_agent(br + k);
-                if ((bw[7] & bw[11] & bw[15] & kBtTag) != 0) break;
-                if (xw::ld_agent(&V.hx->err)) break;
-                xw::pause();
-            }
-            const uint32_t cnt = bw[0] & 0x1FFu;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                if (k >= cnt) continue;
-                const uint32_t d = bw[bt_rec_d(k)], l = bw[bt_rec_l(k)];
-                if (l >= cap_len) continue;                     // as long as the lookahead allows: the finder stage's top entry covers it
-                if (n >= cap) return kNone;
-                out[n++] = fr_key(a + l, d);
-            }
-            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
-            for (uint32_t k = 4; k < cnt; k++) {
-                const uint32_t d = xw::ld_agent(pairs + 2 * k), l = xw::ld_agent(pairs + 2 * k + 1);
-                if (l >= cap_len) continue;
-                if (n >= cap) return kNone;
-                out[n++] = fr_key(a + l, d);
-            }
-        }
-        return n;
-    }
-
-    // sort a short list by descending key and drop dominated entries, in place; returns the count
-    static XW_FN uint32_t sort_filter(unsigned long long *v, uint32_t n)
-    {
-        for (uint32_t x = 1; x < n; x++) {
-            const unsigned long long k = v[x];
-            uint32_t y = x;
-            while (y > 0 && v[y - 1] < k) { v[y] = v[y - 1]; y--; }
-            v[y] = k;
-        }
-        uint32_t no = 0, dmin = kNone;
-        for (uint32_t x = 0; x < n; x++) {
-            const uint32_t d = fr_dist(v[x]);
-            if (d < dmin) { v[no++] = v[x]; dmin = d; }
-        }
-        return no;
-    }
-
-    // write the parser's record of position a from its front (fn entries at f, descending)
-    XW_FN void emit(uint32_t a, uint32_t a1, uint32_t lit, const unsigned long long *f, uint32_t fn)
-    {
-        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-        uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
-        const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
-        uint32_t max_len = umin(mt_max, a1 - a);                // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
-        if (max_len < kMatchMin) max_len = 0;
-        uint32_t ne = 0, uniq = 0, dprev = 0;
-        if (max_len) {
-            uint32_t step = (max_len - kMatchMin) >> 4;         // :1558-1560
-            step += step == 0;
-            uint32_t j = 0;
-            unsigned long long kj = f[0], kn = fn > 1 ? f[1] : 0;
-            unsigned long long held = 0;                        // the edge before, until it goes out with its neighbour
-            for (uint32_t tl = max_len; tl >= kMatchMin; tl -= umin(tl, step)) {
-                while (j + 1 < fn && fr_end(kn) >= a + tl) { j++; kj = kn; kn = j + 1 < fn ? f[j + 1] : 0; }   // the entry with the smallest end >= a + tl
-                const uint32_t d = fr_dist(kj), mm = match_min(d);
-                uint32_t nx, ex;
-                const uint32_t slot = dist_slot(d - 1, nx, ex);
-                const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
-                const uint32_t at = tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31);
-                if (ne & 1u) xw::st_agent128(rec + kTpEdges + 2 * (ne - 1), (uint32_t)held, (uint32_t)(held >> 32), d, at);
-                else held = (unsigned long long)d | ((unsigned long long)at << 32);
-                if (valid && d != dprev) uniq |= 1u << ne;      // the valid samples that bring a distance the one before did not have
-                if (valid) dprev = d;
-                ne++;
-            }
-            if (ne & 1u) xw::st_agent64((unsigned long long *)(rec + kTpEdges + 2 * (ne - 1)), held);
-        }
-        xw::st_agent128(rec, ne | (lit << 8) | (mt_max << 16), fn, uniq, 0u);
-        for (uint32_t k = 0; k + 1 < fn; k += 2)
-            xw::st_agent128(fo + 2 * k, fr_end(f[k]) - a, fr_dist(f[k]), fr_end(f[k + 1]) - a, fr_dist(f[k + 1]));
-        if (fn & 1u) xw::st_agent64((unsigned long long *)(fo + 2 * (fn - 1)), (unsigned long long)(fr_end(f[fn - 1]) - a) | ((unsigned long long)fr_dist(f[fn - 1]) << 32));
-    }
-
-    XW_FN void capture(uint32_t a, const unsigned long long *f, uint32_t fn);
-
-    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end
-    // wait for an LDS word of the stage to reach v
-    XW_FN bool wait_lds(const uint32_t *p, uint32_t v)
+    // wait for an LDS word of the stage to pass v (word - v > 0 as a signed difference); false: the stage is leaving
+    XW_FN bool wait_lds_gt(const uint32_t *p, uint32_t v)
     {
         uint32_t spins = 0;
-        while (xw::readfirst(xw::lds_ld(p)) != v) {
-            if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) return false;
+        while ((int32_t)(xw::readfirst(xw::lds_ld(p)) - v) <= 0) {
+            if (xw::readfirst(xw::lds_ld(&L()->stop))) return false;
+            if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) { if (xw::lane() == 0) xw::lds_st(&L()->stop, 1u); return false; }
             xw::pause();
         }
         xw::after_poll();
         return true;
     }
-
-    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end; seq: the block's number
-    XW_FN void block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end, uint32_t seq)
+    XW_FN void leave(uint32_t site, uint32_t pos)
     {
-        TLds *L = xw::lds<TLds>();
-        TWave *W = &L->w[xw::wave()];
-        const uint32_t i = xw::lane();
-        const bool in_blk = i < n;
-        const uint32_t a = a0 + i;
-        const uint32_t cap_len = in_blk ? umin(la_end - a, kMatchMax) : 0u;
-        const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
-        uint32_t *r = W->recs + i * kFtStride;
-        if (in_blk) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * k));
-                r[2 * k] = (uint32_t)w; r[2 * k + 1] = (uint32_t)(w >> 32);
-            }
-        } else r[0] = 0;
-        const uint32_t lit = (r[0] >> 8) & 0xFFu;
-        W->overflow = 0;
-        xw::wave_sync();
-        const unsigned long long q0 = ptick();
-        // the position's own pairs as a front
-        unsigned long long *mine = W->fr[0] + i * kFrCap;
-        uint32_t cnt = 0;
-        if (in_blk) {
-            cnt = gather(a, cap_len, r, mine, kFrCap);
-            if (cnt == kNone) { W->overflow = 1; cnt = 0; }
-            else cnt = sort_filter(mine, cnt);
-        }
-        const unsigned long long q1 = ptick();
-        // prefix scan: after the step with offset D lane i holds the front of the pairs of lanes (i - 2D, i]
-        uint32_t cur = 0;
-        for (uint32_t D = 1; D < 64; D <<= 1) {
-            xw::wave_sync();
-            const uint32_t ocnt = xw::shfl_up(cnt, D);
-            unsigned long long *dst = W->fr[cur ^ 1] + i * kFrCap;
-            const unsigned long long *own = W->fr[cur] + i * kFrCap;
-            uint32_t nn;
-            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + 1, dst, kFrCap);
-            else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
-            if (nn == kNone) { W->overflow = 1; nn = 0; }
-            cnt = nn;
-            cur ^= 1;
-        }
-        xw::wave_sync();
-        const unsigned long long q2 = ptick();
-        // ---- from here on in block order: the front carried into the block
-        if (!wait_lds(&L->carry_seq, seq)) { err = 1; return; }
-        const unsigned long long q3 = ptick();
-        const uint32_t cn = xw::readfirst(L->carry_n);
-        unsigned long long *fin_f = W->fr[cur ^ 1] + i * kFrCap;
-        uint32_t fn = 0;
-        if (in_blk) {
-            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + 1, fin_f, kFrCap);
-            if (fn == kNone) { W->overflow = 1; fn = 0; }
-        }
-        xw::wave_sync();
-        n_blocks++;
-        if (xw::readfirst(W->overflow)) slow_block(a0, n, a1, la_end);
-        else {
-            if (in_blk) emit(a, a1, lit, fin_f, fn);
-            if (G.cap_words) {
-                for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
-            }
-#ifdef NLZM_SIM
-            if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
-#endif
-            // carry out: the last position's front
-            const uint32_t last_n = xw::readlane(fn, n - 1);
-            for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = W->fr[cur ^ 1][(n - 1) * kFrCap + k];
-            if (i == 0) L->carry_n = last_n;
-        }
-        xw::drain();
-        xw::wave_sync();
-        if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->carry_seq, seq + 1); }
-        tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += ptick() - q3;
+        if (xw::lane() == 0) { xw::lds_st(&L()->stop, 1u); if (!xw::ld_agent(&V.hx->err)) raise(V.hx, kErrInternal + 200, kStTable, site, pos); }
     }
 
-    // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
-    XW_FN void slow_block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    // ---- loader -----------------------------------------------------------------------------------------------------
+    XW_FN void run_loader(uint32_t a_first, uint32_t a_last)
     {
-        TLds *L = xw::lds<TLds>();
-        TWave *W = &L->w[xw::wave()];
-        n_slow++;
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t a = a0 + j;
-            const uint32_t cap_len = umin(la_end - a, kMatchMax);
-            const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
-            uint32_t *r = W->recs;
-            if (xw::lane() < 8) {
-                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * xw::lane()));
-                r[2 * xw::lane()] = (uint32_t)w; r[2 * xw::lane() + 1] = (uint32_t)(w >> 32);
+        TLds *Lp = L();
+        const uint32_t i = xw::lane(), pj = i >> 2, qd = i & 3u;   // lane = position of the step x 16-byte quad of its record
+        uint32_t req = a_first, wr = a_first;                       // requested / written up to
+        uint32_t f_seen = a_first, taken = a_first;
+        uint32_t pend_n = 0, pend_a = 0;
+        uint32_t fq0 = 0, fq1 = 0, fq2 = 0, fq3 = 0, bq0 = 0, bq1 = 0, bq2 = 0, bq3 = 0;
+        const unsigned long long t0 = xw::clock100();
+        uint32_t idle = 0;
+        while (wr < a_last) {
+            // ---- what the last step requested: into LDS (the BT4 record's later quads carry a tag: looked at again if one is not there yet)
+            if (pend_n) {
+                const uint32_t a = pend_a + pj;
+                const bool on = pj < pend_n;
+                // (quad 0 of the finder's record says whether a BT4 record belongs to the position)
+                const uint32_t w0 = xw::shfl(fq0, i & ~3u);
+                if (on) {
+                    if (w0 & kFtBt) {
+                        const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
+                        uint32_t spins = 0;
+                        while (!((qd ? bq3 : bq0) & (qd ? kBtTag : kBtReady))) {
+                            bq0 = xw::ld_agent(br); bq1 = xw::ld_agent(br + 1); bq2 = xw::ld_agent(br + 2); bq3 = xw::ld_agent(br + 3);
+                            if ((++spins & 255u) == 0 && xw::ld_agent(&V.hx->err)) break;
+                        }
+                    }
+                    uint32_t *fd = Lp->frec + (a & (kTRecRing - 1)) * kFtStride + 4 * qd;
+                    fd[0] = fq0; fd[1] = fq1; fd[2] = fq2; fd[3] = fq3;
+                    uint32_t *bd = Lp->brec + (a & (kTRecRing - 1)) * kBtRec + 4 * qd;
+                    bd[0] = bq0; bd[1] = bq1; bd[2] = bq2; bd[3] = bq3;
+                }
+                wr = pend_a + pend_n;
+                xw::wave_sync();
+                if (i == 0) { xw::lds_st(&Lp->staged, wr); xw::st_agent(&V.hx->t_pos, wr); }     // (the ring's records are copied: the finder may overwrite them)
+                pend_n = 0;
             }
-            xw::wave_sync();
-            unsigned long long *t0 = L->tmp, *t1 = L->tmp + 300;
-            if (xw::lane() == 0) {
-                uint32_t c = gather(a, cap_len, r, t0, 300);    // <= 7 + 256 pairs
-                c = sort_filter(t0, c);
-                const uint32_t fn = merge(t0, c, L->carry, L->carry_n, a + 1, t1, kFrontMax + 8);
-                for (uint32_t k = 0; k < fn; k++) L->carry[k] = t1[k];
-                L->carry_n = fn;
-                emit(a, a1, (r[0] >> 8) & 0xFFu, L->carry, fn);
-#ifdef NLZM_SIM
-                sim_on_front(G.hook_user, a, L->carry, fn);
+            // ---- the next positions: what the finder has written, and what the record ring has room for
+            if ((int32_t)(f_seen - req) <= 0) f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
+            xw::after_poll();
+            taken = xw::readfirst(xw::lds_ld(&Lp->u_taken));
+            uint32_t lim = umin(f_seen, umin(taken + kTRecRing, a_last));
+            const uint32_t n = (int32_t)(lim - req) > 0 ? umin(kTLoad, lim - req) : 0u;
+            if (n) {
+                const uint32_t a = req + pj;
+                if (pj < n) {
+                    const uint32_t *fr = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride + 4 * qd;
+                    fq0 = xw::ld_agent(fr); fq1 = xw::ld_agent(fr + 1); fq2 = xw::ld_agent(fr + 2); fq3 = xw::ld_agent(fr + 3);
+                    const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
+                    bq0 = xw::ld_agent(br); bq1 = xw::ld_agent(br + 1); bq2 = xw::ld_agent(br + 2); bq3 = xw::ld_agent(br + 3);
+                }
+                pend_a = req; pend_n = n; req += n;
+                idle = 0;
+            } else {
+                if (xw::readfirst(xw::lds_ld(&Lp->stop))) return;
+                if ((++idle & 63u) == 0) {
+                    if (xw::readfirst(xw::ld_agent(&V.hx->err))) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
+#ifndef NLZM_SIM
+                    if (xw::clock100() - t0 > 30000000000ull) { leave(2, req); return; }    // (a launch takes less than 300 s)
+#else
+                    (void)t0;
 #endif
+                }
+                xw::pause();
             }
-            xw::wave_sync();
-            if (G.cap_words) capture(a, L->carry, xw::readfirst(L->carry_n));
         }
     }
 
-#ifdef NLZM_SIM
-    static void sim_on_front(void *user, uint32_t a, const unsigned long long *f, uint32_t fn);
-#endif
-
-    XW_FN void run(uint32_t c0, uint32_t c1)
+    // ---- updater ------------------------------------------------------------------------------------------------------
+    XW_FN void run_updater(uint32_t c0, uint32_t c1, uint32_t a_first)
     {
-        TLds *L = xw::lds<TLds>();
+        TLds *Lp = L();
         StateV2 *S = (StateV2 *)V.state;
-        const uint32_t i = xw::lane(), w = xw::wave();
-        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        unsigned long long a_last = (unsigned long long)c1 * g.chunk_size;
-        if (a_last > g.n) a_last = g.n;
-        if (w == 0) {
-            const uint32_t cn = xw::readfirst(S->front_n);
-            for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
-            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->stop = 0; }
-        }
-        xw::block_sync();
-        err = 0; n_blocks = n_slow = 0; t_wait = 0;
-        const unsigned long long t_start = xw::tick();
-        uint32_t p_seen = a_first, f_seen = a_first;
-        for (uint32_t seq = w; !err; seq += kTW) {
-            // ---- take the next block (in turn)
-            const unsigned long long tw = xw::tick();
-            if (!wait_lds(&L->turn, seq)) { err = 1; break; }
-            const uint32_t a = xw::readfirst(xw::lds_ld(&L->cursor));
-            if ((unsigned long long)a >= a_last) { if (i == 0) xw::lds_st(&L->turn, seq + 1); break; }
-            const uint32_t ci = a / g.chunk_size;
+        const uint32_t i = xw::lane();
+        // the window the launch before left: ends a_first + 1 .. a_first + 264, and the largest end so far
+        for (uint32_t k = i; k < kGRing; k += 64) Lp->G[k] = kNone;
+        xw::wave_sync();
+        const uint32_t had = xw::readfirst(S->front_n);
+        for (uint32_t k = i; k < kFrontMax && had; k += 64) Lp->G[(a_first + 1 + k) & (kGRing - 1)] = S->front[k];
+        uint32_t maxend = had ? xw::readfirst(S->front[kFrontMax]) : 0u;
+        xw::wave_sync();
+        uint32_t e_safe = a_first;                                  // rows of positions below this are consumed by the emitters
+        for (uint32_t ci = c0; ci < c1; ci++) {
             const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+            if (chunk_abs >= g.n) break;
             const unsigned long long remain = g.n - chunk_abs;
             const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
             const uint32_t a1 = (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), la_end = (uint32_t)chunk_abs + chunk_read;
-            if ((int32_t)(f_seen - a) <= 0) {
-                if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
+            for (uint32_t p = (uint32_t)chunk_abs; p < a1; p++) {
+                const unsigned long long q0 = ptick();
+                if (!wait_lds_gt(&Lp->staged, p)) return;
+                // room in the row ring: the emitters have taken position p - 32
+                if ((int32_t)(p - e_safe) >= (int32_t)kTRowRing) {
+                    for (;;) {
+                        uint32_t m = kNone;
+                        for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
+                        e_safe = m;
+                        if ((int32_t)(p - e_safe) < (int32_t)kTRowRing) break;
+                        if (xw::readfirst(xw::lds_ld(&Lp->stop))) return;
+                        xw::pause();
+                    }
+                    xw::after_poll();
+                }
+                const unsigned long long q1 = ptick();
+                const uint32_t cap_len = umin(la_end - p, kMatchMax);
+                const uint32_t *fr = Lp->frec + (p & (kTRecRing - 1)) * kFtStride, *br = Lp->brec + (p & (kTRecRing - 1)) * kBtRec;
+                const uint32_t w0 = fr[0], bw0 = br[0];             // (the same word in every lane)
+                const uint32_t np = w0 & 7u, cnt = (w0 & kFtBt) ? (bw0 & 0x1FFu) : 0u;
+                // lanes 1..6: the finder's pairs; lane 7: its top entry; lanes 8..11: the first four record-setters of the BT4 descent
+                // (those as long as the lookahead allows are the finder's top entry already)
+                uint32_t d = 0, l = 0;
+                bool ok = false;
+                if (i >= 1 && i < 8) { d = fr[2 * i]; l = fr[2 * i + 1]; ok = i == 7 ? (w0 & kFtTop) != 0 : i - 1 < np; }
+                else if (i >= 8 && i < 12) { d = br[bt_rec_d(i - 8)]; l = br[bt_rec_l(i - 8)]; ok = i - 8 < cnt && l < cap_len; }
+                uint32_t e = ok ? p + l : 0u;
+                if (ok) xw::lds_min(&Lp->G[e & (kGRing - 1)], d);
+                const uint32_t cnt_u = xw::readfirst(cnt);
+                if (NLZM_RARE(cnt_u > 4)) {
+                    const uint32_t *pairs = G.bt_pairs + (unsigned long long)(p - G.batch_a0) * (2 * kBtMaxPairs);
+                    for (uint32_t k = 4 + i; k < cnt_u; k += 64) {
+                        const uint32_t dk = xw::ld_agent(pairs + 2 * k), lk = xw::ld_agent(pairs + 2 * k + 1);
+                        if (lk < cap_len) { xw::lds_min(&Lp->G[(p + lk) & (kGRing - 1)], dk); e = umax(e, p + lk); }
+                    }
+                    n_slow++;
+                }
+                maxend = umax(maxend, xw::readlane(xw::scan_max(e), 63));
+                const uint32_t mt_max = (int32_t)(maxend - p) > 0 ? maxend - p : 0u;
+                xw::wave_sync();
+                // the table as of this position: G's window into the position's row
+                uint32_t *row = Lp->row + (p & (kTRowRing - 1)) * kTRowStride;
+                for (uint32_t c = 0; 64 * c < mt_max; c++) row[64 * c + i] = Lp->G[(p + 1 + 64 * c + i) & (kGRing - 1)];
+                if (i == 0) {
+                    Lp->G[(p + 1) & (kGRing - 1)] = kNone;          // (no later position looks at this end)
+                    Lp->pinfo[p & (kTRowRing - 1)] = mt_max | (((w0 >> 8) & 0xFFu) << 16);
+                    Lp->pa1[p & (kTRowRing - 1)] = a1;
+                }
+                xw::wave_sync();
+                if (i == 0) { xw::lds_st(&Lp->u_pos, p + 1); xw::lds_st(&Lp->u_taken, p + 1); }
+                n_pos++;
+                tt1 += q1 - q0; tt0 += ptick() - q1;
             }
-            f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
-            xw::after_poll();
-            const uint32_t n = umin(64u, umin(a1, f_seen) - a);
-            if ((int32_t)(a + n - p_seen - kTpRing) > 0) {
-                if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
+        }
+        // the window for the launch to come
+        unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
+        if (a_end > g.n) a_end = g.n;
+        xw::wave_sync();
+        for (uint32_t k = i; k < kFrontMax; k += 64) S->front[k] = Lp->G[((uint32_t)a_end + 1 + k) & (kGRing - 1)];
+        if (i == 0) { S->front[kFrontMax] = maxend; S->front_n = 1; }
+    }
+
+    // ---- emitters -----------------------------------------------------------------------------------------------------
+    XW_FN void capture(uint32_t a, uint32_t mt_max, const uint32_t *dense);
+#ifdef NLZM_SIM
+    static void sim_on_table(void *user, uint32_t a, uint32_t mt_max, const uint32_t *dense);
+#endif
+    XW_FN void emit_position(uint32_t p, uint32_t p_seen_io)
+    {
+        TLds *Lp = L();
+        const uint32_t k = xw::lane();
+        const uint32_t info = xw::readfirst(Lp->pinfo[p & (kTRowRing - 1)]), a1 = xw::readfirst(Lp->pa1[p & (kTRowRing - 1)]);
+        const uint32_t mt_max = info & 0x1FFu, lit = (info >> 16) & 0xFFu;
+        const uint32_t *row = Lp->row + (p & (kTRowRing - 1)) * kTRowStride;
+        uint32_t *dense = V.tf + (unsigned long long)(p & (kTpRing - 1)) * kTfStride;
+        // ---- delta[l] = min of the row from l on: chunk by chunk from the top, lane k of a chunk holds length 64 c + 64 - k
+        uint32_t s0 = kNone, s1 = kNone, s2 = kNone, s3 = kNone, s4 = kNone, carry = kNone;
+        auto chunk = [&](uint32_t c, uint32_t &s) __attribute__((always_inline)) {
+            if (64 * c >= mt_max) return;
+            const uint32_t at = 64 * c + 63 - k;                    // length - 1 of this lane
+            uint32_t v = at < mt_max ? row[at] : kNone;
+            v = umin(xw::scan_min_u32(v), carry);
+            carry = xw::readlane(v, 63);
+            s = v;
+            // the dense table for the ring: four lengths a lane, 16-byte stores (lane 4j has lengths - 1 = 64c + 60 - 4j ..+3)
+            const uint32_t v1 = xw::quad_bcast<1>(v), v2 = xw::quad_bcast<2>(v), v3 = xw::quad_bcast<3>(v);
+            if ((k & 3u) == 0 && at - 3 < mt_max) xw::st_agent128(dense + at - 3, v3, v2, v1, v);
+        };
+        chunk(4, s4); chunk(3, s3); chunk(2, s2); chunk(1, s1); chunk(0, s0);
+        // ---- the sampled lengths (:1558-1560), lanes = samples
+        uint32_t max_len = umin(mt_max, a1 - p);                    // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
+        if (max_len < kMatchMin) max_len = 0;
+        uint32_t step = (max_len - kMatchMin) >> 4;
+        step += step == 0;
+        const bool on = max_len && k < kMaxEdges && k * step + kMatchMin <= max_len;
+        const uint32_t ne = (uint32_t)__builtin_popcountll(xw::ballot(on));
+        const uint32_t tl = on ? max_len - k * step : 1u;
+        const uint32_t at = tl - 1, src = 63u - (at & 63u), cq = at >> 6;
+        uint32_t d = xw::shfl(s0, src);
+        if (max_len > 64) {
+            const uint32_t d1 = xw::shfl(s1, src); d = cq == 1 ? d1 : d;
+            if (max_len > 128) {
+                const uint32_t d2 = xw::shfl(s2, src), d3 = xw::shfl(s3, src), d4 = xw::shfl(s4, src);
+                d = cq == 2 ? d2 : (cq == 3 ? d3 : (cq == 4 ? d4 : d));
+            }
+        }
+        if (!on) d = 1;
+        const uint32_t mm = match_min(d);
+        uint32_t nx, ex;
+        const uint32_t slot = dist_slot(d - 1, nx, ex);
+        const bool valid = on && tl >= mm;
+        const uint32_t lv = valid ? tl - mm : 0u;
+        const uint32_t aw = on ? (tl | (lv << 9) | (slot << 18) | (nx << 24) | ((valid ? 1u : 0u) << 31)) : 0u;
+        const uint32_t dw = on ? d : 0u;
+        // the valid samples that bring a distance the valid one before did not have
+        const unsigned long long vm = xw::ballot(valid), below = vm & ((1ull << k) - 1ull);
+        const uint32_t dprev = xw::shfl(d, below ? 63u - (uint32_t)__builtin_clzll(below) : k);
+        const uint32_t uniq = (uint32_t)xw::ballot(valid && (!below || d != dprev));
+        // ---- the record: header + mask, and every two samples, as 16-byte stores
+        uint32_t *rec = V.tp + (unsigned long long)(p & (kTpRing - 1)) * kTpStride;
+        const uint32_t dn = xw::shfl(dw, (k + 1) & 63u), an = xw::shfl(aw, (k + 1) & 63u);
+        if ((k & 1u) == 0 && k < ne) xw::st_agent128(rec + kTpEdges + 2 * k, dw, aw, k + 1 < ne ? dn : 0u, k + 1 < ne ? an : 0u);
+        if (k == 0) xw::st_agent128(rec, ne | (lit << 8) | (mt_max << 16), 0u, uniq, 0u);
+        if (G.cap_words) { xw::drain(); capture(p, mt_max, dense); }
+#ifdef NLZM_SIM
+        xw::wave_sync();
+        if (k == 0) sim_on_table(G.hook_user, p, mt_max, dense);
+#endif
+        (void)p_seen_io;
+    }
+    XW_FN void run_emitter(uint32_t ek, uint32_t a_first, uint32_t a_last)
+    {
+        TLds *Lp = L();
+        const uint32_t i = xw::lane();
+        uint32_t p_seen = a_first;
+        for (uint32_t p = a_first + ek; p < a_last; p += kTEmit) {
+            const unsigned long long q0 = ptick();
+            if (!wait_lds_gt(&Lp->u_pos, p)) return;
+            // room in the parser's ring
+            if ((int32_t)(p + 1 - p_seen - kTpRing) > 0) {
+                if (!wait_word_ge(&V.hx->p_pos, p + 1 - kTpRing, V.hx, 3)) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
                 p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
             }
-            if (i == 0) { xw::lds_st(&L->cursor, a + n); xw::lds_st(&L->turn, seq + 1); }
-            t_wait += xw::tick() - tw;
-            block(a, n, a1, la_end, seq);
-            xw::trace(3, a, n);
+            const unsigned long long q1 = ptick();
+            emit_position(p, p_seen);
+            xw::drain();
+            xw::wave_sync();
+            // records below the smallest "next position" of all emitters are out
+            if (i == 0) xw::lds_st(&Lp->e_done[ek], p + kTEmit);
+            xw::wave_sync();
+            uint32_t m = kNone;
+            for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
+            if (m > a_last) m = a_last;
+            if (i == 0) xw::st_agent(&V.hx->t_out, m);
+            tt3 += q1 - q0; tt2 += ptick() - q1;
         }
-        if (err && i == 0) raise(V.hx, kErrInternal + 200, kStTable, 9, xw::lds_ld(&L->cursor));   // (only if no stage has raised anything: the first code stays)
+        // (nothing of this wave is left: its word no longer holds the others back)
+        if (i == 0) xw::lds_st(&Lp->e_done[ek], kNone);
+        xw::wave_sync();
+        uint32_t m = kNone;
+        for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
+        if (m > a_last) m = a_last;
+        if (i == 0) xw::st_agent(&V.hx->t_out, m);
+    }
+
+    XW_FN void run(uint32_t c0, uint32_t c1)
+    {
+        TLds *Lp = L();
+        const uint32_t i = xw::lane(), w = xw::wave();
+        const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        unsigned long long a_last64 = (unsigned long long)c1 * g.chunk_size;
+        if (a_last64 > g.n) a_last64 = g.n;
+        const uint32_t a_last = (uint32_t)a_last64;
+        if (w == 0 && i == 0) {
+            Lp->staged = a_first; Lp->u_pos = a_first; Lp->u_taken = a_first; Lp->stop = 0;
+            for (uint32_t k = 0; k < kTEmit; k++) Lp->e_done[k] = a_first + k;
+        }
         xw::block_sync();
-        if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {     // where this stage was when it left
+        err = 0;
+        const unsigned long long t_start = xw::tick();
+        if (w == 0) run_loader(a_first, a_last);
+        else if (w == 1) run_updater(c0, c1, a_first);
+        else run_emitter(w - 2, a_first, a_last);
+        xw::block_sync();
+        if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {         // where this stage was when it left
             uint32_t *d = V.hx->dbg[1];
-            xw::st_agent(d + 0, xw::lds_ld(&L->cursor)); xw::st_agent(d + 1, xw::lds_ld(&L->turn)); xw::st_agent(d + 2, xw::lds_ld(&L->carry_seq));
-            xw::st_agent(d + 3, f_seen); xw::st_agent(d + 4, p_seen); xw::st_agent(d + 5, L->carry_n);
+            xw::st_agent(d + 0, xw::lds_ld(&Lp->staged)); xw::st_agent(d + 1, xw::lds_ld(&Lp->u_pos)); xw::st_agent(d + 2, xw::lds_ld(&Lp->e_done[0]));
+            xw::st_agent(d + 3, xw::lds_ld(&Lp->u_taken)); xw::st_agent(d + 4, xw::lds_ld(&Lp->stop)); xw::st_agent(d + 5, 0u);
         }
-        if (i == 0) {       // accounting: summed over the waves
+        if (i == 0) {       // accounting
             unsigned long long *pr = G.persist->prof;
-            xw::atomic_add64_agent(&pr[6], n_blocks); xw::atomic_add64_agent(&pr[7], n_slow);
-            xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
-            xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
-            if (w == 0) { xw::atomic_add64_agent(&pr[18], t_wait); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
-        }
-        if (w == 0) {
-            const uint32_t on = xw::readfirst(L->carry_n);
-            for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
-            if (i == 0) S->front_n = on;
+            if (w == 1) {
+                xw::atomic_add64_agent(&pr[6], n_pos); xw::atomic_add64_agent(&pr[7], n_slow);
+                xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
+                xw::atomic_add64_agent(&pr[18], tt1); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start);
+            }
+            if (w >= 2) { xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3); }
         }
     }
 };
 
-// stage test tap: {position, max_len, delta[2..max_len]} (what the reference copies into mt_carry, :1543)
-XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
+// stage test tap: {position, max_len, delta[2..max_len]} (what the reference copies into mt_carry, :1543).  The emitters finish
+// positions out of order; the tap's words are claimed with an atomic and the host sorts by position.
+XW_FN void Table::capture(uint32_t a, uint32_t mt_max, const uint32_t *dense)
 {
     if (a < G.cap_lo || a >= G.cap_hi) return;
-    const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
-    const unsigned long long used = xw::readfirst64(*G.cap_used);
     const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
+    unsigned long long used = 0;
+    if (xw::lane() == 0) used = xw::atomic_fetch_add64_agent(G.cap_used, need);
+    used = xw::readfirst64(used);
     if (used + need > G.cap_cap) { err = kErrCapture; if (xw::lane() == 0) raise(V.hx, kErrCapture, kStTable, 10, a); return; }
     if (xw::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
-    for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) {
-        uint32_t d = 0;
-        for (uint32_t k = 0; k < fn; k++) if (fr_end(f[k]) >= a + l) d = fr_dist(f[k]);    // the last entry that still reaches
-        G.cap_words[used + l] = d;
-    }
+    for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) G.cap_words[used + l] = xw::ld_agent(dense + tf_index(l));
     xw::drain();
-    if (xw::lane() == 0) *G.cap_used = used + need;
-    xw::drain();
-    xw::wave_sync();
 }
-
 
 // =================================================================================================
 // parser stage
@@ -1105,7 +1099,7 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 //                       candidates of a target arrive in the reference's order (sources ascending; dict before rep), so
 //                       "strictly cheaper" is the reference's rule.  Edges longer than 64 (rare: max_len > 64) go through
 //                       a ring of keys in LDS (far[]) that a lane takes over when its node enters the window.
-//   rows (waves 3..6)   the table stage's record of a node -> a row of 64 entries {distance, dict price | rep price | edge},
+//   rows (waves 3,5,6,7)  the table stage's record of a node -> a row of 64 entries {distance, dict price | rep price | edge},
 //                       entry l-1 = the sampled edge of length l (prices are constant inside a segment, :1491, :1567,
 //                       :1585), the literal edge at entry 0; the node's distinct distances for the probes' "already met"
 //                       test; within 264 of the forced cut the lengths are re-listed from the position's front (:1545).
@@ -1120,7 +1114,7 @@ XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 //                       was retired is compared with the target's final key -- smaller means the chain would have gone
 //                       differently: the step is done again from its saved start state with the step's probe edges handed
 //                       to the chain (applied at their node, after its sampled edges, as the reference does).  Rare, exact.
-//   loader (wave 7)     the table stage's records staged in LDS ahead of everybody (as before).
+//   loader (wave 4)     the table stage's records staged in LDS ahead of everybody (as before).
 // Then backtrack and EMISSION on all eight waves (lanes = commands), unchanged.
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
@@ -1138,7 +1132,8 @@ constexpr uint32_t kFarRing = 512;              // keys of the nodes beyond the 
 constexpr uint32_t kStepMax = 64;               // nodes a step covers at most
 constexpr uint32_t kStepWant = 32;              // ... and the rows the chain waits for (a bounded time) before it starts one
 constexpr uint32_t kLitMark = 0xFFFFFF00u;      // "distance" of the literal edge: this | the byte (no distance is that large)
-constexpr uint32_t kVerifyWaves = 2, kPrepWaves = 4;    // waves 1..2, 3..6
+constexpr uint32_t kVerifyWaves = 2, kPrepWaves = 4;    // waves 1..2; 3, 5, 6, 7
+constexpr uint32_t kLoaderWave = 4;             // (a workgroup's waves go to the SIMDs in turn: wave 4 shares wave 0's, and the loader sleeps most of the time)
 constexpr uint32_t kVBatch = 16;                // nodes per step of a probe wave (four lanes each)
 constexpr uint32_t kVMax = 4 * kStepMax;        // probe edges a step can have
 constexpr uint32_t kInfoFar = 1u << 15;         // node info: max_len (bits 0..8) | distinct distances << 9 | has edges longer than 64
@@ -1147,7 +1142,7 @@ constexpr uint32_t kRowValid = 1u << 31;        //   dict price (13 bits) | rep 
 // link of a lane / a retired node: source | rep << 13 | explicit probe << 14 | sampled edge (or rep slot of a probe) << 26
 constexpr uint32_t kLinkRep = 1u << 13, kLinkProbe = 1u << 14;
 
-struct PFin { uint32_t r[4]; uint32_t cost, link, wdist, node; };       // a retired node: rep set, final cost, winner
+struct PFin { uint32_t r[4]; uint32_t cost, link, wdist, pad; };        // a retired node: rep set, final cost, winner
 struct PVEdge { unsigned long long key; uint32_t r; uint32_t info; };   // a probe's match: key, distance, node | length << 13 | slot << 22
 struct PCtl {
     uint32_t n_s;                               // the step starts at this node; everything before it is final
@@ -1157,11 +1152,12 @@ struct PCtl {
     uint32_t vcount;                            // probe edges of the attempt
     uint32_t xcount;                            // ... of the attempt before, handed to the chain when the step is done again
     uint32_t redo, seg_len, end_snap;
+    uint32_t far_hi, far_hi_snap;               // no node beyond this one has a key in far[]
     uint32_t prep_cur[kPrepWaves];              // rows: wave p has prepared its nodes (n % 4 == p) below this
 };
 
 struct PLds {
-    unsigned long long row[kRowRing * 64];      // node n at [(n & 127) * 64 + l - 1]
+    unsigned long long row[kRowRing * 64];      // node n, edge of length l, at [(n & 127) * 64 + (n + l) % 64]: the target's lane
     unsigned long long far[kFarRing], far_snap[kFarRing];   // node t at [t & 511]: best key of the edges that jump over the window
     uint32_t far_d[kFarRing], far_d_snap[kFarRing];         // ... and the distance of that edge (sampled edges; a probe's is in its source's set)
     PFin fin[kFarRing];                         // node n at [n & 511]
@@ -1185,7 +1181,7 @@ struct PLds {
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
     uint32_t stg[5];                            // loader wave: records requested up to / written up to this position, (2 unused), records of the last step; 4: records staged up to here
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current step on, loaded ahead
-                                                //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
+                                                //   by the loader wave (position a at [((a - launch start) & 127) * kStageQ])
     // the path of a parsed segment (node indices, end first) lives in the rows: nothing reads a row between a parse and its emission
     XW_FN uint16_t *cmdlist() { return (uint16_t *)&row[0]; }
     Counters cnt;
@@ -1200,7 +1196,7 @@ struct Parser {
     uint32_t t_out_seen;
     uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
-    // wave kPW-1: the loader of the record stage (8-byte words counted from the launch's first position)
+    // wave kLoaderWave: the loader of the record stage (8-byte words counted from the launch's first position)
     uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
     unsigned long long pend_v[kPumpLoads];
     // frame writer (CodeFrame, :490-513)
@@ -1404,7 +1400,7 @@ struct Parser {
         }
     }
 
-    // ---- the record stage (wave kPW-1).  One step: what was requested by the last step goes into LDS, the next 64 words are
+    // ---- the record stage (wave kLoaderWave).  One step: what was requested by the last step goes into LDS, the next 64 words are
     // requested (positions below the table stage's t_out as the last step saw it, and below lo + 128: lo is the first
     // position still needed), t_out is requested again.  Nothing is waited for here except the last step's loads.
     XW_FN unsigned long long *staged(uint32_t a) const { return L()->stage + (a & (kStagePos - 1)) * kStageQ; }
@@ -1493,7 +1489,7 @@ struct Parser {
     }
 
     // =============================================================================================
-    // rows (waves 3..6): the record of node m of the segment at seg_a -> its row, distinct distances, info word
+    // rows (waves 3, 5, 6, 7): the record of node m of the segment at seg_a -> its row, distinct distances, info word
     // =============================================================================================
     XW_FN void prep_node(uint32_t seg_a, uint32_t m, uint32_t max_parse, uint32_t pc_dict, uint32_t pc_rep, uint32_t pc_lit)
     {
@@ -1513,20 +1509,16 @@ struct Parser {
         if (xw::readfirst(eff != listed ? 1u : 0u)) {
             // The segment is within 264 of its forced cut (:1469), or this position was listed for the cut of a segment that
             // ended before it: the sampled lengths change with max_len (:1545, :1558-1560).  Re-listed from the position's
-            // front (lanes = samples); the staged copy takes the new list (the ring's record stays as the table stage wrote it).
+            // table (lanes = samples); the staged copy takes the new list (the ring's record stays as the table stage wrote it).
             acc(kAccUndo, 1);
-            const uint32_t fn = (uint32_t)(hd >> 32);
-            const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+            const uint32_t *dense = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;     // the position's table: delta[l] at [l - 1]
             uint32_t step = (eff - kMatchMin) >> 4;
             step += step == 0;
             ne = eff >= kMatchMin ? (eff - kMatchMin) / step + 1 : 0u;
             uint32_t d = 0, valid = 0;
             if (k < ne) {
                 const uint32_t tl = eff - k * step;
-                for (uint32_t j = 0; j < fn; j++) {                 // the last entry (smallest end) that still has >= tl bytes
-                    const unsigned long long fe = xw::ld_agent64((const unsigned long long *)(fo + 2 * j));
-                    if ((uint32_t)fe >= tl) d = (uint32_t)(fe >> 32);
-                }
+                d = xw::ld_agent(dense + tf_index(tl));
                 const uint32_t mm = match_min(d);
                 uint32_t nx, ex;
                 const uint32_t slot = dist_slot(d - 1, nx, ex);
@@ -1553,11 +1545,11 @@ struct Parser {
             const uint32_t lp = Lp->len_price[lv];
             const uint32_t pd = pc_dict + lp + (nx << 5) + Lp->slot_price[umin(lv, 3) * 64 + slot];     // :1208-1251
             const uint32_t pr = pc_rep + lp + (2u << 5);                                                 // :1253-1272
-            if (tl <= 64) row[tl - 1] = (unsigned long long)d | ((unsigned long long)(pd | (pr << 13) | (k << 26) | kRowValid) << 32);
+            if (tl <= 64) row[(m + tl) & 63u] = (unsigned long long)d | ((unsigned long long)(pd | (pr << 13) | (k << 26) | kRowValid) << 32);
         }
         if (k == 0) {
             const uint32_t plit = pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15);     // :1418-1426
-            row[0] = (unsigned long long)(kLitMark | lit) | ((unsigned long long)(plit | (0x1FFFu << 13) | kRowValid) << 32);
+            row[(m + 1) & 63u] = (unsigned long long)(kLitMark | lit) | ((unsigned long long)(plit | (0x1FFFu << 13) | kRowValid) << 32);
         }
         if (k < kMaxEdges && ((uniq >> k) & 1u)) {
             const uint32_t at_dd = (uint32_t)__builtin_popcount(uniq & ((1u << k) - 1u));
@@ -1617,48 +1609,57 @@ struct Parser {
     }
 
     // One step of the chain: nodes n_s .. (below n_e, and while inside the segment).  Returns the node it stopped at.
-    XW_FN uint32_t chain_run(Chain &C, uint32_t seg_a, uint32_t n_s, uint32_t n_e, uint32_t &end_p, uint32_t nx_extra,
+    // Every lane keeps the state of its node in LDS up to date (fin[node & 511]: once a step, whatever the node): the entry of a
+    // node is final from the step the node is processed in -- no lane mask, no branch for the retirement.
+    XW_FN uint32_t chain_run(Chain &C, uint32_t seg_a, uint32_t n_s, uint32_t n_e_in, uint32_t &end_p_io, uint32_t &far_hi_io, uint32_t nx_extra,
                              uint32_t pc_dict, uint32_t pc_rep)
     {
         PLds *Lp = L();
         const uint32_t i = xw::lane();
-        // (lane m % 64: what the rows' wave noted about node m of this step)
-        const uint32_t infov = Lp->ninfo[lane_node(n_s, i) & (kRowRing - 1)];
-        // nodes of the step that have probe edges handed over (the step is being done again)
-        unsigned long long xmask = 0;
+        // (loop control in scalar registers)
+        const uint32_t n_e = xw::readfirst(n_e_in);
+        uint32_t end_p = xw::readfirst(end_p_io), far_hi = xw::readfirst(far_hi_io);
+        // (lane m % 64: what the rows' wave noted about node m of this step; bit 16: the node has probe edges handed over --
+        //  the step is being done again)
+        uint32_t infov = Lp->ninfo[lane_node(n_s, i) & (kRowRing - 1)];
         for (uint32_t b = 0; b < nx_extra; b += 64) {
-            const uint32_t nd = b + i < nx_extra ? (Lp->extras[b + i].info & 0x1FFFu) : n_s;
-            // (64 nodes: one bit each)
-            unsigned long long bit = b + i < nx_extra ? 1ull << ((nd - n_s) & 63u) : 0ull;
-            for (uint32_t s = 32; s; s >>= 1) bit |= xw::shfl64(bit, i ^ s);
-            xmask |= bit;
+            unsigned long long bit = b + i < nx_extra ? 1ull << ((Lp->extras[b + i].info & 0x1FFFu) & 63u) : 0ull;
+            for (uint32_t sh = 32; sh; sh >>= 1) bit |= xw::shfl64(bit, i ^ sh);
+            infov |= (uint32_t)((bit >> i) & 1ull) << 16;
         }
+        uint32_t farlive = far_hi >= n_s + 64 ? 1u : 0u;            // a key may be waiting in far[] for a node that enters the window
         uint32_t n = n_s;
-        const unsigned long long *rows = Lp->row;
-        unsigned long long rw0 = rows[(n & (kRowRing - 1)) * 64 + ((i - n - 1) & 63u)];
-        unsigned long long rw1 = rows[((n + 1) & (kRowRing - 1)) * 64 + ((i - n - 2) & 63u)];
-        unsigned long long fk0 = Lp->far[(n + 64) & (kFarRing - 1)], fk1 = Lp->far[(n + 65) & (kFarRing - 1)];
+        const unsigned long long *rows = Lp->row + i;               // (a row's entry for this lane: the edge that ends at the lane's node)
+        unsigned long long rw0 = rows[(n & (kRowRing - 1)) * 64];
+        unsigned long long rw1 = rows[((n + 1) & (kRowRing - 1)) * 64];
+        uint32_t fslot = lane_node(n, i) & (kFarRing - 1);          // where this lane's node keeps its state
+        xw::setprio_high();
         while (n < n_e && n < end_p) {
             const uint32_t sl = n & 63u;
             const bool me = i == sl;
             const uint32_t cn = xw::readlane(C.cost, sl);
             const uint32_t r0 = xw::readlane(C.r0, sl), r1 = xw::readlane(C.r1, sl), r2 = xw::readlane(C.r2, sl), r3 = xw::readlane(C.r3, sl);
             const uint32_t info = xw::readlane(infov, sl);
-            // ---- the node is final: retired
-            if (me) {
-                PFin &f = Lp->fin[n & (kFarRing - 1)];
+            // ---- the states as they stand (node n's is final), and how far the chain is
+            {
+                PFin &f = Lp->fin[fslot];
                 f.r[0] = C.r0; f.r[1] = C.r1; f.r[2] = C.r2; f.r[3] = C.r3;
-                f.cost = C.cost; f.link = C.link; f.wdist = C.wd; f.node = n;
-                Lp->far[n & (kFarRing - 1)] = kKeyNone;
+                f.cost = C.cost; f.link = C.link; f.wdist = C.wd;
                 xw::lds_st(&Lp->ctl.done, n + 1);
             }
             end_p = umax(end_p, n + (info & 0x1FFu));               // :1550-1554
-            // (two nodes ahead: the row entries, the key waiting for the node that enters the window then)
-            const unsigned long long rw2 = rows[((n + 2) & (kRowRing - 1)) * 64 + ((i - n - 3) & 63u)];
-            unsigned long long fk2 = Lp->far[(n + 66) & (kFarRing - 1)];
+            const unsigned long long rw2 = rows[((n + 2) & (kRowRing - 1)) * 64];     // (two nodes ahead)
             // ---- its lane is node n + 64's now
             C.cost = me ? kInf : C.cost;
-            if (NLZM_RARE(fk0 != kKeyNone)) take_far(me, fk0, n + 64, C);
+            fslot = me ? ((fslot + 64) & (kFarRing - 1)) : fslot;
+            const uint32_t rare = (info >> 15) | farlive;           // (edges longer than the window, probe edges, keys in far[])
+            if (NLZM_RARE(rare)) {
+                // a key that jumped over the window may be waiting for node n + 64 (written before this node was reached)
+                if (far_hi >= n + 64) {
+                    const unsigned long long fk = xw::readfirst64(Lp->far[(n + 64) & (kFarRing - 1)]);
+                    if (fk != kKeyNone) take_far(me, fk, n + 64, C);
+                }
+            }
             // ---- its edges (:1490-1499, :1566-1595): every lane its own
             {
                 const uint32_t d = (uint32_t)rw0, at = (uint32_t)(rw0 >> 32);
@@ -1672,62 +1673,77 @@ struct Parser {
                 C.cost = upd ? cand : C.cost;
                 C.link = upd ? (n | (userep ? kLinkRep : 0u) | (at & 0x7C000000u)) : C.link;
                 C.wd = upd ? d : C.wd;
-                C.r3 = upd ? r3 : C.r3; C.r2 = upd ? r2 : C.r2; C.r1 = upd ? r1 : C.r1; C.r0 = upd ? r0 : C.r0;
-                C.r3 = push ? r2 : C.r3; C.r2 = push ? r1 : C.r2; C.r1 = push ? r0 : C.r1; C.r0 = push ? d : C.r0;
+                // (the set once more in vector registers: a select takes its mask over the scalar operand bus, so its data cannot)
+                const uint32_t v0 = xw::opaque(r0), v1 = xw::opaque(r1), v2 = xw::opaque(r2), v3 = xw::opaque(r3);
+                C.r3 = upd ? (push ? v2 : v3) : C.r3; C.r2 = upd ? (push ? v1 : v2) : C.r2; C.r1 = upd ? (push ? v0 : v1) : C.r1; C.r0 = upd ? (push ? d : v0) : C.r0;
             }
-            // ---- sampled edges longer than the window (max_len > 64: lanes = the sixteen longest samples)
-            if (NLZM_RARE(info & kInfoFar)) {
-                t_q[5]++;
-                const unsigned long long *srec = staged(seg_a + n);
-                const uint32_t ne = (uint32_t)srec[0] & 63u;
-                const unsigned long long e = (i < kStageEdges && i < ne) ? srec[1 + i] : 0ull;
-                const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32), tl = at & 0x1FFu;
-                if ((at >> 31) && tl > 64) {
-                    const uint32_t lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-                    const uint32_t lp = Lp->len_price[lv];
-                    const uint32_t pd = pc_dict + lp + (nx << 5) + Lp->slot_price[umin(lv, 3) * 64 + slot];
-                    const uint32_t pr = pc_rep + lp + (2u << 5);
-                    const bool inset = d == r0 || d == r1 || d == r2 || d == r3;
-                    const bool userep = inset && pr < pd;
-                    const unsigned long long key = ((unsigned long long)(cn + (userep ? pr : pd)) << 32) | (n << 8) | (2 * i + (userep ? 1u : 0u));
-                    const uint32_t t = n + tl;
-                    if (key < Lp->far[t & (kFarRing - 1)]) { Lp->far[t & (kFarRing - 1)] = key; Lp->far_d[t & (kFarRing - 1)] = d; }
+            if (NLZM_RARE(rare)) {
+                // ---- sampled edges longer than the window (max_len > 64: lanes = the sixteen longest samples)
+                if (info & kInfoFar) {
+                    t_q[5]++;
+                    const unsigned long long *srec = staged(seg_a + n);
+                    const uint32_t ne = (uint32_t)srec[0] & 63u;
+                    const unsigned long long e = (i < kStageEdges && i < ne) ? srec[1 + i] : 0ull;
+                    const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32), tl = at & 0x1FFu;
+                    uint32_t t = 0;
+                    if ((at >> 31) && tl > 64) {
+                        const uint32_t lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
+                        const uint32_t lp = Lp->len_price[lv];
+                        const uint32_t pd = pc_dict + lp + (nx << 5) + Lp->slot_price[umin(lv, 3) * 64 + slot];
+                        const uint32_t pr = pc_rep + lp + (2u << 5);
+                        const bool inset = d == r0 || d == r1 || d == r2 || d == r3;
+                        const bool userep = inset && pr < pd;
+                        const unsigned long long key = ((unsigned long long)(cn + (userep ? pr : pd)) << 32) | (n << 8) | (2 * i + (userep ? 1u : 0u));
+                        t = n + tl;
+                        if (key < Lp->far[t & (kFarRing - 1)]) { Lp->far[t & (kFarRing - 1)] = key; Lp->far_d[t & (kFarRing - 1)] = d; }
+                    }
+                    far_hi = umax(far_hi, xw::readlane(xw::scan_max(t), 63));
+                    farlive = 1;
+                    xw::wave_sync();
                 }
-                fk1 = Lp->far[(n + 65) & (kFarRing - 1)]; fk2 = Lp->far[(n + 66) & (kFarRing - 1)];   // (this node may have written them)
-            }
-            // ---- probe edges known from the attempt before (:1598-1628: after the sampled edges, slot by slot)
-            if (NLZM_RARE((xmask >> ((n - n_s) & 63u)) & 1ull)) {
-                t_q[5]++;
+                // ---- probe edges known from the attempt before (:1598-1628: after the sampled edges, slot by slot)
+                if (info & (1u << 16)) {
+                    t_q[5]++;
 #pragma unroll
-                for (uint32_t pi = 0; pi < 4; pi++) {
-                    const uint32_t r = pi == 0 ? r0 : (pi == 1 ? r1 : (pi == 2 ? r2 : r3));
-                    uint32_t ml = 0;
-                    for (uint32_t b = 0; b < nx_extra; b += 64) {
-                        const bool hit = b + i < nx_extra && (Lp->extras[b + i].info & 0x1FFFu) == n && Lp->extras[b + i].r == r;
-                        const unsigned long long hm = xw::ballot(hit);
-                        if (hm) ml = (xw::readlane(b + i < nx_extra ? Lp->extras[b + i].info : 0u, (uint32_t)__builtin_ctzll(hm)) >> 13) & 0x1FFu;
-                    }
-                    if (!ml) continue;
-                    const uint32_t cand = cn + pc_rep + Lp->len_price[ml - match_min(r)] + (2u << 5);        // :1607, :1614
-                    const uint32_t t = n + ml;
-                    end_p = umax(end_p, t);                         // :1608-1612
-                    if (ml <= 64) {
-                        const bool upd = i == (t & 63u) && cand < C.cost;
-                        C.cost = upd ? cand : C.cost;
-                        C.link = upd ? (n | kLinkRep | kLinkProbe | (pi << 26)) : C.link;
-                        C.wd = upd ? r : C.wd;
-                        C.r0 = upd ? r0 : C.r0; C.r1 = upd ? r1 : C.r1; C.r2 = upd ? r2 : C.r2; C.r3 = upd ? r3 : C.r3;
-                    } else {
-                        const unsigned long long key = ((unsigned long long)cand << 32) | (n << 8) | (kRankProbe + pi);
-                        if (i == 0 && key < Lp->far[t & (kFarRing - 1)]) Lp->far[t & (kFarRing - 1)] = key;
-                        xw::wave_sync();
-                        fk1 = Lp->far[(n + 65) & (kFarRing - 1)]; fk2 = Lp->far[(n + 66) & (kFarRing - 1)];
+                    for (uint32_t pi = 0; pi < 4; pi++) {
+                        const uint32_t r = pi == 0 ? r0 : (pi == 1 ? r1 : (pi == 2 ? r2 : r3));
+                        uint32_t ml = 0;
+                        for (uint32_t b = 0; b < nx_extra; b += 64) {
+                            const bool hit = b + i < nx_extra && (Lp->extras[b + i].info & 0x1FFFu) == n && Lp->extras[b + i].r == r;
+                            const unsigned long long hm = xw::ballot(hit);
+                            if (hm) ml = (xw::readlane(b + i < nx_extra ? Lp->extras[b + i].info : 0u, (uint32_t)__builtin_ctzll(hm)) >> 13) & 0x1FFu;
+                        }
+                        if (!ml) continue;
+                        const uint32_t cand = cn + pc_rep + Lp->len_price[ml - match_min(r)] + (2u << 5);        // :1607, :1614
+                        const uint32_t t = n + ml;
+                        end_p = umax(end_p, t);                     // :1608-1612
+                        if (ml <= 64) {
+                            const bool upd = i == (t & 63u) && cand < C.cost;
+                            C.cost = upd ? cand : C.cost;
+                            C.link = upd ? (n | kLinkRep | kLinkProbe | (pi << 26)) : C.link;
+                            C.wd = upd ? r : C.wd;
+                            C.r0 = upd ? r0 : C.r0; C.r1 = upd ? r1 : C.r1; C.r2 = upd ? r2 : C.r2; C.r3 = upd ? r3 : C.r3;
+                        } else {
+                            const unsigned long long key = ((unsigned long long)cand << 32) | (n << 8) | (kRankProbe + pi);
+                            if (i == 0 && key < Lp->far[t & (kFarRing - 1)]) Lp->far[t & (kFarRing - 1)] = key;
+                            far_hi = umax(far_hi, t);
+                            farlive = 1;
+                            xw::wave_sync();
+                        }
                     }
                 }
             }
-            rw0 = rw1; rw1 = rw2; fk0 = fk1; fk1 = fk2;
+            rw0 = rw1; rw1 = rw2;
             n++;
         }
+        xw::setprio_low();
+        // (the node the chain stopped at: its state as it stands, for the step's end)
+        {
+            PFin &f = Lp->fin[fslot];
+            f.r[0] = C.r0; f.r[1] = C.r1; f.r[2] = C.r2; f.r[3] = C.r3;
+            f.cost = C.cost; f.link = C.link; f.wdist = C.wd;
+        }
+        end_p_io = end_p; far_hi_io = far_hi;
         return n;
     }
 
@@ -1768,7 +1784,7 @@ struct Parser {
             } else {
                 // (more than eight distinct distances: the row's entries and the staged samples longer than the window)
                 const unsigned long long *row = Lp->row + (node & (kRowRing - 1)) * 64;
-                for (uint32_t z = 1; z < 64; z++) met = met || (uint32_t)row[z] == r;
+                for (uint32_t z = 0; z < 64; z++) met = met || (uint32_t)row[z] == r;
                 const unsigned long long *srec = staged(seg_a + node);
                 const uint32_t ne = (uint32_t)srec[0] & 63u;
                 for (uint32_t z = 0; z < kStageEdges && z < ne; z++) {
@@ -1814,7 +1830,7 @@ struct Parser {
         // for exactly this word at seg_a (a nice region that starts where the segment before was cut at 4,096 positions,
         // :1469: no edge spans the cut, so nothing else tells it) and the record of seg_a comes only after it.
         if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
-        if (w == kPW - 1) {                                         // (meanwhile: the first node's record, staged)
+        if (w == kLoaderWave) {                                     // (meanwhile: the first node's record, staged)
             if (!stage_need(seg_a)) err = kErrInternal + 100;
             if (i == 0) Lp->sh[4] = err;
         }
@@ -1884,20 +1900,21 @@ struct Parser {
             uint32_t eff0 = umin((h0 >> 16) & 0x1FFu, max_parse);
             n_first = umin(umin(umax(eff0 + 2, 4u), kStepWant), umin(staged_hi() - seg_a, max_parse));
         }
-        if (w >= 1 && w < kPW - 1) for (uint32_t m = w - 1; m < n_first; m += kPW - 2) prep_node(seg_a, m, max_parse, pc_dict, pc_rep, pc_lit);
+        if (w != 0 && w != kLoaderWave) for (uint32_t m = w < kLoaderWave ? w - 1 : w - 2; m < n_first; m += kPW - 2) prep_node(seg_a, m, max_parse, pc_dict, pc_rep, pc_lit);
         for (uint32_t t = tid; t < kFarRing; t += kParserThreads) Lp->far[t] = kKeyNone;
         if (tid == 0) {
             PCtl &c = Lp->ctl;
-            c.n_s = 0; c.stop = 0; c.done = 0; c.end_p = 1; c.vcount = 0; c.xcount = 0; c.redo = 0; c.seg_len = 0; c.end_snap = 1;
+            c.n_s = 0; c.stop = 0; c.done = 0; c.end_p = 1; c.vcount = 0; c.xcount = 0; c.redo = 0; c.seg_len = 0; c.end_snap = 1; c.far_hi = 0; c.far_hi_snap = 0;
             for (uint32_t p = 0; p < kPrepWaves; p++) c.prep_cur[p] = n_first + ((p - n_first) & (kPrepWaves - 1));
             Lp->dbgw[0] = seg_a; Lp->dbgw[1] = 0; Lp->dbgw[2] = max_parse;
             Lp->node_link[0] = 0;
         }
         Chain C{ kInf, kSrcNone, 0, rep0, rep1, rep2, rep3 };       // (wave 0's; node 0 (:1472-1482) on lane 0)
         if (i == 0) C.cost = 0;
-        uint32_t end_p = 1, seg_len = 0;
+        uint32_t end_p = 1, seg_len = 0, far_hi = 0;
         uint32_t cmp_acc = 0;                                       // probe waves: bytes the probes of the attempt looked at
-        uint32_t prep_m = n_first + ((w - 1 - kVerifyWaves - n_first) & (kPrepWaves - 1));     // (rows' waves: the next node of theirs)
+        const uint32_t prep_i = w == 1 + kVerifyWaves ? 0u : w - kLoaderWave;             // (rows' waves 3, 5, 6, 7: 0 .. 3)
+        uint32_t prep_m = n_first + ((prep_i - n_first) & (kPrepWaves - 1));               // ... and the next node of theirs
         xw::block_sync();
         if (w == 0) acc(kAccSetup, xw::tick() - ts);
         for (;;) {
@@ -1930,7 +1947,7 @@ struct Parser {
                     C.cost = Lp->snap[i]; C.link = Lp->snap[64 + i]; C.wd = Lp->snap[128 + i];
                     C.r0 = Lp->snap[192 + i]; C.r1 = Lp->snap[256 + i]; C.r2 = Lp->snap[320 + i]; C.r3 = Lp->snap[384 + i];
                     for (uint32_t t = i; t < kFarRing; t += 64) { Lp->far[t] = Lp->far_snap[t]; Lp->far_d[t] = Lp->far_d_snap[t]; }
-                    end_p = xw::readfirst(Lp->ctl.end_snap);
+                    end_p = xw::readfirst(Lp->ctl.end_snap); far_hi = xw::readfirst(Lp->ctl.far_hi_snap);
                     nx_extra = xw::readfirst(Lp->ctl.xcount);
                     xw::wave_sync();
                 } else {
@@ -1938,11 +1955,11 @@ struct Parser {
                     Lp->snap[i] = C.cost; Lp->snap[64 + i] = C.link; Lp->snap[128 + i] = C.wd;
                     Lp->snap[192 + i] = C.r0; Lp->snap[256 + i] = C.r1; Lp->snap[320 + i] = C.r2; Lp->snap[384 + i] = C.r3;
                     for (uint32_t t = i; t < kFarRing; t += 64) { Lp->far_snap[t] = Lp->far[t]; Lp->far_d_snap[t] = Lp->far_d[t]; }
-                    if (i == 0) Lp->ctl.end_snap = end_p;
+                    if (i == 0) { Lp->ctl.end_snap = end_p; Lp->ctl.far_hi_snap = far_hi; }
                     xw::wave_sync();
                 }
                 const unsigned long long q1 = ptick();
-                const uint32_t n1 = chain_run(C, seg_a, n_s, n_e, end_p, nx_extra, pc_dict, pc_rep);
+                const uint32_t n1 = chain_run(C, seg_a, n_s, n_e, end_p, far_hi, nx_extra, pc_dict, pc_rep);
                 if (i == 0) {
                     // (what the finder stage may be waiting for: how far the segment reaches.  Said before anybody here waits for a record)
                     xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + end_p));
@@ -1975,6 +1992,9 @@ struct Parser {
                     if (i == 0) { Lp->ctl.xcount = cnt; Lp->ctl.redo = 1; Lp->ctl.vcount = 0; Lp->ctl.stop = 0; Lp->ctl.done = n_s; }
                     acc(kAccRedo, 1);
                 } else {
+                    // (the keys of the nodes that were retired are spent)
+                    if (n_s + i < n1) Lp->far[(n_s + i) & (kFarRing - 1)] = kKeyNone;
+                    xw::wave_sync();
                     // probe edges whose target is still ahead: into the keys the chain takes over (:1608-1612 opens the nodes)
                     uint32_t ext = 0;
                     for (uint32_t b = 0; b < cnt; b += 64) {
@@ -1986,7 +2006,7 @@ struct Parser {
                         }
                         ext = umax(ext, xw::readlane(xw::scan_max(t), 63));
                     }
-                    end_p = umax(end_p, ext);
+                    end_p = umax(end_p, ext); far_hi = umax(far_hi, ext);
                     xw::wave_sync();
                     acc(kAccBlocks, 1);
                     uint32_t done_len = 0;
@@ -2035,7 +2055,7 @@ struct Parser {
                     verify_batch(seg_a, seg_q, max_parse, nb0, hi, pc_rep, cmp_acc);
                 }
                 xw::block_sync();
-            } else if (w < kPW - 1) {
+            } else if (w != kLoaderWave) {
                 // ================= rows =================
                 uint32_t spins = 0;
                 for (;;) {
@@ -2045,7 +2065,7 @@ struct Parser {
                         prep_node(seg_a, m, max_parse, pc_dict, pc_rep, pc_lit);
                         prep_m = m + kPrepWaves;
                         xw::wave_sync();
-                        if (i == 0) xw::lds_st(&Lp->ctl.prep_cur[w - 1 - kVerifyWaves], prep_m);
+                        if (i == 0) xw::lds_st(&Lp->ctl.prep_cur[prep_i], prep_m);
                         continue;
                     }
                     const uint32_t st = xw::readfirst(xw::lds_ld(&Lp->ctl.stop));
@@ -2139,7 +2159,7 @@ struct Parser {
             n_seg += nsegs;
             {
                 const unsigned long long te = xw::tick();
-                if (xw::wave() == kPW - 1) pump(seg_a + len);                   // (records of the next segment: requested now, in LDS by the next step)
+                if (xw::wave() == kLoaderWave) pump(seg_a + len);               // (records of the next segment: requested now, in LDS by the next step)
                 emit_commands(ncmds, n_lit, n_dict, n_rep);
                 if (xw::wave() == 0) acc(kAccEmit, xw::tick() - te);
             }

@@ -31,7 +31,7 @@ def one(job):
     world, rank = job
     lo, hi = shard.block_range(STREAM_BYTES, world, rank)
     data = corpus.syn_text(hi - lo, corpus.SEED + rank)
-    with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "oracle", "_ref")) as tmp:
+    with tempfile.TemporaryDirectory(dir=os.environ.get("NLZM_SCRATCH", "/tmp")) as tmp:
         inp, out = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.nlzm")
         data.tofile(inp)
         t0 = time.time()

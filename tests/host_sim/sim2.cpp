@@ -209,25 +209,20 @@ static void ref_on_pos(void *, uint64_t abs_pos, uint32_t max_len, const uint32_
     g_ref.words.push_back(max_len);
     for (uint32_t i = 2; i <= max_len; i++) g_ref.words.push_back(delta[i]);
 }
-void v2::Table::sim_on_front(void *, uint32_t a, const unsigned long long *f, uint32_t fn)
+void v2::Table::sim_on_table(void *, uint32_t a, uint32_t mt, const uint32_t *dense)
 {
     if (g_ref.bad) return;
     if (a >= g_ref.off.size()) { printf("table stage: position %u beyond the oracle's\n", a); g_ref.bad = 1; return; }
     const uint32_t *r = g_ref.words.data() + g_ref.off[a];
     const uint32_t max_len = r[0];
-    const uint32_t mt = fn ? v2::fr_end(f[0]) - a : 0u;
     bool ok = mt == max_len;
-    for (uint32_t l = 2; ok && l <= max_len; l++) {
-        uint32_t d = 0;
-        for (uint32_t k = 0; k < fn; k++) if (v2::fr_end(f[k]) >= a + l) d = v2::fr_dist(f[k]);
-        if (d != r[l - 1]) ok = false;
-    }
+    for (uint32_t l = 2; ok && l <= max_len; l++) if (dense[v2::tf_index(l)] != r[l - 1]) ok = false;
     g_ref.checked++;
     if (!ok) {
         printf("position %u: table differs. oracle max_len %u:", a, max_len);
         for (uint32_t l = 2; l <= max_len && l < 40; l++) printf(" %u", r[l - 1]);
-        printf("\n  sim front (%u):", fn);
-        for (uint32_t k = 0; k < fn && k < 40; k++) printf(" (len %u, d %u)", v2::fr_end(f[k]) - a, v2::fr_dist(f[k]));
+        printf("\n  sim max_len %u:", mt);
+        for (uint32_t l = 2; l <= mt && l < 40; l++) printf(" %u", dense[v2::tf_index(l)]);
         printf("\n");
         g_ref.bad = 1;
     }
