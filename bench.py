@@ -71,35 +71,58 @@ def algorithmic_bytes(st: dict) -> int:
             + 8 * st["ht_rows"] + 4 * st["rk_probes"] + 4 * st["rk_inserts"])
 
 
-def cpu_baseline(sample: np.ndarray) -> dict:
-    """Time the reference's single-threaded CPU path on a bounded sample (rank 0, N=1 only), pinned to one core."""
-    import shutil
-    ref = os.path.join(ROOT, "oracle", "_ref", "nlzm_ref")
-    geo = nlzm_amd.geometry(int(sample.size), WINDOW)
-    desc = (f"bytes [0, {sample.size}) of the workload as a file of its own, -window:{WINDOW} "
-            f"(the reference shrinks it to {geo['hist_bits']} for a file of this size, NLZM.cpp:1716-1718, which favours it: "
-            f"over the whole 1e9-byte stream at window 28 it ran at 0.77 MB/s on a host core of an MI355X box, "
-            f"profiles/r02_ref_full_1e9.json)")
-    pin = []
-    if shutil.which("taskset"):
+class CpuBaseline:
+    """The reference's single-threaded CPU path (oracle/_ref/nlzm_ref, built from /root/reference at build time), pinned to
+    one core each, started BEFORE the GPU legs and collected after them (the host idles while the GPU runs, so it costs
+    no wall time; rank 0, N = 1 only):
+      * the headline configuration's depth: the first `deep_bytes` (> 2^28, so the window stays at 28, NLZM.cpp:1716-1718)
+        of the workload as a file, -window:28 -- `value`;
+      * the first 25 MB as a file of its own (the window shrinks to 25 there, which favours it) -- `shallow`.
+    Without the reference binary the oracle port is timed on the small sample only, in the foreground (kind "port")."""
+
+    def __init__(self, host: np.ndarray, deep_bytes: int, shallow_bytes: int):
+        import shutil
+        self.ref = os.path.join(ROOT, "oracle", "_ref", "nlzm_ref")
+        self.host, self.deep_n, self.shallow_n = host, int(min(host.size, deep_bytes)), int(min(host.size, shallow_bytes))
+        self.tmp, self.jobs = None, []
         cores = sorted(os.sched_getaffinity(0))
-        pin = ["taskset", "-c", str(cores[len(cores) // 2])]
-    if os.path.exists(ref):
-        with tempfile.TemporaryDirectory() as tmp:
-            inp, out = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.nlzm")
-            sample.tofile(inp)
+        self.pins = [cores[len(cores) // 2], cores[len(cores) // 2 + 1 if len(cores) > 2 else 0]]
+        self.taskset = shutil.which("taskset")
+        if os.path.exists(self.ref):
+            self.tmp = tempfile.TemporaryDirectory()
+            for k, n in enumerate((self.deep_n, self.shallow_n)):
+                inp, out = os.path.join(self.tmp.name, f"in{k}.bin"), os.path.join(self.tmp.name, f"out{k}.nlzm")
+                host[:n].tofile(inp)
+                pin = [self.taskset, "-c", str(self.pins[k])] if self.taskset else []
+                # (wall time of the process itself, taken by a shell around it: the parent is busy with the GPU legs)
+                cmd = pin + ["bash", "-c", f's=$(date +%s.%N); "{self.ref}" -window:{WINDOW} c "{inp}" "{out}" > /dev/null; e=$(date +%s.%N); echo "$s $e"']
+                self.jobs.append((n, pin, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)))
+
+    def collect(self) -> dict:
+        base = {"unit": "MB/s", "cores": 1, "host_cores_present": os.cpu_count()}
+        if not self.jobs:
+            from tests import oracle_py       # the oracle is only the timed CPU leg here, never the product
+            sample = self.host[:self.shallow_n]
             t0 = time.perf_counter()
-            subprocess.run(pin + [ref, f"-window:{WINDOW}", "c", inp, out], check=True, capture_output=True)
+            oracle_py.compress(sample, WINDOW)
             dt = time.perf_counter() - t0
-        kind = "reference"
-    else:
-        from tests import oracle_py       # the oracle is only the timed CPU leg here, never the product
-        t0 = time.perf_counter()
-        oracle_py.compress(sample, WINDOW)
-        dt = time.perf_counter() - t0
-        kind = "port"
-    return {"value": round(sample.size / 1e6 / dt, 4), "unit": "MB/s", "cores": 1, "kind": kind, "sample": desc,
-            "seconds": round(dt, 2), "pinned": " ".join(pin) if pin else None, "host_cores_present": os.cpu_count()}
+            return dict(base, value=round(sample.size / 1e6 / dt, 4), kind="port", seconds=round(dt, 2), pinned=None,
+                        sample=f"bytes [0, {sample.size}) of the workload as a file of its own, -window:{WINDOW} (oracle port: the reference binary is absent)")
+        res = []
+        for n, pin, pr in self.jobs:
+            out, _ = pr.communicate()
+            s, e = (float(x) for x in out.split())
+            geo = nlzm_amd.geometry(n, WINDOW)
+            res.append({"bytes": n, "seconds": round(e - s, 2), "value": round(n / 1e6 / (e - s), 4), "window_after_shrink": geo["hist_bits"],
+                        "pinned": " ".join(pin[1:]) if pin else None})
+        self.tmp.cleanup()
+        deep, shallow = res
+        return dict(base, value=deep["value"], kind="reference", seconds=deep["seconds"], pinned=deep["pinned"],
+                    sample=f"bytes [0, {deep['bytes']}) of the workload as a file, -window:{WINDOW} (a file of more than 2^28 bytes keeps the window at "
+                           f"{deep['window_after_shrink']}: the depth the headline is quoted on), run in the background of the GPU legs on a core of its own; "
+                           f"over the whole 1e9-byte stream it ran at 0.77 MB/s on a host core of an MI355X box (profiles/r02_ref_full_1e9.json)",
+                    shallow={"value": shallow["value"], "seconds": shallow["seconds"], "pinned": shallow["pinned"],
+                             "sample": f"bytes [0, {shallow['bytes']}) as a file of its own: the window shrinks to {shallow['window_after_shrink']}, which favours the reference"})
 
 
 def copy_peak_gbs(torch, dev) -> float:
@@ -151,7 +174,7 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
         ran += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out.update({"value": round((done.value - d0) / 1e6 / dt, 4), "unit": "MB/s", "steps": ran, "warmup": warmup,
+    out.update({"value": round((done.value - d0) / 1e6 / dt, 4), "per_gpu": [round((done.value - d0) / 1e6 / dt, 4)], "unit": "MB/s", "steps": ran, "warmup": warmup,
                 "ms_per_step": round(1e3 * dt / max(1, ran), 2), "bytes_timed": int(done.value - d0), "seconds": round(dt, 3)})
     if not fin.value:
         lib.nlzm_hip_blocks_abandon()
@@ -190,7 +213,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-chunks", type=int, default=8)
-    ap.add_argument("--cpu-sample-mb", type=float, default=25.0, help="size of the CPU leg's sample (a prefix of the stream)")
+    ap.add_argument("--cpu-sample-mb", type=float, default=25.0, help="size of the CPU leg's small sample (a prefix of the stream as a file of its own)")
+    ap.add_argument("--cpu-deep-mb", type=float, default=280.0, help="size of the CPU leg's sample at the headline's depth (> 2^28 bytes keeps -window:28)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--block-streams", type=int, default=32,
                     help="also time the independent-block mode with this many streams in flight on each GPU (0: skip)")
@@ -234,6 +258,10 @@ def main():
         # independent streams anyway, and this avoids generating up to 875 MB per rank to skip over)
         host = corpus.syn_text(need, corpus.SEED + rank)
         data_kind = "synthetic"
+    cpu_leg = None
+    if world == 1 and not args.no_cpu:
+        # (needs the bytes on the host: a run of a few steps generates a prefix only, and the CPU leg takes what there is)
+        cpu_leg = CpuBaseline(host, int(args.cpu_deep_mb * 1e6), int(args.cpu_sample_mb * 1e6))
     d_in = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)     # bytes past `need` are never read by the timed steps
     d_in[:need].copy_(torch.from_numpy(host[:need]))
     cap = int(lib.nlzm_hip_compress_bound(n))
@@ -296,16 +324,23 @@ def main():
             raise SystemExit(f"stream_finish failed: {lib.nlzm_hip_last_error().decode()}")
         stream_len = int(dst_len.value)
         stream_sha = hashlib.sha256(d_out[:stream_len].cpu().numpy().tobytes()).hexdigest()
-        golds = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))["cases"]}
-        # (N = 1: the 1e9-byte stand-in; N = 8: rank 1's block is the 125,000,000-byte case of the GPU suite)
-        gold = golds.get("text_1g_w28") if world == 1 else (golds.get("block_125m_w28") if (world, rank) == (8, 1) else None)
+        # N = 1: the 1e9-byte stand-in (tests/golden/full.json); N > 1: every rank's block has the reference's own stream in
+        # tests/golden/gpus.json (oracle/make_golden_gpus.py: one reference run per block, NLZM.cpp:1711 with the auto-shrink of :1716-1718)
+        if world == 1:
+            gold = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))["cases"]}.get("text_1g_w28")
+        else:
+            gp = os.path.join(ROOT, "tests", "golden", "gpus.json")
+            gold = {(r["world"], r["rank"]): r for r in json.load(open(gp))["ranks"]}.get((world, rank)) if os.path.exists(gp) else None
         if data_kind == "synthetic" and gold and gold["size"] == n:
             bit_exact = bool(gold["stream_size"] == stream_len and gold["stream_sha256"] == stream_sha)
     if world > 1:
         flags = [None] * world
         dist.all_gather_object(flags, bit_exact)
         checked = [f for f in flags if f is not None]
+        ranks_checked = len(checked)
         bit_exact = all(checked) if checked else None
+    else:
+        ranks_checked = 1 if bit_exact is not None else 0
 
     # ---- block mode inside each GPU ----------------------------------------------------------------------------------
     blocks = None
@@ -322,6 +357,7 @@ def main():
                 agg = dict(allb[0])
                 if not errs:
                     agg["value"] = round(sum(b["bytes_timed"] for b in allb) / 1e6 / max(b["seconds"] for b in allb), 4)
+                    agg["per_gpu"] = [b["value"] for b in allb]
                     agg["bytes_timed"] = sum(b["bytes_timed"] for b in allb)
                     agg["workload"] = f"every one of the {world} GPUs: " + agg["workload"]
                 else:
@@ -350,7 +386,8 @@ def main():
                               f"[{first_b}, {last_b}) of {n}" + (", i.e. to the end of the stream" if fin.value else " (a prefix: fewer than 25 steps were asked for)"),
                 "window_bits": WINDOW, "batch_chunks": B, "launches_per_step": per_step, "bytes_timed": int(total_in),
                 "whole_stream": bool(fin.value), "bit_exact": bit_exact,
-                "bit_exact_against": ("tests/golden/full.json (the reference's own stream for this input)" if bit_exact is not None
+                "ranks_checked": ranks_checked,
+                "bit_exact_against": (("tests/golden/full.json" if world == 1 else "tests/golden/gpus.json") + " (the reference's own stream for this input" + (", every rank's block)" if world > 1 else ")") if bit_exact is not None
                                       else "nothing: " + ("a prefix has no reference stream; run --steps 20 --warmup 5" if not fin.value else "no reference stream for this input")),
                 "stream_bytes": stream_len, "stream_sha256": stream_sha,
             },
@@ -379,10 +416,7 @@ def main():
                 res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT)
         except Exception:
             pass
-        if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(host[:int(min(n, args.cpu_sample_mb * 1e6))])
-        else:
-            res["cpu_baseline"] = None
+        res["cpu_baseline"] = cpu_leg.collect() if cpu_leg is not None else None
         if blocks is not None:
             res["blocks"] = blocks
             if "error" in blocks:

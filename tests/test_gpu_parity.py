@@ -84,6 +84,25 @@ def test_blocks_at_bench_geometry(gpu):
         assert (len(stream), hashlib.sha256(stream).hexdigest()) == (ref["stream_size"], ref["stream_sha256"]), f"block {i}"
 
 
+def test_config5_eight_blocks_of_125m(gpu):
+    """BASELINE config 5 as it is defined: the 1e9-byte workload as eight independent 125,000,000-byte blocks, each its own
+    NLZM stream at -window:28 (27 after the auto-shrink, NLZM.cpp:1716-1718) -- the blocks `bench.py --gpus 8` feeds its
+    ranks (syn_text(125,000,000, SEED + rank)), here all eight in flight on the one GPU (block mode), every stream against
+    the REFERENCE run on that block alone (tests/golden/gpus.json, oracle/make_golden_gpus.py)."""
+    from nlzm_amd import shard
+    g = {r["rank"]: r for r in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpus.json")))["ranks"] if r["world"] == 8}
+    assert sorted(g) == list(range(8))
+    data = np.concatenate([corpus.syn_text(125_000_000, corpus.SEED + r) for r in range(8)])
+    got = gpu.compress_blocks(data, 8, 28)
+    assert len(got) == 8
+    for r, stream in enumerate(got):
+        lo, hi = shard.block_range(data.size, 8, r)
+        assert hi - lo == g[r]["size"] == 125_000_000
+        assert hashlib.sha256(data[lo:hi].tobytes()).hexdigest() == g[r]["input_sha256"]
+        assert (stream[0] << 8 | stream[1]) == g[r]["hist_bits"] == 27
+        assert (len(stream), hashlib.sha256(stream).hexdigest()) == (g[r]["stream_size"], g[r]["stream_sha256"]), f"rank {r}"
+
+
 def test_batching_is_invisible(gpu):
     """State carried across persistent launches (model, finders, carry table) is exact."""
     data = corpus.syn_text(700_000, corpus.SEED + 21)
