@@ -54,6 +54,7 @@ namespace {
 
 char g_err[2048] = "";
 std::mutex g_err_mu;            // block streams run on host threads
+char *thread_err();             // the error text of the device state this thread works for (a multi-device call: one per device)
 int set_err(int code, const char *fmt, ...)
 {
     std::lock_guard<std::mutex> lk(g_err_mu);
@@ -61,6 +62,7 @@ int set_err(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    if (char *te = thread_err()) memcpy(te, g_err, sizeof g_err);
     return code;
 }
 
@@ -75,6 +77,14 @@ int set_err(int code, const char *fmt, ...)
 void blocks_close();         // defined with the block-set entry points
 
 inline uint32_t clampu(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One allocation for everything a stream keeps on the device (block mode: one for the whole block set).  A context without a
+// pool takes every buffer from hipMalloc by itself.
+struct Pool {
+    uint8_t *base = nullptr;
+    size_t size = 0, used = 0;
+    bool measuring = false;             // only add up what the stream would take
+};
 
 struct Ctx {
     bool inited = false;
@@ -94,7 +104,11 @@ struct Ctx {
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
     int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
     int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
+    int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
+    // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
+    uint32_t run_worker_blocks = 0, run_worker_threads = 0;
+    double acct[8] = {};                    // of the last finished stream, cycles per position: finder total / wait / of it for BT4, table total / wait, parser total / wait / chain
 
 
     // stream state
@@ -141,21 +155,44 @@ struct Ctx {
     nlzm_hip_stats stats{};
     nlzm_hip_timing tm{};
     unsigned long long last_dry_runs = 0, last_flag_waits = 0;
+    Pool *pool = nullptr;                   // (block mode) where the stream's buffers come from
+    bool pooled = false;                    // the open stream's buffers are the pool's: not freed one by one
 };
+
+// a device buffer of the stream: from its pool, or from hipMalloc
+template <class T> int dev_alloc(Ctx &C, T **p, size_t bytes)
+{
+    if (!C.pool) {
+        const hipError_t e = hipMalloc((void **)p, bytes);
+        if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? NLZM_HIP_E_NOMEM : NLZM_HIP_E_NODEVICE, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return 0;
+    }
+    Pool &P = *C.pool;
+    const size_t at = (P.used + 255) & ~(size_t)255;
+    if (!P.measuring && at + bytes > P.size) return set_err(NLZM_HIP_E_NOMEM, "stream pool of %zu bytes is too small", P.size);
+    *p = P.measuring ? nullptr : (T *)(P.base + at);
+    P.used = at + bytes;
+    return 0;
+}
+#define DEVALLOC(ptr, bytes) do { const int rc_ = dev_alloc(C, &(ptr), (bytes)); if (rc_) return rc_; } while (0)
+#define DEVFILL(expr) do { if (!(C.pool && C.pool->measuring)) HIPCHK(expr); } while (0)
 
 struct BlockJob {
     Ctx c;
     uint64_t lo = 0, n = 0, len = 0, bound = 0;
     uint8_t *d_out = nullptr;
     int rc = 0;
+    Pool pool;                                      // this stream's slice of the block set's one allocation
 };
 
 // Everything the entry points keep per device: the single-stream context and the open block set.  The process-wide one serves
 // the one-device API (nlzm_hip_init picks its device); a multi-device call gives each of its per-device host threads one
 // of its own and points `t_dev` at it, so that the same code runs on every device at once.
 struct DevState {
+    char err[sizeof g_err] = "";                    // the last error raised by a thread that works for this state
     Ctx ctx;                                        // the context behind the single-stream entry points
     std::vector<BlockJob> jobs;                     // the open block set (nlzm_hip_blocks_begin .. _finish)
+    uint8_t *blocks_pool = nullptr;                 // ... and the one allocation all its streams' buffers lie in
     std::vector<hipStream_t> group_st;              // one HIP stream and an event pair per shared launch of a round
     std::vector<std::array<hipEvent_t, 2>> group_ev;
     void *pack_host = nullptr, *pack_dev = nullptr; // the streams' launch arguments of a round: pinned host copy, device copy
@@ -179,6 +216,7 @@ constexpr uint64_t kFeedPiece = 32ull << 20;        // bytes per staging buffer
 DevState g_dev0;
 thread_local DevState *t_dev = nullptr;
 inline DevState &cur() { return t_dev ? *t_dev : g_dev0; }
+char *thread_err() { return t_dev ? t_dev->err : nullptr; }
 #define g_ctx (cur().ctx)
 #define g_jobs (cur().jobs)
 #define g_group_st (cur().group_st)
@@ -196,7 +234,8 @@ void free_stream_buffers(Ctx &C)
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
                      C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo, C.hot_of_bin, C.hot_list, C.hot_undo,
                      C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (!C.pooled) for (void *p : ptrs) if (p) (void)hipFree(p);
+    C.pooled = false;
     C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
     C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = C.hot_of_bin = C.hot_list = nullptr; C.hot_undo = nullptr; C.wcnt = nullptr;
@@ -245,11 +284,11 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     C.stats.in_bytes = n;
 
     const size_t ht3_rows = (size_t)2 << (32 - g.ht3_shift);
-    HIPCHK(hipMalloc(&C.rkhash, (n + 1024) * 4 + 16));
-    HIPCHK(hipMalloc(&C.ht2, 4096 * 4));
-    HIPCHK(hipMalloc(&C.ht3, ht3_rows * 4));
-    HIPCHK(hipMalloc(&C.rk_table, (size_t)4 << (32 - g.rk_shift)));
-    HIPCHK(hipMalloc(&C.bt_heads, (size_t)4 << (32 - g.bt_shift)));
+    DEVALLOC(C.rkhash, (n + 1024) * 4 + 16);
+    DEVALLOC(C.ht2, 4096 * 4);
+    DEVALLOC(C.ht3, ht3_rows * 4);
+    DEVALLOC(C.rk_table, (size_t)4 << (32 - g.rk_shift));
+    DEVALLOC(C.bt_heads, (size_t)4 << (32 - g.bt_shift));
     {
         // node slots >= W + positions per launch (see Geom::bt_tmask)
         uint32_t b = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
@@ -259,13 +298,13 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         while (slots < need) slots <<= 1;
         C.g.bt_tmask = (uint32_t)(slots - 1);
     }
-    HIPCHK(hipMalloc(&C.bt_tree, ((size_t)C.g.bt_tmask + 1) * 8));
-    HIPCHK(hipMalloc(&C.persist, sizeof(Persist)));
-    HIPCHK(hipMemsetAsync(C.ht2, 0xFF, 4096 * 4, C.st));                         // :902
-    HIPCHK(hipMemsetAsync(C.ht3, 0xFF, ht3_rows * 4, C.st));
-    HIPCHK(hipMemsetAsync(C.rk_table, 0xFF, (size_t)4 << (32 - g.rk_shift), C.st));   // :1040
-    HIPCHK(hipMemsetAsync(C.bt_heads, 0xFF, (size_t)4 << (32 - g.bt_shift), C.st));   // :968
-    HIPCHK(hipMemsetAsync(C.bt_tree, 0xFF, ((size_t)C.g.bt_tmask + 1) * 8, C.st));     // :969
+    DEVALLOC(C.bt_tree, ((size_t)C.g.bt_tmask + 1) * 8);
+    DEVALLOC(C.persist, sizeof(Persist));
+    DEVFILL(hipMemsetAsync(C.ht2, 0xFF, 4096 * 4, C.st));                         // :902
+    DEVFILL(hipMemsetAsync(C.ht3, 0xFF, ht3_rows * 4, C.st));
+    DEVFILL(hipMemsetAsync(C.rk_table, 0xFF, (size_t)4 << (32 - g.rk_shift), C.st));   // :1040
+    DEVFILL(hipMemsetAsync(C.bt_heads, 0xFF, (size_t)4 << (32 - g.bt_shift), C.st));   // :968
+    DEVFILL(hipMemsetAsync(C.bt_tree, 0xFF, ((size_t)C.g.bt_tmask + 1) * 8, C.st));     // :969
 
     Persist P;
     memset(&P, 0, sizeof P);
@@ -274,7 +313,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         for (uint32_t i = 0; i <= ns; i++) P.cdf[ctx * kCdfStride + i] = (uint16_t)(i * (16384 / ns));
     }
     for (int i = 0; i < 4; i++) P.rep[i] = (uint32_t)i + 1;                       // :1154-1158
-    HIPCHK(hipMemcpyAsync(C.persist, &P, sizeof P, hipMemcpyHostToDevice, C.st));
+    DEVFILL(hipMemcpyAsync(C.persist, &P, sizeof P, hipMemcpyHostToDevice, C.st));
 
     C.batch = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
     if (C.batch > g.nchunks && g.nchunks) C.batch = g.nchunks;
@@ -289,12 +328,12 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     C.syms_stride = 3ull * g.chunk_size + 4096;          // <= 3 symbols per input byte
     C.bits_stride = 2ull * g.chunk_size + 64;            // <= 13 raw bits per input byte
     C.frame_stride = 12 + C.bits_stride + 16 + 2 * C.syms_stride;
-    HIPCHK(hipMalloc(&C.syms, C.batch * C.syms_stride * 4));
-    HIPCHK(hipMalloc(&C.scratch, C.batch * C.syms_stride * 4));
-    HIPCHK(hipMalloc(&C.bits, C.batch * C.bits_stride));
-    HIPCHK(hipMalloc(&C.frames, C.batch * C.frame_stride));
-    HIPCHK(hipMalloc(&C.fmeta, C.batch * sizeof(FrameMeta)));
-    HIPCHK(hipMalloc(&C.dst_off, C.batch * sizeof(unsigned long long)));
+    DEVALLOC(C.syms, C.batch * C.syms_stride * 4);
+    DEVALLOC(C.scratch, C.batch * C.syms_stride * 4);
+    DEVALLOC(C.bits, C.batch * C.bits_stride);
+    DEVALLOC(C.frames, C.batch * C.frame_stride);
+    DEVALLOC(C.fmeta, C.batch * sizeof(FrameMeta));
+    DEVALLOC(C.dst_off, C.batch * sizeof(unsigned long long));
 
     // worker mode: pre-filter tables, per-launch hand-off arrays, bins
     C.workers = true;
@@ -312,67 +351,60 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         const unsigned long long lanes = (unsigned long long)(C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks) * (unsigned long long)C.opt_worker_threads;
         if (lanes < C.nheads) C.nheads = (uint32_t)lanes;
     }
+    C.run_worker_blocks = (uint32_t)(C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks);
+    C.run_worker_threads = (uint32_t)C.opt_worker_threads;
     if (C.workers) {
         const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
         uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
         C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
         if ((int64_t)C.t_bits > C.opt_tbits_max) C.t_bits = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);   // (smaller: only more `unc` marks)
         C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
-        HIPCHK(hipMalloc(&C.pf_T, (size_t)4 << C.t_bits));
-        HIPCHK(hipMalloc(&C.pf_M, (size_t)4 << C.m_bits));
-        HIPCHK(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
-        HIPCHK(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
-        HIPCHK(hipMalloc(&C.pf_h, bpos * 4));
-        HIPCHK(hipMalloc(&C.pf_c1, bpos));
-        HIPCHK(hipMalloc(&C.unc, bpos + 16));
-        {   // hand-off arrays between workgroups on different XCDs (each XCD has its own L2)
-            const char *hm = getenv("NLZM_HANDOFF_MEM");
-            const unsigned fl = hm && !strcmp(hm, "uncached") ? hipDeviceMallocUncached : (hm && !strcmp(hm, "fine") ? hipDeviceMallocFinegrained : 0u);
-            if (fl) {
-                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_ready, bpos * 4 * kBtRec, fl));
-                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4), fl));
-                HIPCHK(hipExtMallocWithFlags((void **)&C.bt_flag, bpos * 4, fl));
-            } else {
-                HIPCHK(hipMalloc(&C.bt_ready, bpos * 4 * kBtRec));
-                HIPCHK(hipMalloc(&C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4)));      // worst case, 2 KiB per position
-                HIPCHK(hipMalloc(&C.bt_flag, bpos * 4));
-            }
-        }
-        HIPCHK(hipMalloc(&C.abort_word, 4));
-        HIPCHK(hipMalloc(&C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4));
-        HIPCHK(hipMalloc(&C.bin_cur, (size_t)C.batch * C.nheads * 4));
-        HIPCHK(hipMalloc(&C.bin_pos, bpos * 8));
-        HIPCHK(hipMalloc(&C.wcnt, sizeof(WorkerCounters)));
-        HIPCHK(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
-        HIPCHK(hipMalloc(&C.bt_undo, (size_t)C.nheads * worker_undo_bytes_per_lane()));     // (6 KB per lane)
+        DEVALLOC(C.pf_T, (size_t)4 << C.t_bits);
+        DEVALLOC(C.pf_M, (size_t)4 << C.m_bits);
+        DEVFILL(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
+        DEVFILL(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
+        DEVALLOC(C.pf_h, bpos * 4);
+        DEVALLOC(C.pf_c1, bpos);
+        DEVALLOC(C.unc, bpos + 16);
+        // hand-off arrays between workgroups (written with sc1 stores, read with sc1 loads: plain device memory)
+        DEVALLOC(C.bt_ready, bpos * 4 * kBtRec);
+        DEVALLOC(C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4));      // worst case, 2 KiB per position
+        DEVALLOC(C.bt_flag, bpos * 4);
+        DEVALLOC(C.abort_word, 4);
+        DEVALLOC(C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4);
+        DEVALLOC(C.bin_cur, (size_t)C.batch * C.nheads * 4);
+        DEVALLOC(C.bin_pos, bpos * 8);
+        DEVALLOC(C.wcnt, sizeof(WorkerCounters));
+        DEVFILL(hipMemsetAsync(C.wcnt, 0, sizeof(WorkerCounters), C.st));
+        DEVALLOC(C.bt_undo, (size_t)C.nheads * worker_undo_bytes_per_lane());     // (6 KB per lane)
         {   // hot bins: the waves of a worker block behind its bin-taking lanes (none in block mode, where every lane takes bins)
             int64_t hw = C.opt_hot_waves;
-            if (const char *e = getenv("NLZM_HOT_WAVES")) hw = atoll(e);            // (experiments)
-            if (const char *e = getenv("NLZM_HOT_MIN")) C.opt_hot_min = atoll(e);
             const int64_t spare = (512 - C.opt_worker_threads) / 64;
             if (hw > spare) hw = spare;
-            C.hot_max = hw > 0 ? (uint32_t)(hw * C.opt_worker_blocks) : 0u;
+            C.hot_max = hw > 0 ? (uint32_t)(hw * (C.opt_worker_blocks < 1 ? 1 : C.opt_worker_blocks)) : 0u;
             if (C.hot_max) {
-                HIPCHK(hipMalloc(&C.hot_of_bin, (size_t)C.nheads * 4));
-                HIPCHK(hipMalloc(&C.hot_list, ((size_t)C.hot_max + 1) * 4));
-                HIPCHK(hipMalloc(&C.hot_undo, (size_t)C.hot_max * worker_hot_undo_bytes_per_wave()));
+                DEVALLOC(C.hot_of_bin, (size_t)C.nheads * 4);
+                DEVALLOC(C.hot_list, ((size_t)C.hot_max + 1) * 4);
+                DEVALLOC(C.hot_undo, (size_t)C.hot_max * worker_hot_undo_bytes_per_wave());
             }
         }
     }
 
     // hand-off between the finder, table and parser stages
-    HIPCHK(hipMalloc(&C.v2_ft, (size_t)v2::kFtRing * v2::kFtStride * 4));
-    HIPCHK(hipMalloc(&C.v2_tp, (size_t)v2::kTpRing * v2::kTpStride * 4));
-    HIPCHK(hipMalloc(&C.v2_tf, (size_t)v2::kTpRing * v2::kTfStride * 4));
-    HIPCHK(hipMalloc(&C.v2_state, sizeof(v2::StateV2)));
-    HIPCHK(hipMalloc(&C.v2_hx, sizeof(v2::Hx)));
-    HIPCHK(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
+    DEVALLOC(C.v2_ft, (size_t)v2::kFtRing * v2::kFtStride * 4);
+    DEVALLOC(C.v2_tp, (size_t)v2::kTpRing * v2::kTpStride * 4);
+    DEVALLOC(C.v2_tf, (size_t)v2::kTpRing * v2::kTfStride * 4);
+    DEVALLOC(C.v2_state, sizeof(v2::StateV2));
+    DEVALLOC(C.v2_hx, sizeof(v2::Hx));
+    DEVFILL(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
 
     // stream header (:1762-1766)
     const uint8_t hdr[4] = { (uint8_t)(g.wbits >> 8), (uint8_t)g.wbits, (uint8_t)(g.frame_bits >> 8), (uint8_t)g.frame_bits };
-    HIPCHK(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
+    DEVFILL(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
     C.out_pos = 4;
 
+    C.pooled = C.pool != nullptr;
+    if (C.pool && C.pool->measuring) { C.pooled = false; return 0; }
     HIPCHK(hipStreamSynchronize(C.st));
     C.open = true;
     return 0;
@@ -412,7 +444,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
     if (C.workers) {
         const unsigned long long cnt = a1 - a0;
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
-        G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads; G.wthreads = (uint32_t)C.opt_worker_threads;
+        G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads; G.wthreads = C.run_worker_threads;
         G.abort_word = C.abort_word; G.wcnt = C.wcnt; G.bt_undo = C.bt_undo;
         HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4 * kBtRec, C.st));
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
@@ -528,7 +560,7 @@ int stream_step(Ctx &C, uint32_t max_chunks, uint64_t *in_done, uint64_t *out_do
         int rc = step_pre(C, todo, P);
         if (rc) return rc;
         HIPCHK(hipEventRecord(C.ev[0], C.st));
-        launch_pipeline2(g, P.G, P.V, P.c0, P.c1, (uint32_t)C.opt_worker_blocks, C.st);
+        launch_pipeline2(g, P.G, P.V, P.c0, P.c1, C.run_worker_blocks, C.st);
         rc = step_post(C, P, -1.0f);
         if (rc) return rc;
         todo -= P.nb;
@@ -553,7 +585,12 @@ int refresh_stats(Ctx &C)
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
-    if (getenv("NLZM_WAIT_PRINT")) {
+    {
+        const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
+        C.acct[0] = P.prof[17] / n; C.acct[1] = P.prof[16] / n; C.acct[2] = P.prof[25] / n; C.acct[3] = P.prof[19] / n; C.acct[4] = P.prof[18] / n;
+        C.acct[5] = P.prof[21] / n; C.acct[6] = P.prof[20] / n; C.acct[7] = P.prof[24] / n;
+    }
+    if (C.opt_report) {
         // per-stage accounting of the three-stage pipeline (Persist::prof, filled by nlzm_v2.h)
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
         fprintf(stderr, "cycles/position  finder: total %.0f wait %.0f (%.0f of it for worker results) | table: total %.0f wait %.0f | parser: total %.0f wait %.0f (block set-up %.0f, passes %.0f, emit %.0f)\n",
@@ -594,12 +631,12 @@ int refresh_stats(Ctx &C)
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
-        if (getenv("NLZM_WAIT_PRINT"))
+        if (C.opt_report)
             fprintf(stderr, "worker lanes: %llu calls made with their fate open (at and behind a position not decided yet), %llu decisions that took calls back, %llu calls made again for it\n",
                     wc.dry_runs, wc.spec_calls, wc.spec_good);
-        if (getenv("NLZM_WAIT_PRINT") && C.hot_max)
+        if (C.opt_report && C.hot_max)
             fprintf(stderr, "hot bins (a wave each): %llu over all launches, %llu of %llu calls made by their waves\n", wc.hot_bins, wc.hot_calls, wc.bt_calls);
-        if (getenv("NLZM_WAIT_PRINT") && wc.call_tests)
+        if (C.opt_report && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));
     }
@@ -777,6 +814,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "hot_waves out of range"); C.opt_hot_waves = value; return 0; }
     if (!strcmp(key, "hot_min")) { if (value < 1 || value > (1 << 30)) return set_err(NLZM_HIP_E_ARG, "hot_min out of range"); C.opt_hot_min = value; return 0; }
     if (!strcmp(key, "worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "worker_threads out of range"); C.opt_worker_threads = value; return 0; }
+    if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
 }
@@ -896,6 +934,7 @@ namespace {
 int block_ctx_init(Ctx &c, int device, int64_t worker_blocks, int64_t batch)
 {
     c.device = device;
+    c.opt_report = 0;
     c.opt_workers = 1; c.opt_worker_blocks = worker_blocks; c.opt_batch = batch; c.opt_worker_threads = 512;        // (block mode: a stream has few worker CUs, every lane of them takes bins)
     HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
@@ -915,8 +954,9 @@ void block_ctx_destroy(Ctx &c)
 namespace {
 void blocks_close()
 {
-    for (auto &j : g_jobs) { if (j.d_out) (void)hipFree(j.d_out); j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
+    for (auto &j : g_jobs) { j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
     g_jobs.clear();
+    if (cur().blocks_pool) { (void)hipFree(cur().blocks_pool); cur().blocks_pool = nullptr; }
     for (auto &st : g_group_st) (void)hipStreamDestroy(st);
     for (auto &ev : g_group_ev) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
     g_group_st.clear(); g_group_ev.clear();
@@ -997,11 +1037,40 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         g_jobs[i].bound = nlzm_hip_compress_bound(g_jobs[i].n);
     }
     const int device = C.device;
+    {   // ONE allocation for the whole block set: what a stream takes is added up first (the same code path, nothing touched on
+        // the device), then every stream gets its slice -- some thirty-five hipMalloc calls per stream otherwise
+        std::vector<size_t> need(nblocks);
+        for (uint32_t i = 0; i < nblocks; i++) {
+            Ctx m;                                  // (a scratch context: options as the streams will have them)
+            m.inited = true; m.device = device; m.st = C.st;
+            m.opt_workers = 1; m.opt_worker_blocks = wb; m.opt_batch = batch; m.opt_worker_threads = 512; m.opt_tbits_max = tbits_max; m.cu_count = C.cu_count;
+            m.opt_hot_waves = C.opt_hot_waves; m.opt_hot_min = C.opt_hot_min;
+            Pool mp; mp.measuring = true;
+            m.pool = &mp;
+            uint8_t *fake_out = nullptr;
+            const int rc = stream_begin(m, g_blocks_src + g_jobs[i].lo, g_jobs[i].n, hist_bits_req, (void *)(uintptr_t)16, g_jobs[i].bound);
+            (void)fake_out;
+            m.st = nullptr;
+            if (rc) { blocks_close(); return rc; }
+            need[i] = ((mp.used + 255) & ~(size_t)255) + ((g_jobs[i].bound + 255) & ~(size_t)255) + 4096;
+        }
+        size_t total = 0;
+        for (size_t v : need) total += v;
+        if (hipMalloc(&cur().blocks_pool, total) != hipSuccess) { blocks_close(); return set_err(NLZM_HIP_E_NOMEM, "block set: %zu bytes for %u streams", total, nblocks); }
+        size_t at = 0;
+        for (uint32_t i = 0; i < nblocks; i++) {
+            g_jobs[i].pool.base = cur().blocks_pool + at; g_jobs[i].pool.size = need[i]; g_jobs[i].pool.used = 0; g_jobs[i].pool.measuring = false;
+            at += need[i];
+        }
+    }
     for_blocks(nblocks, [&](uint32_t i, BlockJob &j) {
         j.rc = block_ctx_init(j.c, device, wb, batch);
         j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
-        if (!j.rc && hipMalloc(&j.d_out, j.bound) != hipSuccess) j.rc = set_err(NLZM_HIP_E_NOMEM, "block %u: output buffer", i);
+        j.c.opt_hot_waves = C.opt_hot_waves; j.c.opt_hot_min = C.opt_hot_min;
+        j.c.pool = &j.pool;
+        if (!j.rc) j.rc = dev_alloc(j.c, &j.d_out, j.bound);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
+        (void)i;
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
     const int rc = [&]() -> int {
@@ -1120,6 +1189,19 @@ int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, u
     if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
     if (!d_dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
     for_blocks((uint32_t)g_jobs.size(), [&](uint32_t, BlockJob &j) { j.rc = stream_finish(j.c, &j.len); });
+    if (C.opt_report) {
+        // which stage limits a stream under load: smallest / median / largest over the streams, cycles per position
+        static const char *const what[8] = { "finder total", "finder waiting", "  of it for BT4 results", "table updater total", "table updater waiting",
+                                             "parser total", "parser waiting (records)", "parser chain" };
+        fprintf(stderr, "block set of %zu streams, %lld worker CUs each -- per stream, cycles per position (min / median / max over the streams):\n", g_jobs.size(), (long long)g_blocks_wb);
+        for (int k = 0; k < 8; k++) {
+            std::vector<double> v;
+            for (auto &j : g_jobs) if (!j.rc) v.push_back(j.c.acct[k]);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "  %-26s %8.0f %8.0f %8.0f\n", what[k], v.front(), v[v.size() / 2], v.back());
+        }
+    }
     int rc = 0;
     uint64_t pos = 0;
     memset(&C.stats, 0, sizeof C.stats);
@@ -1154,7 +1236,7 @@ int nlzm_hip_compress_blocks_dev(const void *d_src, uint64_t n, uint32_t nblocks
     if (rc) return rc;              // (the failed step has closed the set)
     const auto t2 = std::chrono::steady_clock::now();
     rc = nlzm_hip_blocks_finish(d_dst, dst_cap, block_len, dst_len);
-    if (getenv("NLZM_WAIT_PRINT")) {
+    if (g_ctx.opt_report) {
         const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "block set of %u: begin (tables, pre-filter) %.0f ms, steps %.0f ms (device %.0f ms), finish (gather) %.0f ms\n", nblocks,
                 ms(t0, t1), ms(t1, t2), dev_ms, ms(t2, std::chrono::steady_clock::now()));
@@ -1317,8 +1399,12 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
         uint8_t *d_in = nullptr, *d_out = nullptr;
         std::vector<uint64_t> blens;
         char msg[sizeof g_err] = "";
+        bool pinned = false, direct = false;
+        double h2d_ms = 0, run_ms = 0, gather_ms = 0;
     };
     std::vector<Part> parts(ndev);
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);                // (the caller's current device is put back on the way out)
     auto run_part = [&](uint32_t i) {
         Part &P = parts[i];
         t_dev = &P.D;
@@ -1331,14 +1417,31 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
         P.rc = [&]() -> int {
             int rc = dev_init(P.D, P.device);
             if (rc) return rc;
+            {   // the options set through nlzm_hip_set_option hold for every device of the call
+                const Ctx &o = g_dev0.ctx; Ctx &c = P.D.ctx;
+                c.opt_batch = o.opt_batch; c.opt_worker_blocks = o.opt_worker_blocks; c.opt_worker_threads = o.opt_worker_threads;
+                c.opt_hot_waves = o.opt_hot_waves; c.opt_hot_min = o.opt_hot_min; c.opt_report = o.opt_report;
+            }
             HIPCHK(hipMalloc(&P.d_in, P.n + 512));
             HIPCHK(hipMalloc(&P.d_out, P.bound));
             HIPCHK(hipMemset(P.d_in + P.n, 0, 512));
-            if (P.n) HIPCHK(hipMemcpy(P.d_in, src + P.lo, P.n, hipMemcpyHostToDevice));
+            const auto t0 = std::chrono::steady_clock::now();
+            if (P.n) {
+                // (the caller's pages pinned for the upload when the driver allows it: a pageable copy goes through a bounce buffer)
+                P.pinned = hipHostRegister((void *)(src + P.lo), P.n, hipHostRegisterDefault) == hipSuccess;
+                if (!P.pinned) (void)hipGetLastError();
+                const hipError_t e = hipMemcpy(P.d_in, src + P.lo, P.n, hipMemcpyHostToDevice);
+                if (P.pinned) (void)hipHostUnregister((void *)(src + P.lo));
+                HIPCHK(e);
+            }
+            const auto t1 = std::chrono::steady_clock::now();
             P.D.blocks_per = per;
-            return nlzm_hip_compress_blocks_dev(P.d_in, P.n, blocks_per_dev, hist_bits_req, P.d_out, P.bound, P.blens.data(), &P.len);
+            rc = nlzm_hip_compress_blocks_dev(P.d_in, P.n, blocks_per_dev, hist_bits_req, P.d_out, P.bound, P.blens.data(), &P.len);
+            P.h2d_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            P.run_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            return rc;
         }();
-        if (P.rc) { std::lock_guard<std::mutex> lk(g_err_mu); snprintf(P.msg, sizeof P.msg, "device %d: %.*s", P.device, (int)sizeof P.msg - 32, g_err); }
+        if (P.rc) snprintf(P.msg, sizeof P.msg, "device %d: %.*s", P.device, (int)sizeof P.msg - 32, P.D.err);      // (this thread's own text)
         t_dev = nullptr;
     };
     {
@@ -1360,10 +1463,22 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
             HIPCHK(hipMalloc(&d_all, total ? total : 1));
             uint64_t off = 0;
             for (auto &P : parts) {
+                // GPU to GPU: directly over the link where the root may address the device's memory (xGMI inside a node),
+                // else staged by the runtime; which it was is reported
+                if (P.device != root) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, root, P.device) == hipSuccess && can) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(P.device, 0);
+                        P.direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                        (void)hipGetLastError();
+                    }
+                } else P.direct = true;
+                const auto g0 = std::chrono::steady_clock::now();
                 if (P.len) HIPCHK(hipMemcpyPeerAsync(d_all + off, root, P.d_out, P.device, P.len, nullptr));
+                HIPCHK(hipDeviceSynchronize());
+                P.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
                 off += P.len;
             }
-            HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipMemcpy(dst, d_all, total, hipMemcpyDeviceToHost));
             return 0;
         }();
@@ -1383,7 +1498,12 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
         if (P.d_out) (void)hipFree(P.d_out);
         dev_shutdown(P.D);
     }
-    if (g_dev0.ctx.inited) (void)hipSetDevice(g_dev0.ctx.device);
+    if (g_dev0.ctx.opt_report)
+        for (auto &P : parts)
+            fprintf(stderr, "device %d: %llu bytes in %u blocks -- upload %.1f ms (%s), compress %.1f ms, gather %.1f ms (%s), %llu bytes out\n", P.device,
+                    (unsigned long long)P.n, blocks_per_dev, P.h2d_ms, P.pinned ? "pinned" : "pageable", P.run_ms, P.gather_ms,
+                    P.device == parts[0].device ? "local" : (P.direct ? "peer access" : "staged by the runtime"), (unsigned long long)P.len);
+    if (dev_before >= 0) (void)hipSetDevice(dev_before);
     return rc;
 }
 

@@ -466,9 +466,10 @@ struct Finder {
 
         const unsigned long long f5 = ptick();
         // ---- BT4: the worker lanes' result (longest record-setter in the record's words 9, 10).
-        // A worker lane walks its bin in position order and, at an `unc` position, waits for this stage's decision before
-        // it goes on: the result of a later position of the same bin cannot arrive before this block is committed.
-        // Such a position becomes lane 0 of the next block.
+        // A worker lane walks its bin in position order.  At an `unc` position it does not wait for this stage's decision: it
+        // assumes it and goes on, but the RESULTS of the calls behind such a position are held back until the decision is
+        // stored (a decision the other way takes those calls back).  So the result of a later position of the same bin cannot
+        // arrive before this block is committed: such a position becomes lane 0 of the next block.
         uint32_t cut_bin = 64;
         if (G.workers) {
             const uint32_t bin = (hash4(v4) >> g.bt_shift) % G.nheads;
@@ -712,36 +713,32 @@ struct Finder {
 // -- a match is a POINT in G (one LDS atomic min, whatever its length), moving to the next position costs nothing (G is
 // indexed by the absolute end), and the table of a position is a suffix minimum over the window e in (p, p + 264].
 // (The one entry whose end moves with p, the top entry while it keeps extending :1503-1512, arrives from the finder
-// stage as a fresh pair per position.)  The stage is a pipeline of its own, one workgroup:
+// stage as a fresh pair per position.)  One workgroup, nothing serial in it:
 //
 //   loader   (wave 0)     the finder's records and the worker lanes' BT4 records of the positions to come, staged in LDS
-//                         (sixteen positions a step, the next step's loads in flight while this step's are written)
-//   updater  (wave 1)     position by position, the only serial part: lanes = the position's pairs (six of the finder's, its
-//                         top entry, four of the BT4 record; more than four record-setters, rare, from HBM): one atomic min into G,
-//                         the largest end so far (mt.max_len = that - p), then G's window copied into the position's row
-//                         -- the table as of THIS position, while the wave goes on to the next
-//   emitters (waves 2..7) a position each, in turn: suffix minimum of the row by DPP scans (lanes = lengths, 64 a chunk), the
-//                         dense table to the ring the parser re-lists from near a forced cut (:1545) and the stage test reads,
-//                         then the sampled lengths of :1558-1562 with the lanes as SAMPLES: distance, length value, distance
-//                         slot, extra bits, the mask of samples that bring a new distance; 16-byte stores.
+//                         (32 positions a step, three steps in flight)
+//   emitters (waves 1..7) every one keeps a G of its OWN and applies the pairs of EVERY position to it -- lanes = the position's
+//                         pairs (six of the finder's, its top entry, twelve record-setters of the BT4 descent; more of them,
+//                         rare, from HBM): one atomic min instruction a position -- and emits every seventh position: suffix
+//                         minimum of G's window by DPP scans (lanes = lengths, 64 a chunk), the dense table to the ring the parser
+//                         re-lists from near a forced cut (:1545) and the stage test reads, then the sampled lengths of
+//                         :1558-1562 with the lanes as SAMPLES: distance, length value, distance slot, extra bits, the mask of
+//                         samples that bring a new distance; 16-byte stores, waited for once every few positions.
 constexpr uint32_t kTW = 8;                     // waves of the stage
-constexpr uint32_t kTEmit = kTW - 2;            // emitters
-constexpr uint32_t kTRecRing = 64;              // positions whose records are staged
-constexpr uint32_t kTRowRing = 32;              // positions whose rows are in flight between the updater and the emitters
-constexpr uint32_t kTRowStride = 5 * 64;        // entries of a row: lengths 1 .. 264, in chunks of 64
+constexpr uint32_t kTEmit = kTW - 1;            // emitters
+constexpr uint32_t kTRecRing = 256;             // positions whose records are staged
 constexpr uint32_t kGRing = 512;
-constexpr uint32_t kTLoad = 16;                 // positions the loader requests a step
+constexpr uint32_t kTLoad = 32;                 // positions the loader requests a step
+constexpr uint32_t kTDrainEvery = 4;            // positions an emitter writes between two waits for its stores
+constexpr uint32_t kTInline = 12;               // record-setters of a BT4 descent staged in LDS (four in the record, eight from the pair list)
+constexpr uint32_t kTRecWords = kFtStride + kBtRec + 16;    // a position's staged words: the finder's record, the BT4 record, record-setters 4 .. 11
 
 struct TLds {
-    uint32_t G[kGRing];                         // end e at [e & 511]
-    uint32_t row[kTRowRing * kTRowStride];      // position p, length l at [(p & 31) * 320 + l - 1]: G[p + l] as of position p
-    uint32_t frec[kTRecRing * kFtStride];       // finder records, position p at [(p & 63) * 16]
-    uint32_t brec[kTRecRing * kBtRec];          // BT4 records
-    uint32_t pinfo[kTRowRing], pa1[kTRowRing];  // mt.max_len | byte << 16; the chunk's last position + 1
+    uint32_t G[kTEmit][kGRing];                 // emitter k's G: end e at [k][e & 511]
+    uint32_t rec[kTRecRing * kTRecWords];       // position p at [(p & 255) * 48]
     uint32_t staged;                            // loader: records of positions below this are in LDS
-    uint32_t u_pos;                             // updater: rows of positions below this are written
-    uint32_t e_done[kTEmit];                    // emitter k: the next position it will write (its positions below are out)
-    uint32_t u_taken;                           // updater: records of positions below this are consumed
+    uint32_t e_done[kTEmit];                    // emitter k: its records of the positions below this are in memory
+    uint32_t e_taken[kTEmit];                   // emitter k: the staged records of the positions below this are applied
     uint32_t stop;                              // nonzero: leave
 };
 
@@ -753,7 +750,7 @@ struct Table {
     GlobalsV2 V;
     uint32_t err;
     unsigned long long n_pos = 0, n_slow = 0, t_wait = 0;
-    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: updater work / wait, emitter work / wait
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build, emitters: applying pairs, emitting, waiting for records, for the stores
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
 #else
@@ -779,59 +776,92 @@ struct Table {
     }
 
     // ---- loader -----------------------------------------------------------------------------------------------------
+    // Three steps in flight, 32 positions each (lane = position x 16-byte quad, two positions a lane): the records requested;
+    // a step later written to LDS, and for the positions whose BT4 descent had more than four record-setters the next eight of
+    // them requested (bt_pairs: in memory before the record's ready word, nlzm_core.h); a step later those written, and the
+    // positions said to be staged.
     XW_FN void run_loader(uint32_t a_first, uint32_t a_last)
     {
         TLds *Lp = L();
-        const uint32_t i = xw::lane(), pj = i >> 2, qd = i & 3u;   // lane = position of the step x 16-byte quad of its record
-        uint32_t req = a_first, wr = a_first;                       // requested / written up to
+        const uint32_t i = xw::lane(), pj = i >> 2, qd = i & 3u;
+        uint32_t req = a_first;
         uint32_t f_seen = a_first, taken = a_first;
-        uint32_t pend_n = 0, pend_a = 0;
-        uint32_t fq0 = 0, fq1 = 0, fq2 = 0, fq3 = 0, bq0 = 0, bq1 = 0, bq2 = 0, bq3 = 0;
+        uint32_t r_n = 0, r_a = 0, x_n = 0, x_a = 0;                // the step whose records / extra pairs are on their way
+        uint32_t fq[2][4] = {}, bq[2][4] = {}, xq[2][4] = {};
         const unsigned long long t0 = xw::clock100();
         uint32_t idle = 0;
-        while (wr < a_last) {
-            // ---- what the last step requested: into LDS (the BT4 record's later quads carry a tag: looked at again if one is not there yet)
-            if (pend_n) {
-                const uint32_t a = pend_a + pj;
-                const bool on = pj < pend_n;
-                // (quad 0 of the finder's record says whether a BT4 record belongs to the position)
-                const uint32_t w0 = xw::shfl(fq0, i & ~3u);
-                if (on) {
-                    if (w0 & kFtBt) {
+        uint32_t staged = a_first;
+        while (staged < a_last) {
+            // ---- extra pairs of the step before the last: into LDS; its positions are staged
+            if (x_n) {
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    const uint32_t a = x_a + pj + 16 * h;
+                    if (pj + 16 * h < x_n) {
+                        uint32_t *xd = Lp->rec + (a & (kTRecRing - 1)) * kTRecWords + kFtStride + kBtRec + 4 * qd;
+                        xd[0] = xq[h][0]; xd[1] = xq[h][1]; xd[2] = xq[h][2]; xd[3] = xq[h][3];
+                    }
+                }
+                staged = x_a + x_n;
+                xw::wave_sync();
+                if (i == 0) xw::lds_st(&Lp->staged, staged);
+                x_n = 0;
+            }
+            // ---- records of the last step: into LDS (the BT4 record's quads carry a ready bit / a tag: looked at again if one is
+            // not there yet); the extra pairs requested
+            if (r_n) {
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    const uint32_t a = r_a + pj + 16 * h;
+                    const bool on = pj + 16 * h < r_n;
+                    // (quad 0 of the finder's record says whether a BT4 record belongs to the position; quad 0 of that one how many pairs)
+                    const uint32_t w0 = xw::shfl(fq[h][0], i & ~3u);
+                    if (on && (w0 & kFtBt)) {
                         const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
                         uint32_t spins = 0;
-                        while (!((qd ? bq3 : bq0) & (qd ? kBtTag : kBtReady))) {
-                            bq0 = xw::ld_agent(br); bq1 = xw::ld_agent(br + 1); bq2 = xw::ld_agent(br + 2); bq3 = xw::ld_agent(br + 3);
+                        while (!((qd ? bq[h][3] : bq[h][0]) & (qd ? kBtTag : kBtReady))) {
+                            bq[h][0] = xw::ld_agent(br); bq[h][1] = xw::ld_agent(br + 1); bq[h][2] = xw::ld_agent(br + 2); bq[h][3] = xw::ld_agent(br + 3);
                             if ((++spins & 255u) == 0 && xw::ld_agent(&V.hx->err)) break;
                         }
                     }
-                    uint32_t *fd = Lp->frec + (a & (kTRecRing - 1)) * kFtStride + 4 * qd;
-                    fd[0] = fq0; fd[1] = fq1; fd[2] = fq2; fd[3] = fq3;
-                    uint32_t *bd = Lp->brec + (a & (kTRecRing - 1)) * kBtRec + 4 * qd;
-                    bd[0] = bq0; bd[1] = bq1; bd[2] = bq2; bd[3] = bq3;
+                    const uint32_t bw0 = xw::shfl(bq[h][0], i & ~3u);
+                    if (on) {
+                        uint32_t *fd = Lp->rec + (a & (kTRecRing - 1)) * kTRecWords + 4 * qd;
+                        fd[0] = fq[h][0]; fd[1] = fq[h][1]; fd[2] = fq[h][2]; fd[3] = fq[h][3];
+                        uint32_t *bd = fd + kFtStride;
+                        bd[0] = bq[h][0]; bd[1] = bq[h][1]; bd[2] = bq[h][2]; bd[3] = bq[h][3];
+                        if ((w0 & kFtBt) && (bw0 & 0x1FFu) > 4) {
+                            // pairs 4 .. 11 of the descent: words 8 .. 23 of the position's pair list
+                            const uint32_t *xp = G.bt_pairs + (unsigned long long)(a - G.batch_a0) * (2 * kBtMaxPairs) + 8 + 4 * qd;
+                            xq[h][0] = xw::ld_agent(xp); xq[h][1] = xw::ld_agent(xp + 1); xq[h][2] = xw::ld_agent(xp + 2); xq[h][3] = xw::ld_agent(xp + 3);
+                        }
+                    }
                 }
-                wr = pend_a + pend_n;
+                x_a = r_a; x_n = r_n; r_n = 0;
                 xw::wave_sync();
-                if (i == 0) { xw::lds_st(&Lp->staged, wr); xw::st_agent(&V.hx->t_pos, wr); }     // (the ring's records are copied: the finder may overwrite them)
-                pend_n = 0;
+                if (i == 0) xw::st_agent(&V.hx->t_pos, x_a + x_n);   // (the ring's records are copied: the finder may overwrite them)
             }
             // ---- the next positions: what the finder has written, and what the record ring has room for
             if ((int32_t)(f_seen - req) <= 0) f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
             xw::after_poll();
-            taken = xw::readfirst(xw::lds_ld(&Lp->u_taken));
-            uint32_t lim = umin(f_seen, umin(taken + kTRecRing, a_last));
+            taken = kNone;
+            for (uint32_t k = 0; k < kTEmit; k++) taken = umin(taken, xw::readfirst(xw::lds_ld(&Lp->e_taken[k])));
+            const uint32_t lim = umin(f_seen, umin(taken + kTRecRing, a_last));
             const uint32_t n = (int32_t)(lim - req) > 0 ? umin(kTLoad, lim - req) : 0u;
             if (n) {
-                const uint32_t a = req + pj;
-                if (pj < n) {
-                    const uint32_t *fr = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride + 4 * qd;
-                    fq0 = xw::ld_agent(fr); fq1 = xw::ld_agent(fr + 1); fq2 = xw::ld_agent(fr + 2); fq3 = xw::ld_agent(fr + 3);
-                    const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
-                    bq0 = xw::ld_agent(br); bq1 = xw::ld_agent(br + 1); bq2 = xw::ld_agent(br + 2); bq3 = xw::ld_agent(br + 3);
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    const uint32_t a = req + pj + 16 * h;
+                    if (pj + 16 * h < n) {
+                        const uint32_t *fr = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride + 4 * qd;
+                        fq[h][0] = xw::ld_agent(fr); fq[h][1] = xw::ld_agent(fr + 1); fq[h][2] = xw::ld_agent(fr + 2); fq[h][3] = xw::ld_agent(fr + 3);
+                        const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
+                        bq[h][0] = xw::ld_agent(br); bq[h][1] = xw::ld_agent(br + 1); bq[h][2] = xw::ld_agent(br + 2); bq[h][3] = xw::ld_agent(br + 3);
+                    }
                 }
-                pend_a = req; pend_n = n; req += n;
+                r_a = req; r_n = n; req += n;
                 idle = 0;
-            } else {
+            } else if (!x_n) {
                 if (xw::readfirst(xw::lds_ld(&Lp->stop))) return;
                 if ((++idle & 63u) == 0) {
                     if (xw::readfirst(xw::ld_agent(&V.hx->err))) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
@@ -846,110 +876,67 @@ struct Table {
         }
     }
 
-    // ---- updater ------------------------------------------------------------------------------------------------------
-    XW_FN void run_updater(uint32_t c0, uint32_t c1, uint32_t a_first)
-    {
-        TLds *Lp = L();
-        StateV2 *S = (StateV2 *)V.state;
-        const uint32_t i = xw::lane();
-        // the window the launch before left: ends a_first + 1 .. a_first + 264, and the largest end so far
-        for (uint32_t k = i; k < kGRing; k += 64) Lp->G[k] = kNone;
-        xw::wave_sync();
-        const uint32_t had = xw::readfirst(S->front_n);
-        for (uint32_t k = i; k < kFrontMax && had; k += 64) Lp->G[(a_first + 1 + k) & (kGRing - 1)] = S->front[k];
-        uint32_t maxend = had ? xw::readfirst(S->front[kFrontMax]) : 0u;
-        xw::wave_sync();
-        uint32_t e_safe = a_first;                                  // rows of positions below this are consumed by the emitters
-        for (uint32_t ci = c0; ci < c1; ci++) {
-            const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
-            if (chunk_abs >= g.n) break;
-            const unsigned long long remain = g.n - chunk_abs;
-            const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
-            const uint32_t a1 = (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), la_end = (uint32_t)chunk_abs + chunk_read;
-            for (uint32_t p = (uint32_t)chunk_abs; p < a1; p++) {
-                const unsigned long long q0 = ptick();
-                if (!wait_lds_gt(&Lp->staged, p)) return;
-                // room in the row ring: the emitters have taken position p - 32
-                if ((int32_t)(p - e_safe) >= (int32_t)kTRowRing) {
-                    for (;;) {
-                        uint32_t m = kNone;
-                        for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
-                        e_safe = m;
-                        if ((int32_t)(p - e_safe) < (int32_t)kTRowRing) break;
-                        if (xw::readfirst(xw::lds_ld(&Lp->stop))) return;
-                        xw::pause();
-                    }
-                    xw::after_poll();
-                }
-                const unsigned long long q1 = ptick();
-                const uint32_t cap_len = umin(la_end - p, kMatchMax);
-                const uint32_t *fr = Lp->frec + (p & (kTRecRing - 1)) * kFtStride, *br = Lp->brec + (p & (kTRecRing - 1)) * kBtRec;
-                const uint32_t w0 = fr[0], bw0 = br[0];             // (the same word in every lane)
-                const uint32_t np = w0 & 7u, cnt = (w0 & kFtBt) ? (bw0 & 0x1FFu) : 0u;
-                // lanes 1..6: the finder's pairs; lane 7: its top entry; lanes 8..11: the first four record-setters of the BT4 descent
-                // (those as long as the lookahead allows are the finder's top entry already)
-                uint32_t d = 0, l = 0;
-                bool ok = false;
-                if (i >= 1 && i < 8) { d = fr[2 * i]; l = fr[2 * i + 1]; ok = i == 7 ? (w0 & kFtTop) != 0 : i - 1 < np; }
-                else if (i >= 8 && i < 12) { d = br[bt_rec_d(i - 8)]; l = br[bt_rec_l(i - 8)]; ok = i - 8 < cnt && l < cap_len; }
-                uint32_t e = ok ? p + l : 0u;
-                if (ok) xw::lds_min(&Lp->G[e & (kGRing - 1)], d);
-                const uint32_t cnt_u = xw::readfirst(cnt);
-                if (NLZM_RARE(cnt_u > 4)) {
-                    const uint32_t *pairs = G.bt_pairs + (unsigned long long)(p - G.batch_a0) * (2 * kBtMaxPairs);
-                    for (uint32_t k = 4 + i; k < cnt_u; k += 64) {
-                        const uint32_t dk = xw::ld_agent(pairs + 2 * k), lk = xw::ld_agent(pairs + 2 * k + 1);
-                        if (lk < cap_len) { xw::lds_min(&Lp->G[(p + lk) & (kGRing - 1)], dk); e = umax(e, p + lk); }
-                    }
-                    n_slow++;
-                }
-                maxend = umax(maxend, xw::readlane(xw::scan_max(e), 63));
-                const uint32_t mt_max = (int32_t)(maxend - p) > 0 ? maxend - p : 0u;
-                xw::wave_sync();
-                // the table as of this position: G's window into the position's row
-                uint32_t *row = Lp->row + (p & (kTRowRing - 1)) * kTRowStride;
-                for (uint32_t c = 0; 64 * c < mt_max; c++) row[64 * c + i] = Lp->G[(p + 1 + 64 * c + i) & (kGRing - 1)];
-                if (i == 0) {
-                    Lp->G[(p + 1) & (kGRing - 1)] = kNone;          // (no later position looks at this end)
-                    Lp->pinfo[p & (kTRowRing - 1)] = mt_max | (((w0 >> 8) & 0xFFu) << 16);
-                    Lp->pa1[p & (kTRowRing - 1)] = a1;
-                }
-                xw::wave_sync();
-                if (i == 0) { xw::lds_st(&Lp->u_pos, p + 1); xw::lds_st(&Lp->u_taken, p + 1); }
-                n_pos++;
-                tt1 += q1 - q0; tt0 += ptick() - q1;
-            }
-        }
-        // the window for the launch to come
-        unsigned long long a_end = (unsigned long long)c1 * g.chunk_size;
-        if (a_end > g.n) a_end = g.n;
-        xw::wave_sync();
-        for (uint32_t k = i; k < kFrontMax; k += 64) S->front[k] = Lp->G[((uint32_t)a_end + 1 + k) & (kGRing - 1)];
-        if (i == 0) { S->front[kFrontMax] = maxend; S->front_n = 1; }
-    }
-
     // ---- emitters -----------------------------------------------------------------------------------------------------
     XW_FN void capture(uint32_t a, uint32_t mt_max, const uint32_t *dense);
 #ifdef NLZM_SIM
     static void sim_on_table(void *user, uint32_t a, uint32_t mt_max, const uint32_t *dense);
 #endif
-    XW_FN void emit_position(uint32_t p, uint32_t p_seen_io)
+    // the chunk of position p: its last position + 1, the end of its lookahead
+    struct Chunk { uint32_t lo, a1, la_end; };
+    XW_FN Chunk chunk_of(uint32_t ci) const
+    {
+        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+        const unsigned long long remain = g.n - chunk_abs;
+        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+        return Chunk{ (uint32_t)chunk_abs, (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), (uint32_t)chunk_abs + chunk_read };
+    }
+    // the pairs of position q into this wave's G: lanes 1..6 the finder's pairs, lane 7 its top entry, lanes 8..19 the first
+    // twelve record-setters of the BT4 descent (those as long as the lookahead allows are the finder's top entry already).
+    // Returns the largest end among them (0: none).
+    XW_FN uint32_t apply_pairs(uint32_t *Gw, uint32_t q, uint32_t la_end, uint32_t &lit)
     {
         TLds *Lp = L();
+        const uint32_t i = xw::lane();
+        const uint32_t cap_len = umin(la_end - q, kMatchMax);
+        const uint32_t *r = Lp->rec + (q & (kTRecRing - 1)) * kTRecWords;
+        const uint32_t w0 = xw::readfirst(r[0]), bw0 = xw::readfirst(r[kFtStride]);
+        lit = (w0 >> 8) & 0xFFu;
+        const uint32_t np = w0 & 7u, cnt = (w0 & kFtBt) ? (bw0 & 0x1FFu) : 0u;
+        // (where a lane's pair sits in the staged words: the finder's at 2i, 2i + 1; the BT4 record's first four as bt_rec_d / _l say;
+        //  the next eight behind the record)
+        const uint32_t k = i - 8;
+        const uint32_t od = i < 8 ? 2 * i : (i < 12 ? kFtStride + bt_rec_d(k & 3u) : kFtStride + kBtRec + 2 * ((i - 12) & 7u));
+        const uint32_t ol = i < 8 ? 2 * i + 1 : (i < 12 ? kFtStride + bt_rec_l(k & 3u) : od + 1);
+        const uint32_t d = r[od], l = r[ol];
+        const bool ok = i >= 1 && i < 8 + kTInline && (i < 7 ? i - 1 < np : (i == 7 ? (w0 & kFtTop) != 0 : (k < cnt && l < cap_len)));
+        // (the slot of the one end that becomes possible at this position: used 512 ends ago)
+        Gw[(q + kMatchMax) & (kGRing - 1)] = kNone;
+        xw::wave_sync();
+        uint32_t e = ok ? q + l : 0u;
+        if (ok) xw::lds_min(&Gw[e & (kGRing - 1)], d);
+        if (NLZM_RARE(cnt > kTInline)) {
+            const uint32_t *pairs = G.bt_pairs + (unsigned long long)(q - G.batch_a0) * (2 * kBtMaxPairs);
+            for (uint32_t j = kTInline + i; j < cnt; j += 64) {
+                const uint32_t dk = xw::ld_agent(pairs + 2 * j), lk = xw::ld_agent(pairs + 2 * j + 1);
+                if (lk < cap_len) { xw::lds_min(&Gw[(q + lk) & (kGRing - 1)], dk); e = umax(e, q + lk); }
+            }
+            n_slow++;
+        }
+        return xw::readlane(xw::scan_max(e), 63);
+    }
+    XW_FN void emit_position(const uint32_t *Gw, uint32_t p, uint32_t mt_max, uint32_t lit, uint32_t a1)
+    {
         const uint32_t k = xw::lane();
-        const uint32_t info = xw::readfirst(Lp->pinfo[p & (kTRowRing - 1)]), a1 = xw::readfirst(Lp->pa1[p & (kTRowRing - 1)]);
-        const uint32_t mt_max = info & 0x1FFu, lit = (info >> 16) & 0xFFu;
-        const uint32_t *row = Lp->row + (p & (kTRowRing - 1)) * kTRowStride;
         uint32_t *dense = V.tf + (unsigned long long)(p & (kTpRing - 1)) * kTfStride;
-        // ---- delta[l] = min of the row from l on: chunk by chunk from the top, lane k of a chunk holds length 64 c + 64 - k
+        // ---- delta[l] = min of G from end p + l on: chunk by chunk from the top, lane k of a chunk holds length 64 c + 64 - k
         uint32_t s0 = kNone, s1 = kNone, s2 = kNone, s3 = kNone, s4 = kNone, carry = kNone;
-        auto chunk = [&](uint32_t c, uint32_t &s) __attribute__((always_inline)) {
+        auto chunk = [&](uint32_t c, uint32_t &sv) __attribute__((always_inline)) {
             if (64 * c >= mt_max) return;
             const uint32_t at = 64 * c + 63 - k;                    // length - 1 of this lane
-            uint32_t v = at < mt_max ? row[at] : kNone;
+            uint32_t v = at < mt_max ? Gw[(p + 1 + at) & (kGRing - 1)] : kNone;
             v = umin(xw::scan_min_u32(v), carry);
             carry = xw::readlane(v, 63);
-            s = v;
+            sv = v;
             // the dense table for the ring: four lengths a lane, 16-byte stores (lane 4j has lengths - 1 = 64c + 60 - 4j ..+3)
             const uint32_t v1 = xw::quad_bcast<1>(v), v2 = xw::quad_bcast<2>(v), v3 = xw::quad_bcast<3>(v);
             if ((k & 3u) == 0 && at - 3 < mt_max) xw::st_agent128(dense + at - 3, v3, v2, v1, v);
@@ -994,41 +981,81 @@ struct Table {
         xw::wave_sync();
         if (k == 0) sim_on_table(G.hook_user, p, mt_max, dense);
 #endif
-        (void)p_seen_io;
     }
-    XW_FN void run_emitter(uint32_t ek, uint32_t a_first, uint32_t a_last)
+    XW_FN void run_emitter(uint32_t ek, uint32_t c0, uint32_t c1, uint32_t a_first, uint32_t a_last)
     {
         TLds *Lp = L();
+        StateV2 *S = (StateV2 *)V.state;
         const uint32_t i = xw::lane();
-        uint32_t p_seen = a_first;
-        for (uint32_t p = a_first + ek; p < a_last; p += kTEmit) {
+        uint32_t *Gw = Lp->G[ek];
+        // the window the launch before left: ends a_first + 1 .. a_first + 264, and the largest end so far
+        for (uint32_t k = i; k < kGRing; k += 64) Gw[k] = kNone;
+        xw::wave_sync();
+        const uint32_t had = xw::readfirst(S->front_n);
+        for (uint32_t k = i; k < kFrontMax && had; k += 64) Gw[(a_first + 1 + k) & (kGRing - 1)] = S->front[k];
+        uint32_t maxend = had ? xw::readfirst(S->front[kFrontMax]) : 0u;
+        xw::wave_sync();
+        uint32_t p_seen = a_first, staged_seen = a_first;
+        uint32_t since = 0;                                         // positions written since this wave's stores were last waited for
+        uint32_t ci = c0;
+        Chunk ch = chunk_of(ci);
+        for (uint32_t q = a_first; q < a_last; q++) {
+            if (q >= ch.a1) { ci++; ch = chunk_of(ci); }
             const unsigned long long q0 = ptick();
-            if (!wait_lds_gt(&Lp->u_pos, p)) return;
-            // room in the parser's ring
-            if ((int32_t)(p + 1 - p_seen - kTpRing) > 0) {
-                if (!wait_word_ge(&V.hx->p_pos, p + 1 - kTpRing, V.hx, 3)) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
-                p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
+            if ((int32_t)(staged_seen - q) <= 0) {
+                // (while there is nothing to do: what was written goes out)
+                if (since && (int32_t)(xw::readfirst(xw::lds_ld(&Lp->staged)) - q) <= 0) { publish(ek, own_next(ek, q, a_first), a_last); since = 0; }
+                if (!wait_lds_gt(&Lp->staged, q)) return;
+                staged_seen = xw::readfirst(xw::lds_ld(&Lp->staged));
             }
             const unsigned long long q1 = ptick();
-            emit_position(p, p_seen);
-            xw::drain();
+            uint32_t lit;
+            maxend = umax(maxend, apply_pairs(Gw, q, ch.la_end, lit));
+            const bool mine = (q - a_first) % kTEmit == ek;
+            if ((q & 15u) == 15u || mine) { xw::wave_sync(); if (i == 0) xw::lds_st(&Lp->e_taken[ek], q + 1); }
+            const unsigned long long q2 = ptick();
+            tt2 += q1 - q0; tt0 += q2 - q1;
+            if (!mine) continue;
+            // ---- this wave's position: room in the parser's ring, then the record
+            if ((int32_t)(q + 1 - p_seen - kTpRing) > 0) {
+                if (since) { publish(ek, q, a_last); since = 0; }      // (q is this wave's own position)
+                if (!wait_word_ge(&V.hx->p_pos, q + 1 - kTpRing, V.hx, 3)) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
+                p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
+            }
             xw::wave_sync();
-            // records below the smallest "next position" of all emitters are out
-            if (i == 0) xw::lds_st(&Lp->e_done[ek], p + kTEmit);
-            xw::wave_sync();
-            uint32_t m = kNone;
-            for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
-            if (m > a_last) m = a_last;
-            if (i == 0) xw::st_agent(&V.hx->t_out, m);
-            tt3 += q1 - q0; tt2 += ptick() - q1;
+            emit_position(Gw, q, (int32_t)(maxend - q) > 0 ? maxend - q : 0u, lit, ch.a1);
+            n_pos++;
+            // the stores of a position take microseconds to land: waited for once every few positions, then all of them are said to be out
+            if (++since == kTDrainEvery) { publish(ek, q + kTEmit, a_last); since = 0; }
+            tt1 += ptick() - q2;
         }
         // (nothing of this wave is left: its word no longer holds the others back)
-        if (i == 0) xw::lds_st(&Lp->e_done[ek], kNone);
+        publish(ek, kNone, a_last);
+        if (i == 0) xw::lds_st(&Lp->e_taken[ek], kNone);
+        if (ek == 0) {
+            // the window for the launch to come (every emitter has applied every position: this one says so)
+            xw::wave_sync();
+            for (uint32_t k = i; k < kFrontMax; k += 64) S->front[k] = Gw[(a_last + 1 + k) & (kGRing - 1)];
+            if (i == 0) { S->front[kFrontMax] = maxend; S->front_n = 1; }
+        }
+    }
+    // the first position from q on that is emitter ek's
+    XW_FN static uint32_t own_next(uint32_t ek, uint32_t q, uint32_t a_first) { const uint32_t r = (q - a_first) % kTEmit; return q + (ek >= r ? ek - r : ek + kTEmit - r); }
+    // this wave's records of its positions below `next` (one of its own, or beyond the end) are in memory: with the other emitters'
+    // words, how far the parser may read
+    XW_FN void publish(uint32_t ek, uint32_t next, uint32_t a_last)
+    {
+        TLds *Lp = L();
+        const unsigned long long q0 = ptick();
+        xw::drain();
+        xw::wave_sync();
+        if (xw::lane() == 0) xw::lds_st(&Lp->e_done[ek], next);
         xw::wave_sync();
         uint32_t m = kNone;
         for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
         if (m > a_last) m = a_last;
-        if (i == 0) xw::st_agent(&V.hx->t_out, m);
+        if (xw::lane() == 0) xw::st_agent(&V.hx->t_out, m);
+        tt3 += ptick() - q0;
     }
 
     XW_FN void run(uint32_t c0, uint32_t c1)
@@ -1040,29 +1067,25 @@ struct Table {
         if (a_last64 > g.n) a_last64 = g.n;
         const uint32_t a_last = (uint32_t)a_last64;
         if (w == 0 && i == 0) {
-            Lp->staged = a_first; Lp->u_pos = a_first; Lp->u_taken = a_first; Lp->stop = 0;
-            for (uint32_t k = 0; k < kTEmit; k++) Lp->e_done[k] = a_first + k;
+            Lp->staged = a_first; Lp->stop = 0;
+            for (uint32_t k = 0; k < kTEmit; k++) { Lp->e_done[k] = a_first + k; Lp->e_taken[k] = a_first; }
         }
         xw::block_sync();
         err = 0;
         const unsigned long long t_start = xw::tick();
         if (w == 0) run_loader(a_first, a_last);
-        else if (w == 1) run_updater(c0, c1, a_first);
-        else run_emitter(w - 2, a_first, a_last);
+        else run_emitter(w - 1, c0, c1, a_first, a_last);
         xw::block_sync();
         if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {         // where this stage was when it left
             uint32_t *d = V.hx->dbg[1];
-            xw::st_agent(d + 0, xw::lds_ld(&Lp->staged)); xw::st_agent(d + 1, xw::lds_ld(&Lp->u_pos)); xw::st_agent(d + 2, xw::lds_ld(&Lp->e_done[0]));
-            xw::st_agent(d + 3, xw::lds_ld(&Lp->u_taken)); xw::st_agent(d + 4, xw::lds_ld(&Lp->stop)); xw::st_agent(d + 5, 0u);
+            xw::st_agent(d + 0, xw::lds_ld(&Lp->staged)); xw::st_agent(d + 1, xw::lds_ld(&Lp->e_taken[0])); xw::st_agent(d + 2, xw::lds_ld(&Lp->e_done[0]));
+            xw::st_agent(d + 3, xw::lds_ld(&Lp->e_done[1])); xw::st_agent(d + 4, xw::lds_ld(&Lp->stop)); xw::st_agent(d + 5, 0u);
         }
-        if (i == 0) {       // accounting
+        if (i == 0 && w >= 1) {     // accounting
             unsigned long long *pr = G.persist->prof;
-            if (w == 1) {
-                xw::atomic_add64_agent(&pr[6], n_pos); xw::atomic_add64_agent(&pr[7], n_slow);
-                xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
-                xw::atomic_add64_agent(&pr[18], tt1); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start);
-            }
-            if (w >= 2) { xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3); }
+            xw::atomic_add64_agent(&pr[6], n_pos); xw::atomic_add64_agent(&pr[7], n_slow);
+            xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1); xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
+            if (w == 1) { xw::atomic_add64_agent(&pr[18], tt2 + tt3); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
         }
     }
 };

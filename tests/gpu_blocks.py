@@ -12,6 +12,8 @@ mb = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 hb = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ks = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
 nlzm_amd.init(0)
+if os.environ.get("NLZM_WAIT_PRINT"):       # (a switch of this script: the library has no environment knobs)
+    nlzm_amd.set_option("stage_report", 1)
 for k in ks:
     data = corpus.syn_text(int(mb * 1e6) * k, corpus.SEED + 11)
     t = time.time()
