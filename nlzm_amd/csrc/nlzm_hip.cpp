@@ -597,7 +597,7 @@ int refresh_stats(Ctx &C)
                 P.prof[17] / n, P.prof[16] / n, P.prof[25] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[24] / n, P.prof[22] / n);
         fprintf(stderr, "finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
                 P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
-        fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
+        fprintf(stderr, "table: %llu positions emitted, %llu applications of a descent with more than twelve record-setters; parser: %llu steps (%.1f positions each), %.2f attempts per step (%.0f cycles of the chain wave per attempt), (%llu) probe rounds %llu, steps done again %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
@@ -605,25 +605,13 @@ int refresh_stats(Ctx &C)
         if (P.prof[88]) fprintf(stderr, "finder sections (cycles/position, profile build): predict %.0f, own loads %.0f, HT rows %.0f, candidates + jobs %.0f, record + RK256 %.0f, "
                                 "BT4 results (wait included) %.0f, verify %.0f, commit %.0f\n", P.prof[88] / n, P.prof[89] / n, P.prof[90] / n, P.prof[91] / n, P.prof[92] / n,
                                 P.prof[93] / n, P.prof[94] / n, P.prof[95] / n);
-        if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position, profile build): gather %.0f, scan %.0f, emit %.0f\n", P.prof[44] / n, P.prof[45] / n, P.prof[46] / n);
-        if (P.prof[32]) {
-            const double np = (double)(P.prof[13] ? P.prof[13] : 1);
-            fprintf(stderr, "parser, cycles per pass (profile build): relax waves %.0f %.0f %.0f, probe wave %.0f (of it: sets that changed %.0f, mask fills %.0f), update %.0f, "
-                            "barrier waits per wave %.0f %.0f %.0f %.0f; block end %.0f cycles/position\n",
-                    P.prof[32] / np, P.prof[33] / np, P.prof[34] / np, P.prof[35] / np, P.prof[43] / np, P.prof[41] / np, P.prof[40] / np,
-                    P.prof[36] / np, P.prof[37] / np, P.prof[38] / np, P.prof[39] / np, P.prof[42] / n);
-            fprintf(stderr, "parser, cycles per pass by wave 0..7 (profile build): work");
-            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[64 + w] / np);
-            fprintf(stderr, " | barrier wait");
-            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[72 + w] / np);
-            fprintf(stderr, " | update");
-            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[80 + w] / np);
-            fprintf(stderr, "\n");
-            const double nbk = (double)(P.prof[8] ? P.prof[8] : 1);
-            fprintf(stderr, "parser loader wave, cycles per block set-up: block size + barrier %.0f, re-list %.0f, own edges %.0f, all edges %.0f, literal scan + clear + barrier %.0f\n",
-                    P.prof[56] / nbk, P.prof[57] / nbk, P.prof[58] / nbk, P.prof[59] / nbk, P.prof[60] / nbk);
-            fprintf(stderr, "parser wave 0, cycles per pass: relax %.0f, probe %.0f, clear %.0f | update: keys + cost scan %.0f, membership %.0f, winner sets %.0f, rest %.0f\n",
-                    P.prof[48] / np, P.prof[49] / np, P.prof[50] / np, P.prof[51] / np, P.prof[52] / np, P.prof[53] / np, P.prof[54] / np);
+        if (P.prof[44]) fprintf(stderr, "table stage, cycles/position summed over the seven emitter waves (profile build): applying pairs %.0f, emitting %.0f, waiting for records %.0f, for their stores %.0f\n",
+                                P.prof[44] / n, P.prof[45] / n, P.prof[46] / n, P.prof[47] / n);
+        if (P.prof[57]) {
+            const double steps = (double)(P.prof[13] ? P.prof[13] : 1), nodes = (double)(P.prof[60] ? P.prof[60] : 1);
+            fprintf(stderr, "parser chain wave (profile build): per attempt of a step: start (merge, snapshot) %.0f, chain %.0f (%.0f cycles per node, %.1f nodes), waiting for the other waves %.0f, decide %.0f cycles; "
+                            "nodes on a rare path (edges longer than the window, handed-over probe edges) %llu of %llu\n",
+                    P.prof[56] / steps, P.prof[57] / steps, P.prof[57] / nodes, nodes / steps, P.prof[58] / steps, P.prof[59] / steps, P.prof[61], P.prof[60]);
         }
     }
     if (C.workers) {

@@ -737,6 +737,7 @@ struct TLds {
     uint32_t G[kTEmit][kGRing];                 // emitter k's G: end e at [k][e & 511]
     uint32_t rec[kTRecRing * kTRecWords];       // position p at [(p & 255) * 48]
     uint32_t staged;                            // loader: records of positions below this are in LDS
+    uint32_t maxend[kTEmit];                    // emitter k: the largest end of any pair it has applied (mt.max_len = that - p)
     uint32_t e_done[kTEmit];                    // emitter k: its records of the positions below this are in memory
     uint32_t e_taken[kTEmit];                   // emitter k: the staged records of the positions below this are applied
     uint32_t stop;                              // nonzero: leave
@@ -891,16 +892,16 @@ struct Table {
         return Chunk{ (uint32_t)chunk_abs, (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), (uint32_t)chunk_abs + chunk_read };
     }
     // the pairs of position q into this wave's G: lanes 1..6 the finder's pairs, lane 7 its top entry, lanes 8..19 the first
-    // twelve record-setters of the BT4 descent (those as long as the lookahead allows are the finder's top entry already).
-    // Returns the largest end among them (0: none).
-    XW_FN uint32_t apply_pairs(uint32_t *Gw, uint32_t q, uint32_t la_end, uint32_t &lit)
+    // twelve record-setters of the BT4 descent (those as long as the lookahead allows are the finder's top entry already); the
+    // largest end among them into *mx (an LDS word of this wave).  Every emitter does this for every position: kept short --
+    // no scalar detour (every lane reads the record's head words itself), no reduction (LDS atomic max).
+    XW_FN void apply_pairs(uint32_t *Gw, uint32_t *mx, uint32_t q, uint32_t la_end)
     {
         TLds *Lp = L();
         const uint32_t i = xw::lane();
         const uint32_t cap_len = umin(la_end - q, kMatchMax);
         const uint32_t *r = Lp->rec + (q & (kTRecRing - 1)) * kTRecWords;
-        const uint32_t w0 = xw::readfirst(r[0]), bw0 = xw::readfirst(r[kFtStride]);
-        lit = (w0 >> 8) & 0xFFu;
+        const uint32_t w0 = r[0], bw0 = r[kFtStride];
         const uint32_t np = w0 & 7u, cnt = (w0 & kFtBt) ? (bw0 & 0x1FFu) : 0u;
         // (where a lane's pair sits in the staged words: the finder's at 2i, 2i + 1; the BT4 record's first four as bt_rec_d / _l say;
         //  the next eight behind the record)
@@ -912,17 +913,15 @@ struct Table {
         // (the slot of the one end that becomes possible at this position: used 512 ends ago)
         Gw[(q + kMatchMax) & (kGRing - 1)] = kNone;
         xw::wave_sync();
-        uint32_t e = ok ? q + l : 0u;
-        if (ok) xw::lds_min(&Gw[e & (kGRing - 1)], d);
-        if (NLZM_RARE(cnt > kTInline)) {
+        if (ok) { xw::lds_min(&Gw[(q + l) & (kGRing - 1)], d); xw::lds_max(mx, q + l); }
+        if (NLZM_RARE(xw::any(cnt > kTInline))) {
             const uint32_t *pairs = G.bt_pairs + (unsigned long long)(q - G.batch_a0) * (2 * kBtMaxPairs);
             for (uint32_t j = kTInline + i; j < cnt; j += 64) {
                 const uint32_t dk = xw::ld_agent(pairs + 2 * j), lk = xw::ld_agent(pairs + 2 * j + 1);
-                if (lk < cap_len) { xw::lds_min(&Gw[(q + lk) & (kGRing - 1)], dk); e = umax(e, q + lk); }
+                if (lk < cap_len) { xw::lds_min(&Gw[(q + lk) & (kGRing - 1)], dk); xw::lds_max(mx, q + lk); }
             }
             n_slow++;
         }
-        return xw::readlane(xw::scan_max(e), 63);
     }
     XW_FN void emit_position(const uint32_t *Gw, uint32_t p, uint32_t mt_max, uint32_t lit, uint32_t a1)
     {
@@ -993,9 +992,10 @@ struct Table {
         xw::wave_sync();
         const uint32_t had = xw::readfirst(S->front_n);
         for (uint32_t k = i; k < kFrontMax && had; k += 64) Gw[(a_first + 1 + k) & (kGRing - 1)] = S->front[k];
-        uint32_t maxend = had ? xw::readfirst(S->front[kFrontMax]) : 0u;
+        if (i == 0) Lp->maxend[ek] = had ? S->front[kFrontMax] : 0u;
         xw::wave_sync();
         uint32_t p_seen = a_first, staged_seen = a_first;
+        uint32_t own = a_first + ek;                                // this wave's next position
         uint32_t since = 0;                                         // positions written since this wave's stores were last waited for
         uint32_t ci = c0;
         Chunk ch = chunk_of(ci);
@@ -1009,9 +1009,10 @@ struct Table {
                 staged_seen = xw::readfirst(xw::lds_ld(&Lp->staged));
             }
             const unsigned long long q1 = ptick();
-            uint32_t lit;
-            maxend = umax(maxend, apply_pairs(Gw, q, ch.la_end, lit));
-            const bool mine = (q - a_first) % kTEmit == ek;
+            apply_pairs(Gw, &Lp->maxend[ek], q, ch.la_end);
+            const bool mine = q == own;
+            // (the position's byte, while its record is still this wave's to read: the word below frees the slot for the loader)
+            const uint32_t lit = mine ? (xw::readfirst(Lp->rec[(q & (kTRecRing - 1)) * kTRecWords]) >> 8) & 0xFFu : 0u;
             if ((q & 15u) == 15u || mine) { xw::wave_sync(); if (i == 0) xw::lds_st(&Lp->e_taken[ek], q + 1); }
             const unsigned long long q2 = ptick();
             tt2 += q1 - q0; tt0 += q2 - q1;
@@ -1023,6 +1024,8 @@ struct Table {
                 p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
             }
             xw::wave_sync();
+            own += kTEmit;
+            const uint32_t maxend = xw::readfirst(xw::lds_ld(&Lp->maxend[ek]));
             emit_position(Gw, q, (int32_t)(maxend - q) > 0 ? maxend - q : 0u, lit, ch.a1);
             n_pos++;
             // the stores of a position take microseconds to land: waited for once every few positions, then all of them are said to be out
@@ -1036,7 +1039,7 @@ struct Table {
             // the window for the launch to come (every emitter has applied every position: this one says so)
             xw::wave_sync();
             for (uint32_t k = i; k < kFrontMax; k += 64) S->front[k] = Gw[(a_last + 1 + k) & (kGRing - 1)];
-            if (i == 0) { S->front[kFrontMax] = maxend; S->front_n = 1; }
+            if (i == 0) { S->front[kFrontMax] = Lp->maxend[ek]; S->front_n = 1; }
         }
     }
     // the first position from q on that is emitter ek's
@@ -1147,8 +1150,8 @@ constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
-constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave ...
-constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: twelve records a step
+constexpr uint32_t kPumpLoads = 8;              // loads per lane and step of the loader wave ...
+constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: 24 records a step, two steps in flight
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kRowRing = 128;              // nodes whose rows are kept: the step being parsed and what is prepared ahead
 constexpr uint32_t kFarRing = 512;              // keys of the nodes beyond the chain's window; final states of the last nodes
@@ -1202,7 +1205,7 @@ struct PLds {
     uint32_t dbgw[4];                           // error dump: the segment being parsed, its step, the node count so far
     unsigned long long acc[11];                 // cycles waited / emitting / in set-up / in the chain; steps, attempts, ...
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
-    uint32_t stg[5];                            // loader wave: records requested up to / written up to this position, (2 unused), records of the last step; 4: records staged up to here
+    uint32_t stg[5];                            // 4: the loader wave has staged the records below this position (0..3 unused)
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current step on, loaded ahead
                                                 //   by the loader wave (position a at [((a - launch start) & 127) * kStageQ])
     // the path of a parsed segment (node indices, end first) lives in the rows: nothing reads a row between a parse and its emission
@@ -1220,8 +1223,9 @@ struct Parser {
     uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
     // wave kLoaderWave: the loader of the record stage (8-byte words counted from the launch's first position)
-    uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
-    unsigned long long pend_v[kPumpLoads];
+    uint32_t pend_t[2];                         // (t_out as read with a step's loads)
+    unsigned long long pend_v[2][kPumpLoads];
+    uint32_t ld_req, ld_wr, ld_n[2], ld_turn;    // records requested / written up to this position; records a set's loads are for; the set whose turn it is
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops;       // (every wave follows the counts; `word`, the bits of the byte not yet full, is wave 7's)
@@ -1428,39 +1432,47 @@ struct Parser {
     // position still needed), t_out is requested again.  Nothing is waited for here except the last step's loads.
     XW_FN unsigned long long *staged(uint32_t a) const { return L()->stage + (a & (kStagePos - 1)) * kStageQ; }
     XW_FN uint32_t staged_hi() const { return xw::readfirst(xw::lds_ld(&L()->stg[4])); }
-    XW_FN void pump(uint32_t lo)
+    // Two such steps are in flight (two sets of load registers taken in turn: 48 records), so that a step's loads have a whole
+    // other step to arrive in.
+    template <uint32_t kSet> XW_FN void pump_set(uint32_t lo)
     {
         // (counted in records: a load instruction fetches the 18 words of three records on lanes 0..53, so that a lane's
         //  place in a record is the same in every step and no step divides by 18)
         const uint32_t i = xw::lane();
         const uint32_t ri = i / kStageQ, wi = i - ri * kStageQ;
         const bool on = i < kPumpRecs * kStageQ;
-        uint32_t st_req = xw::readfirst(L()->stg[0]), st_wr = xw::readfirst(L()->stg[1]);
-        const uint32_t pend_n = xw::readfirst(L()->stg[3]);
+        const uint32_t pend_n = ld_n[kSet];
         if (pend_n) {
 #pragma unroll
             for (uint32_t u = 0; u < kPumpLoads; u++) {
                 const uint32_t rr = kPumpRecs * u + ri;
-                if (on && rr < pend_n) L()->stage[((st_wr + rr) & (kStagePos - 1)) * kStageQ + wi] = pend_v[u];
+                if (on && rr < pend_n) L()->stage[((ld_wr + rr) & (kStagePos - 1)) * kStageQ + wi] = pend_v[kSet][u];
             }
-            st_wr += pend_n;
+            ld_wr += pend_n;
         }
-        t_out_seen = xw::readfirst(pend_t);
+        t_out_seen = xw::readfirst(pend_t[kSet]);                   // (as this set's last step read it)
         xw::after_poll();
         uint32_t lim = lo + kStagePos;
         if ((int32_t)(t_out_seen - lim) < 0) lim = t_out_seen;
-        const uint32_t n = (int32_t)(lim - st_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - st_req) : 0u;
+        const uint32_t n = (int32_t)(lim - ld_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - ld_req) : 0u;
         const uint32_t wsrc = wi == 0 ? 0u : (wi == kStageQ - 1 ? kTpUniq / 2 : kTpEdges / 2 + wi - 1);   // (staged: header, sixteen edges, mask)
 #pragma unroll
         for (uint32_t u = 0; u < kPumpLoads; u++) {
             const uint32_t rr = kPumpRecs * u + ri;
             if (on && rr < n)
-                pend_v[u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)((st_req + rr) & (kTpRing - 1)) * kTpStride) + wsrc);
+                pend_v[kSet][u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)((ld_req + rr) & (kTpRing - 1)) * kTpStride) + wsrc);
         }
-        pend_t = xw::ld_agent(&V.hx->t_out);
+        pend_t[kSet] = xw::ld_agent(&V.hx->t_out);
+        ld_n[kSet] = n; ld_req += n;
         xw::wave_sync();                                            // (the records are in LDS before the word that says so)
-        if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[3] = n; xw::lds_st(&L()->stg[4], st_wr); }
+        if (i == 0) xw::lds_st(&L()->stg[4], ld_wr);
     }
+    XW_FN void pump(uint32_t lo)
+    {
+        if (ld_turn) pump_set<1>(lo); else pump_set<0>(lo);
+        ld_turn ^= 1u;
+    }
+    XW_FN bool pump_idle() const { return ld_n[0] + ld_n[1] == 0; }
     // until the record of position a is staged (false: another stage failed, or the wait timed out)
     XW_FN bool stage_need(uint32_t a)
     {
@@ -1482,7 +1494,7 @@ struct Parser {
                 (void)t0;
 #endif
             }
-            if (!xw::readfirst(L()->stg[3])) xw::pause();
+            if (pump_idle()) xw::pause();
         }
         acc(kAccWait, xw::tick() - tw);
         acc(kAccNeed, 1); acc(kAccAhead, t_out_seen - a);             // (how far the table stage was ahead when this stage had to wait for its loader)
@@ -1650,7 +1662,7 @@ struct Parser {
             for (uint32_t sh = 32; sh; sh >>= 1) bit |= xw::shfl64(bit, i ^ sh);
             infov |= (uint32_t)((bit >> i) & 1ull) << 16;
         }
-        uint32_t farlive = far_hi >= n_s + 64 ? 1u : 0u;            // a key may be waiting in far[] for a node that enters the window
+        unsigned long long fkv = far_hi >= n_s + 64 ? Lp->far[(n_s + 64) & (kFarRing - 1)] : kKeyNone;      // the key waiting for the node that enters the window (the same in every lane)
         uint32_t n = n_s;
         const unsigned long long *rows = Lp->row + i;               // (a row's entry for this lane: the edge that ends at the lane's node)
         unsigned long long rw0 = rows[(n & (kRowRing - 1)) * 64];
@@ -1675,16 +1687,8 @@ struct Parser {
             // ---- its lane is node n + 64's now
             C.cost = me ? kInf : C.cost;
             fslot = me ? ((fslot + 64) & (kFarRing - 1)) : fslot;
-            const uint32_t rare = (info >> 15) | farlive;           // (edges longer than the window, probe edges, keys in far[])
-            if (NLZM_RARE(rare)) {
-                // a key that jumped over the window may be waiting for node n + 64 (written before this node was reached)
-                if (far_hi >= n + 64) {
-                    const unsigned long long fk = xw::readfirst64(Lp->far[(n + 64) & (kFarRing - 1)]);
-                    if (fk != kKeyNone) take_far(me, fk, n + 64, C);
-                }
-            }
             // ---- its edges (:1490-1499, :1566-1595): every lane its own
-            {
+            auto relax = [&]() __attribute__((always_inline)) {
                 const uint32_t d = (uint32_t)rw0, at = (uint32_t)(rw0 >> 32);
                 const bool valid = (int32_t)at < 0;
                 const bool inset = d == r0 || d == r1 || d == r2 || d == r3;
@@ -1699,8 +1703,13 @@ struct Parser {
                 // (the set once more in vector registers: a select takes its mask over the scalar operand bus, so its data cannot)
                 const uint32_t v0 = xw::opaque(r0), v1 = xw::opaque(r1), v2 = xw::opaque(r2), v3 = xw::opaque(r3);
                 C.r3 = upd ? (push ? v2 : v3) : C.r3; C.r2 = upd ? (push ? v1 : v2) : C.r2; C.r1 = upd ? (push ? v0 : v1) : C.r1; C.r0 = upd ? (push ? d : v0) : C.r0;
-            }
-            if (NLZM_RARE(rare)) {
+            };
+            if (!NLZM_RARE((info >> 15) | (far_hi >= n + 64 ? 1u : 0u))) relax();        // (no edge longer than the window, no probe edge handed over, no key in far[])
+            else {
+                // a key that jumped over the window may be waiting for node n + 64 (written before this node was reached; requested a node ago)
+                const unsigned long long fk0 = xw::readfirst64(fkv);
+                if (fk0 != kKeyNone) take_far(me, fk0, n + 64, C);
+                relax();
                 // ---- sampled edges longer than the window (max_len > 64: lanes = the sixteen longest samples)
                 if (info & kInfoFar) {
                     t_q[5]++;
@@ -1720,8 +1729,8 @@ struct Parser {
                         t = n + tl;
                         if (key < Lp->far[t & (kFarRing - 1)]) { Lp->far[t & (kFarRing - 1)] = key; Lp->far_d[t & (kFarRing - 1)] = d; }
                     }
-                    far_hi = umax(far_hi, xw::readlane(xw::scan_max(t), 63));
-                    farlive = 1;
+                    (void)t;
+                    far_hi = umax(far_hi, n + (info & 0x1FFu));     // (no key beyond the node's longest edge)
                     xw::wave_sync();
                 }
                 // ---- probe edges known from the attempt before (:1598-1628: after the sampled edges, slot by slot)
@@ -1750,11 +1759,12 @@ struct Parser {
                             const unsigned long long key = ((unsigned long long)cand << 32) | (n << 8) | (kRankProbe + pi);
                             if (i == 0 && key < Lp->far[t & (kFarRing - 1)]) Lp->far[t & (kFarRing - 1)] = key;
                             far_hi = umax(far_hi, t);
-                            farlive = 1;
                             xw::wave_sync();
                         }
                     }
                 }
+                // (the key for the node that enters the window next: after this node's own keys are written)
+                fkv = far_hi >= n + 65 ? Lp->far[(n + 65) & (kFarRing - 1)] : kKeyNone;
             }
             rw0 = rw1; rw1 = rw2;
             n++;
@@ -1955,7 +1965,7 @@ struct Parser {
                         uint32_t e = kNone;
                         for (uint32_t p = 0; p < kPrepWaves; p++) e = umin(e, xw::readfirst(xw::lds_ld(&Lp->ctl.prep_cur[p])));
                         n_e = umin(e, umin(n_s + kStepMax, max_parse));
-                        const uint32_t want_n = umin(kStepWant, umin(end_p, max_parse) - n_s);
+                        const uint32_t want_n = umin(kStepWant, max_parse - n_s);      // (the chain stops by itself where the segment ends)
                         if (n_e >= n_s + want_n || (n_e > n_s && spins >= 8)) break;
                         if ((++spins & 63u) == 0 && (xw::readfirst(xw::ld_agent(&V.hx->err)) || xw::readfirst(xw::lds_ld(&Lp->sh[4])))) { n_e = n_s; break; }
                         xw::pause();
@@ -2123,7 +2133,7 @@ struct Parser {
                         (void)t0;
 #endif
                     }
-                    if (!xw::readfirst(L()->stg[3])) xw::pause();
+                    if (pump_idle()) xw::pause();
                 }
                 if (err && i == 0) xw::lds_st(&Lp->sh[4], err);
                 xw::block_sync();
@@ -2223,8 +2233,9 @@ struct Parser {
         tab_dirty = true;
         t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
         if (tid < 5) L()->stg[tid] = (tid == 3 || tid == 2) ? 0u : t_out_seen;
+        ld_req = ld_wr = t_out_seen; ld_n[0] = ld_n[1] = 0; ld_turn = 0;
         if (tid < 16) L()->sh[tid] = 0;
-        pend_t = t_out_seen;                                        // (as if t_out had been read before the table stage started)
+        pend_t[0] = pend_t[1] = t_out_seen;                         // (as if t_out had been read before the table stage started)
         n_eq_rounds = 0; n_cmp = 0;
         if (tid < kAccN) L()->acc[tid] = 0;
         xw::block_sync();
