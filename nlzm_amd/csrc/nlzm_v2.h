@@ -33,7 +33,7 @@ constexpr uint32_t kMaxEdges = 32;              // sampled lengths per position 
 constexpr uint32_t kTpStride = 2 + 2 + 2 * kMaxEdges;   // header (2), the mask of samples with a new distance (2), edges (distance, attributes)
 constexpr uint32_t kTpUniq = 2, kTpEdges = 4;           // (header + mask, and every two edges, are ONE 16-byte store of the table stage)
 constexpr uint32_t kFrontMax = 264;             // entries of a front (one per length at most)
-constexpr uint32_t kTfStride = 5 * 64;          // words per position in the ring of dense tables: delta[l] at [l - 1]
+constexpr uint32_t kTfStride = 2 * kFrontMax;   // words per position in the front ring (end, distance)
 
 // finder -> table record:
 //   w0        number of pairs in w2.. (bits 0..2) | BT4 ran: take the worker record's list (bit 3) | top pair present (bit 4)
@@ -43,7 +43,7 @@ constexpr uint32_t kTfStride = 5 * 64;          // words per position in the rin
 constexpr uint32_t kFtBt = 8u, kFtTop = 16u;
 // table -> parser record:
 //   w0        edges (bits 0..5) | input byte << 8 | table length (mt.max_len) << 16
-//   w1        (unused)
+//   w1        entries of the front in the front ring
 //   w2, w3    the mask of sampled lengths that bring a new distance
 //   w4..      per sampled length: distance, length | length value << 9 | distance slot << 18 | extra bits << 24 | valid << 31
 struct Hx {                                     // progress words, one 128-byte line each
@@ -706,494 +706,439 @@ struct Finder {
 // =================================================================================================
 // The match table of a position (mt_carry as :1543 leaves it) is delta[l] = smallest distance of any match found at a
 // position q <= p that still has >= l bytes left at p (Update is an element-wise min, :835-852; CarryFrom shifts by
-// one, :823-833).  With e = q + length (the match's absolute end):
-//
-//     delta[l] at p  =  min { G[e'] : e' >= p + l },     G[e] = smallest distance of the matches that END exactly at e
-//
-// -- a match is a POINT in G (one LDS atomic min, whatever its length), moving to the next position costs nothing (G is
-// indexed by the absolute end), and the table of a position is a suffix minimum over the window e in (p, p + 264].
+// one, :823-833).  With e = q + length (the match's absolute end), delta[l] at p is the smallest distance among the
+// entries with e >= p + l: only the Pareto front over (e larger, distance smaller) matters, and dominance between two
+// entries does not depend on p.  So the front at p is the Pareto front of ALL pairs found at positions <= p, cut to
+// e >= p + 2 -- an associative merge, computed for the 64 positions of a block by a parallel prefix scan.
 // (The one entry whose end moves with p, the top entry while it keeps extending :1503-1512, arrives from the finder
-// stage as a fresh pair per position.)  One workgroup, nothing serial in it:
-//
-//   loader   (wave 0)     the finder's records and the worker lanes' BT4 records of the positions to come, staged in LDS
-//                         (32 positions a step, three steps in flight)
-//   emitters (waves 1..7) every one keeps a G of its OWN and applies the pairs of EVERY position to it -- lanes = the position's
-//                         pairs (six of the finder's, its top entry, twelve record-setters of the BT4 descent; more of them,
-//                         rare, from HBM): one atomic min instruction a position -- and emits every seventh position: suffix
-//                         minimum of G's window by DPP scans (lanes = lengths, 64 a chunk), the dense table to the ring the parser
-//                         re-lists from near a forced cut (:1545) and the stage test reads, then the sampled lengths of
-//                         :1558-1562 with the lanes as SAMPLES: distance, length value, distance slot, extra bits, the mask of
-//                         samples that bring a new distance; 16-byte stores, waited for once every few positions.
-constexpr uint32_t kTW = 8;                     // waves of the stage
-constexpr uint32_t kTEmit = kTW - 1;            // emitters
-constexpr uint32_t kTRecRing = 256;             // positions whose records are staged
-constexpr uint32_t kGRing = 512;
-constexpr uint32_t kTLoad = 32;                 // positions the loader requests a step
-constexpr uint32_t kTDrainEvery = 4;            // positions an emitter writes between two waits for its stores
-constexpr uint32_t kTInline = 12;               // record-setters of a BT4 descent staged in LDS (four in the record, eight from the pair list)
-constexpr uint32_t kTRecWords = kFtStride + kBtRec + 16;    // a position's staged words: the finder's record, the BT4 record, record-setters 4 .. 11
+// stage as a fresh pair per position.)
+constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
 
+#ifndef NLZM_KTW
+#define NLZM_KTW 3
+#endif
+constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn
+struct TWave {
+    unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
+    uint32_t recs[64 * kFtStride];              // the block's finder records
+    uint32_t overflow;
+};
 struct TLds {
-    uint32_t G[kTEmit][kGRing];                 // emitter k's G: end e at [k][e & 511]
-    uint32_t rec[kTRecRing * kTRecWords];       // position p at [(p & 255) * 48]
-    uint32_t staged;                            // loader: records of positions below this are in LDS
-    uint32_t maxend[kTEmit];                    // emitter k: the largest end of any pair it has applied (mt.max_len = that - p)
-    uint32_t e_done[kTEmit];                    // emitter k: its records of the positions below this are in memory
-    uint32_t e_taken[kTEmit];                   // emitter k: the staged records of the positions below this are applied
-    uint32_t stop;                              // nonzero: leave
+    TWave w[kTW];
+    unsigned long long carry[kFrontMax + 8];    // front after the last finished position
+    unsigned long long tmp[2 * kFrontMax + 300];
+    uint32_t carry_n;
+    uint32_t turn;                              // blocks are taken in turn: the wave whose sequence number this is cuts the next block
+    uint32_t cursor;                            // first position not yet in a block
+    uint32_t carry_seq;                         // ... and finished in that order: the block with this sequence number takes the carry
+    uint32_t stop;
 };
 
-NLZM_HD uint32_t tf_index(uint32_t l) { return l - 1; }     // dense table of a position in the ring: delta[l]
+NLZM_HD unsigned long long fr_key(uint32_t e, uint32_t d) { return ((unsigned long long)e << 32) | (0xFFFFFFFFu - d); }
+NLZM_HD uint32_t fr_end(unsigned long long k) { return (uint32_t)(k >> 32); }
+NLZM_HD uint32_t fr_dist(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
 
 struct Table {
     Geom g;
     Globals G;
     GlobalsV2 V;
     uint32_t err;
-    unsigned long long n_pos = 0, n_slow = 0, t_wait = 0;
-    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build, emitters: applying pairs, emitting, waiting for records, for the stores
+    uint32_t p_pos_seen;
+    unsigned long long n_blocks, n_slow, t_wait;
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: gather, scan, carry + emit, wait for the carry
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
 #else
     XW_FN unsigned long long ptick() const { return 0; }
 #endif
-    XW_FN TLds *L() const { return xw::lds<TLds>(); }
 
-    // wait for an LDS word of the stage to pass v (word - v > 0 as a signed difference); false: the stage is leaving
-    XW_FN bool wait_lds_gt(const uint32_t *p, uint32_t v)
+    // merge two fronts (each sorted by descending key, at most na / nb entries at pa / pb with stride 1) into out;
+    // entries of b that end before `low` are left out.  Returns the count, or kNone if it exceeds cap.
+    static XW_FN uint32_t merge(const unsigned long long *pa, uint32_t na, const unsigned long long *pb, uint32_t nb, uint32_t low,
+                                unsigned long long *out, uint32_t cap)
+    {
+        while (nb && fr_end(pb[nb - 1]) < low) nb--;            // (ends fall along the list: the expired ones are at its tail)
+        while (na && fr_end(pa[na - 1]) < low) na--;
+        uint32_t ia = 0, ib = 0, no = 0, dmin = kNone;
+        unsigned long long ka = na ? pa[0] : 0, kb = nb ? pb[0] : 0;
+        while (ia < na || ib < nb) {
+            const bool ta = ib >= nb || (ia < na && ka >= kb);
+            const unsigned long long k = ta ? ka : kb;
+            if (ta) { ia++; ka = ia < na ? pa[ia] : 0; } else { ib++; kb = ib < nb ? pb[ib] : 0; }
+            const uint32_t d = fr_dist(k);
+            if (d < dmin) {                                     // not dominated by an entry that ends at least as late
+                if (no >= cap) return kNone;
+                out[no++] = k; dmin = d;
+            }
+        }
+        return no;
+    }
+
+    // pairs of position a into a list (unsorted); returns the count or kNone (more than cap)
+    XW_FN uint32_t gather(uint32_t a, uint32_t cap_len, const uint32_t *rec, unsigned long long *out, uint32_t cap)
+    {
+        uint32_t n = 0;
+        const uint32_t w0 = rec[0], np = w0 & 7u;
+        for (uint32_t k = 0; k < np; k++) {
+            if (n >= cap) return kNone;
+            out[n++] = fr_key(a + rec[3 + 2 * k], rec[2 + 2 * k]);
+        }
+        if (w0 & kFtTop) { if (n >= cap) return kNone; out[n++] = fr_key(a + rec[15], rec[14]); }
+        if (w0 & kFtBt) {
+            // the worker lane's record: the record-setters of the descent, lengths and distances growing along the list
+            // (count and first four pairs in one 64-byte record: requested together)
+            const unsigned long long bi = (unsigned long long)(a - G.batch_a0);
+            const uint32_t *br = G.bt_ready + bi * kBtRec;
+            // (the finder stage saw quad 0 before it wrote this position's record; quads 1..3 were stored before quad 0 and carry a tag:
+            //  looked at again in the rare case that one is not there yet)
+            uint32_t bw[16];
+            for (;;) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) bw[k] = xw::ld_agent(br + k);
+                if ((bw[7] & bw[11] & bw[15] & kBtTag) != 0) break;
+                if (xw::ld_agent(&V.hx->err)) break;
+                xw::pause();
+            }
+            const uint32_t cnt = bw[0] & 0x1FFu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (k >= cnt) continue;
+                const uint32_t d = bw[bt_rec_d(k)], l = bw[bt_rec_l(k)];
+                if (l >= cap_len) continue;                     // as long as the lookahead allows: the finder stage's top entry covers it
+                if (n >= cap) return kNone;
+                out[n++] = fr_key(a + l, d);
+            }
+            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+            for (uint32_t k = 4; k < cnt; k++) {
+                const uint32_t d = xw::ld_agent(pairs + 2 * k), l = xw::ld_agent(pairs + 2 * k + 1);
+                if (l >= cap_len) continue;
+                if (n >= cap) return kNone;
+                out[n++] = fr_key(a + l, d);
+            }
+        }
+        return n;
+    }
+
+    // sort a short list by descending key and drop dominated entries, in place; returns the count
+    static XW_FN uint32_t sort_filter(unsigned long long *v, uint32_t n)
+    {
+        for (uint32_t x = 1; x < n; x++) {
+            const unsigned long long k = v[x];
+            uint32_t y = x;
+            while (y > 0 && v[y - 1] < k) { v[y] = v[y - 1]; y--; }
+            v[y] = k;
+        }
+        uint32_t no = 0, dmin = kNone;
+        for (uint32_t x = 0; x < n; x++) {
+            const uint32_t d = fr_dist(v[x]);
+            if (d < dmin) { v[no++] = v[x]; dmin = d; }
+        }
+        return no;
+    }
+
+    // write the parser's record of position a from its front (fn entries at f, descending)
+    XW_FN void emit(uint32_t a, uint32_t a1, uint32_t lit, const unsigned long long *f, uint32_t fn)
+    {
+        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+        const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
+        uint32_t max_len = umin(mt_max, a1 - a);                // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
+        if (max_len < kMatchMin) max_len = 0;
+        uint32_t ne = 0, uniq = 0, dprev = 0;
+        if (max_len) {
+            uint32_t step = (max_len - kMatchMin) >> 4;         // :1558-1560
+            step += step == 0;
+            uint32_t j = 0;
+            unsigned long long kj = f[0], kn = fn > 1 ? f[1] : 0;
+            unsigned long long held = 0;                        // the edge before, until it goes out with its neighbour
+            for (uint32_t tl = max_len; tl >= kMatchMin; tl -= umin(tl, step)) {
+                while (j + 1 < fn && fr_end(kn) >= a + tl) { j++; kj = kn; kn = j + 1 < fn ? f[j + 1] : 0; }   // the entry with the smallest end >= a + tl
+                const uint32_t d = fr_dist(kj), mm = match_min(d);
+                uint32_t nx, ex;
+                const uint32_t slot = dist_slot(d - 1, nx, ex);
+                const uint32_t valid = tl >= mm ? 1u : 0u, lv = valid ? tl - mm : 0u;
+                const uint32_t at = tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31);
+                if (ne & 1u) xw::st_agent128(rec + kTpEdges + 2 * (ne - 1), (uint32_t)held, (uint32_t)(held >> 32), d, at);
+                else held = (unsigned long long)d | ((unsigned long long)at << 32);
+                if (valid && d != dprev) uniq |= 1u << ne;      // the valid samples that bring a distance the one before did not have
+                if (valid) dprev = d;
+                ne++;
+            }
+            if (ne & 1u) xw::st_agent64((unsigned long long *)(rec + kTpEdges + 2 * (ne - 1)), held);
+        }
+        xw::st_agent128(rec, ne | (lit << 8) | (mt_max << 16), fn, uniq, 0u);
+        for (uint32_t k = 0; k + 1 < fn; k += 2)
+            xw::st_agent128(fo + 2 * k, fr_end(f[k]) - a, fr_dist(f[k]), fr_end(f[k + 1]) - a, fr_dist(f[k + 1]));
+        if (fn & 1u) xw::st_agent64((unsigned long long *)(fo + 2 * (fn - 1)), (unsigned long long)(fr_end(f[fn - 1]) - a) | ((unsigned long long)fr_dist(f[fn - 1]) << 32));
+    }
+
+    XW_FN void capture(uint32_t a, const unsigned long long *f, uint32_t fn);
+
+    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end
+    // wait for an LDS word of the stage to reach v
+    XW_FN bool wait_lds(const uint32_t *p, uint32_t v)
     {
         uint32_t spins = 0;
-        while ((int32_t)(xw::readfirst(xw::lds_ld(p)) - v) <= 0) {
-            if (xw::readfirst(xw::lds_ld(&L()->stop))) return false;
-            if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) { if (xw::lane() == 0) xw::lds_st(&L()->stop, 1u); return false; }
+        while (xw::readfirst(xw::lds_ld(p)) != v) {
+            if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) return false;
             xw::pause();
         }
         xw::after_poll();
         return true;
     }
-    XW_FN void leave(uint32_t site, uint32_t pos)
-    {
-        if (xw::lane() == 0) { xw::lds_st(&L()->stop, 1u); if (!xw::ld_agent(&V.hx->err)) raise(V.hx, kErrInternal + 200, kStTable, site, pos); }
-    }
 
-    // ---- loader -----------------------------------------------------------------------------------------------------
-    // Three steps in flight, 32 positions each (lane = position x 16-byte quad, two positions a lane): the records requested;
-    // a step later written to LDS, and for the positions whose BT4 descent had more than four record-setters the next eight of
-    // them requested (bt_pairs: in memory before the record's ready word, nlzm_core.h); a step later those written, and the
-    // positions said to be staged.
-    XW_FN void run_loader(uint32_t a_first, uint32_t a_last)
+    // positions [a0, a0 + n) of a chunk whose positions end at a1 and whose lookahead ends at la_end; seq: the block's number
+    XW_FN void block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end, uint32_t seq)
     {
-        TLds *Lp = L();
-        const uint32_t i = xw::lane(), pj = i >> 2, qd = i & 3u;
-        uint32_t req = a_first;
-        uint32_t f_seen = a_first, taken = a_first;
-        uint32_t r_n = 0, r_a = 0, x_n = 0, x_a = 0;                // the step whose records / extra pairs are on their way
-        uint32_t fq[2][4] = {}, bq[2][4] = {}, xq[2][4] = {};
-        const unsigned long long t0 = xw::clock100();
-        uint32_t idle = 0;
-        uint32_t staged = a_first;
-        while (staged < a_last) {
-            // ---- extra pairs of the step before the last: into LDS; its positions are staged
-            if (x_n) {
-#pragma unroll
-                for (uint32_t h = 0; h < 2; h++) {
-                    const uint32_t a = x_a + pj + 16 * h;
-                    if (pj + 16 * h < x_n) {
-                        uint32_t *xd = Lp->rec + (a & (kTRecRing - 1)) * kTRecWords + kFtStride + kBtRec + 4 * qd;
-                        xd[0] = xq[h][0]; xd[1] = xq[h][1]; xd[2] = xq[h][2]; xd[3] = xq[h][3];
-                    }
-                }
-                staged = x_a + x_n;
-                xw::wave_sync();
-                if (i == 0) xw::lds_st(&Lp->staged, staged);
-                x_n = 0;
-            }
-            // ---- records of the last step: into LDS (the BT4 record's quads carry a ready bit / a tag: looked at again if one is
-            // not there yet); the extra pairs requested
-            if (r_n) {
-#pragma unroll
-                for (uint32_t h = 0; h < 2; h++) {
-                    const uint32_t a = r_a + pj + 16 * h;
-                    const bool on = pj + 16 * h < r_n;
-                    // (quad 0 of the finder's record says whether a BT4 record belongs to the position; quad 0 of that one how many pairs)
-                    const uint32_t w0 = xw::shfl(fq[h][0], i & ~3u);
-                    if (on && (w0 & kFtBt)) {
-                        const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
-                        uint32_t spins = 0;
-                        while (!((qd ? bq[h][3] : bq[h][0]) & (qd ? kBtTag : kBtReady))) {
-                            bq[h][0] = xw::ld_agent(br); bq[h][1] = xw::ld_agent(br + 1); bq[h][2] = xw::ld_agent(br + 2); bq[h][3] = xw::ld_agent(br + 3);
-                            if ((++spins & 255u) == 0 && xw::ld_agent(&V.hx->err)) break;
-                        }
-                    }
-                    const uint32_t bw0 = xw::shfl(bq[h][0], i & ~3u);
-                    if (on) {
-                        uint32_t *fd = Lp->rec + (a & (kTRecRing - 1)) * kTRecWords + 4 * qd;
-                        fd[0] = fq[h][0]; fd[1] = fq[h][1]; fd[2] = fq[h][2]; fd[3] = fq[h][3];
-                        uint32_t *bd = fd + kFtStride;
-                        bd[0] = bq[h][0]; bd[1] = bq[h][1]; bd[2] = bq[h][2]; bd[3] = bq[h][3];
-                        if ((w0 & kFtBt) && (bw0 & 0x1FFu) > 4) {
-                            // pairs 4 .. 11 of the descent: words 8 .. 23 of the position's pair list
-                            const uint32_t *xp = G.bt_pairs + (unsigned long long)(a - G.batch_a0) * (2 * kBtMaxPairs) + 8 + 4 * qd;
-                            xq[h][0] = xw::ld_agent(xp); xq[h][1] = xw::ld_agent(xp + 1); xq[h][2] = xw::ld_agent(xp + 2); xq[h][3] = xw::ld_agent(xp + 3);
-                        }
-                    }
-                }
-                x_a = r_a; x_n = r_n; r_n = 0;
-                xw::wave_sync();
-                if (i == 0) xw::st_agent(&V.hx->t_pos, x_a + x_n);   // (the ring's records are copied: the finder may overwrite them)
-            }
-            // ---- the next positions: what the finder has written, and what the record ring has room for
-            if ((int32_t)(f_seen - req) <= 0) f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
-            xw::after_poll();
-            taken = kNone;
-            for (uint32_t k = 0; k < kTEmit; k++) taken = umin(taken, xw::readfirst(xw::lds_ld(&Lp->e_taken[k])));
-            const uint32_t lim = umin(f_seen, umin(taken + kTRecRing, a_last));
-            const uint32_t n = (int32_t)(lim - req) > 0 ? umin(kTLoad, lim - req) : 0u;
-            if (n) {
-#pragma unroll
-                for (uint32_t h = 0; h < 2; h++) {
-                    const uint32_t a = req + pj + 16 * h;
-                    if (pj + 16 * h < n) {
-                        const uint32_t *fr = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride + 4 * qd;
-                        fq[h][0] = xw::ld_agent(fr); fq[h][1] = xw::ld_agent(fr + 1); fq[h][2] = xw::ld_agent(fr + 2); fq[h][3] = xw::ld_agent(fr + 3);
-                        const uint32_t *br = G.bt_ready + (unsigned long long)(a - G.batch_a0) * kBtRec + 4 * qd;
-                        bq[h][0] = xw::ld_agent(br); bq[h][1] = xw::ld_agent(br + 1); bq[h][2] = xw::ld_agent(br + 2); bq[h][3] = xw::ld_agent(br + 3);
-                    }
-                }
-                r_a = req; r_n = n; req += n;
-                idle = 0;
-            } else if (!x_n) {
-                if (xw::readfirst(xw::lds_ld(&Lp->stop))) return;
-                if ((++idle & 63u) == 0) {
-                    if (xw::readfirst(xw::ld_agent(&V.hx->err))) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
-#ifndef NLZM_SIM
-                    if (xw::clock100() - t0 > 30000000000ull) { leave(2, req); return; }    // (a launch takes less than 300 s)
-#else
-                    (void)t0;
-#endif
-                }
-                xw::pause();
-            }
-        }
-    }
-
-    // ---- emitters -----------------------------------------------------------------------------------------------------
-    XW_FN void capture(uint32_t a, uint32_t mt_max, const uint32_t *dense);
-#ifdef NLZM_SIM
-    static void sim_on_table(void *user, uint32_t a, uint32_t mt_max, const uint32_t *dense);
-#endif
-    // the chunk of position p: its last position + 1, the end of its lookahead
-    struct Chunk { uint32_t lo, a1, la_end; };
-    XW_FN Chunk chunk_of(uint32_t ci) const
-    {
-        const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
-        const unsigned long long remain = g.n - chunk_abs;
-        const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
-        return Chunk{ (uint32_t)chunk_abs, (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), (uint32_t)chunk_abs + chunk_read };
-    }
-    // the pairs of position q into this wave's G: lanes 1..6 the finder's pairs, lane 7 its top entry, lanes 8..19 the first
-    // twelve record-setters of the BT4 descent (those as long as the lookahead allows are the finder's top entry already); the
-    // largest end among them into *mx (an LDS word of this wave).  Every emitter does this for every position: kept short --
-    // no scalar detour (every lane reads the record's head words itself), no reduction (LDS atomic max).
-    XW_FN void apply_pairs(uint32_t *Gw, uint32_t *mx, uint32_t q, uint32_t la_end)
-    {
-        TLds *Lp = L();
+        TLds *L = xw::lds<TLds>();
+        TWave *W = &L->w[xw::wave()];
         const uint32_t i = xw::lane();
-        const uint32_t cap_len = umin(la_end - q, kMatchMax);
-        const uint32_t *r = Lp->rec + (q & (kTRecRing - 1)) * kTRecWords;
-        const uint32_t w0 = r[0], bw0 = r[kFtStride];
-        const uint32_t np = w0 & 7u, cnt = (w0 & kFtBt) ? (bw0 & 0x1FFu) : 0u;
-        // (where a lane's pair sits in the staged words: the finder's at 2i, 2i + 1; the BT4 record's first four as bt_rec_d / _l say;
-        //  the next eight behind the record)
-        const uint32_t k = i - 8;
-        const uint32_t od = i < 8 ? 2 * i : (i < 12 ? kFtStride + bt_rec_d(k & 3u) : kFtStride + kBtRec + 2 * ((i - 12) & 7u));
-        const uint32_t ol = i < 8 ? 2 * i + 1 : (i < 12 ? kFtStride + bt_rec_l(k & 3u) : od + 1);
-        const uint32_t d = r[od], l = r[ol];
-        const bool ok = i >= 1 && i < 8 + kTInline && (i < 7 ? i - 1 < np : (i == 7 ? (w0 & kFtTop) != 0 : (k < cnt && l < cap_len)));
-        // (the slot of the one end that becomes possible at this position: used 512 ends ago)
-        Gw[(q + kMatchMax) & (kGRing - 1)] = kNone;
-        xw::wave_sync();
-        if (ok) { xw::lds_min(&Gw[(q + l) & (kGRing - 1)], d); xw::lds_max(mx, q + l); }
-        if (NLZM_RARE(xw::any(cnt > kTInline))) {
-            const uint32_t *pairs = G.bt_pairs + (unsigned long long)(q - G.batch_a0) * (2 * kBtMaxPairs);
-            for (uint32_t j = kTInline + i; j < cnt; j += 64) {
-                const uint32_t dk = xw::ld_agent(pairs + 2 * j), lk = xw::ld_agent(pairs + 2 * j + 1);
-                if (lk < cap_len) { xw::lds_min(&Gw[(q + lk) & (kGRing - 1)], dk); xw::lds_max(mx, q + lk); }
+        const bool in_blk = i < n;
+        const uint32_t a = a0 + i;
+        const uint32_t cap_len = in_blk ? umin(la_end - a, kMatchMax) : 0u;
+        const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
+        uint32_t *r = W->recs + i * kFtStride;
+        if (in_blk) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * k));
+                r[2 * k] = (uint32_t)w; r[2 * k + 1] = (uint32_t)(w >> 32);
             }
-            n_slow++;
-        }
-    }
-    XW_FN void emit_position(const uint32_t *Gw, uint32_t p, uint32_t mt_max, uint32_t lit, uint32_t a1)
-    {
-        const uint32_t k = xw::lane();
-        uint32_t *dense = V.tf + (unsigned long long)(p & (kTpRing - 1)) * kTfStride;
-        // ---- delta[l] = min of G from end p + l on: chunk by chunk from the top, lane k of a chunk holds length 64 c + 64 - k
-        uint32_t s0 = kNone, s1 = kNone, s2 = kNone, s3 = kNone, s4 = kNone, carry = kNone;
-        auto chunk = [&](uint32_t c, uint32_t &sv) __attribute__((always_inline)) {
-            if (64 * c >= mt_max) return;
-            const uint32_t at = 64 * c + 63 - k;                    // length - 1 of this lane
-            uint32_t v = at < mt_max ? Gw[(p + 1 + at) & (kGRing - 1)] : kNone;
-            v = umin(xw::scan_min_u32(v), carry);
-            carry = xw::readlane(v, 63);
-            sv = v;
-            // the dense table for the ring: four lengths a lane, 16-byte stores (lane 4j has lengths - 1 = 64c + 60 - 4j ..+3)
-            const uint32_t v1 = xw::quad_bcast<1>(v), v2 = xw::quad_bcast<2>(v), v3 = xw::quad_bcast<3>(v);
-            if ((k & 3u) == 0 && at - 3 < mt_max) xw::st_agent128(dense + at - 3, v3, v2, v1, v);
-        };
-        chunk(4, s4); chunk(3, s3); chunk(2, s2); chunk(1, s1); chunk(0, s0);
-        // ---- the sampled lengths (:1558-1560), lanes = samples
-        uint32_t max_len = umin(mt_max, a1 - p);                    // :1545-1548 (the 4096 cap is the parser's: it knows the segment)
-        if (max_len < kMatchMin) max_len = 0;
-        uint32_t step = (max_len - kMatchMin) >> 4;
-        step += step == 0;
-        const bool on = max_len && k < kMaxEdges && k * step + kMatchMin <= max_len;
-        const uint32_t ne = (uint32_t)__builtin_popcountll(xw::ballot(on));
-        const uint32_t tl = on ? max_len - k * step : 1u;
-        const uint32_t at = tl - 1, src = 63u - (at & 63u), cq = at >> 6;
-        uint32_t d = xw::shfl(s0, src);
-        if (max_len > 64) {
-            const uint32_t d1 = xw::shfl(s1, src); d = cq == 1 ? d1 : d;
-            if (max_len > 128) {
-                const uint32_t d2 = xw::shfl(s2, src), d3 = xw::shfl(s3, src), d4 = xw::shfl(s4, src);
-                d = cq == 2 ? d2 : (cq == 3 ? d3 : (cq == 4 ? d4 : d));
-            }
-        }
-        if (!on) d = 1;
-        const uint32_t mm = match_min(d);
-        uint32_t nx, ex;
-        const uint32_t slot = dist_slot(d - 1, nx, ex);
-        const bool valid = on && tl >= mm;
-        const uint32_t lv = valid ? tl - mm : 0u;
-        const uint32_t aw = on ? (tl | (lv << 9) | (slot << 18) | (nx << 24) | ((valid ? 1u : 0u) << 31)) : 0u;
-        const uint32_t dw = on ? d : 0u;
-        // the valid samples that bring a distance the valid one before did not have
-        const unsigned long long vm = xw::ballot(valid), below = vm & ((1ull << k) - 1ull);
-        const uint32_t dprev = xw::shfl(d, below ? 63u - (uint32_t)__builtin_clzll(below) : k);
-        const uint32_t uniq = (uint32_t)xw::ballot(valid && (!below || d != dprev));
-        // ---- the record: header + mask, and every two samples, as 16-byte stores
-        uint32_t *rec = V.tp + (unsigned long long)(p & (kTpRing - 1)) * kTpStride;
-        const uint32_t dn = xw::shfl(dw, (k + 1) & 63u), an = xw::shfl(aw, (k + 1) & 63u);
-        if ((k & 1u) == 0 && k < ne) xw::st_agent128(rec + kTpEdges + 2 * k, dw, aw, k + 1 < ne ? dn : 0u, k + 1 < ne ? an : 0u);
-        if (k == 0) xw::st_agent128(rec, ne | (lit << 8) | (mt_max << 16), 0u, uniq, 0u);
-        if (G.cap_words) { xw::drain(); capture(p, mt_max, dense); }
-#ifdef NLZM_SIM
+        } else r[0] = 0;
+        const uint32_t lit = (r[0] >> 8) & 0xFFu;
+        W->overflow = 0;
         xw::wave_sync();
-        if (k == 0) sim_on_table(G.hook_user, p, mt_max, dense);
-#endif
-    }
-    XW_FN void run_emitter(uint32_t ek, uint32_t c0, uint32_t c1, uint32_t a_first, uint32_t a_last)
-    {
-        TLds *Lp = L();
-        StateV2 *S = (StateV2 *)V.state;
-        const uint32_t i = xw::lane();
-        uint32_t *Gw = Lp->G[ek];
-        // the window the launch before left: ends a_first + 1 .. a_first + 264, and the largest end so far
-        for (uint32_t k = i; k < kGRing; k += 64) Gw[k] = kNone;
-        xw::wave_sync();
-        const uint32_t had = xw::readfirst(S->front_n);
-        for (uint32_t k = i; k < kFrontMax && had; k += 64) Gw[(a_first + 1 + k) & (kGRing - 1)] = S->front[k];
-        if (i == 0) Lp->maxend[ek] = had ? S->front[kFrontMax] : 0u;
-        xw::wave_sync();
-        uint32_t p_seen = a_first, staged_seen = a_first;
-        uint32_t own = a_first + ek;                                // this wave's next position
-        uint32_t since = 0;                                         // positions written since this wave's stores were last waited for
-        uint32_t ci = c0;
-        Chunk ch = chunk_of(ci);
-        for (uint32_t q = a_first; q < a_last; q++) {
-            if (q >= ch.a1) { ci++; ch = chunk_of(ci); }
-            const unsigned long long q0 = ptick();
-            if ((int32_t)(staged_seen - q) <= 0) {
-                // (while there is nothing to do: what was written goes out)
-                if (since && (int32_t)(xw::readfirst(xw::lds_ld(&Lp->staged)) - q) <= 0) { publish(ek, own_next(ek, q, a_first), a_last); since = 0; }
-                if (!wait_lds_gt(&Lp->staged, q)) return;
-                staged_seen = xw::readfirst(xw::lds_ld(&Lp->staged));
-            }
-            const unsigned long long q1 = ptick();
-            apply_pairs(Gw, &Lp->maxend[ek], q, ch.la_end);
-            const bool mine = q == own;
-            // (the position's byte, while its record is still this wave's to read: the word below frees the slot for the loader)
-            const uint32_t lit = mine ? (xw::readfirst(Lp->rec[(q & (kTRecRing - 1)) * kTRecWords]) >> 8) & 0xFFu : 0u;
-            if ((q & 15u) == 15u || mine) { xw::wave_sync(); if (i == 0) xw::lds_st(&Lp->e_taken[ek], q + 1); }
-            const unsigned long long q2 = ptick();
-            tt2 += q1 - q0; tt0 += q2 - q1;
-            if (!mine) continue;
-            // ---- this wave's position: room in the parser's ring, then the record
-            if ((int32_t)(q + 1 - p_seen - kTpRing) > 0) {
-                if (since) { publish(ek, q, a_last); since = 0; }      // (q is this wave's own position)
-                if (!wait_word_ge(&V.hx->p_pos, q + 1 - kTpRing, V.hx, 3)) { if (i == 0) xw::lds_st(&Lp->stop, 1u); return; }
-                p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
-            }
-            xw::wave_sync();
-            own += kTEmit;
-            const uint32_t maxend = xw::readfirst(xw::lds_ld(&Lp->maxend[ek]));
-            emit_position(Gw, q, (int32_t)(maxend - q) > 0 ? maxend - q : 0u, lit, ch.a1);
-            n_pos++;
-            // the stores of a position take microseconds to land: waited for once every few positions, then all of them are said to be out
-            if (++since == kTDrainEvery) { publish(ek, q + kTEmit, a_last); since = 0; }
-            tt1 += ptick() - q2;
-        }
-        // (nothing of this wave is left: its word no longer holds the others back)
-        publish(ek, kNone, a_last);
-        if (i == 0) xw::lds_st(&Lp->e_taken[ek], kNone);
-        if (ek == 0) {
-            // the window for the launch to come (every emitter has applied every position: this one says so)
-            xw::wave_sync();
-            for (uint32_t k = i; k < kFrontMax; k += 64) S->front[k] = Gw[(a_last + 1 + k) & (kGRing - 1)];
-            if (i == 0) { S->front[kFrontMax] = Lp->maxend[ek]; S->front_n = 1; }
-        }
-    }
-    // the first position from q on that is emitter ek's
-    XW_FN static uint32_t own_next(uint32_t ek, uint32_t q, uint32_t a_first) { const uint32_t r = (q - a_first) % kTEmit; return q + (ek >= r ? ek - r : ek + kTEmit - r); }
-    // this wave's records of its positions below `next` (one of its own, or beyond the end) are in memory: with the other emitters'
-    // words, how far the parser may read
-    XW_FN void publish(uint32_t ek, uint32_t next, uint32_t a_last)
-    {
-        TLds *Lp = L();
         const unsigned long long q0 = ptick();
+        // the position's own pairs as a front
+        unsigned long long *mine = W->fr[0] + i * kFrCap;
+        uint32_t cnt = 0;
+        if (in_blk) {
+            cnt = gather(a, cap_len, r, mine, kFrCap);
+            if (cnt == kNone) { W->overflow = 1; cnt = 0; }
+            else cnt = sort_filter(mine, cnt);
+        }
+        const unsigned long long q1 = ptick();
+        // prefix scan: after the step with offset D lane i holds the front of the pairs of lanes (i - 2D, i]
+        uint32_t cur = 0;
+        for (uint32_t D = 1; D < 64; D <<= 1) {
+            xw::wave_sync();
+            const uint32_t ocnt = xw::shfl_up(cnt, D);
+            unsigned long long *dst = W->fr[cur ^ 1] + i * kFrCap;
+            const unsigned long long *own = W->fr[cur] + i * kFrCap;
+            uint32_t nn;
+            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + 1, dst, kFrCap);
+            else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
+            if (nn == kNone) { W->overflow = 1; nn = 0; }
+            cnt = nn;
+            cur ^= 1;
+        }
+        xw::wave_sync();
+        const unsigned long long q2 = ptick();
+        // ---- from here on in block order: the front carried into the block
+        if (!wait_lds(&L->carry_seq, seq)) { err = 1; return; }
+        const unsigned long long q3 = ptick();
+        const uint32_t cn = xw::readfirst(L->carry_n);
+        unsigned long long *fin_f = W->fr[cur ^ 1] + i * kFrCap;
+        uint32_t fn = 0;
+        if (in_blk) {
+            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + 1, fin_f, kFrCap);
+            if (fn == kNone) { W->overflow = 1; fn = 0; }
+        }
+        xw::wave_sync();
+        n_blocks++;
+        if (xw::readfirst(W->overflow)) slow_block(a0, n, a1, la_end);
+        else {
+            if (in_blk) emit(a, a1, lit, fin_f, fn);
+            if (G.cap_words) {
+                for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
+            }
+#ifdef NLZM_SIM
+            if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
+#endif
+            // carry out: the last position's front
+            const uint32_t last_n = xw::readlane(fn, n - 1);
+            for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = W->fr[cur ^ 1][(n - 1) * kFrCap + k];
+            if (i == 0) L->carry_n = last_n;
+        }
         xw::drain();
         xw::wave_sync();
-        if (xw::lane() == 0) xw::lds_st(&Lp->e_done[ek], next);
-        xw::wave_sync();
-        uint32_t m = kNone;
-        for (uint32_t k = 0; k < kTEmit; k++) m = umin(m, xw::readfirst(xw::lds_ld(&Lp->e_done[k])));
-        if (m > a_last) m = a_last;
-        if (xw::lane() == 0) xw::st_agent(&V.hx->t_out, m);
-        tt3 += ptick() - q0;
+        if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->carry_seq, seq + 1); }
+        tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += ptick() - q3;
     }
+
+    // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
+    XW_FN void slow_block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
+    {
+        TLds *L = xw::lds<TLds>();
+        TWave *W = &L->w[xw::wave()];
+        n_slow++;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t a = a0 + j;
+            const uint32_t cap_len = umin(la_end - a, kMatchMax);
+            const uint32_t *rec = V.ft + (unsigned long long)(a & (kFtRing - 1)) * kFtStride;
+            uint32_t *r = W->recs;
+            if (xw::lane() < 8) {
+                const unsigned long long w = xw::ld_agent64((const unsigned long long *)(rec + 2 * xw::lane()));
+                r[2 * xw::lane()] = (uint32_t)w; r[2 * xw::lane() + 1] = (uint32_t)(w >> 32);
+            }
+            xw::wave_sync();
+            unsigned long long *t0 = L->tmp, *t1 = L->tmp + 300;
+            if (xw::lane() == 0) {
+                uint32_t c = gather(a, cap_len, r, t0, 300);    // <= 7 + 256 pairs
+                c = sort_filter(t0, c);
+                const uint32_t fn = merge(t0, c, L->carry, L->carry_n, a + 1, t1, kFrontMax + 8);
+                for (uint32_t k = 0; k < fn; k++) L->carry[k] = t1[k];
+                L->carry_n = fn;
+                emit(a, a1, (r[0] >> 8) & 0xFFu, L->carry, fn);
+#ifdef NLZM_SIM
+                sim_on_front(G.hook_user, a, L->carry, fn);
+#endif
+            }
+            xw::wave_sync();
+            if (G.cap_words) capture(a, L->carry, xw::readfirst(L->carry_n));
+        }
+    }
+
+#ifdef NLZM_SIM
+    static void sim_on_front(void *user, uint32_t a, const unsigned long long *f, uint32_t fn);
+#endif
 
     XW_FN void run(uint32_t c0, uint32_t c1)
     {
-        TLds *Lp = L();
+        TLds *L = xw::lds<TLds>();
+        StateV2 *S = (StateV2 *)V.state;
         const uint32_t i = xw::lane(), w = xw::wave();
         const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
-        unsigned long long a_last64 = (unsigned long long)c1 * g.chunk_size;
-        if (a_last64 > g.n) a_last64 = g.n;
-        const uint32_t a_last = (uint32_t)a_last64;
-        if (w == 0 && i == 0) {
-            Lp->staged = a_first; Lp->stop = 0;
-            for (uint32_t k = 0; k < kTEmit; k++) { Lp->e_done[k] = a_first + k; Lp->e_taken[k] = a_first; }
+        unsigned long long a_last = (unsigned long long)c1 * g.chunk_size;
+        if (a_last > g.n) a_last = g.n;
+        if (w == 0) {
+            const uint32_t cn = xw::readfirst(S->front_n);
+            for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
+            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->stop = 0; }
         }
         xw::block_sync();
-        err = 0;
+        err = 0; n_blocks = n_slow = 0; t_wait = 0;
         const unsigned long long t_start = xw::tick();
-        if (w == 0) run_loader(a_first, a_last);
-        else run_emitter(w - 1, c0, c1, a_first, a_last);
-        xw::block_sync();
-        if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {         // where this stage was when it left
-            uint32_t *d = V.hx->dbg[1];
-            xw::st_agent(d + 0, xw::lds_ld(&Lp->staged)); xw::st_agent(d + 1, xw::lds_ld(&Lp->e_taken[0])); xw::st_agent(d + 2, xw::lds_ld(&Lp->e_done[0]));
-            xw::st_agent(d + 3, xw::lds_ld(&Lp->e_done[1])); xw::st_agent(d + 4, xw::lds_ld(&Lp->stop)); xw::st_agent(d + 5, 0u);
+        uint32_t p_seen = a_first, f_seen = a_first;
+        for (uint32_t seq = w; !err; seq += kTW) {
+            // ---- take the next block (in turn)
+            const unsigned long long tw = xw::tick();
+            if (!wait_lds(&L->turn, seq)) { err = 1; break; }
+            const uint32_t a = xw::readfirst(xw::lds_ld(&L->cursor));
+            if ((unsigned long long)a >= a_last) { if (i == 0) xw::lds_st(&L->turn, seq + 1); break; }
+            const uint32_t ci = a / g.chunk_size;
+            const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
+            const unsigned long long remain = g.n - chunk_abs;
+            const uint32_t chunk_read = (uint32_t)(remain < g.feed ? remain : g.feed);
+            const uint32_t a1 = (uint32_t)chunk_abs + umin(g.chunk_size, chunk_read), la_end = (uint32_t)chunk_abs + chunk_read;
+            if ((int32_t)(f_seen - a) <= 0) {
+                if (!wait_word_ge(&V.hx->f_pos, a + 1, V.hx, 2)) { err = 1; break; }
+            }
+            f_seen = xw::readfirst(xw::ld_agent(&V.hx->f_pos));
+            xw::after_poll();
+            const uint32_t n = umin(64u, umin(a1, f_seen) - a);
+            if ((int32_t)(a + n - p_seen - kTpRing) > 0) {
+                if (!wait_word_ge(&V.hx->p_pos, a + n - kTpRing, V.hx, 3)) { err = 1; break; }
+                p_seen = xw::readfirst(xw::ld_agent(&V.hx->p_pos));
+            }
+            if (i == 0) { xw::lds_st(&L->cursor, a + n); xw::lds_st(&L->turn, seq + 1); }
+            t_wait += xw::tick() - tw;
+            block(a, n, a1, la_end, seq);
+            xw::trace(3, a, n);
         }
-        if (i == 0 && w >= 1) {     // accounting
+        if (err && i == 0) raise(V.hx, kErrInternal + 200, kStTable, 9, xw::lds_ld(&L->cursor));   // (only if no stage has raised anything: the first code stays)
+        xw::block_sync();
+        if (w == 0 && i == 0 && xw::ld_agent(&V.hx->err)) {     // where this stage was when it left
+            uint32_t *d = V.hx->dbg[1];
+            xw::st_agent(d + 0, xw::lds_ld(&L->cursor)); xw::st_agent(d + 1, xw::lds_ld(&L->turn)); xw::st_agent(d + 2, xw::lds_ld(&L->carry_seq));
+            xw::st_agent(d + 3, f_seen); xw::st_agent(d + 4, p_seen); xw::st_agent(d + 5, L->carry_n);
+        }
+        if (i == 0) {       // accounting: summed over the waves
             unsigned long long *pr = G.persist->prof;
-            xw::atomic_add64_agent(&pr[6], n_pos); xw::atomic_add64_agent(&pr[7], n_slow);
-            xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1); xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
-            if (w == 1) { xw::atomic_add64_agent(&pr[18], tt2 + tt3); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
+            xw::atomic_add64_agent(&pr[6], n_blocks); xw::atomic_add64_agent(&pr[7], n_slow);
+            xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
+            xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
+            if (w == 0) { xw::atomic_add64_agent(&pr[18], t_wait); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
+        }
+        if (w == 0) {
+            const uint32_t on = xw::readfirst(L->carry_n);
+            for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
+            if (i == 0) S->front_n = on;
         }
     }
 };
 
-// stage test tap: {position, max_len, delta[2..max_len]} (what the reference copies into mt_carry, :1543).  The emitters finish
-// positions out of order; the tap's words are claimed with an atomic and the host sorts by position.
-XW_FN void Table::capture(uint32_t a, uint32_t mt_max, const uint32_t *dense)
+// stage test tap: {position, max_len, delta[2..max_len]} (what the reference copies into mt_carry, :1543)
+XW_FN void Table::capture(uint32_t a, const unsigned long long *f, uint32_t fn)
 {
     if (a < G.cap_lo || a >= G.cap_hi) return;
+    const uint32_t mt_max = fn ? fr_end(f[0]) - a : 0u;
+    const unsigned long long used = xw::readfirst64(*G.cap_used);
     const unsigned long long need = 2 + (mt_max >= 2 ? mt_max - 1 : 0);
-    unsigned long long used = 0;
-    if (xw::lane() == 0) used = xw::atomic_fetch_add64_agent(G.cap_used, need);
-    used = xw::readfirst64(used);
     if (used + need > G.cap_cap) { err = kErrCapture; if (xw::lane() == 0) raise(V.hx, kErrCapture, kStTable, 10, a); return; }
     if (xw::lane() == 0) { G.cap_words[used] = a; G.cap_words[used + 1] = mt_max; }
-    for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) G.cap_words[used + l] = xw::ld_agent(dense + tf_index(l));
+    for (uint32_t l = 2 + xw::lane(); l <= mt_max; l += 64) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < fn; k++) if (fr_end(f[k]) >= a + l) d = fr_dist(f[k]);    // the last entry that still reaches
+        G.cap_words[used + l] = d;
+    }
     xw::drain();
+    if (xw::lane() == 0) *G.cap_used = used + need;
+    xw::drain();
+    xw::wave_sync();
 }
+
 
 // =================================================================================================
 // parser stage
 // =================================================================================================
 // parse_table (:1464-1651) visits the nodes of a segment in order; node p takes the literal edge of p-1, then relaxes
 // its own sampled-length edges (dict, then rep where the distance is in the node's rep set) and its explicit rep
-// probes, all with strict '>'.  The stage does the same, IN ORDER, with the lanes of ONE wave as the TARGETS:
+// probes, all with strict '>'.  For a target node the candidates therefore arrive ordered by (source, rank inside the
+// source) and the first of the cheapest wins: the winner is the minimum of key = cost << 32 | source << 8 | rank.
 //
-//   chain (wave 0)      lane L holds the state of the one node t with t % 64 == L among the 64 nodes from the next one to
-//                       be processed on: cost, winning edge (source, sampled edge, dict / rep), its distance, and the rep
-//                       set the node would have (RepModel::Add applied to the source's set, :1160-1171).  Processing node
-//                       n: its cost and rep set are read off lane n % 64 (v_readlane), the lane is retired (final state
-//                       to LDS) and becomes node n + 64; every lane reads ITS entry of node n's row -- the edge of length
-//                       (L - n) mod 64, priced ahead of time -- and takes it if it is strictly cheaper than what it holds:
-//                       one compare per lane and node, every edge is relaxed exactly once, no atomics, no passes.  The
-//                       candidates of a target arrive in the reference's order (sources ascending; dict before rep), so
-//                       "strictly cheaper" is the reference's rule.  Edges longer than 64 (rare: max_len > 64) go through
-//                       a ring of keys in LDS (far[]) that a lane takes over when its node enters the window.
-//   rows (waves 3,5,6,7)  the table stage's record of a node -> a row of 64 entries {distance, dict price | rep price | edge},
-//                       entry l-1 = the sampled edge of length l (prices are constant inside a segment, :1491, :1567,
-//                       :1585), the literal edge at entry 0; the node's distinct distances for the probes' "already met"
-//                       test; within 264 of the forced cut the lengths are re-listed from the position's front (:1545).
-//                       Prepared up to 128 nodes ahead of the chain.
-//   probes (waves 1..2) the explicit rep probes (:1598-1628) need the node's rep set, which only the chain knows, and
-//                       bytes from HBM.  The chain does NOT wait for them: it goes on as if no probe found a match (18 % of
-//                       the nodes have one, 0.07 % have one that changes anything), and these waves follow it: for every
-//                       retired node the four probes are made (lanes = node x slot, 16 nodes per wave step) and each match
-//                       becomes an edge (key = cost << 32 | source << 8 | rank, the reference's order of candidates).
-//   decide (per step)   a step = up to 64 nodes.  When the chain has stopped and the probes of the step's nodes are in: a
-//                       probe edge whose target is still ahead is merged into the chain's state (far[]); one whose target
-//                       was retired is compared with the target's final key -- smaller means the chain would have gone
-//                       differently: the step is done again from its saved start state with the step's probe edges handed
-//                       to the chain (applied at their node, after its sampled edges, as the reference does).  Rare, exact.
-//   loader (wave 4)     the table stage's records staged in LDS ahead of everybody (as before).
-// Then backtrack and EMISSION on all eight waves (lanes = commands), unchanged.
+// The state of node t (cost, winning edge, rep set, inside the segment or not) is a function of the states of the
+// nodes < t alone, so the segment's states are the unique fixed point of "recompute every node from the others".
+// A block of up to 64 nodes is iterated to that fixed point with the lanes as NODES (Jacobi passes):
+//   push    every node relaxes its edges from its state of the previous pass: 64-bit LDS atomic min per edge, the
+//           sampled edges split over three waves, the explicit rep probes on a fourth;
+//   update  keys -> costs through the literal edges by a (min,+) prefix scan, membership by a prefix max of the
+//           edges' reach, rep sets from the winners' sources;
+// until a pass changes nothing.  A node is right after pass k if its winner chain has at most k match edges inside
+// the block; literal runs cost no pass.  Then the block's edges that end beyond it are merged into the keys of the
+// nodes to come, and the next block starts.
 constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
-constexpr uint32_t kPW = 8;                     // waves of the stage
+constexpr uint32_t kPW = 8;                     // waves of the stage.  A node has up to 32 sampled edges, nearly always fewer than 16:
+constexpr uint32_t kEdgesPerWave = 5;           //   waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
+                                                //   ahead), waves 0..3 four of the rare ones each and make the explicit probe of rep slot w
+NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
+{
+    if (w < 4) return j < 4 ? 16 + w + 4 * j : kMaxEdges;
+    if (w < 7) return (w - 4) + 3 * j;
+    return j == 0 ? 15u : kMaxEdges;
+}
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
-constexpr uint32_t kPumpLoads = 8;              // loads per lane and step of the loader wave ...
-constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: 24 records a step, two steps in flight
+constexpr uint32_t kGatherNodes = 32, kGatherRounds = 3;   // a block waits this many loader steps for this many records before it runs shorter
+constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave ...
+constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: twelve records a step
 constexpr uint32_t kInf = 0x3FFFFFFFu;
-constexpr uint32_t kRowRing = 128;              // nodes whose rows are kept: the step being parsed and what is prepared ahead
-constexpr uint32_t kFarRing = 512;              // keys of the nodes beyond the chain's window; final states of the last nodes
-constexpr uint32_t kStepMax = 64;               // nodes a step covers at most
-constexpr uint32_t kStepWant = 32;              // ... and the rows the chain waits for (a bounded time) before it starts one
-constexpr uint32_t kLitMark = 0xFFFFFF00u;      // "distance" of the literal edge: this | the byte (no distance is that large)
-constexpr uint32_t kVerifyWaves = 2, kPrepWaves = 4;    // waves 1..2; 3, 5, 6, 7
-constexpr uint32_t kLoaderWave = 4;             // (a workgroup's waves go to the SIMDs in turn: wave 4 shares wave 0's, and the loader sleeps most of the time)
-constexpr uint32_t kVBatch = 16;                // nodes per step of a probe wave (four lanes each)
-constexpr uint32_t kVMax = 4 * kStepMax;        // probe edges a step can have
-constexpr uint32_t kInfoFar = 1u << 15;         // node info: max_len (bits 0..8) | distinct distances << 9 | has edges longer than 64
-// row entry: low word the distance, high word
-constexpr uint32_t kRowValid = 1u << 31;        //   dict price (13 bits) | rep price << 13 | sampled edge << 26 | valid
-// link of a lane / a retired node: source | rep << 13 | explicit probe << 14 | sampled edge (or rep slot of a probe) << 26
-constexpr uint32_t kLinkRep = 1u << 13, kLinkProbe = 1u << 14;
-
-struct PFin { uint32_t r[4]; uint32_t cost, link, wdist, pad; };        // a retired node: rep set, final cost, winner
-struct PVEdge { unsigned long long key; uint32_t r; uint32_t info; };   // a probe's match: key, distance, node | length << 13 | slot << 22
-struct PCtl {
-    uint32_t n_s;                               // the step starts at this node; everything before it is final
-    uint32_t stop;                              // chain: 0 while it runs, then 1 + the node it stopped at
-    uint32_t done;                              // chain: nodes below this are retired (in this attempt)
-    uint32_t end_p;                             // chain, with stop: the segment's end so far (:1550-1554)
-    uint32_t vcount;                            // probe edges of the attempt
-    uint32_t xcount;                            // ... of the attempt before, handed to the chain when the step is done again
-    uint32_t redo, seg_len, end_snap;
-    uint32_t far_hi, far_hi_snap;               // no node beyond this one has a key in far[]
-    uint32_t prep_cur[kPrepWaves];              // rows: wave p has prepared its nodes (n % 4 == p) below this
-};
+constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
 struct PLds {
-    unsigned long long row[kRowRing * 64];      // node n, edge of length l, at [(n & 127) * 64 + (n + l) % 64]: the target's lane
-    unsigned long long far[kFarRing], far_snap[kFarRing];   // node t at [t & 511]: best key of the edges that jump over the window
-    uint32_t far_d[kFarRing], far_d_snap[kFarRing];         // ... and the distance of that edge (sampled edges; a probe's is in its source's set)
-    PFin fin[kFarRing];                         // node n at [n & 511]
-    uint32_t snap[7 * 64];                      // the chain's registers at the start of the step
-    uint32_t dd[kRowRing * 8];                  // the first eight distinct distances of a node's valid sampled edges
-    uint32_t ninfo[kRowRing];
-    PVEdge vlist[kVMax], extras[kVMax];
-    PCtl ctl;
-    uint32_t sh[16];                            // 4 error, 12..15 model rep set after the segment
-    uint16_t node_link[kParseMax + 2];          // final nodes: length (0: literal) | cmd << 9 | rep index << 11
+    unsigned long long mprev[512];              // node n at [n & 511]: best key over the edges of finished blocks
+    unsigned long long mcur[3][512];            // ... over the edges of the block being iterated: pass p relaxes into [p % 3]
+    uint32_t nrep[512 * 4];                     // rep set of the nodes of finished blocks (CarriedState ring, :1460-1467)
+    uint32_t brep[2][64 * 4];                   // ... of the block's nodes after pass p at [p & 1]
+    uint32_t edge_d[512 * kMaxEdges];           // distances of the sampled edges of position a at [(a & 511) * 32 + k]
+    uint32_t reach[3][64];                      // furthest node an edge or probe of the node ends at, as pass p found it at [p % 3]
+    uint32_t sh[16];                            // wave 0 -> all: 0 block size, 4 error, 5 price tables stale, 6 / 9 bytes of literal edges across
+                                                //   block borders, 10 / 11 price, cost of the literal edge out of the block, 12..15 model rep set; 1: staged records end here
+    uint32_t node_link[kParseMax + 2];          // final nodes: from | len << 13 | cmd << 22 | rep index << 24
     uint32_t node_delta[kParseMax + 2];         // distance (dict, rep), the byte (literal)
     uint16_t cdf[kNumCtx * kCdfStride];
     uint16_t price[kNumCtx * 16];               // log2_lut[freq >> 6] per (context, symbol) (:435-438)
@@ -1202,14 +1147,14 @@ struct PLds {
     uint16_t slot_price[4 * 64];                // price of the two distance-slot symbols by (length class, slot) (:1245-1248)
     uint32_t ncmds;
     uint32_t bitbuf[64];                        // raw bits of a batch of commands (wave 7)
-    uint32_t dbgw[4];                           // error dump: the segment being parsed, its step, the node count so far
-    unsigned long long acc[11];                 // cycles waited / emitting / in set-up / in the chain; steps, attempts, ...
+    uint32_t dbgw[4];                           // error dump: the segment being parsed, its block, the node count so far
+    unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
-    uint32_t stg[5];                            // 4: the loader wave has staged the records below this position (0..3 unused)
-    unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current step on, loaded ahead
-                                                //   by the loader wave (position a at [((a - launch start) & 127) * kStageQ])
-    // the path of a parsed segment (node indices, end first) lives in the rows: nothing reads a row between a parse and its emission
-    XW_FN uint16_t *cmdlist() { return (uint16_t *)&row[0]; }
+    uint32_t stg[5];                            // loader wave: records requested up to / written up to this position, (2 unused), records of the last step; 4: records staged up to here
+    unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
+                                                //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
+    // the path of a parsed segment (node indices, end first) lives in mcur: nothing relaxes between a parse and its emission
+    XW_FN uint16_t *cmdlist() { return (uint16_t *)&mcur[0][0]; }
     Counters cnt;
 };
 
@@ -1222,20 +1167,20 @@ struct Parser {
     uint32_t t_out_seen;
     uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
-    // wave kLoaderWave: the loader of the record stage (8-byte words counted from the launch's first position)
-    uint32_t pend_t[2];                         // (t_out as read with a step's loads)
-    unsigned long long pend_v[2][kPumpLoads];
-    uint32_t ld_req, ld_wr, ld_n[2], ld_turn;    // records requested / written up to this position; records a set's loads are for; the set whose turn it is
+    // wave kPW-1: the loader of the record stage (8-byte words counted from the launch's first position)
+    uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
+    unsigned long long pend_v[kPumpLoads];
     // frame writer (CodeFrame, :490-513)
     uint32_t *fsyms; uint8_t *fbits;
     uint32_t nsyms, nbits, word, word_bits, num_ops;       // (every wave follows the counts; `word`, the bits of the byte not yet full, is wave 7's)
     uint32_t err;
-    uint32_t n_eq_rounds;                       // (per launch)
+    uint32_t n_eq_fill, n_eq_rounds;            // (per launch)
     uint32_t n_cmp;                             // (per lane and launch: well below 2^32)
-    // the stage's accounting lives in LDS (L()->acc: it is touched once a step or less, and scalar registers are short)
+    unsigned long long t_s[7] = {}, t_q[5] = {};
+    // the stage's accounting lives in LDS (L()->acc: it is touched once a block or less, and scalar registers are short)
     enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccNeed, kAccAhead, kAccN };
     XW_FN void acc(uint32_t k, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(&L()->acc[k], v); }
-    unsigned long long t_q[6] = {};             // profile build, wave 0: start of a step, chain, waiting for the others, decide; nodes, far / extra paths
+    unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
 #else
@@ -1354,7 +1299,7 @@ struct Parser {
                 const uint32_t node = L()->cmdlist()[k0 - 1 - e];
                 const uint32_t link = L()->node_link[node];
                 dv = L()->node_delta[node];
-                cmd = (link >> 9) & 3u; len = link & 0x1FFu; idx = link >> 11;
+                cmd = (link >> 22) & 3u; len = (link >> 13) & 0x1FFu; idx = link >> 24;
             }
             const bool islit = cmd == 0, ismatch = cmd == 1, isrep = cmd == 2, haslen = ismatch || isrep;
             const uint32_t lv = haslen ? len - match_min(dv) : 0u;  // :1281, :1350
@@ -1427,52 +1372,43 @@ struct Parser {
         }
     }
 
-    // ---- the record stage (wave kLoaderWave).  One step: what was requested by the last step goes into LDS, the next 64 words are
+    // ---- the record stage (wave kPW-1).  One step: what was requested by the last step goes into LDS, the next 64 words are
     // requested (positions below the table stage's t_out as the last step saw it, and below lo + 128: lo is the first
     // position still needed), t_out is requested again.  Nothing is waited for here except the last step's loads.
-    XW_FN unsigned long long *staged(uint32_t a) const { return L()->stage + (a & (kStagePos - 1)) * kStageQ; }
-    XW_FN uint32_t staged_hi() const { return xw::readfirst(xw::lds_ld(&L()->stg[4])); }
-    // Two such steps are in flight (two sets of load registers taken in turn: 48 records), so that a step's loads have a whole
-    // other step to arrive in.
-    template <uint32_t kSet> XW_FN void pump_set(uint32_t lo)
+    XW_FN const unsigned long long *staged(uint32_t a) const { return L()->stage + (a & (kStagePos - 1)) * kStageQ; }
+    XW_FN uint32_t staged_hi() const { return xw::readfirst(L()->stg[4]); }
+    XW_FN void pump(uint32_t lo)
     {
         // (counted in records: a load instruction fetches the 18 words of three records on lanes 0..53, so that a lane's
         //  place in a record is the same in every step and no step divides by 18)
         const uint32_t i = xw::lane();
         const uint32_t ri = i / kStageQ, wi = i - ri * kStageQ;
         const bool on = i < kPumpRecs * kStageQ;
-        const uint32_t pend_n = ld_n[kSet];
+        uint32_t st_req = xw::readfirst(L()->stg[0]), st_wr = xw::readfirst(L()->stg[1]);
+        const uint32_t pend_n = xw::readfirst(L()->stg[3]);
         if (pend_n) {
 #pragma unroll
             for (uint32_t u = 0; u < kPumpLoads; u++) {
                 const uint32_t rr = kPumpRecs * u + ri;
-                if (on && rr < pend_n) L()->stage[((ld_wr + rr) & (kStagePos - 1)) * kStageQ + wi] = pend_v[kSet][u];
+                if (on && rr < pend_n) L()->stage[((st_wr + rr) & (kStagePos - 1)) * kStageQ + wi] = pend_v[u];
             }
-            ld_wr += pend_n;
+            st_wr += pend_n;
         }
-        t_out_seen = xw::readfirst(pend_t[kSet]);                   // (as this set's last step read it)
+        t_out_seen = xw::readfirst(pend_t);
         xw::after_poll();
         uint32_t lim = lo + kStagePos;
         if ((int32_t)(t_out_seen - lim) < 0) lim = t_out_seen;
-        const uint32_t n = (int32_t)(lim - ld_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - ld_req) : 0u;
+        const uint32_t n = (int32_t)(lim - st_req) > 0 ? umin(kPumpRecs * kPumpLoads, lim - st_req) : 0u;
         const uint32_t wsrc = wi == 0 ? 0u : (wi == kStageQ - 1 ? kTpUniq / 2 : kTpEdges / 2 + wi - 1);   // (staged: header, sixteen edges, mask)
 #pragma unroll
         for (uint32_t u = 0; u < kPumpLoads; u++) {
             const uint32_t rr = kPumpRecs * u + ri;
             if (on && rr < n)
-                pend_v[kSet][u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)((ld_req + rr) & (kTpRing - 1)) * kTpStride) + wsrc);
+                pend_v[u] = xw::ld_agent64((const unsigned long long *)(V.tp + (unsigned long long)((st_req + rr) & (kTpRing - 1)) * kTpStride) + wsrc);
         }
-        pend_t[kSet] = xw::ld_agent(&V.hx->t_out);
-        ld_n[kSet] = n; ld_req += n;
-        xw::wave_sync();                                            // (the records are in LDS before the word that says so)
-        if (i == 0) xw::lds_st(&L()->stg[4], ld_wr);
+        pend_t = xw::ld_agent(&V.hx->t_out);
+        if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[3] = n; L()->stg[4] = st_wr; }
     }
-    XW_FN void pump(uint32_t lo)
-    {
-        if (ld_turn) pump_set<1>(lo); else pump_set<0>(lo);
-        ld_turn ^= 1u;
-    }
-    XW_FN bool pump_idle() const { return ld_n[0] + ld_n[1] == 0; }
     // until the record of position a is staged (false: another stage failed, or the wait timed out)
     XW_FN bool stage_need(uint32_t a)
     {
@@ -1494,15 +1430,60 @@ struct Parser {
                 (void)t0;
 #endif
             }
-            if (pump_idle()) xw::pause();
+            if (!xw::readfirst(L()->stg[3])) xw::pause();
         }
         acc(kAccWait, xw::tick() - tw);
         acc(kAccNeed, 1); acc(kAccAhead, t_out_seen - a);             // (how far the table stage was ahead when this stage had to wait for its loader)
         return ok;
     }
 
+    // The segment is within 264 of its forced cut (:1469): the sampled lengths of position a change with the smaller
+    // max_len (:1545, :1558-1560).  Re-listed from the position's front into its ring record (lanes = samples; the
+    // record is this stage's until p_pos passes it).
+    XW_FN void resample(uint32_t a, uint32_t max_len)
+    {
+        acc(kAccRedo, 1);
+        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        const unsigned long long h = xw::readfirst64(xw::ld_agent64((const unsigned long long *)rec));
+        const uint32_t fn = (uint32_t)(h >> 32);
+        const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+        uint32_t step = (max_len - kMatchMin) >> 4;
+        step += step == 0;
+        const uint32_t k = xw::lane();
+        uint32_t ne = 0;
+        if (max_len >= kMatchMin) ne = (max_len - kMatchMin) / step + 1;
+        uint32_t d = 0, valid = 0;
+        if (k < ne) {
+            const uint32_t tl = max_len - k * step;
+            for (uint32_t j = 0; j < fn; j++) {                     // the last entry (smallest end) that still has >= tl bytes
+                const unsigned long long e = xw::ld_agent64((const unsigned long long *)(fo + 2 * j));
+                if ((uint32_t)e >= tl) d = (uint32_t)(e >> 32);
+            }
+            const uint32_t mm = match_min(d);
+            uint32_t nx, ex;
+            const uint32_t slot = dist_slot(d - 1, nx, ex);
+            valid = tl >= mm ? 1u : 0u;
+            const uint32_t lv = valid ? tl - mm : 0u;
+            const unsigned long long e = (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32);
+            xw::st_agent64((unsigned long long *)(rec + kTpEdges + 2 * k), e);
+            if (k < kStageEdges) L()->stage[(a & (kStagePos - 1)) * kStageQ + 1 + k] = e;
+        }
+        // the valid samples that bring a distance the valid one before did not have (as the table stage lists them)
+        const unsigned long long vm = xw::ballot(valid != 0), below = vm & ((1ull << k) - 1ull);
+        const uint32_t dprev = xw::shfl(d, below ? 63u - (uint32_t)__builtin_clzll(below) : k);
+        const uint32_t uniq = (uint32_t)xw::ballot(valid && (!below || d != dprev));
+        if (k == 0) {
+            xw::st_agent64((unsigned long long *)rec, (h & ~63ull) | ne);
+            xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
+            L()->stage[(a & (kStagePos - 1)) * kStageQ] = (h & ~63ull) | ne;
+            L()->stage[(a & (kStagePos - 1)) * kStageQ + kStageQ - 1] = uniq;
+        }
+        xw::drain();
+    }
+
     // ---- explicit rep probe (:1598-1628): match length of (position a, distance r), at most c bytes ------------------
-    // Every lane compares for itself, eight bytes a round: `own` holds the eight bytes at a, `first` the eight bytes at a - r.
+    // Every lane compares for itself, eight bytes a round: `own` holds the eight bytes at a (loaded once per block), `first` the
+    // eight bytes at a - r (requested by the caller ahead of time, so that their latency passes behind other work).
     // Nearly every probe ends inside its first eight bytes; the others go on round by round.
     XW_FN uint32_t probe_finish(bool want, uint32_t a, uint32_t r, uint32_t c, unsigned long long own, unsigned long long first)
     {
@@ -1523,329 +1504,33 @@ struct Parser {
         return len;
     }
 
-    // =============================================================================================
-    // rows (waves 3, 5, 6, 7): the record of node m of the segment at seg_a -> its row, distinct distances, info word
-    // =============================================================================================
-    XW_FN void prep_node(uint32_t seg_a, uint32_t m, uint32_t max_parse, uint32_t pc_dict, uint32_t pc_rep, uint32_t pc_lit)
+    // rep set of a node from its winner (RepModel::Add of a dict edge's distance, :1160-1171) and what the emitter needs of the
+    // winner: source | length << 13 | cmd << 22 | rep index << 24, and the distance (dict, rep).  The source's set: of a finished block from the
+    // ring, of this block as the pass before left it.
+    XW_FN void winner_set(uint32_t seg_a, uint32_t b0, uint32_t pbuf, uint32_t node, unsigned long long key, uint32_t &o0, uint32_t &o1,
+                          uint32_t &o2, uint32_t &o3, uint32_t &link, uint32_t &delta) const
     {
-        PLds *Lp = L();
-        const uint32_t k = xw::lane();
-        const uint32_t a = seg_a + m;
-        unsigned long long *srec = staged(a);
-        const unsigned long long hd = srec[0];
-        uint32_t ne = (uint32_t)hd & 63u;
-        const uint32_t lit = ((uint32_t)hd >> 8) & 0xFFu, mt_max = ((uint32_t)hd >> 16) & 0x1FFu;
-        const uint32_t listed = ne ? ((uint32_t)(srec[1] >> 32) & 0x1FFu) : 0u;
-        uint32_t eff = umin(mt_max, max_parse - m);                 // :1545-1548
-        if (eff < kMatchMin) eff = 0;
-        const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-        unsigned long long e = 0;
-        uint32_t uniq = 0;
-        if (xw::readfirst(eff != listed ? 1u : 0u)) {
-            // The segment is within 264 of its forced cut (:1469), or this position was listed for the cut of a segment that
-            // ended before it: the sampled lengths change with max_len (:1545, :1558-1560).  Re-listed from the position's
-            // table (lanes = samples); the staged copy takes the new list (the ring's record stays as the table stage wrote it).
-            acc(kAccUndo, 1);
-            const uint32_t *dense = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;     // the position's table: delta[l] at [l - 1]
-            uint32_t step = (eff - kMatchMin) >> 4;
-            step += step == 0;
-            ne = eff >= kMatchMin ? (eff - kMatchMin) / step + 1 : 0u;
-            uint32_t d = 0, valid = 0;
-            if (k < ne) {
-                const uint32_t tl = eff - k * step;
-                d = xw::ld_agent(dense + tf_index(tl));
-                const uint32_t mm = match_min(d);
-                uint32_t nx, ex;
-                const uint32_t slot = dist_slot(d - 1, nx, ex);
-                valid = tl >= mm ? 1u : 0u;
-                const uint32_t lv = valid ? tl - mm : 0u;
-                e = (unsigned long long)d | ((unsigned long long)(tl | (lv << 9) | (slot << 18) | (nx << 24) | (valid << 31)) << 32);
-                if (k < kStageEdges) srec[1 + k] = e;
-            }
-            // the valid samples that bring a distance the valid one before did not have (as the table stage lists them)
-            const unsigned long long vm = xw::ballot(valid != 0), below = vm & ((1ull << k) - 1ull);
-            const uint32_t dprev = xw::shfl(d, below ? 63u - (uint32_t)__builtin_clzll(below) : k);
-            uniq = (uint32_t)xw::ballot(valid && (!below || d != dprev));
-            if (k == 0) { srec[0] = (hd & ~63ull) | ne; srec[kStageQ - 1] = uniq; }
-        } else {
-            if (k < ne) e = k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k));
-            uniq = ne ? (uint32_t)srec[kStageQ - 1] : 0u;
-        }
-        unsigned long long *row = Lp->row + (m & (kRowRing - 1)) * 64;
-        row[k] = 0;
-        xw::wave_sync();
-        const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32);
-        if (at >> 31) {
-            const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-            const uint32_t lp = Lp->len_price[lv];
-            const uint32_t pd = pc_dict + lp + (nx << 5) + Lp->slot_price[umin(lv, 3) * 64 + slot];     // :1208-1251
-            const uint32_t pr = pc_rep + lp + (2u << 5);                                                 // :1253-1272
-            if (tl <= 64) row[(m + tl) & 63u] = (unsigned long long)d | ((unsigned long long)(pd | (pr << 13) | (k << 26) | kRowValid) << 32);
-        }
-        if (k == 0) {
-            const uint32_t plit = pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15);     // :1418-1426
-            row[(m + 1) & 63u] = (unsigned long long)(kLitMark | lit) | ((unsigned long long)(plit | (0x1FFFu << 13) | kRowValid) << 32);
-        }
-        if (k < kMaxEdges && ((uniq >> k) & 1u)) {
-            const uint32_t at_dd = (uint32_t)__builtin_popcount(uniq & ((1u << k) - 1u));
-            if (at_dd < 8) Lp->dd[(m & (kRowRing - 1)) * 8 + at_dd] = d;
-        }
-#ifdef DBG_PROBE_SIM
-        if (seg_a + m - base == 100 && k < 3) fprintf(stderr, "P m %u k %u eff %u listed %u ne %u uniq %x e %llx\n", m, k, eff, listed, ne, uniq, e);
-#endif
-        if (k == 0) Lp->ninfo[m & (kRowRing - 1)] = eff | ((uint32_t)__builtin_popcount(uniq) << 9) | (eff > 64 ? kInfoFar : 0u);
-    }
-
-    // =============================================================================================
-    // chain (wave 0)
-    // =============================================================================================
-    struct Chain { uint32_t cost, link, wd, r0, r1, r2, r3; };
-    XW_FN static uint32_t rank_of(uint32_t link, uint32_t wd)
-    {
-        if (wd >= kLitMark) return kRankLit;
-        if (link & kLinkProbe) return kRankProbe + ((link >> 26) & 3u);
-        return 2 * ((link >> 26) & 31u) + ((link >> 13) & 1u);
-    }
-    XW_FN static unsigned long long key_of(uint32_t cost, uint32_t link, uint32_t wd)
-    {
-        return ((unsigned long long)cost << 32) | ((link & 0x1FFFu) << 8) | rank_of(link, wd);
-    }
-    // the lanes of `take` become what the key fk of node t says (an edge that jumped over the window, or a probe's)
-    XW_FN void take_far(bool take, unsigned long long fk, uint32_t t, Chain &C) const
-    {
-        if (!take) return;
-        const PLds *Lp = L();
-        const uint32_t src = (uint32_t)(fk >> 8) & 0x1FFFu, rank = (uint32_t)fk & 0xFFu;
-        const PFin &fs = Lp->fin[src & (kFarRing - 1)];
-        const uint32_t s0 = fs.r[0], s1 = fs.r[1], s2 = fs.r[2], s3 = fs.r[3];
-        C.cost = (uint32_t)(fk >> 32);
-        C.r0 = s0; C.r1 = s1; C.r2 = s2; C.r3 = s3;
-        if (rank >= kRankProbe) {
-            const uint32_t idx = rank - kRankProbe;
-            C.wd = idx == 0 ? s0 : (idx == 1 ? s1 : (idx == 2 ? s2 : s3));
-            C.link = src | kLinkRep | kLinkProbe | (idx << 26);
-        } else {
-            const uint32_t d = Lp->far_d[t & (kFarRing - 1)];
-            C.wd = d;
-            C.link = src | ((rank & 1u) ? kLinkRep : 0u) | ((rank >> 1) << 26);
-            if (!(rank & 1u) && !(d == s0 || d == s1 || d == s2 || d == s3)) { C.r0 = d; C.r1 = s0; C.r2 = s1; C.r3 = s2; }
-        }
-    }
-    // node of lane i when node n is the next to be processed
-    XW_FN static uint32_t lane_node(uint32_t n, uint32_t i) { return n + ((i - n) & 63u); }
-    // keys that arrived for the nodes of the window (probe edges of the step before; far edges that were pushed while the node was
-    // outside): every lane looks at its node's key
-    XW_FN void merge_window(uint32_t n, Chain &C) const
-    {
-        const uint32_t t = lane_node(n, xw::lane());
-        const unsigned long long fk = L()->far[t & (kFarRing - 1)];
-        const bool take = fk != kKeyNone && fk < key_of(C.cost, C.link, C.wd);
-        if (xw::any(take)) take_far(take, fk, t, C);
-    }
-
-    // One step of the chain: nodes n_s .. (below n_e, and while inside the segment).  Returns the node it stopped at.
-    // Every lane keeps the state of its node in LDS up to date (fin[node & 511]: once a step, whatever the node): the entry of a
-    // node is final from the step the node is processed in -- no lane mask, no branch for the retirement.
-    XW_FN uint32_t chain_run(Chain &C, uint32_t seg_a, uint32_t n_s, uint32_t n_e_in, uint32_t &end_p_io, uint32_t &far_hi_io, uint32_t nx_extra,
-                             uint32_t pc_dict, uint32_t pc_rep)
-    {
-        PLds *Lp = L();
-        const uint32_t i = xw::lane();
-        // (loop control in scalar registers)
-        const uint32_t n_e = xw::readfirst(n_e_in);
-        uint32_t end_p = xw::readfirst(end_p_io), far_hi = xw::readfirst(far_hi_io);
-        // (lane m % 64: what the rows' wave noted about node m of this step; bit 16: the node has probe edges handed over --
-        //  the step is being done again)
-        uint32_t infov = Lp->ninfo[lane_node(n_s, i) & (kRowRing - 1)];
-        for (uint32_t b = 0; b < nx_extra; b += 64) {
-            unsigned long long bit = b + i < nx_extra ? 1ull << ((Lp->extras[b + i].info & 0x1FFFu) & 63u) : 0ull;
-            for (uint32_t sh = 32; sh; sh >>= 1) bit |= xw::shfl64(bit, i ^ sh);
-            infov |= (uint32_t)((bit >> i) & 1ull) << 16;
-        }
-        unsigned long long fkv = far_hi >= n_s + 64 ? Lp->far[(n_s + 64) & (kFarRing - 1)] : kKeyNone;      // the key waiting for the node that enters the window (the same in every lane)
-        uint32_t n = n_s;
-        const unsigned long long *rows = Lp->row + i;               // (a row's entry for this lane: the edge that ends at the lane's node)
-        unsigned long long rw0 = rows[(n & (kRowRing - 1)) * 64];
-        unsigned long long rw1 = rows[((n + 1) & (kRowRing - 1)) * 64];
-        uint32_t fslot = lane_node(n, i) & (kFarRing - 1);          // where this lane's node keeps its state
-        xw::setprio_high();
-        while (n < n_e && n < end_p) {
-            const uint32_t sl = n & 63u;
-            const bool me = i == sl;
-            const uint32_t cn = xw::readlane(C.cost, sl);
-            const uint32_t r0 = xw::readlane(C.r0, sl), r1 = xw::readlane(C.r1, sl), r2 = xw::readlane(C.r2, sl), r3 = xw::readlane(C.r3, sl);
-            const uint32_t info = xw::readlane(infov, sl);
-            // ---- the states as they stand (node n's is final), and how far the chain is
-            {
-                PFin &f = Lp->fin[fslot];
-                f.r[0] = C.r0; f.r[1] = C.r1; f.r[2] = C.r2; f.r[3] = C.r3;
-                f.cost = C.cost; f.link = C.link; f.wdist = C.wd;
-                xw::lds_st(&Lp->ctl.done, n + 1);
-            }
-            end_p = umax(end_p, n + (info & 0x1FFu));               // :1550-1554
-            const unsigned long long rw2 = rows[((n + 2) & (kRowRing - 1)) * 64];     // (two nodes ahead)
-            // ---- its lane is node n + 64's now
-            C.cost = me ? kInf : C.cost;
-            fslot = me ? ((fslot + 64) & (kFarRing - 1)) : fslot;
-            // ---- its edges (:1490-1499, :1566-1595): every lane its own
-            auto relax = [&]() __attribute__((always_inline)) {
-                const uint32_t d = (uint32_t)rw0, at = (uint32_t)(rw0 >> 32);
-                const bool valid = (int32_t)at < 0;
-                const bool inset = d == r0 || d == r1 || d == r2 || d == r3;
-                const uint32_t pd = at & 0x1FFFu, pr = (at >> 13) & 0x1FFFu;
-                const bool userep = inset && pr < pd;               // (dict is tried first: rep only if strictly cheaper)
-                const uint32_t cand = cn + (userep ? pr : pd);
-                const bool upd = valid && cand < C.cost;
-                const bool push = upd && !(inset || d >= kLitMark); // RepModel::Add of a new distance
-                C.cost = upd ? cand : C.cost;
-                C.link = upd ? (n | (userep ? kLinkRep : 0u) | (at & 0x7C000000u)) : C.link;
-                C.wd = upd ? d : C.wd;
-                // (the set once more in vector registers: a select takes its mask over the scalar operand bus, so its data cannot)
-                const uint32_t v0 = xw::opaque(r0), v1 = xw::opaque(r1), v2 = xw::opaque(r2), v3 = xw::opaque(r3);
-                C.r3 = upd ? (push ? v2 : v3) : C.r3; C.r2 = upd ? (push ? v1 : v2) : C.r2; C.r1 = upd ? (push ? v0 : v1) : C.r1; C.r0 = upd ? (push ? d : v0) : C.r0;
-            };
-            if (!NLZM_RARE((info >> 15) | (far_hi >= n + 64 ? 1u : 0u))) relax();        // (no edge longer than the window, no probe edge handed over, no key in far[])
+        const uint32_t src = (uint32_t)(key >> 8) & 0xFFFFFFu, rank = (uint32_t)key & 0xFFu;
+        if (src == kSrcNone) { o0 = rep0; o1 = rep1; o2 = rep2; o3 = rep3; link = kSrcNone; delta = 0; return; }   // node 0 (:1476)
+        const uint32_t *sr = src >= b0 ? L()->brep[pbuf] + (src - b0) * 4 : L()->nrep + (src & 511u) * 4;
+        const uint32_t s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+        o0 = s0; o1 = s1; o2 = s2; o3 = s3;
+        uint32_t cmd = 0, len = 0, idx = 0;
+        delta = 0;
+        if (rank != kRankLit) {
+            len = node - src;
+            if (rank >= kRankProbe) { cmd = 2; idx = rank - kRankProbe; delta = idx == 0 ? s0 : (idx == 1 ? s1 : (idx == 2 ? s2 : s3)); }
             else {
-                // a key that jumped over the window may be waiting for node n + 64 (written before this node was reached; requested a node ago)
-                const unsigned long long fk0 = xw::readfirst64(fkv);
-                if (fk0 != kKeyNone) take_far(me, fk0, n + 64, C);
-                relax();
-                // ---- sampled edges longer than the window (max_len > 64: lanes = the sixteen longest samples)
-                if (info & kInfoFar) {
-                    t_q[5]++;
-                    const unsigned long long *srec = staged(seg_a + n);
-                    const uint32_t ne = (uint32_t)srec[0] & 63u;
-                    const unsigned long long e = (i < kStageEdges && i < ne) ? srec[1 + i] : 0ull;
-                    const uint32_t d = (uint32_t)e, at = (uint32_t)(e >> 32), tl = at & 0x1FFu;
-                    uint32_t t = 0;
-                    if ((at >> 31) && tl > 64) {
-                        const uint32_t lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-                        const uint32_t lp = Lp->len_price[lv];
-                        const uint32_t pd = pc_dict + lp + (nx << 5) + Lp->slot_price[umin(lv, 3) * 64 + slot];
-                        const uint32_t pr = pc_rep + lp + (2u << 5);
-                        const bool inset = d == r0 || d == r1 || d == r2 || d == r3;
-                        const bool userep = inset && pr < pd;
-                        const unsigned long long key = ((unsigned long long)(cn + (userep ? pr : pd)) << 32) | (n << 8) | (2 * i + (userep ? 1u : 0u));
-                        t = n + tl;
-                        if (key < Lp->far[t & (kFarRing - 1)]) { Lp->far[t & (kFarRing - 1)] = key; Lp->far_d[t & (kFarRing - 1)] = d; }
-                    }
-                    (void)t;
-                    far_hi = umax(far_hi, n + (info & 0x1FFu));     // (no key beyond the node's longest edge)
-                    xw::wave_sync();
-                }
-                // ---- probe edges known from the attempt before (:1598-1628: after the sampled edges, slot by slot)
-                if (info & (1u << 16)) {
-                    t_q[5]++;
-#pragma unroll
-                    for (uint32_t pi = 0; pi < 4; pi++) {
-                        const uint32_t r = pi == 0 ? r0 : (pi == 1 ? r1 : (pi == 2 ? r2 : r3));
-                        uint32_t ml = 0;
-                        for (uint32_t b = 0; b < nx_extra; b += 64) {
-                            const bool hit = b + i < nx_extra && (Lp->extras[b + i].info & 0x1FFFu) == n && Lp->extras[b + i].r == r;
-                            const unsigned long long hm = xw::ballot(hit);
-                            if (hm) ml = (xw::readlane(b + i < nx_extra ? Lp->extras[b + i].info : 0u, (uint32_t)__builtin_ctzll(hm)) >> 13) & 0x1FFu;
-                        }
-                        if (!ml) continue;
-                        const uint32_t cand = cn + pc_rep + Lp->len_price[ml - match_min(r)] + (2u << 5);        // :1607, :1614
-                        const uint32_t t = n + ml;
-                        end_p = umax(end_p, t);                     // :1608-1612
-                        if (ml <= 64) {
-                            const bool upd = i == (t & 63u) && cand < C.cost;
-                            C.cost = upd ? cand : C.cost;
-                            C.link = upd ? (n | kLinkRep | kLinkProbe | (pi << 26)) : C.link;
-                            C.wd = upd ? r : C.wd;
-                            C.r0 = upd ? r0 : C.r0; C.r1 = upd ? r1 : C.r1; C.r2 = upd ? r2 : C.r2; C.r3 = upd ? r3 : C.r3;
-                        } else {
-                            const unsigned long long key = ((unsigned long long)cand << 32) | (n << 8) | (kRankProbe + pi);
-                            if (i == 0 && key < Lp->far[t & (kFarRing - 1)]) Lp->far[t & (kFarRing - 1)] = key;
-                            far_hi = umax(far_hi, t);
-                            xw::wave_sync();
-                        }
-                    }
-                }
-                // (the key for the node that enters the window next: after this node's own keys are written)
-                fkv = far_hi >= n + 65 ? Lp->far[(n + 65) & (kFarRing - 1)] : kKeyNone;
-            }
-            rw0 = rw1; rw1 = rw2;
-            n++;
-        }
-        xw::setprio_low();
-        // (the node the chain stopped at: its state as it stands, for the step's end)
-        {
-            PFin &f = Lp->fin[fslot];
-            f.r[0] = C.r0; f.r[1] = C.r1; f.r[2] = C.r2; f.r[3] = C.r3;
-            f.cost = C.cost; f.link = C.link; f.wdist = C.wd;
-        }
-        end_p_io = end_p; far_hi_io = far_hi;
-        return n;
-    }
-
-    // =============================================================================================
-    // probes (waves 1..2): the four explicit rep probes (:1598-1628) of nodes nb0 .. hi-1, lanes = node x slot
-    // =============================================================================================
-    XW_FN void verify_batch(uint32_t seg_a, uint32_t seg_q, uint32_t max_parse, uint32_t nb0, uint32_t hi, uint32_t pc_rep, uint32_t &cmp_acc)
-    {
-        PLds *Lp = L();
-        const uint32_t i = xw::lane(), pi = i & 3u;
-        const uint32_t node = nb0 + (i >> 2);
-        const bool on = node < hi;
-        uint32_t r = 1, cost = 0;
-        bool want = false;
-        if (on) {
-            const PFin &f = Lp->fin[node & (kFarRing - 1)];
-            const uint32_t s0 = f.r[0], s1 = f.r[1], s2 = f.r[2], s3 = f.r[3];
-            r = pi == 0 ? s0 : (pi == 1 ? s1 : (pi == 2 ? s2 : s3));
-            cost = f.cost;
-            if (pi == 0 && node > 0) {
-                // what the emitter needs of the node's winner: length (0: literal) | cmd << 9 | rep index << 11; distance or byte
-                const uint32_t link = f.link, wd = f.wdist;
-                uint32_t out = 0, delta = wd;
-                if (wd >= kLitMark) delta = wd & 0xFFu;
+                const uint32_t d = L()->edge_d[((seg_a + src) & 511u) * kMaxEdges + (rank >> 1)];
+                delta = d;
+                if (rank & 1u) { cmd = 2; idx = d == s0 ? 0u : (d == s1 ? 1u : (d == s2 ? 2u : 3u)); }
                 else {
-                    const uint32_t len = node - (link & 0x1FFFu);
-                    if (link & kLinkRep) out = len | (2u << 9) | ((wd == s0 ? 0u : (wd == s1 ? 1u : (wd == s2 ? 2u : 3u))) << 11);   // (:1173-1181: the first slot that holds it)
-                    else out = len | (1u << 9);
-                }
-                Lp->node_link[node] = (uint16_t)out; Lp->node_delta[node] = delta;
-            }
-            // a slot whose distance a valid sampled edge of the node has is not probed (:1580-1584, :1600)
-            const uint32_t nd = (Lp->ninfo[node & (kRowRing - 1)] >> 9) & 63u;
-            bool met = false;
-            if (nd <= 8) {
-#pragma unroll
-                for (uint32_t z = 0; z < 8; z++) met = met || (z < nd && Lp->dd[(node & (kRowRing - 1)) * 8 + z] == r);
-            } else {
-                // (more than eight distinct distances: the row's entries and the staged samples longer than the window)
-                const unsigned long long *row = Lp->row + (node & (kRowRing - 1)) * 64;
-                for (uint32_t z = 0; z < 64; z++) met = met || (uint32_t)row[z] == r;
-                const unsigned long long *srec = staged(seg_a + node);
-                const uint32_t ne = (uint32_t)srec[0] & 63u;
-                for (uint32_t z = 0; z < kStageEdges && z < ne; z++) {
-                    const unsigned long long e = srec[1 + z];
-                    met = met || ((uint32_t)(e >> 32) >> 31 && (uint32_t)e == r);
+                    cmd = 1;
+                    if (!(d == s0 || d == s1 || d == s2 || d == s3)) { o0 = d; o1 = s0; o2 = s1; o3 = s2; }
                 }
             }
-            want = !met && r < seg_q + node;                        // :1601
         }
-        const uint32_t pcap = on ? umin(max_parse - node, kMatchMax) : 0u;                              // :1605-1606
-        const uint32_t a = seg_a + node;
-        uint32_t ml = 0;
-        if (xw::any(want)) {
-            const unsigned long long yo = want ? load64u(G.in + a) : 0ull, xo = want ? load64u(G.in + a - r) : 0ull;
-            ml = probe_finish(want, a, r, pcap, yo, xo);
-        }
-        if (want) cmp_acc += ml + (ml < pcap);
-#ifdef DBG_PROBE_SIM
-        if (want && seg_q + node == 100) fprintf(stderr, "D node %u info %x dd0 %u uniq? ne %u\n", node, Lp->ninfo[node & (kRowRing - 1)], Lp->dd[(node & (kRowRing - 1)) * 8], (uint32_t)staged(seg_a + node)[0] & 63u);
-        if (want) fprintf(stderr, "S %u %u %u %u\n", seg_q + node, pi, r, ml);
-#endif
-        if (want && ml >= match_min(r)) {
-            const uint32_t pw = pc_rep + Lp->len_price[ml - match_min(r)] + (2u << 5);                 // :1607, :1614
-            const uint32_t at = xw::lds_inc(&Lp->ctl.vcount);
-            PVEdge &v = Lp->vlist[at];
-            v.key = ((unsigned long long)(cost + pw) << 32) | (node << 8) | (kRankProbe + pi);
-            v.r = r; v.info = node | (ml << 13) | (pi << 22);
-        }
+        link = src | (len << 13) | (cmd << 22) | (idx << 24);
     }
 
     // ---- one parse segment: nodes 0.. of positions seg_a.. (every thread of the stage); returns its length, the path
@@ -1857,20 +1542,27 @@ struct Parser {
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
-        PLds *Lp = L();
-        const unsigned long long ts = xw::tick();
         // A segment starts at seg_a: said BEFORE this stage asks for the position's record.  The finder stage may be waiting
         // for exactly this word at seg_a (a nice region that starts where the segment before was cut at 4,096 positions,
         // :1469: no edge spans the cut, so nothing else tells it) and the record of seg_a comes only after it.
         if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
-        if (w == kLoaderWave) {                                     // (meanwhile: the first node's record, staged)
+        if (w == kPW - 1) {                                         // (meanwhile: the first node's record, staged)
             if (!stage_need(seg_a)) err = kErrInternal + 100;
-            if (i == 0) Lp->sh[4] = err;
+            if (i == 0) L()->sh[4] = err;
         }
         seg_tables(tab_dirty);                                      // (tab_dirty is the same in every wave: run_chunk, run)
         tab_dirty = false;
         const uint32_t pc_dict = price(kCtxCmd, 1), pc_rep = price(kCtxCmd, 2), pc_lit = price(kCtxCmd, 0);
-        if (Lp->sh[4]) { err = kErrInternal + 100; return 0; }
+        // node 0 (:1472-1482)
+        if (tid == 0) {
+            L()->dbgw[0] = seg_a; L()->dbgw[1] = 0; L()->dbgw[2] = max_parse;
+            L()->mprev[0] = ((unsigned long long)kSrcNone << 8) | kRankLit;
+            L()->mprev[1] = kKeyNone;
+            L()->node_link[0] = kSrcNone;
+        }
+        uint32_t end_p = 1, end_open = 1, b0 = 0;
+        uint32_t seg_len = 0;
+        if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
         {
             // A position without any match is a segment of its own (more than half of all segments are): its node has no
             // sampled edge, and if none of the four rep probes finds anything (:1598-1628) the only command is the literal.
@@ -1879,8 +1571,7 @@ struct Parser {
             const uint32_t sh_hi = staged_hi();
             const uint32_t kmax = umin(64u, umin(sh_hi - seg_a, chunk_left));
             const uint32_t hj = i < kmax ? (uint32_t)staged(seg_a + i)[0] : 1u;
-            const unsigned long long withm = xw::ballot((hj & 63u) != 0 || ((hj >> 16) & 0x1FFu) >= kMatchMin);   // (lanes >= kmax count as having a match;
-                                                                    //  a table a forced cut left without samples still has its matches)
+            const unsigned long long withm = xw::ballot((hj & 63u) != 0);        // (lanes >= kmax count as having a match)
             const uint32_t p0 = withm ? (uint32_t)__builtin_ctzll(withm) : 64u;    // the leading positions without any match
             if (p0) {
                 uint32_t counted = 0;
@@ -1896,276 +1587,333 @@ struct Parser {
                     }
                     if (want) { counted = l + (l < pcap); n_cmp += counted; }
                     const unsigned long long okm = xw::ballot(want && l >= match_min(r));
-                    if (i == 0) Lp->fpm[w] = okm;
+                    if (i == 0) L()->fpm[w] = okm;
                 }
                 xw::block_sync();
-                const unsigned long long hit = Lp->fpm[0] | Lp->fpm[1] | Lp->fpm[2] | Lp->fpm[3];
+                const unsigned long long hit = L()->fpm[0] | L()->fpm[1] | L()->fpm[2] | L()->fpm[3];
                 const uint32_t run = hit ? umin(p0, (uint32_t)__builtin_ctzll(hit)) : p0;           // positions that are segments of one literal
-                // (fpm is written again only after another barrier: the one below, or the chain's)
+                // (fpm is written again only after another barrier: the one below, or the first block's)
                 if (i >= run) n_cmp -= counted;     // (not part of the run: their probes are made, and counted, when their segment is parsed)
                 if (run) {
                     if (w == 0 && i < run) {
-                        Lp->node_link[i + 1] = 0; Lp->node_delta[i + 1] = (hj >> 8) & 0xFFu;         // literal: from the node before, the byte
-                        Lp->cmdlist()[run - 1 - i] = (uint16_t)(i + 1);
+                        L()->node_link[i + 1] = 0; L()->node_delta[i + 1] = (hj >> 8) & 0xFFu;       // literal: from the node before, the byte
+                        L()->cmdlist()[run - 1 - i] = (uint16_t)(i + 1);
                     }
                     if (tid == 0) {
-                        Lp->sh[12] = rep0; Lp->sh[13] = rep1; Lp->sh[14] = rep2; Lp->sh[15] = rep3;    // (literals leave the rep set alone)
-                        Lp->ncmds = run;
+                        L()->sh[12] = rep0; L()->sh[13] = rep1; L()->sh[14] = rep2; L()->sh[15] = rep3;    // (literals leave the rep set alone)
+                        L()->ncmds = run;
                         xw::st_agent(&V.hx->p_pos, seg_a);
                         if (run > 1) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)(seg_a + run - 1) << 32) | (seg_a + run));
                     }
                     xw::block_sync();
                     ncmds = run;
                     nsegs = run;
-#ifdef NLZM_SIM
-                    if (tid == 0) for (uint32_t c = 0; c < run; c++) { xw::trace(4, seg_a + c, 1, 1); xw::trace(5, 0, 0, 0); }
-#endif
                     return run;
                 }
             }
         }
-        // ---- the chain parse.  State shared by the waves: Lp->ctl
-        // The rows of the first nodes are made by all six helper waves before anything else: as many as the first node's table
-        // says the segment has at least (and the records that are there)
-        uint32_t n_first;
-        {
-            const uint32_t h0 = (uint32_t)staged(seg_a)[0];
-            uint32_t eff0 = umin((h0 >> 16) & 0x1FFu, max_parse);
-            n_first = umin(umin(umax(eff0 + 2, 4u), kStepWant), umin(staged_hi() - seg_a, max_parse));
-        }
-        if (w != 0 && w != kLoaderWave) for (uint32_t m = w < kLoaderWave ? w - 1 : w - 2; m < n_first; m += kPW - 2) prep_node(seg_a, m, max_parse, pc_dict, pc_rep, pc_lit);
-        for (uint32_t t = tid; t < kFarRing; t += kParserThreads) Lp->far[t] = kKeyNone;
-        if (tid == 0) {
-            PCtl &c = Lp->ctl;
-            c.n_s = 0; c.stop = 0; c.done = 0; c.end_p = 1; c.vcount = 0; c.xcount = 0; c.redo = 0; c.seg_len = 0; c.end_snap = 1; c.far_hi = 0; c.far_hi_snap = 0;
-            for (uint32_t p = 0; p < kPrepWaves; p++) c.prep_cur[p] = n_first + ((p - n_first) & (kPrepWaves - 1));
-            Lp->dbgw[0] = seg_a; Lp->dbgw[1] = 0; Lp->dbgw[2] = max_parse;
-            Lp->node_link[0] = 0;
-        }
-        Chain C{ kInf, kSrcNone, 0, rep0, rep1, rep2, rep3 };       // (wave 0's; node 0 (:1472-1482) on lane 0)
-        if (i == 0) C.cost = 0;
-        uint32_t end_p = 1, seg_len = 0, far_hi = 0;
-        uint32_t cmp_acc = 0;                                       // probe waves: bytes the probes of the attempt looked at
-        const uint32_t prep_i = w == 1 + kVerifyWaves ? 0u : w - kLoaderWave;             // (rows' waves 3, 5, 6, 7: 0 .. 3)
-        uint32_t prep_m = n_first + ((prep_i - n_first) & (kPrepWaves - 1));               // ... and the next node of theirs
-        xw::block_sync();
-        if (w == 0) acc(kAccSetup, xw::tick() - ts);
-        for (;;) {
-            const uint32_t n_s = xw::readfirst(xw::lds_ld(&Lp->ctl.n_s));
-            const bool redo = xw::readfirst(xw::lds_ld(&Lp->ctl.redo)) != 0;
-            if (w == 0) {
-                // ================= chain =================
-                const unsigned long long q0 = ptick();
-                const unsigned long long tp0 = xw::tick();
-                uint32_t n_e;
-                {   // rows that are ready: below the smallest cursor of the rows' waves.  When this stage has caught up with the
-                    // table stage it gives it a moment (bounded: the finder may be waiting for this stage's word) rather than run on a few nodes
-                    uint32_t spins = 0;
-                    for (;;) {
-                        uint32_t e = kNone;
-                        for (uint32_t p = 0; p < kPrepWaves; p++) e = umin(e, xw::readfirst(xw::lds_ld(&Lp->ctl.prep_cur[p])));
-                        n_e = umin(e, umin(n_s + kStepMax, max_parse));
-                        const uint32_t want_n = umin(kStepWant, max_parse - n_s);      // (the chain stops by itself where the segment ends)
-                        if (n_e >= n_s + want_n || (n_e > n_s && spins >= 8)) break;
-                        if ((++spins & 63u) == 0 && (xw::readfirst(xw::ld_agent(&V.hx->err)) || xw::readfirst(xw::lds_ld(&Lp->sh[4])))) { n_e = n_s; break; }
-                        xw::pause();
+        while (!seg_len) {
+            const unsigned long long ts = xw::tick();
+            const unsigned long long q0 = ptick();
+            if (b0 == end_p || b0 >= max_parse) {
+                // node b0 is the segment's last node: no edges leave it; its key is complete
+                if (tid == 0) {
+                    uint32_t r0, r1, r2, r3, link, delta;
+                    const unsigned long long k = L()->mprev[b0 & 511u];
+                    winner_set(seg_a, b0, 0, b0, k, r0, r1, r2, r3, link, delta);
+                    if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[9];      // the byte of position b0 - 1
+                    L()->node_link[b0] = link; L()->node_delta[b0] = delta;
+                    L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3;    // the model's rep set after the segment
+                }
+                seg_len = b0;
+                break;
+            }
+            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
+            if (w == kPW - 1) {
+                const uint32_t a_first = seg_a + b0;
+                if (!stage_need(a_first)) err = kErrInternal + 100;
+                uint32_t nb = umin(64u, max_parse - b0);
+                uint32_t sh_hi = staged_hi();
+                if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) < 0) {
+                    // A block costs about the same whatever its size: when this stage has caught up with the table stage, it
+                    // gives it a moment (bounded: the finder may be waiting for this stage's word) rather than run on a few nodes
+                    const unsigned long long tg = xw::tick();
+                    for (uint32_t round = 0; round < kGatherRounds; round++) {      // (a step waits for the loads of the one before)
+                        pump(a_first);
+                        sh_hi = staged_hi();
+                        if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) >= 0) break;
                     }
-                    xw::after_poll();
-                    if (n_e > n_s) n_e = n_s + xw::readfirst(xw::test_cut(n_e - n_s));    // (identity on the device; the simulation cuts steps at random here, as
+                    acc(kAccWait, xw::tick() - tg);
+                }
+                if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
+                nb = xw::test_cut(nb);                              // (identity on the device; the simulation cuts blocks at random here, as
                                                                     //  the device does when this stage catches up with the table stage)
-                }
-                uint32_t nx_extra = 0;
-                if (redo) {
-                    // the step again, from its start state, with the probe edges the attempt before has found
-                    C.cost = Lp->snap[i]; C.link = Lp->snap[64 + i]; C.wd = Lp->snap[128 + i];
-                    C.r0 = Lp->snap[192 + i]; C.r1 = Lp->snap[256 + i]; C.r2 = Lp->snap[320 + i]; C.r3 = Lp->snap[384 + i];
-                    for (uint32_t t = i; t < kFarRing; t += 64) { Lp->far[t] = Lp->far_snap[t]; Lp->far_d[t] = Lp->far_d_snap[t]; }
-                    end_p = xw::readfirst(Lp->ctl.end_snap); far_hi = xw::readfirst(Lp->ctl.far_hi_snap);
-                    nx_extra = xw::readfirst(Lp->ctl.xcount);
-                    xw::wave_sync();
-                } else {
-                    merge_window(n_s, C);
-                    Lp->snap[i] = C.cost; Lp->snap[64 + i] = C.link; Lp->snap[128 + i] = C.wd;
-                    Lp->snap[192 + i] = C.r0; Lp->snap[256 + i] = C.r1; Lp->snap[320 + i] = C.r2; Lp->snap[384 + i] = C.r3;
-                    for (uint32_t t = i; t < kFarRing; t += 64) { Lp->far_snap[t] = Lp->far[t]; Lp->far_d_snap[t] = Lp->far_d[t]; }
-                    if (i == 0) { Lp->ctl.end_snap = end_p; Lp->ctl.far_hi_snap = far_hi; }
-                    xw::wave_sync();
-                }
-                const unsigned long long q1 = ptick();
-                const uint32_t n1 = chain_run(C, seg_a, n_s, n_e, end_p, far_hi, nx_extra, pc_dict, pc_rep);
-                if (i == 0) {
-                    // (what the finder stage may be waiting for: how far the segment reaches.  Said before anybody here waits for a record)
-                    xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + end_p));
-                    xw::lds_st(&Lp->ctl.end_p, end_p);
-                    xw::lds_st(&Lp->ctl.stop, n1 + 1);
-                }
-                acc(kAccPass, xw::tick() - tp0); acc(kAccPasses, 1);
-                const unsigned long long q2 = ptick();
-                t_q[0] += q1 - q0; t_q[1] += q2 - q1; t_q[4] += n1 - n_s;
-                xw::block_sync();
-                const unsigned long long q3 = ptick();
-                // ================= decide =================
-                const uint32_t cnt = xw::readfirst(xw::lds_ld(&Lp->ctl.vcount));
-                bool matters = false;
-                for (uint32_t b = 0; b < cnt; b += 64) {
-                    bool m = false;
-                    if (b + i < cnt) {
-                        const PVEdge &v = Lp->vlist[b + i];
-                        const uint32_t t = (v.info & 0x1FFFu) + ((v.info >> 13) & 0x1FFu);
-                        if (t < n1) {                               // the target was retired without this edge
-                            const PFin &f = Lp->fin[t & (kFarRing - 1)];
-                            m = v.key < key_of(f.cost, f.link, f.wdist);
-                        }
-                    }
-                    matters = matters || xw::any(m);
-                }
-                if (cnt && !redo && xw::readfirst(xw::test_cut(1000u)) < 20u) matters = true;     // (simulation with NLZM_SIM_RANDOM_BLOCKS: a step done again for nothing)
-                if (matters) {
-                    for (uint32_t b = i; b < cnt; b += 64) Lp->extras[b] = Lp->vlist[b];
-                    if (i == 0) { Lp->ctl.xcount = cnt; Lp->ctl.redo = 1; Lp->ctl.vcount = 0; Lp->ctl.stop = 0; Lp->ctl.done = n_s; }
-                    acc(kAccRedo, 1);
-                } else {
-                    // (the keys of the nodes that were retired are spent)
-                    if (n_s + i < n1) Lp->far[(n_s + i) & (kFarRing - 1)] = kKeyNone;
-                    xw::wave_sync();
-                    // probe edges whose target is still ahead: into the keys the chain takes over (:1608-1612 opens the nodes)
-                    uint32_t ext = 0;
-                    for (uint32_t b = 0; b < cnt; b += 64) {
-                        uint32_t t = 0;
-                        if (b + i < cnt) {
-                            const PVEdge &v = Lp->vlist[b + i];
-                            t = (v.info & 0x1FFFu) + ((v.info >> 13) & 0x1FFu);
-                            if (t >= n1) xw::lds_min64(&Lp->far[t & (kFarRing - 1)], v.key); else t = 0;
-                        }
-                        ext = umax(ext, xw::readlane(xw::scan_max(t), 63));
-                    }
-                    end_p = umax(end_p, ext); far_hi = umax(far_hi, ext);
-                    xw::wave_sync();
-                    acc(kAccBlocks, 1);
-                    uint32_t done_len = 0;
-                    if (n1 >= end_p) {
-                        // the segment ends at node n1: no edges leave it; its key is complete once the keys that waited for it are in
-                        merge_window(n1, C);
-                        if (i == (n1 & 63u)) {
-                            uint32_t out = 0, delta = C.wd;
-                            if (C.wd >= kLitMark) delta = C.wd & 0xFFu;
-                            else {
-                                const uint32_t len = n1 - (C.link & 0x1FFFu);
-                                if (C.link & kLinkRep) out = len | (2u << 9) | ((C.wd == C.r0 ? 0u : (C.wd == C.r1 ? 1u : (C.wd == C.r2 ? 2u : 3u))) << 11);
-                                else out = len | (1u << 9);
-                            }
-                            Lp->node_link[n1] = (uint16_t)out; Lp->node_delta[n1] = delta;
-                            Lp->sh[12] = C.r0; Lp->sh[13] = C.r1; Lp->sh[14] = C.r2; Lp->sh[15] = C.r3;    // the model's rep set after the segment
-                        }
-                        done_len = n1;
-                    }
-                    if (i == 0) {
-                        PCtl &c = Lp->ctl;
-                        c.n_s = n1; c.redo = 0; c.xcount = 0; c.vcount = 0; c.stop = 0; c.done = n1; c.seg_len = done_len;
-                        Lp->dbgw[1] = n1;
-                        xw::st_agent(&V.hx->p_pos, seg_a + n1);
-                        xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + end_p));
+                if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; xw::st_agent(&V.hx->p_pos, a_first); }
+            }
+            xw::block_sync();
+            const unsigned long long q1 = ptick();
+            const uint32_t nb = L()->sh[0];
+            if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
+            const bool inb = i < nb;
+            const uint32_t node = b0 + i, a = seg_a + node;
+            // within 264 of the forced cut the table is cut short (:1545): such records are re-listed first
+            if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax) {
+                if (w == kPW - 1) {
+                    const uint32_t h0 = inb ? (uint32_t)staged(a)[0] : 0u;
+                    const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
+                    for (unsigned long long m = xw::ballot(inb && ml > max_parse - node); m; m &= m - 1) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        resample(seg_a + b0 + j, max_parse - (b0 + j));
                     }
                 }
-                xw::wave_sync();
-                t_q[2] += q3 - q2; t_q[3] += ptick() - q3;
-            } else if (w <= kVerifyWaves) {
-                // ================= probes =================
-                if (redo) cmp_acc = 0;
-                else { n_cmp += cmp_acc; cmp_acc = 0; }             // (the attempt before stood)
-                for (uint32_t b = w - 1;; b += kVerifyWaves) {
-                    const uint32_t nb0 = n_s + b * kVBatch;
-                    uint32_t st = 0, spins = 0;
-                    for (;;) {
-                        st = xw::readfirst(xw::lds_ld(&Lp->ctl.stop));
-                        if (st || xw::readfirst(xw::lds_ld(&Lp->ctl.done)) >= nb0 + kVBatch) break;
-                        if ((++spins & 255u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) { st = nb0 + 1; break; }
-                        xw::pause();
-                    }
-                    xw::after_poll();
-                    const uint32_t hi = st ? umin(nb0 + kVBatch, st - 1) : nb0 + kVBatch;
-                    if (nb0 >= hi) break;
-                    verify_batch(seg_a, seg_q, max_parse, nb0, hi, pc_rep, cmp_acc);
-                }
-                xw::block_sync();
-            } else if (w != kLoaderWave) {
-                // ================= rows =================
-                uint32_t spins = 0;
-                for (;;) {
-                    const uint32_t m = prep_m;
-                    if (m < n_s + kRowRing && m < max_parse && (int32_t)(staged_hi() - (seg_a + m + 1)) >= 0) {
-                        xw::after_poll();
-                        prep_node(seg_a, m, max_parse, pc_dict, pc_rep, pc_lit);
-                        prep_m = m + kPrepWaves;
-                        xw::wave_sync();
-                        if (i == 0) xw::lds_st(&Lp->ctl.prep_cur[prep_i], prep_m);
-                        continue;
-                    }
-                    const uint32_t st = xw::readfirst(xw::lds_ld(&Lp->ctl.stop));
-                    if (st) {
-                        // (the node the chain stopped at, if the segment goes on there, is the least the next step needs)
-                        const uint32_t n1 = st - 1;
-                        if (m > n1 || n1 >= xw::readfirst(xw::lds_ld(&Lp->ctl.end_p)) || n1 >= max_parse) break;
-                    }
-                    if ((++spins & 255u) == 0 && (xw::readfirst(xw::ld_agent(&V.hx->err)) || xw::readfirst(xw::lds_ld(&Lp->sh[4])))) break;
-                    xw::pause();
-                }
-                xw::block_sync();
-            } else {
-                // ================= loader =================
-                uint32_t spins = 0;
-                const unsigned long long t0 = xw::clock100();
-                for (;;) {
-                    pump(seg_a + n_s);
-                    const uint32_t st = xw::readfirst(xw::lds_ld(&Lp->ctl.stop));
-                    if (st) {
-                        const uint32_t n1 = st - 1;
-                        if (n1 >= xw::readfirst(xw::lds_ld(&Lp->ctl.end_p)) || n1 >= max_parse || (int32_t)(staged_hi() - (seg_a + n1 + 1)) >= 0) break;
-                    }
-                    if ((++spins & 63u) == 0) {
-                        if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; break; }
-#ifndef NLZM_SIM
-                        if (st && xw::clock100() - t0 > 3000000000ull) {
-                            if (i == 0) raise(V.hx, kErrTimeout * 100 + 4, kStParser, 5, seg_a + st - 1, staged_hi(), t_out_seen);
-                            err = kErrInternal + 100; break;
-                        }
-#else
-                        (void)t0;
-#endif
-                    }
-                    if (pump_idle()) xw::pause();
-                }
-                if (err && i == 0) xw::lds_st(&Lp->sh[4], err);
                 xw::block_sync();
             }
-            xw::block_sync();                                       // (the chain's wave has decided)
-            if (xw::readfirst(xw::lds_ld(&Lp->sh[4])) || xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 0; }
-            seg_len = xw::readfirst(xw::lds_ld(&Lp->ctl.seg_len));
-            if (seg_len) break;
+            const unsigned long long own8 = (w < 4 && inb) ? load64u(G.in + a) : 0ull;     // (probe waves: the bytes at the node's position, on their way during the set-up)
+            const unsigned long long q2 = ptick();
+            // ---- set-up: the block's records, from the stage.  Every wave: the node's header, its distinct distances (for
+            // the probes' "already met" test) and the wave's own edges; their distances also go into the ring the winners'
+            // distances are looked up in.
+            const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+            const unsigned long long *srec = staged(a);
+            const unsigned long long hd = inb ? srec[0] : 0ull;
+            const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
+            const uint32_t uniq = ne ? (uint32_t)srec[kStageQ - 1] : 0u;
+            const uint32_t nd = (uint32_t)__builtin_popcount(uniq);
+            const uint32_t max_len = ne ? ((uint32_t)(srec[1] >> 32) & 0x1FFu) : 0u;
+            const uint32_t sreach = inb ? node + max_len : 0u;                      // :1550
+            uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) { ed[j] = 0; ea[j] = 0; }
+            // (requested here, used after the literal prices below: an edge beyond the sixteen that are staged comes from the ring
+            //  in HBM, and nearly every block has a node with one)
+            unsigned long long er[kEdgesPerWave];
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                const uint32_t k = edge_of(w, j);
+                er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
+            }
+            const unsigned long long q3 = ptick();
+            uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };            // the node's first eight distinct valid distances (probe waves)
+            if (w < 4) {
+                uint32_t um = uniq;
+#pragma unroll
+                for (uint32_t z = 0; z < 8; z++) {
+                    const uint32_t k = um ? (uint32_t)__builtin_ctz(um) : 0u;
+                    dd[z] = um ? (k < kStageEdges ? (uint32_t)srec[1 + k] : xw::ld_agent(rec + kTpEdges + 2 * k)) : 0u;
+                    um &= um - 1;
+                }
+            }
+            if (w == 0) L()->reach[1][i] = sreach;
+            const unsigned long long q4 = ptick();
+            const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
+            const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
+            if (w == 0 && i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                const uint32_t k = edge_of(w, j);
+                if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
+                const uint32_t at = (uint32_t)(er[j] >> 32);
+                if (at >> 31) {
+                    const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
+                    const uint32_t lp = L()->len_price[lv];
+                    const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
+                    ed[j] = (uint32_t)er[j];
+                    ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
+                }
+            }
+            for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
+            xw::block_sync();
+            if (w == 0) acc(kAccSetup, xw::tick() - ts);
+            t_q[0] += q1 - q0; t_q[1] += q2 - q1; t_q[2] += q3 - q2; t_q[3] += q4 - q3; t_q[4] += ptick() - q4;
+            const unsigned long long tp0 = xw::tick();
+            // ---- passes.  Every wave keeps the state of its lane's node in registers (all waves compute the same update)
+            unsigned long long key = kKeyNone;
+            uint32_t c = kInf, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            bool lv = false;
+            uint32_t istar = 64, blk_end = end_p, pass = 0;
+            // this wave's rep slot: what was measured for which distance, and the probe edge it gives under the node's present set
+            uint32_t mr = 0, ml = 0, cr = 0, pw = 0, pt = 0;
+            bool want = false;
+            const uint32_t pcap = umin(max_parse - node, kMatchMax);                                    // :1605-1606
+            for (;;) {
+                const uint32_t buf = pass % 3u, nbuf = (pass + 1) % 3u;
+                const unsigned long long k0 = ptick();
+                if (w == kPW - 1) pump(seg_a + b0);                 // (the records of the blocks to come)
+                // the explicit probe of rep slot w, unless a sampled edge has met that distance (:1598-1628): what is to be
+                // measured anew is decided first and its bytes are requested, so that they arrive behind the relaxation
+                bool dirty = false, wnt = false, fresh = false;
+                uint32_t r = 0;
+                unsigned long long px = 0;
+                if (pass > 0 && w < 4) {
+                    r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+                    dirty = lv && r != cr;
+                    if (xw::any(dirty)) {
+                        bool met = false;
+#pragma unroll
+                        for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
+                        if (xw::any(dirty && nd > 8)) {
+                            if (dirty && nd > 8) {
+                                for (uint32_t um = uniq; um; um &= um - 1)
+                                    met = met || L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)] == r;
+                            }
+                        }
+                        wnt = dirty && !met && r < seg_q + node;                                        // :1601
+                        fresh = wnt && mr != r && pcap > 0;
+                        if (fresh) px = load64u(G.in + a - r);
+                    }
+                }
+                if (pass > 0 && lv) {
+                    // relax this wave's sampled edges of the node (:1566-1595)
+#pragma unroll
+                    for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                        if (!ea[j]) continue;
+                        const uint32_t k = edge_of(w, j);
+                        const uint32_t tl = ea[j] & 0x1FFu, wd = (ea[j] >> 9) & 0xFFFu, lp = ea[j] >> 21;
+                        unsigned long long *dst = &L()->mcur[buf][(node + tl) & 511u];
+                        xw::lds_min64(dst, ((unsigned long long)(c + pc_dict + wd) << 32) | (node << 8) | (2 * k));
+                        const uint32_t d = ed[j];
+                        if (d == r0 || d == r1 || d == r2 || d == r3)
+                            xw::lds_min64(dst, ((unsigned long long)(c + pc_rep + lp + (2u << 5)) << 32) | (node << 8) | (2 * k + 1));
+                    }
+                }
+                const unsigned long long k0a = ptick();
+                if (pass > 0 && w < 4) {
+                    if (xw::any(dirty)) {
+                        if (xw::any(fresh)) { const uint32_t l = probe_finish(fresh, a, r, pcap, own8, px); if (fresh) { mr = r; ml = l; } }
+                        if (wnt && mr != r) { mr = r; ml = 0; }     // (nothing to compare: no room for a match)
+                        if (dirty) {
+                            cr = r; want = wnt; pw = 0; pt = 0;
+                            if (wnt && ml >= match_min(r)) { pw = pc_rep + L()->len_price[ml - match_min(r)] + (2u << 5); pt = ml; }   // :1607, :1614
+                        }
+                    }
+                    if (lv && pw) {
+                        xw::lds_min64(&L()->mcur[buf][(node + pt) & 511u], ((unsigned long long)(c + pw) << 32) | (node << 8) | (kRankProbe + w));
+                        xw::lds_max(&L()->reach[buf][i], node + pt);        // :1608-1612
+                    }
+                }
+                const unsigned long long k0b = ptick();
+                // the buffers of the next pass
+                for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
+                if (w == 0) L()->reach[nbuf][i] = sreach;
+                const unsigned long long k1 = ptick();
+                xw::block_sync();
+                const unsigned long long k2 = ptick();
+                // ---- update: every node of the block from the keys (the same in every wave)
+                unsigned long long kin = kKeyNone;
+                if (inb) {
+                    if (node <= end_open) kin = L()->mprev[node & 511u];
+                    if (i >= 1 && pass > 0) { const unsigned long long kc = L()->mcur[buf][node & 511u]; if (kc < kin) kin = kc; }
+                }
+                const uint32_t mc = kin == kKeyNone ? kInf : (uint32_t)(kin >> 32);
+                // cost through the literal edges: c[i] = min(mc[i], c[i-1] + litw[i-1]) = S[i] + min_{j<=i} (mc[j] - S[j])
+                const uint32_t nc = (uint32_t)(xw::scan_min_i32((int32_t)mc - (int32_t)S) + (int32_t)S);
+                const bool litwin = i >= 1 && nc < mc;                                                   // :1492 (the literal edge comes last: strict)
+                const unsigned long long nkey = litwin ? (((unsigned long long)nc << 32) | ((node - 1) << 8) | kRankLit) : kin;
+                const unsigned long long u1 = ptick();
+                // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
+                const uint32_t rlive = (lv && pass > 0) ? L()->reach[buf][i] : 0u;     // (a node's reach counts once it was inside: it has relaxed its edges)
+                const uint32_t pm = xw::scan_max(rlive);
+                const uint32_t before = umax(xw::lane_below(pm, 0u), end_p);
+                const bool inside = inb && node < before;
+                const unsigned long long dead = xw::ballot(!inside);
+                istar = dead ? (uint32_t)__builtin_ctzll(dead) : 64u;      // (lanes >= nb count as dead)
+                const bool act = i <= istar && inb;                 // nodes b0 .. b0+istar: inside, or the segment's last node
+                const bool nlv = i < istar && inb;
+                const unsigned long long u2 = ptick();
+                // rep sets from the winners (the sources' sets as of the last pass)
+                uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, link = 0, delta = 0;
+                if (act && nkey != kKeyNone) winner_set(seg_a, b0, (pass + 1) & 1u, node, nkey, o0, o1, o2, o3, link, delta);
+                {   // a run of literal winners carries the set of the node in front of the run (:1498): taken from that lane
+                    // in THIS pass, so that a literal run costs no pass
+                    const uint32_t root = xw::scan_max(litwin ? 0u : i);
+                    const uint32_t t0 = xw::shfl(o0, root), t1 = xw::shfl(o1, root), t2 = xw::shfl(o2, root), t3 = xw::shfl(o3, root);
+                    if (litwin) { o0 = t0; o1 = t1; o2 = t2; o3 = t3; }
+                }
+                const unsigned long long u3 = ptick();
+                const bool same = !act || (key == nkey && r0 == o0 && r1 == o1 && r2 == o2 && r3 == o3 && lv == nlv);
+                const bool changed = xw::any(!same);
+                if (act) { key = nkey; c = nc; r0 = o0; r1 = o1; r2 = o2; r3 = o3; }
+                lv = nlv;
+                if (w == 0 && act) { uint32_t *dr = L()->brep[pass & 1u] + i * 4; dr[0] = o0; dr[1] = o1; dr[2] = o2; dr[3] = o3; }
+                {
+                    const uint32_t done_n = umin(istar, nb);
+                    blk_end = done_n ? umax(end_p, xw::readlane(pm, done_n - 1)) : end_p;
+                }
+                t_work += k1 - k0; t_bar += k2 - k1; t_upd += ptick() - k2;
+                t_s[0] += k0a - k0; t_s[1] += k0b - k0a; t_s[2] += k1 - k0b; t_s[3] += u1 - k2; t_s[4] += u2 - u1; t_s[5] += u3 - u2; t_s[6] += ptick() - u3;
+                if (!changed) break;
+                pass++;
+            }
+            if (w == 0) { acc(kAccPass, xw::tick() - tp0); acc(kAccBlocks, 1); acc(kAccPasses, pass + 1); }
+            const unsigned long long e0 = ptick();
+            // ---- the block is at its fixed point: final nodes, the edges that end beyond it
+            const uint32_t lbuf = pass % 3u;                         // the buffer the last update read
+            const uint32_t done = umin(istar, nb);                   // nodes b0 .. b0+done-1 are inside
+            if (w == 0) {
+                const uint32_t lit_before = xw::lane_below(lit, 0u);   // the byte of the position before the node
+                if (i <= istar && inb) {
+                    uint32_t o0, o1, o2, o3, link, delta;
+                    winner_set(seg_a, b0, (pass + 1) & 1u, node, key, o0, o1, o2, o3, link, delta);
+                    if (((uint32_t)key & 0xFFu) == kRankLit && node > 0) delta = i ? lit_before : L()->sh[9];
+                    L()->node_link[node] = link; L()->node_delta[node] = delta;
+                    uint32_t *dr = L()->nrep + (node & 511u) * 4;
+                    dr[0] = r0; dr[1] = r1; dr[2] = r2; dr[3] = r3;
+                    if (i == istar) { L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3; }   // (the segment's last node, if it ends here)
+                }
+                if (i == nb - 1) L()->sh[11] = c;
+            }
+            if (w < 4 && i < done && want) n_cmp += ml + (ml < pcap);  // bytes the final probe of this slot looked at (counter parity)
+            xw::block_sync();
+            if (istar < nb) {
+                seg_len = b0 + istar;                               // the segment ends inside the block
+                // The positions after it belong to the next segment, whose cut is elsewhere: what was re-listed for this
+                // segment's forced cut goes back to the full sampling (:1545 with the new max_parse).
+                if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax && w == kPW - 1) {
+                    const uint32_t h0 = (inb && i >= istar) ? (uint32_t)staged(a)[0] : 0u;
+                    const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
+                    uint32_t full = umin((h0 >> 16) & 0x1FFu, chunk_left - node);
+                    if (full < kMatchMin) full = 0;
+                    for (unsigned long long m = xw::ballot(inb && i >= istar && ml != full); m; m &= m - 1) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        resample(seg_a + b0 + j, xw::readlane(full, j));
+                        acc(kAccUndo, 1);
+                    }
+                }
+            } else {
+                // the nodes the block has made reachable: its edges that end beyond it become their keys (merged with what earlier
+                // blocks left for the nodes that were open already); the literal edge of the block's last node goes the same way
+                const uint32_t new_end = blk_end;
+                for (uint32_t t = b0 + nb + tid; t <= new_end; t += kParserThreads) {
+                    unsigned long long k = L()->mcur[lbuf][t & 511u];
+                    if (t <= end_open) { const unsigned long long kp = L()->mprev[t & 511u]; if (kp < k) k = kp; }
+                    if (t == b0 + nb) {
+                        const unsigned long long kl = ((unsigned long long)(L()->sh[11] + L()->sh[10]) << 32) | ((b0 + nb - 1) << 8) | kRankLit;
+                        if (kl < k) k = kl;                         // (equal cost: the smaller source wins, :1492 strict)
+                        L()->sh[9] = L()->sh[6];
+                    }
+                    L()->mprev[t & 511u] = k;
+                }
+                if (tid == 0 && new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
+                if (new_end > end_open) end_open = new_end;
+                end_p = new_end;
+                b0 += nb;
+                xw::block_sync();
+            }
+            t_fin += ptick() - e0;
         }
-        if (w >= 1 && w <= kVerifyWaves) n_cmp += cmp_acc;         // (the last attempt stood)
+        xw::block_sync();
         // backtrack (:1633-1650): node indices of the path, end first
         if (w == 0) {
             uint32_t n = 0, cur = seg_len;
             while (cur != 0) {
-                if (i == 0) Lp->cmdlist()[n] = (uint16_t)cur;
+                if (i == 0) L()->cmdlist()[n] = (uint16_t)cur;
                 n++;
-                const uint32_t l = xw::readfirst((uint32_t)Lp->node_link[cur]) & 0x1FFu;
-                cur -= l ? l : 1u;
+                cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
             }
-            if (i == 0) Lp->ncmds = n;
+            if (i == 0) L()->ncmds = n;
         }
         xw::block_sync();
-        ncmds = Lp->ncmds;
-#ifdef NLZM_SIM
-        if (tid == 0) {                                             // (simulation: the segment's commands, for a diff against the oracle's)
-            xw::trace(4, seg_a, seg_len, ncmds);
-            for (uint32_t c = ncmds; c > 0; c--) {
-                const uint32_t nd = Lp->cmdlist()[c - 1], lk = Lp->node_link[nd], cmd = (lk >> 9) & 3u;
-                xw::trace(5, cmd, lk & 0x1FFu, cmd == 2 ? lk >> 11 : (cmd == 0 ? 0u : Lp->node_delta[nd]));
-            }
-        }
-#endif
+        ncmds = L()->ncmds;
         return seg_len;
     }
 
@@ -2192,7 +1940,7 @@ struct Parser {
             n_seg += nsegs;
             {
                 const unsigned long long te = xw::tick();
-                if (xw::wave() == kLoaderWave) pump(seg_a + len);               // (records of the next segment: requested now, in LDS by the next step)
+                if (xw::wave() == kPW - 1) pump(seg_a + len);                   // (records of the next segment: requested now, in LDS by the next step)
                 emit_commands(ncmds, n_lit, n_dict, n_rep);
                 if (xw::wave() == 0) acc(kAccEmit, xw::tick() - te);
             }
@@ -2233,10 +1981,8 @@ struct Parser {
         tab_dirty = true;
         t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
         if (tid < 5) L()->stg[tid] = (tid == 3 || tid == 2) ? 0u : t_out_seen;
-        ld_req = ld_wr = t_out_seen; ld_n[0] = ld_n[1] = 0; ld_turn = 0;
-        if (tid < 16) L()->sh[tid] = 0;
-        pend_t[0] = pend_t[1] = t_out_seen;                         // (as if t_out had been read before the table stage started)
-        n_eq_rounds = 0; n_cmp = 0;
+        pend_t = t_out_seen;                                        // (as if t_out had been read before the table stage started)
+        n_eq_fill = n_eq_rounds = 0; n_cmp = 0;
         if (tid < kAccN) L()->acc[tid] = 0;
         xw::block_sync();
         if (tid == 0) L()->acc[kAccTotal] = 0ull - xw::tick();
@@ -2244,14 +1990,22 @@ struct Parser {
         for (; ci < c1 && !err; ci++) run_chunk(ci);
         xw::block_sync();
 #ifdef NLZM_PROFILE
-        if (xw::lane() == 0 && xw::wave() == 0) for (int z = 0; z < 6; z++) xw::atomic_add64_agent(&P->prof[56 + z], t_q[z]);
+        if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) xw::atomic_add64_agent(&P->prof[56 + z], t_q[z]);
+        if (xw::lane() == 0) { xw::atomic_add64_agent(&P->prof[64 + xw::wave()], t_work); xw::atomic_add64_agent(&P->prof[72 + xw::wave()], t_bar); xw::atomic_add64_agent(&P->prof[80 + xw::wave()], t_upd); }
+        if (xw::lane() == 0 && xw::wave() < 4) {   // per wave: relax + probe work of a pass, barrier wait, update; mask fills
+            xw::atomic_add64_agent(&P->prof[32 + xw::wave()], t_work); xw::atomic_add64_agent(&P->prof[36 + xw::wave()], t_bar);
+            if (xw::wave() == 0) {
+                xw::atomic_add64_agent(&P->prof[40], t_upd); xw::atomic_add64_agent(&P->prof[42], t_fin); xw::atomic_add64_agent(&P->prof[41], t_fill);
+                for (int z = 0; z < 7; z++) { xw::atomic_add64_agent(&P->prof[48 + z], t_s[z]); t_s[z] = 0; }
+            }
+        }
 #endif
-        {   // bytes the probes looked at, probe rounds: summed over the waves
+        {   // bytes the probes looked at, mask fills, probe rounds: summed over the waves
             unsigned long long n_cmp64 = n_cmp;
             for (uint32_t d = 32; d; d >>= 1) n_cmp64 += xw::shfl64(n_cmp64, xw::lane() ^ d);      // (kept per lane)
             if (xw::lane() == 0) {
                 xw::lds_add64(&L()->cnt.cmp_bytes, n_cmp64);
-                xw::lds_add64(&L()->cnt.stale_rk, n_eq_rounds);     // (a counter the stages do not use otherwise)
+                xw::lds_add64(&L()->cnt.stale_ht, n_eq_fill); xw::lds_add64(&L()->cnt.stale_rk, n_eq_rounds);     // (counters the new stages do not use otherwise)
             }
         }
         xw::block_sync();
@@ -2264,7 +2018,7 @@ struct Parser {
                 unsigned long long *pr = P->prof;
                 auto add = [](unsigned long long *q, unsigned long long v) __attribute__((always_inline)) { xw::atomic_add64_agent(q, v); };
                 add(&pr[8], L()->acc[kAccBlocks]); add(&pr[13], L()->acc[kAccPasses]); add(&pr[14], L()->acc[kAccUndo]); add(&pr[26], L()->acc[kAccNeed]); add(&pr[27], L()->acc[kAccAhead]);
-                add(&pr[10], L()->cnt.stale_rk); add(&pr[11], L()->acc[kAccRedo]);
+                add(&pr[9], L()->cnt.stale_ht); add(&pr[10], L()->cnt.stale_rk); add(&pr[11], L()->acc[kAccRedo]);
                 Counters &c = P->cnt;
                 const Counters &lc = L()->cnt;
                 add(&c.n_literal, lc.n_literal); add(&c.n_dict, lc.n_dict); add(&c.n_rep, lc.n_rep); add(&c.segments, lc.segments);

@@ -74,20 +74,6 @@ XW_FN int32_t scan_min_i32(int32_t x)
     t = XW_DPP(id, v, 0x143, 0xC); v = (int32_t)t < (int32_t)v ? t : v;
     return (int32_t)v;
 }
-XW_FN uint32_t scan_min_u32(uint32_t v)
-{
-    const uint32_t id = 0xFFFFFFFFu;
-    uint32_t t;
-    t = XW_DPP(id, v, 0x111, 0xF); v = t < v ? t : v;
-    t = XW_DPP(id, v, 0x112, 0xF); v = t < v ? t : v;
-    t = XW_DPP(id, v, 0x114, 0xF); v = t < v ? t : v;
-    t = XW_DPP(id, v, 0x118, 0xF); v = t < v ? t : v;
-    t = XW_DPP(id, v, 0x142, 0xA); v = t < v ? t : v;
-    t = XW_DPP(id, v, 0x143, 0xC); v = t < v ? t : v;
-    return v;
-}
-// value of lane Q of the lane's group of four (quad_perm)
-template <int Q> XW_FN uint32_t quad_bcast(uint32_t v) { return XW_DPP(v, v, Q * 0x55, 0xF); }
 XW_FN uint32_t scan_add(uint32_t v)
 {
     v += XW_DPP(0u, v, 0x111, 0xF);
@@ -106,9 +92,6 @@ XW_FN void wave_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_ba
 XW_FN void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 XW_FN void block_sync() { __syncthreads(); }
 XW_FN void pause() { __builtin_amdgcn_s_sleep(1); }
-// a wave on the stage's serial chain: first at its SIMD's issue port while it holds this
-XW_FN void setprio_high() { __builtin_amdgcn_s_setprio(3); }
-XW_FN void setprio_low() { __builtin_amdgcn_s_setprio(0); }
 XW_FN void pause_long() { __builtin_amdgcn_s_sleep(16); }
 // agent-scope (sc1: write-through / L1-bypassing) accesses for words shared between workgroups
 XW_FN void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -126,7 +109,6 @@ XW_FN void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t
 }
 XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-XW_FN unsigned long long atomic_fetch_add64_agent(unsigned long long *p, unsigned long long v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // *p = v if *p == expect; returns what was there
 XW_FN uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v)
 {
@@ -149,7 +131,6 @@ XW_FN void lds_add64(unsigned long long *p, unsigned long long v)
 XW_FN void lds_or(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_inc(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_max(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-XW_FN void lds_min(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // the value as it is, but not to be reasoned about (keeps the compiler from turning a choice between two members of a
@@ -245,15 +226,11 @@ inline unsigned long long shfl_up64(unsigned long long v, uint32_t d) { const ui
 inline uint32_t scan_max(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = shfl_up(v, d); if (lane() >= d && o > v) v = o; } return v; }
 inline int32_t scan_min_i32(int32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const int32_t o = (int32_t)shfl_up((uint32_t)v, d); if (lane() >= d && o < v) v = o; } return v; }
 inline uint32_t scan_add(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = shfl_up(v, d); if (lane() >= d) v += o; } return v; }
-inline uint32_t scan_min_u32(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = shfl_up(v, d); if (lane() >= d && o < v) v = o; } return v; }
-template <int Q> inline uint32_t quad_bcast(uint32_t v) { return shfl(v, (lane() & ~3u) + Q); }
 inline uint32_t lane_below(uint32_t v, uint32_t fill) { const uint32_t o = shfl_up(v, 1); return lane() ? o : fill; }
 inline void wave_sync() { (void)collective(cSync, 0, 0); }
 inline void drain() {}
 inline void block_sync() { yield_to_sched(kBarrier); }
 inline void pause() { yield_to_sched(kPause); }
-inline void setprio_high() {}
-inline void setprio_low() {}
 inline void pause_long() { yield_to_sched(kPause); }
 inline void st_agent(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t ld_agent(const uint32_t *p) { return *(volatile const uint32_t *)p; }
@@ -262,7 +239,6 @@ inline unsigned long long ld_agent64(const unsigned long long *p) { return *(vol
 inline void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
-inline unsigned long long atomic_fetch_add64_agent(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 inline uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v) { const uint32_t o = *p; if (o == expect) *p = v; return o; }
 inline void acquire_agent() {}
 inline void after_poll() {}
@@ -271,7 +247,6 @@ inline void lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_inc(uint32_t *p) { return (*p)++; }
 inline void lds_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
-inline void lds_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 inline void lds_st(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t lds_ld(const uint32_t *p) { return *(volatile const uint32_t *)p; }
 inline uint32_t opaque(uint32_t v) { return v; }

@@ -168,20 +168,6 @@ void xw::trace(int what, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_
     if (what == 1 && seg) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a, b, c);
     if (what == 2 && all) fprintf(stderr, "F block a0 %u n %u m %u reach %u slider %u d %u end %u\n", a, b, c, d, e, f, g);
     if (what == 3 && all) fprintf(stderr, "T block a %u n %u\n", a, b);
-    // NLZM_SIM_SEGS=file: every segment the parser stage ends (start, length, commands) and every command of it (cmd, length, distance / byte / rep slot)
-    static FILE *segs = getenv("NLZM_SIM_SEGS") ? fopen(getenv("NLZM_SIM_SEGS"), "w") : nullptr;
-    if (what == 4 && segs) fprintf(segs, "seg %u len %u cmds %u\n", a, b, c);
-    if (what == 5 && segs) fprintf(segs, " %u %u %u\n", a, b, c);
-    if (segs) fflush(segs);
-}
-// NLZM_SIM_SEGS_ORACLE=file: the same list from the oracle
-static void ref_on_seg(void *, uint64_t abs_start, uint32_t seg_len, const nlzm_oracle_cmd *cmds, uint32_t ncmds)
-{
-    static FILE *segs = getenv("NLZM_SIM_SEGS_ORACLE") ? fopen(getenv("NLZM_SIM_SEGS_ORACLE"), "w") : nullptr;
-    if (!segs) return;
-    fprintf(segs, "seg %u len %u cmds %u\n", (uint32_t)abs_start, seg_len, ncmds);
-    for (uint32_t i = 0; i < ncmds; i++) fprintf(segs, " %u %u %u\n", cmds[i].cmd, cmds[i].len, cmds[i].cmd ? cmds[i].delta : 0u);
-    fflush(segs);
 }
 // NLZM_SIM_RANDOM_BLOCKS=k: the parser's blocks are cut to 1..k nodes at random
 uint32_t xw::test_cut(uint32_t nb)
@@ -209,20 +195,25 @@ static void ref_on_pos(void *, uint64_t abs_pos, uint32_t max_len, const uint32_
     g_ref.words.push_back(max_len);
     for (uint32_t i = 2; i <= max_len; i++) g_ref.words.push_back(delta[i]);
 }
-void v2::Table::sim_on_table(void *, uint32_t a, uint32_t mt, const uint32_t *dense)
+void v2::Table::sim_on_front(void *, uint32_t a, const unsigned long long *f, uint32_t fn)
 {
     if (g_ref.bad) return;
     if (a >= g_ref.off.size()) { printf("table stage: position %u beyond the oracle's\n", a); g_ref.bad = 1; return; }
     const uint32_t *r = g_ref.words.data() + g_ref.off[a];
     const uint32_t max_len = r[0];
+    const uint32_t mt = fn ? v2::fr_end(f[0]) - a : 0u;
     bool ok = mt == max_len;
-    for (uint32_t l = 2; ok && l <= max_len; l++) if (dense[v2::tf_index(l)] != r[l - 1]) ok = false;
+    for (uint32_t l = 2; ok && l <= max_len; l++) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < fn; k++) if (v2::fr_end(f[k]) >= a + l) d = v2::fr_dist(f[k]);
+        if (d != r[l - 1]) ok = false;
+    }
     g_ref.checked++;
     if (!ok) {
         printf("position %u: table differs. oracle max_len %u:", a, max_len);
         for (uint32_t l = 2; l <= max_len && l < 40; l++) printf(" %u", r[l - 1]);
-        printf("\n  sim max_len %u:", mt);
-        for (uint32_t l = 2; l <= mt && l < 40; l++) printf(" %u", dense[v2::tf_index(l)]);
+        printf("\n  sim front (%u):", fn);
+        for (uint32_t k = 0; k < fn && k < 40; k++) printf(" (len %u, d %u)", v2::fr_end(f[k]) - a, v2::fr_dist(f[k]));
         printf("\n");
         g_ref.bad = 1;
     }
@@ -278,7 +269,6 @@ int main(int argc, char **argv)
     // the oracle first: its tables are the reference the table stage is checked against as it goes
     nlzm_oracle_hooks hk; memset(&hk, 0, sizeof hk);
     hk.on_position = ref_on_pos;
-    hk.on_segment = ref_on_seg;
     std::vector<uint8_t> out(nlzm_oracle_bound((uint64_t)n));
     uint64_t out_n = 0; nlzm_oracle_stats st;
     if (nlzm_oracle_compress(in.data(), (uint64_t)n, hb, out.data(), out.size(), &out_n, &st, &hk)) { printf("oracle failed\n"); return 1; }
