@@ -104,9 +104,10 @@ struct Ctx {
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
     int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
     int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
-    int64_t opt_block_threads = 256;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
-    int64_t opt_block_hot_waves = 4;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
+    int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
+    int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
                                             // (profiles/r04_block_mode.txt): under load a stream waits for the serial chains of its busiest heads
+    int64_t opt_tbits_per = 3;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -360,10 +361,12 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
         uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
         C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
-        {   // (... and by the input: four entries per position keep the table as sparse as on the 1e9-byte stream at -window:28;
+        {   // (... and by the input: 2^tbits_per entries per position (default 8; the 1e9-byte stream at -window:28 has four, the cap): a denser table marks more
+            //  positions as undecided -- 300 MB with four instead of eight entries per position waited twice as long for BT4 results;
             //  every entry is cleared when a stream begins, which is what opening a set of 32 blocks spent most of its time on)
             uint32_t lgn = 1; while ((1ull << lgn) < g.n) lgn++;
-            if (lgn + 2 < C.t_bits) C.t_bits = lgn + 2 < 16 ? 16 : lgn + 2;
+            const uint32_t want = lgn + (uint32_t)C.opt_tbits_per;
+            if (want < C.t_bits) C.t_bits = want < 16 ? 16 : want;
         }
         if ((int64_t)C.t_bits > C.opt_tbits_max) C.t_bits = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);   // (smaller: only more `unc` marks)
         C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
@@ -812,6 +815,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "worker_threads out of range"); C.opt_worker_threads = value; return 0; }
     if (!strcmp(key, "block_worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "block_worker_threads out of range"); C.opt_block_threads = value; return 0; }
     if (!strcmp(key, "block_hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "block_hot_waves out of range"); C.opt_block_hot_waves = value; return 0; }
+    if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
@@ -1042,7 +1046,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
             Ctx m;                                  // (a scratch context: options as the streams will have them)
             m.inited = true; m.device = device; m.st = C.st;
             m.opt_workers = 1; m.opt_worker_blocks = wb; m.opt_batch = batch; m.opt_worker_threads = C.opt_block_threads; m.opt_tbits_max = tbits_max; m.cu_count = C.cu_count;
-            m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min;
+            m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min; m.opt_tbits_per = C.opt_tbits_per;
             Pool mp; mp.measuring = true;
             m.pool = &mp;
             uint8_t *fake_out = nullptr;
@@ -1064,7 +1068,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     for_blocks(nblocks, [&](uint32_t i, BlockJob &j) {
         j.rc = block_ctx_init(j.c, device, wb, batch);
         j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
-        j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min;
+        j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min; j.c.opt_tbits_per = C.opt_tbits_per;
         j.c.pool = &j.pool;
         if (!j.rc) j.rc = dev_alloc(j.c, &j.d_out, j.bound);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
