@@ -25,9 +25,11 @@ The JSON line also carries:
                 the device's own operation counters / the kernel's mean launch time measured
                 with HIP events on the library's stream; peak_measured = a device copy on this GPU; b_min = the bytes
                 that must move at least (input + output)
-  cpu_baseline  the reference itself (oracle/_ref/nlzm_ref, built from /root/reference at build time) or, if
-                that binary is absent, the oracle port, pinned to one core (taskset), on a bounded prefix of the same
-                stream as a file of its own
+  cpu_baseline  the reference itself (oracle/_ref/nlzm_ref, built from /root/reference at build time), pinned to one core
+                (taskset), started in the background BEFORE the GPU legs and collected after them: `value` on the first
+                280 MB of the same stream at -window:28 (a file of more than 2^28 bytes keeps the window at 28: the depth the
+                headline is quoted on), `shallow` on the first 25 MB as a file of its own (window 25, which favours the
+                reference).  If that binary is absent: the oracle port on the small sample
   blocks        the path's only shard axis used INSIDE each GPU: this rank's input split into
                 --block-streams independent blocks, all in flight at once.  A second measurement next to `value`,
                 never part of it (k streams instead of one).  At N = 1 every block's stream is compared with the
@@ -69,6 +71,24 @@ def algorithmic_bytes(st: dict) -> int:
     """bytes a bit-exact implementation must move, from the operation counters."""
     return (st["in_bytes_step"] + st["out_bytes_step"] + 16 * st["bt_calls"] + 12 * st["bt_tests"] + 2 * st["cmp_bytes"]
             + 8 * st["ht_rows"] + 4 * st["rk_probes"] + 4 * st["rk_inserts"])
+
+
+def algorithmic_bytes_lines(st: dict) -> int:
+    """The same operations at the granularity memory moves them: a 64-byte line per random access -- per BT4 test the pair read,
+    the compare's first line and the link store's line (written back whole); per call the head's line read and written and the
+    two terminal links; an HT row read and written; an RK256 probe / insert; byte compares and the streams as they are."""
+    return (st["in_bytes_step"] + st["out_bytes_step"] + 256 * st["bt_calls"] + 192 * st["bt_tests"] + 2 * st["cmp_bytes"]
+            + 128 * st["ht_rows"] + 64 * st["rk_probes"] + 64 * st["rk_inserts"])
+
+
+def csrc_sha16() -> str:
+    """what the library is built from (tests/prof_summarise.py records the same over the profiled tree)"""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.hip"))
+                    + glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.cpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 class CpuBaseline:
@@ -397,7 +417,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms_per_launch": round(k_ms, 3),
                          "launches_timed": int(launches),
                          "b_min_bytes_per_launch": int((d["in_bytes_step"] + d["out_bytes_step"]) / launches),
-                         "algorithmic_bytes_per_input_byte": round(algorithmic_bytes(d) / max(1, d["in_bytes_step"]), 2)},
+                         "algorithmic_bytes_per_input_byte": round(algorithmic_bytes(d) / max(1, d["in_bytes_step"]), 2),
+                         "algorithmic_bytes_line_granular": int(algorithmic_bytes_lines(d) / launches),
+                         "frac_line_granular": round(algorithmic_bytes_lines(d) / launches / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 8) if k_ms > 0 else 0.0},
             "kernel_ms": {"prep": round(tm1["prep_ms"] - tm0["prep_ms"], 3),
                           "match_parse": round(tm1["match_parse_ms"] - tm0["match_parse_ms"], 3),
                           "rans_gather": round(tm1["rans_ms"] - tm0["rans_ms"], 3)},
@@ -412,8 +434,13 @@ def main():
             prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
             pj = json.load(open(prof))
             if pj.get("kernel") == "pipeline2_kernel" and pj["bench_line_under_profiler"]["config"]["batch_chunks"] == B and world == 1:
-                res["roofline"]["traffic"] = int(pj["traffic_bytes_per_launch"]["total_with_fetch_x2"])
-                res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT)
+                if pj.get("csrc_sha16") != csrc_sha16():
+                    # (counters of other kernels than the ones timed here: not this run's traffic)
+                    res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT) + " refused: recorded for other kernel sources (csrc_sha16 differs)"
+                else:
+                    t = pj["traffic_bytes_per_launch"]
+                    res["roofline"]["traffic"] = int(t.get("total_calibrated", t["total_with_fetch_x2"]))
+                    res["roofline"]["traffic_source"] = os.path.relpath(prof, ROOT) + (" (FETCH_SIZE calibrated on random 8-byte reads)" if "total_calibrated" in t else " (FETCH_SIZE x 2)")
         except Exception:
             pass
         res["cpu_baseline"] = cpu_leg.collect() if cpu_leg is not None else None

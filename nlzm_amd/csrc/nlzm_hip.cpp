@@ -107,7 +107,7 @@ struct Ctx {
     int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
     int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
                                             // (profiles/r04_block_mode.txt): under load a stream waits for the serial chains of its busiest heads
-    int64_t opt_tbits_per = 3;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
+    int64_t opt_tbits_per = 4;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -124,6 +124,7 @@ struct Ctx {
     uint32_t next_chunk = 0;
 
     // device buffers
+    unsigned long long rkhash_len = 0;      // entries of rkhash (a launch's positions and their lookahead)
     uint32_t *rkhash = nullptr, *ht2 = nullptr, *ht3 = nullptr, *rk_table = nullptr, *bt_heads = nullptr, *bt_tree = nullptr;
     Persist *persist = nullptr;
     uint32_t *syms = nullptr, *scratch = nullptr;
@@ -288,7 +289,10 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     C.stats.in_bytes = n;
 
     const size_t ht3_rows = (size_t)2 << (32 - g.ht3_shift);
-    DEVALLOC(C.rkhash, (n + 1024) * 4 + 16);
+    // (RK256 hashes of ONE launch's positions -- the array is indexed by absolute position through a base pointer moved back by
+    //  the launch's first hashed position, so only a launch's worth is ever resident: 4 B x (launch + lookahead) instead of 4 B
+    //  per input byte, which was 4 GB at 1e9 bytes)
+    C.rkhash_len = 0;
     DEVALLOC(C.ht2, 4096 * 4);
     DEVALLOC(C.ht3, ht3_rows * 4);
     DEVALLOC(C.rk_table, (size_t)4 << (32 - g.rk_shift));
@@ -329,6 +333,9 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         const double per_chunk = 2300.0 * g.chunk_size + 8.0 * g.chunk_size * 4;
         if (room > per_chunk && (double)C.batch * per_chunk > room) C.batch = (uint32_t)(room / per_chunk);
     }
+    C.rkhash_len = (unsigned long long)C.batch * g.chunk_size + g.feed + 256 + 1024 + 2048;
+    if (C.rkhash_len > n + 2048) C.rkhash_len = n + 2048;
+    DEVALLOC(C.rkhash, C.rkhash_len * 4 + 16);
     C.syms_stride = 3ull * g.chunk_size + 4096;          // <= 3 symbols per input byte
     C.bits_stride = 2ull * g.chunk_size + 64;            // <= 13 raw bits per input byte
     C.frame_stride = 12 + C.bits_stride + 16 + 2 * C.syms_stride;
@@ -361,7 +368,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
         uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
         C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
-        {   // (... and by the input: 2^tbits_per entries per position (default 8; the 1e9-byte stream at -window:28 has four, the cap): a denser table marks more
+        {   // (... and by the input: 2^tbits_per entries per position (default 16; the 1e9-byte stream at -window:28 has four, the cap): a denser table marks more
             //  positions as undecided -- 300 MB with four instead of eight entries per position waited twice as long for BT4 results;
             //  every entry is cleared when a stream begins, which is what opening a set of 32 blocks spent most of its time on)
             uint32_t lgn = 1; while ((1ull << lgn) < g.n) lgn++;
@@ -434,7 +441,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
     P.c0 = c0; P.c1 = c1; P.nb = nb;
     Globals &G = P.G;
     memset(&G, 0, sizeof G);
-    G.in = C.d_in; G.rkhash = C.rkhash; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
+    G.in = C.d_in; G.rkhash = nullptr; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
     G.bt_heads = C.bt_heads; G.bt_tree = C.bt_tree; G.persist = C.persist;
     G.syms = C.syms; G.syms_stride = C.syms_stride; G.bits = C.bits; G.bits_stride = C.bits_stride;
     G.fmeta = C.fmeta; G.chunk0 = c0;
@@ -449,7 +456,9 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         unsigned long long hi = a1 + g.feed + 256;
         if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
         HIPCHK(hipEventRecord(C.ev[7], C.st));
-        if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash, C.st);
+        if (hi > lo && hi - lo > C.rkhash_len) return set_err(NLZM_HIP_E_ARG, "launch of %u chunks is larger than the stream was opened for", nb);
+        G.rkhash = C.rkhash - lo;                       // rkhash[a] for a in [lo, hi): the launch's own array
+        if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash - lo, C.st);
     }
     HIPCHK(hipEventRecord(C.ev[5], C.st));
     if (C.workers) {
@@ -1020,7 +1029,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         const double per_stream = 0.85 * (double)free_b / nblocks;
         Geom g0;
         make_geom(per_fixed ? per_fixed : (n + nblocks - 1) / nblocks, hist_bits_req, g0);
-        const double fixed = 8.0 * ((double)g0.wmask + 1) * 2 + 4.0 * (double)g0.n + 5e7;     // BT4 tree (widened), RK hashes, the rest
+        const double fixed = 8.0 * ((double)g0.wmask + 1) * 2 + 5e7;     // BT4 tree (widened), the rest
         double left = per_stream - fixed;
         if (left < 2e8) return set_err(NLZM_HIP_E_NOMEM, "%u streams of %llu bytes at -window:%u do not fit %.1f GB of free memory", nblocks,
                                        (unsigned long long)g0.n, g0.wbits, free_b / 1e9);
