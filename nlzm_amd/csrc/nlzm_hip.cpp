@@ -160,6 +160,8 @@ struct Ctx {
     nlzm_hip_stats stats{};
     nlzm_hip_timing tm{};
     unsigned long long last_dry_runs = 0, last_flag_waits = 0;
+    // what the step's frame coder has reported (step_post_issue .. _done)
+    std::vector<FrameMeta> post_hm; std::vector<unsigned long long> post_hoff; Persist post_P; uint32_t post_aborted = 0; unsigned long long post_pos = 0;
     Pool *pool = nullptr;                   // (block mode) where the stream's buffers come from
     bool pooled = false;                    // the open stream's buffers are the pool's: not freed one by one
 };
@@ -492,22 +494,34 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
 }
 
 // pipe_ms: time of the persistent launch when it was not this stream's own (group launch), else < 0
-int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
+// (in three parts, so that the streams of a block set have their frame coders and gathers in flight together: every part of
+//  every stream is queued before the next part waits for any of them)
+int step_post_issue(Ctx &C, const StepPlan &P)
 {
-    const Geom &g = C.g;
-    const uint32_t c0 = P.c0, c1 = P.c1, nb = P.nb;
-    std::vector<FrameMeta> hm(nb);
-    std::vector<unsigned long long> hoff(nb);
+    const uint32_t nb = P.nb;
+    C.post_hm.resize(nb); C.post_hoff.resize(nb);
+    std::vector<FrameMeta> &hm = C.post_hm;
+    Persist &Pst = C.post_P;
+    uint32_t &aborted = C.post_aborted;
+    aborted = 0;
     HIPCHK(hipEventRecord(C.ev[1], C.st));
     launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
                 C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
     HIPCHK(hipEventRecord(C.ev[2], C.st));
     HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
-    Persist Pst;
     HIPCHK(hipMemcpyAsync(&Pst, C.persist, sizeof Pst, hipMemcpyDeviceToHost, C.st));
-    uint32_t aborted = 0;
     if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
     HIPCHK(hipMemcpyAsync(&C.hx_host, C.v2_hx, sizeof(v2::Hx), hipMemcpyDeviceToHost, C.st));
+    return 0;
+}
+int step_post_check(Ctx &C, const StepPlan &P)
+{
+    const Geom &g = C.g;
+    const uint32_t c0 = P.c0, c1 = P.c1, nb = P.nb;
+    std::vector<FrameMeta> &hm = C.post_hm;
+    std::vector<unsigned long long> &hoff = C.post_hoff;
+    const Persist &Pst = C.post_P;
+    const uint32_t aborted = C.post_aborted;
     HIPCHK(hipStreamSynchronize(C.st));
     HIPCHK(hipGetLastError());
     float rk_ms = 0, pre_ms = 0;
@@ -556,6 +570,13 @@ int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
     HIPCHK(hipEventRecord(C.ev[3], C.st));
     launch_gather(C.frames, C.frame_stride, C.dst_off, C.fmeta, C.d_dst, nb, C.st);
     HIPCHK(hipEventRecord(C.ev[4], C.st));
+    C.post_pos = pos;
+    return 0;
+}
+int step_post_done(Ctx &C, const StepPlan &P, float pipe_ms)
+{
+    const unsigned long long pos = C.post_pos;
+    const uint32_t c1 = P.c1;
     HIPCHK(hipStreamSynchronize(C.st));
     float a = pipe_ms, b = 0, c = 0;
     if (pipe_ms < 0) HIPCHK(hipEventElapsedTime(&a, C.ev[0], C.ev[1]));
@@ -567,6 +588,13 @@ int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
     C.out_pos = pos;
     C.next_chunk = c1;
     return 0;
+}
+int step_post(Ctx &C, const StepPlan &P, float pipe_ms)
+{
+    int rc = step_post_issue(C, P);
+    if (!rc) rc = step_post_check(C, P);
+    if (!rc) rc = step_post_done(C, P, pipe_ms);
+    return rc;
 }
 
 int stream_step(Ctx &C, uint32_t max_chunks, uint64_t *in_done, uint64_t *out_done, int *finished)
@@ -1159,14 +1187,18 @@ static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_tot
         {   // (every stream of the round is looked at, so that the first failure is reported with its own diagnostics)
             int first_rc = 0;
             char first_msg[sizeof g_err] = "";
-            for (uint32_t i : act) {
-                const int rc = step_post(g_jobs[i].c, plan[i], 0.0f);
+            std::vector<int> rcs(nj, 0);
+            auto note = [&](uint32_t i, int rc) {
+                if (rc && !rcs[i]) rcs[i] = rc;
                 if (rc && !first_rc) {
                     first_rc = rc;
                     std::lock_guard<std::mutex> lk(g_err_mu);
                     snprintf(first_msg, sizeof first_msg, "block %u: %.*s", i, (int)sizeof first_msg - 32, g_err);
                 }
-            }
+            };
+            for (uint32_t i : act) note(i, step_post_issue(g_jobs[i].c, plan[i]));
+            for (uint32_t i : act) if (!rcs[i]) note(i, step_post_check(g_jobs[i].c, plan[i]));
+            for (uint32_t i : act) if (!rcs[i]) note(i, step_post_done(g_jobs[i].c, plan[i], 0.0f));
             if (first_rc) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, first_msg, sizeof g_err); return first_rc; }
         }
         for (uint32_t gi = 0; gi < ngroups; gi++) {
