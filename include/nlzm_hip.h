@@ -177,6 +177,12 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
                                    const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
                                    uint8_t *dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
 
+/* Block mode's placement rule, for inspection (no device needed): workgroup `workgroup` of the shared persistent launch of
+ * nstreams streams with blocks_per_stream workgroups each (three stage workgroups + the worker CUs) belongs to *stream and is
+ * its block *local (0 finder, 1 table, 2 parser, 3.. workers).  With a multiple of eight streams all blocks of a stream have the
+ * same workgroup index modulo 8, i.e. lie on one XCD under the round-robin dispatch (speed only). */
+void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uint32_t workgroup, uint32_t *stream, uint32_t *local);
+
 /* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
 /* key: "workers" (only 1: BT4 runs on per-head worker lanes), "batch_chunks" (chunks per persistent launch), "worker_blocks" (worker CUs of a stream, default 60),
  * "worker_threads" (bin-taking lanes per worker CU, 64..512, default 128), "hot_waves" (waves per worker CU that take a hot

@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "nlzm_hip_blocks_begin", "nlzm_hip_blocks_step", "nlzm_hip_blocks_finish", "nlzm_hip_blocks_abandon",
     "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks", "nlzm_hip_compress_blocks_multi",
     "nlzm_hip_feed_begin", "nlzm_hip_feed", "nlzm_hip_feed_output", "nlzm_hip_feed_finish", "nlzm_hip_feed_end",
+    "nlzm_hip_block_placement",
 ]
 
 

@@ -88,6 +88,16 @@ constexpr uint32_t kErrTimeout = 2;
 constexpr uint32_t kErrInternal = 3;
 constexpr uint32_t kErrCapture = 4;
 
+// Block mode: which stream, and which of its blocks (0, 1, 2: finder, table, parser stage; 3..: worker CUs), workgroup b of a
+// launch of `grid` workgroups is, with bps blocks per stream.  Workgroups go to the eight XCDs round-robin (blocks b and b + 8
+// share one: for speed only, nothing depends on it): with a multiple of eight streams every stream's blocks are dealt to ONE
+// XCD, so that its hand-off rings, BT4 records and tree are served from one L2 -- stream s = x + 8 * group on XCD x.
+NLZM_HD void multi_block_of(uint32_t grid, uint32_t bps, uint32_t b, uint32_t &stream, uint32_t &local)
+{
+    if ((grid / bps) % 8 == 0) { const uint32_t x = b % 8, j = b / 8; stream = x + 8 * (j / bps); local = j % bps; }
+    else { stream = b / bps; local = b % bps; }
+}
+
 struct FrameMeta {
     uint32_t nsyms, nbits_bytes, num_ops, out_len;
 };

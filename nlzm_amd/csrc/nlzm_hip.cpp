@@ -453,7 +453,10 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
     unsigned long long a1 = (unsigned long long)c1 * g.chunk_size;
     if (a1 > g.n) a1 = g.n;
     G.batch_a0 = (uint32_t)a0;
-    {   // pre-pass: RK256 hash of every window the launch can touch (catch-up inserts reach back < 512 bytes)
+    {   // pre-pass: RK256 hash of every window the launch can touch (catch-up inserts reach back < 512 bytes).
+        // Feed mode: the hashes of windows beyond the launch's last position (up to a1 + feed + 511) may be computed from bytes
+        // whose upload is still in flight (feed_chunks_ready guarantees a1 + (feed - chunk) + 1024 only).  They are never used:
+        // the finder reads rkhash[p] for p < a1 only, and the next launch hashes again from its own a0 - 1024 on.
         const unsigned long long lo = a0 > 1024 ? a0 - 1024 : 0;
         unsigned long long hi = a1 + g.feed + 256;
         if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
@@ -836,6 +839,14 @@ int nlzm_hip_get_timing(nlzm_hip_timing *out)
     if (!out) return set_err(NLZM_HIP_E_ARG, "null argument");
     *out = C.tm;
     return 0;
+}
+
+void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uint32_t workgroup, uint32_t *stream, uint32_t *local)
+{
+    uint32_t s = 0, l = 0;
+    multi_block_of(nstreams * blocks_per_stream, blocks_per_stream, workgroup, s, l);
+    if (stream) *stream = s;
+    if (local) *local = l;
 }
 
 int nlzm_hip_set_option(const char *key, int64_t value)
@@ -1327,6 +1338,8 @@ static uint32_t feed_chunks_ready(const Geom &g, uint64_t arrived)
 {
     if (arrived >= g.n) return g.nchunks;
     const uint64_t slack = (uint64_t)g.feed - g.chunk_size + 1024;      // lookahead of the last chunk + RK256 / pre-filter windows
+    // (what a launch READS AND USES lies below its last position + slack; its RK256 pre-pass also hashes a little further, into bytes
+    //  that may still be arriving -- those hashes are recomputed by the next launch before anything looks at them: step_pre)
     if (arrived < slack + g.chunk_size) return 0;
     return (uint32_t)((arrived - slack) / g.chunk_size);
 }

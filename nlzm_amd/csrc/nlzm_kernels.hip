@@ -916,12 +916,8 @@ struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; };
 constexpr uint32_t kMaxStreams2PerLaunch = 64;          // (the pack lives in device memory: the kernel-argument segment holds 4 KB)
 __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args *__restrict__ pack, uint32_t bps)
 {
-    // Workgroups go to the eight XCDs round-robin (blocks b and b + 8 share one: guide, XCD placement -- for speed only, nothing
-    // depends on it).  With a multiple of eight streams every stream's stage and worker blocks are dealt to ONE XCD, so that
-    // its hand-off rings, BT4 records and tree are served from one L2: stream s = x + 8 * group on XCD x.
     uint32_t s, local;
-    if ((gridDim.x / bps) % 8 == 0) { const uint32_t x = blockIdx.x % 8, j = blockIdx.x / 8; s = x + 8 * (j / bps); local = j % bps; }
-    else { s = blockIdx.x / bps; local = blockIdx.x % bps; }
+    multi_block_of(gridDim.x, bps, blockIdx.x, s, local);       // (a stream's blocks on one XCD: nlzm_core.h)
     Stream2Args a = pack[s];
     // pointers read from memory: tell the compiler they are global ones (flat accesses would count on both wait counters)
 #define NLZM_GLOBAL_PTR(p) p = (decltype(p))(__attribute__((address_space(1))) std::remove_pointer_t<decltype(p)> *)(unsigned long long)(p)

@@ -1111,7 +1111,11 @@ constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
 constexpr uint32_t kPW = 8;                     // waves of the stage.  A node has up to 32 sampled edges, nearly always fewer than 16:
-constexpr uint32_t kEdgesPerWave = 5;           //   waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
+#ifndef NLZM_EDGE_SPLIT
+#define NLZM_EDGE_SPLIT 1
+#endif
+#if NLZM_EDGE_SPLIT == 0
+constexpr uint32_t kEdgesPerWave = 5;           //   (round 3) waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
                                                 //   ahead), waves 0..3 four of the rare ones each and make the explicit probe of rep slot w
 NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
 {
@@ -1119,6 +1123,17 @@ NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w 
     if (w < 7) return (w - 4) + 3 * j;
     return j == 0 ? 15u : kMaxEdges;
 }
+#else
+// The probe waves 0..3 are a pass's critical path (relax 890 + probe 775 cycles against 1,100 of the others, which then wait
+// 650 at the barrier): they keep two of the rare edges each (16..23), waves 4..6 take two more (24..29), wave 7 the last two.
+constexpr uint32_t kEdgesPerWave = 7;
+NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
+{
+    if (w < 4) return j < 2 ? 16 + w + 4 * j : kMaxEdges;
+    if (w < 7) return j < 5 ? (w - 4) + 3 * j : 24 + (w - 4) + 3 * (j - 5);
+    return j == 0 ? 15u : (j < 3 ? 29 + j : kMaxEdges);
+}
+#endif
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)

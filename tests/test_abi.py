@@ -59,6 +59,29 @@ def test_geometry_needs_no_device(lib):
     assert lib.nlzm_hip_compress_bound(0) >= 8
 
 
+def test_block_mode_placement_rule(lib):
+    """The persistent launch of a block set deals every stream's workgroups (three stages + its worker CUs) to ONE XCD when the
+    number of streams is a multiple of eight (workgroups go to the XCDs round-robin: equal index modulo 8), and in every case
+    each (stream, block) pair is some workgroup exactly once.  No device needed."""
+    import ctypes as C
+    f = lib.nlzm_hip_block_placement
+    f.restype = None
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for nstreams in (1, 3, 8, 16, 24, 32, 40, 64):
+        for bps in (4, 5, 7, 8, 31):
+            seen = {}
+            for wg in range(nstreams * bps):
+                s, l = C.c_uint32(), C.c_uint32()
+                f(nstreams, bps, wg, C.byref(s), C.byref(l))
+                assert s.value < nstreams and l.value < bps
+                assert (s.value, l.value) not in seen
+                seen[(s.value, l.value)] = wg
+            assert len(seen) == nstreams * bps
+            if nstreams % 8 == 0:
+                for st in range(nstreams):
+                    assert len({seen[(st, l)] % 8 for l in range(bps)}) == 1, (nstreams, bps, st)
+
+
 def test_fails_loudly_without_gpu(lib):
     import torch
     if torch.cuda.is_available():

@@ -207,6 +207,30 @@ def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
     assert shard.split_streams(b"".join(got)) == got
 
 
+def test_block_mode_options_are_invisible(gpu):
+    """How a block set's worker CUs are used (bin-taking lanes, hot-bin waves), how dense the pre-filter table is and how many
+    chunks a launch takes must not change a byte of any stream."""
+    data = corpus.mixed(6_000_000, corpus.SEED + 31)
+    want = gpu.compress_blocks(data, 8, 20)
+    try:
+        for opts in ({"block_worker_threads": 512, "block_hot_waves": 0}, {"block_worker_threads": 128, "block_hot_waves": 6},
+                     {"prefilter_bits_per_position": 0}, {"prefilter_bits_per_position": 6, "batch_chunks": 3}):
+            for k, v in opts.items():
+                gpu.set_option(k, v)
+            assert gpu.compress_blocks(data, 8, 20) == want, opts
+            for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "batch_chunks": 32}.items():
+                gpu.set_option(k, v)
+    finally:
+        for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "batch_chunks": 32}.items():
+            gpu.set_option(k, v)
+    # the single-stream path with a sparse and a dense table
+    one = gpu.compress(data[:2_000_000], 20)
+    for bits in (0, 7):
+        gpu.set_option("prefilter_bits_per_position", bits)
+        assert gpu.compress(data[:2_000_000], 20) == one, bits
+    gpu.set_option("prefilter_bits_per_position", 4)
+
+
 def test_blocks_ragged_and_empty(gpu):
     """Fewer bytes than blocks: trailing blocks are empty streams (header + terminator), as the reference writes for an
     empty file; a last block shorter than the others; one block = the plain stream."""
