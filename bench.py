@@ -65,7 +65,7 @@ WINDOW = 28
 CHUNK = 122_368
 STEPS_PER_STREAM = 25      # a step is 1/25 of the stream's launches: --steps 20 --warmup 5 is the whole stream
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E
-BLOCKS_BATCH = 16          # block-mode leg: chunks of every block per shared persistent launch
+BLOCKS_BATCH = 8           # block-mode leg: chunks of every block per shared persistent launch
 
 
 def algorithmic_bytes(st: dict) -> int:
@@ -169,8 +169,8 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
     of it: the bytes differ from the single-stream output -- each block's stream equals the reference run on that
     block alone, which `check` verifies against tests/golden/blocks_1g.json when all the steps were run."""
     per = -(-n // k)
-    B = BLOCKS_BATCH                    # (chunks of every block per shared launch: fewer, longer launches lose less at their ends;
-    nlzm_amd.set_option("batch_chunks", B)      #  measured 8 -> 16: 72.9 -> 78.9 MB/s, profiles/r04_block_mode.txt)
+    B = BLOCKS_BATCH                    # (chunks of every block per shared launch.  The launches of consecutive rounds are queued back
+    nlzm_amd.set_option("batch_chunks", B)      #  to back, so their length matters little: 6 / 8 / 12 / 16 chunks 88.9 / 89.8 / 88.7 / 89.6 MB/s, profiles/r04_block_mode.txt)
     nb_launch = -(-(-(-per // CHUNK)) // B)
     per_step = max(1, -(-nb_launch // STEPS_PER_STREAM)) * B
     geo = nlzm_amd.geometry(per, WINDOW)

@@ -138,7 +138,11 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
  * the stages of its serial half and at least one CU of BT4 worker lanes, so k <= CUs / 4 (64 on an MI355X; the CUs left
  * are divided among the streams); an MI355X does best with 32 to 40.  d_src needs 128 readable bytes behind it (the host-buffer entry points allocate 512).
  * begin binds the input and allocates every stream's state, each step advances every stream by max_chunks chunks
- * (0: to its end), finish appends the terminators and concatenates into d_dst.  A begin or step that fails has closed
+ * (0: to its end), finish appends the terminators and concatenates into d_dst.  The launches of consecutive rounds are
+ * queued back to back (the pre-pass kernels of the next round and the frame coder of the round before run beside a launch,
+ * out of two sets of per-launch buffers), and a step that has delivered its max_chunks leaves the NEXT round of the same
+ * size queued on the device for the next step to collect, so that the device does not idle between the calls: in_done_total
+ * counts what has been collected.  A begin or step that fails has closed
  * the set (every stream's buffers freed, nothing left queued that reads d_src): there is nothing to abandon then;
  * nlzm_hip_blocks_abandon() drops a set the caller does not want to finish. */
 int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req);

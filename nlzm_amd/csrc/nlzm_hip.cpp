@@ -31,8 +31,10 @@ void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, u
 unsigned long long stream2_pack_size();
 uint32_t stream2_pack_capacity();
 uint32_t pipeline2_role_blocks();
-void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1);
+void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, v2::RoundSnap *snap);
 void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
+void launch_round_open(const void *dev_pack, uint32_t nstreams, hipStream_t st);
+void launch_round_close(const void *dev_pack, uint32_t nstreams, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
 unsigned long long worker_undo_bytes_per_lane();
@@ -91,6 +93,7 @@ struct Ctx {
     int device = 0;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
+    hipEvent_t ev_b[8] = {};                // (block mode) the events of the second launch set
 
     // options
     int64_t opt_workers = 1;
@@ -112,7 +115,7 @@ struct Ctx {
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
     uint32_t run_worker_blocks = 0, run_worker_threads = 0;
-    double acct[8] = {};                    // of the last finished stream, cycles per position: finder total / wait / of it for BT4, table total / wait, parser total / wait / chain
+    double acct[8] = {};                    // of the last finished stream, cycles per position: finder total / wait / of it for BT4, table total / wait, parser total / wait / passes
 
 
     // stream state
@@ -121,7 +124,8 @@ struct Ctx {
     const uint8_t *d_in = nullptr;
     uint8_t *d_dst = nullptr;
     uint64_t dst_cap = 0, out_pos = 0;
-    uint32_t next_chunk = 0;
+    uint32_t next_chunk = 0;                // chunks below this are coded and gathered
+    uint32_t pre_chunk = 0;                 // chunks below this have had their pre-pass queued (block mode runs it a launch ahead)
 
     // device buffers
     unsigned long long rkhash_len = 0;      // entries of rkhash (a launch's positions and their lookahead)
@@ -162,9 +166,32 @@ struct Ctx {
     unsigned long long last_dry_runs = 0, last_flag_waits = 0;
     // what the step's frame coder has reported (step_post_issue .. _done)
     std::vector<FrameMeta> post_hm; std::vector<unsigned long long> post_hoff; Persist post_P; uint32_t post_aborted = 0; unsigned long long post_pos = 0;
+    // Block mode queues launch k + 1 (and runs its pre-pass) while launch k is on the device and codes the frames of launch k
+    // while launch k + 1 is: everything a pre-pass writes or a frame coder reads exists twice, and swap_sets() makes the other
+    // set the current one (the members above) before a pre-pass.
+    bool double_sets = false;
+    uint32_t set_idx = 0;
+    struct LaunchSet {
+        uint32_t *rkhash = nullptr, *bt_ready = nullptr, *bt_flag = nullptr, *abort_word = nullptr, *bin_off = nullptr, *bin_pos = nullptr,
+                 *hot_of_bin = nullptr, *hot_list = nullptr, *syms = nullptr;
+        uint8_t *unc = nullptr, *bits = nullptr;
+        FrameMeta *fmeta = nullptr;
+        v2::RoundSnap *snap = nullptr;
+    } alt;
+    v2::RoundSnap *snap = nullptr;          // (current set) what round_close_kernel copies aside for the host
+    v2::RoundSnap post_snap;
     Pool *pool = nullptr;                   // (block mode) where the stream's buffers come from
     bool pooled = false;                    // the open stream's buffers are the pool's: not freed one by one
 };
+
+void swap_sets(Ctx &C)
+{
+    Ctx::LaunchSet &A = C.alt;
+    std::swap(C.rkhash, A.rkhash); std::swap(C.bt_ready, A.bt_ready); std::swap(C.bt_flag, A.bt_flag); std::swap(C.abort_word, A.abort_word);
+    std::swap(C.bin_off, A.bin_off); std::swap(C.bin_pos, A.bin_pos); std::swap(C.hot_of_bin, A.hot_of_bin); std::swap(C.hot_list, A.hot_list);
+    std::swap(C.syms, A.syms); std::swap(C.unc, A.unc); std::swap(C.bits, A.bits); std::swap(C.fmeta, A.fmeta); std::swap(C.snap, A.snap);
+    C.set_idx ^= 1;
+}
 
 // a device buffer of the stream: from its pool, or from hipMalloc
 template <class T> int dev_alloc(Ctx &C, T **p, size_t bytes)
@@ -184,6 +211,14 @@ template <class T> int dev_alloc(Ctx &C, T **p, size_t bytes)
 #define DEVALLOC(ptr, bytes) do { const int rc_ = dev_alloc(C, &(ptr), (bytes)); if (rc_) return rc_; } while (0)
 #define DEVFILL(expr) do { if (!(C.pool && C.pool->measuring)) HIPCHK(expr); } while (0)
 
+//   (the plan keeps the launch set and the events the step was queued with: block mode has two steps of a stream open at a time)
+struct StepPlan {
+    uint32_t c0 = 0, c1 = 0, nb = 0; Globals G; v2::GlobalsV2 V;
+    hipEvent_t ev[8] = {};
+    uint32_t *syms = nullptr, *abort_word = nullptr; uint8_t *bits = nullptr; FrameMeta *fmeta = nullptr;
+    v2::RoundSnap *snap = nullptr;              // non-null: the launch is followed by round_close_kernel, the host reads this
+};
+
 struct BlockJob {
     Ctx c;
     uint64_t lo = 0, n = 0, len = 0, bound = 0;
@@ -201,13 +236,21 @@ struct DevState {
     std::vector<BlockJob> jobs;                     // the open block set (nlzm_hip_blocks_begin .. _finish)
     uint8_t *blocks_pool = nullptr;                 // ... and the one allocation all its streams' buffers lie in
     std::vector<hipStream_t> group_st;              // one HIP stream and an event pair per shared launch of a round
-    std::vector<std::array<hipEvent_t, 2>> group_ev;
+    std::vector<std::array<hipEvent_t, 3>> group_ev;   // per launch set: launch begins / ends / its results are copied aside
     void *pack_host = nullptr, *pack_dev = nullptr; // the streams' launch arguments of a round: pinned host copy, device copy
     uint64_t blocks_n = 0;
     const uint8_t *blocks_src = nullptr;
     uint32_t blocks_hist = 0;
     int64_t blocks_wb = 0;
     uint64_t blocks_per = 0;                        // bytes per block when the caller fixes the partition (0: ceil(n / nblocks))
+    // the rounds of the block set (blocks_step_impl): two are open at a time, and one may stay queued when a step returns
+    struct Rounds {
+        bool have = false;                          // round `q` is queued (pre-passes and launch) and not collected yet
+        uint32_t q = 0;
+        uint32_t last_max = 0;
+        std::vector<StepPlan> plan[2];
+        std::vector<uint32_t> act[2];
+    } rounds;
     // streaming host input (nlzm_hip_feed_*): two pinned staging buffers on a copy stream of their own
     struct Feed {
         bool open = false;
@@ -243,6 +286,7 @@ void free_stream_buffers(Ctx &C)
                      C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
     if (!C.pooled) for (void *p : ptrs) if (p) (void)hipFree(p);
     C.pooled = false;
+    C.alt = Ctx::LaunchSet{}; C.snap = nullptr; C.set_idx = 0;      // (a second launch set only ever comes from a pool)
     C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
     C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = C.hot_of_bin = C.hot_list = nullptr; C.hot_undo = nullptr; C.wcnt = nullptr;
@@ -285,7 +329,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     make_geom(n, hist_bits_req, C.g);
     const Geom &g = C.g;
     C.d_in = (const uint8_t *)d_src; C.d_dst = (uint8_t *)d_dst; C.dst_cap = dst_cap;
-    C.out_pos = 0; C.next_chunk = 0;
+    C.out_pos = 0; C.next_chunk = 0; C.pre_chunk = 0;
     memset(&C.stats, 0, sizeof C.stats);
     memset(&C.tm, 0, sizeof C.tm);
     C.stats.in_bytes = n;
@@ -418,6 +462,28 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     DEVALLOC(C.v2_hx, sizeof(v2::Hx));
     DEVFILL(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
 
+    if (C.double_sets) {
+        if (!C.pool) return set_err(NLZM_HIP_E_ARG, "a second launch set needs a pool");
+        const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
+        Ctx::LaunchSet &A = C.alt;
+        DEVALLOC(A.rkhash, C.rkhash_len * 4 + 16);
+        DEVALLOC(A.syms, C.batch * C.syms_stride * 4);
+        DEVALLOC(A.bits, C.batch * C.bits_stride);
+        DEVALLOC(A.fmeta, C.batch * sizeof(FrameMeta));
+        DEVALLOC(A.unc, bpos + 16);
+        DEVALLOC(A.bt_ready, bpos * 4 * kBtRec);
+        DEVALLOC(A.bt_flag, bpos * 4);
+        DEVALLOC(A.abort_word, 4);
+        DEVALLOC(A.bin_off, (size_t)C.batch * (C.nheads + 1) * 4);
+        DEVALLOC(A.bin_pos, bpos * 8);
+        if (C.hot_max) {
+            DEVALLOC(A.hot_of_bin, (size_t)C.nheads * 4);
+            DEVALLOC(A.hot_list, ((size_t)C.hot_max + 1) * 4);
+        }
+        DEVALLOC(A.snap, sizeof(v2::RoundSnap));
+        DEVALLOC(C.snap, sizeof(v2::RoundSnap));
+    }
+
     // stream header (:1762-1766)
     const uint8_t hdr[4] = { (uint8_t)(g.wbits >> 8), (uint8_t)g.wbits, (uint8_t)(g.frame_bits >> 8), (uint8_t)g.frame_bits };
     DEVFILL(hipMemcpyAsync(C.d_dst, hdr, 4, hipMemcpyHostToDevice, C.st));
@@ -434,13 +500,17 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
 //   step_pre   pre-pass kernels and the hand-off arrays of chunks [c0, c1) on the stream's own HIP stream
 //   (launch)   pipeline_kernel for this stream alone, or pipeline_multi_kernel for a group of streams
 //   step_post  frame coder, frame lengths back to the host, checks, gather into the output
-struct StepPlan { uint32_t c0 = 0, c1 = 0, nb = 0; Globals G; v2::GlobalsV2 V; };
-
-int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
+// ahead: the launch before this one may still be on the device (block mode; the other launch set is made the current one, and
+// the progress words are set by round_open_kernel on the launch's own HIP stream instead of a copy here)
+int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
 {
     const Geom &g = C.g;
-    const uint32_t c0 = C.next_chunk, nb = todo < C.batch ? todo : C.batch, c1 = c0 + nb;
+    if (ahead) { if (!C.double_sets) return set_err(NLZM_HIP_E_ARG, "no second launch set"); swap_sets(C); }
+    const uint32_t c0 = C.pre_chunk, nb = todo < C.batch ? todo : C.batch, c1 = c0 + nb;
+    C.pre_chunk = c1;
     P.c0 = c0; P.c1 = c1; P.nb = nb;
+    memcpy(P.ev, C.set_idx ? C.ev_b : C.ev, sizeof P.ev);
+    P.syms = C.syms; P.bits = C.bits; P.fmeta = C.fmeta; P.abort_word = C.abort_word; P.snap = ahead ? C.snap : nullptr;
     Globals &G = P.G;
     memset(&G, 0, sizeof G);
     G.in = C.d_in; G.rkhash = nullptr; G.ht2 = C.ht2; G.ht3 = C.ht3; G.rk_table = C.rk_table;
@@ -460,12 +530,12 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         const unsigned long long lo = a0 > 1024 ? a0 - 1024 : 0;
         unsigned long long hi = a1 + g.feed + 256;
         if (hi + 255 > g.n) hi = g.n >= 255 ? g.n - 255 : 0;
-        HIPCHK(hipEventRecord(C.ev[7], C.st));
+        HIPCHK(hipEventRecord(P.ev[7], C.st));
         if (hi > lo && hi - lo > C.rkhash_len) return set_err(NLZM_HIP_E_ARG, "launch of %u chunks is larger than the stream was opened for", nb);
         G.rkhash = C.rkhash - lo;                       // rkhash[a] for a in [lo, hi): the launch's own array
         if (g.n >= 256 && hi > lo) launch_rk_hash(C.d_in, g.n, lo, hi, C.rkhash - lo, C.st);
     }
-    HIPCHK(hipEventRecord(C.ev[5], C.st));
+    HIPCHK(hipEventRecord(P.ev[5], C.st));
     if (C.workers) {
         const unsigned long long cnt = a1 - a0;
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
@@ -488,11 +558,11 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P)
         memset(&h, 0, sizeof h);
         h.f_pos = h.t_pos = h.t_out = h.p_pos = (uint32_t)a0;
         h.p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
-        HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
+        if (!ahead) HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
         P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state;
         G.progress = &C.v2_hx->f_pos;
     }
-    HIPCHK(hipEventRecord(C.ev[6], C.st));
+    HIPCHK(hipEventRecord(P.ev[6], C.st));
     return 0;
 }
 
@@ -507,13 +577,17 @@ int step_post_issue(Ctx &C, const StepPlan &P)
     Persist &Pst = C.post_P;
     uint32_t &aborted = C.post_aborted;
     aborted = 0;
-    HIPCHK(hipEventRecord(C.ev[1], C.st));
-    launch_rans(C.syms, C.syms_stride, C.bits, C.bits_stride, C.fmeta, C.scratch, C.syms_stride, C.frames,
+    HIPCHK(hipEventRecord(P.ev[1], C.st));
+    launch_rans(P.syms, C.syms_stride, P.bits, C.bits_stride, P.fmeta, C.scratch, C.syms_stride, C.frames,
                 C.frame_stride, (uint32_t)C.frame_stride, nb, C.st);
-    HIPCHK(hipEventRecord(C.ev[2], C.st));
-    HIPCHK(hipMemcpyAsync(hm.data(), C.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
+    HIPCHK(hipEventRecord(P.ev[2], C.st));
+    HIPCHK(hipMemcpyAsync(hm.data(), P.fmeta, nb * sizeof(FrameMeta), hipMemcpyDeviceToHost, C.st));
+    if (P.snap) {           // (the stream's next launch may be running: the copy round_close_kernel made)
+        HIPCHK(hipMemcpyAsync(&C.post_snap, P.snap, sizeof(v2::RoundSnap), hipMemcpyDeviceToHost, C.st));
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(&Pst, C.persist, sizeof Pst, hipMemcpyDeviceToHost, C.st));
-    if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, C.abort_word, 4, hipMemcpyDeviceToHost, C.st));
+    if (C.workers) HIPCHK(hipMemcpyAsync(&aborted, P.abort_word, 4, hipMemcpyDeviceToHost, C.st));
     HIPCHK(hipMemcpyAsync(&C.hx_host, C.v2_hx, sizeof(v2::Hx), hipMemcpyDeviceToHost, C.st));
     return 0;
 }
@@ -523,13 +597,14 @@ int step_post_check(Ctx &C, const StepPlan &P)
     const uint32_t c0 = P.c0, c1 = P.c1, nb = P.nb;
     std::vector<FrameMeta> &hm = C.post_hm;
     std::vector<unsigned long long> &hoff = C.post_hoff;
-    const Persist &Pst = C.post_P;
-    const uint32_t aborted = C.post_aborted;
     HIPCHK(hipStreamSynchronize(C.st));
     HIPCHK(hipGetLastError());
+    if (P.snap) { C.post_P.error = C.post_snap.error; C.post_P.next_chunk = C.post_snap.next_chunk; C.post_aborted = C.post_snap.aborted; C.hx_host = C.post_snap.hx; }
+    const Persist &Pst = C.post_P;
+    const uint32_t aborted = C.post_aborted;
     float rk_ms = 0, pre_ms = 0;
-    HIPCHK(hipEventElapsedTime(&rk_ms, C.ev[7], C.ev[5]));
-    HIPCHK(hipEventElapsedTime(&pre_ms, C.ev[5], C.ev[6]));
+    HIPCHK(hipEventElapsedTime(&rk_ms, P.ev[7], P.ev[5]));
+    HIPCHK(hipEventElapsedTime(&pre_ms, P.ev[5], P.ev[6]));
     C.tm.prep_ms += rk_ms + pre_ms; C.tm.prep_launches += C.workers ? 5 : 1; C.tm.total_ms += rk_ms + pre_ms;
     if (Pst.error || C.hx_host.err) {
         // the first error any stage raised, and where every stage was when it left (nlzm_v2.h: raise(), Hx::dbg)
@@ -565,14 +640,14 @@ int step_post_check(Ctx &C, const StepPlan &P)
         const uint32_t f = (uint32_t)(C.want_frame - c0);
         C.got_meta = hm[f];
         C.got_syms.resize(hm[f].nsyms); C.got_bits.resize(hm[f].nbits_bytes);
-        HIPCHK(hipMemcpy(C.got_syms.data(), C.syms + f * C.syms_stride, hm[f].nsyms * 4ull, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(C.got_bits.data(), C.bits + f * C.bits_stride, hm[f].nbits_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(C.got_syms.data(), P.syms + f * C.syms_stride, hm[f].nsyms * 4ull, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(C.got_bits.data(), P.bits + f * C.bits_stride, hm[f].nbits_bytes, hipMemcpyDeviceToHost));
         C.got = true;
     }
     HIPCHK(hipMemcpyAsync(C.dst_off, hoff.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, C.st));
-    HIPCHK(hipEventRecord(C.ev[3], C.st));
-    launch_gather(C.frames, C.frame_stride, C.dst_off, C.fmeta, C.d_dst, nb, C.st);
-    HIPCHK(hipEventRecord(C.ev[4], C.st));
+    HIPCHK(hipEventRecord(P.ev[3], C.st));
+    launch_gather(C.frames, C.frame_stride, C.dst_off, P.fmeta, C.d_dst, nb, C.st);
+    HIPCHK(hipEventRecord(P.ev[4], C.st));
     C.post_pos = pos;
     return 0;
 }
@@ -582,9 +657,9 @@ int step_post_done(Ctx &C, const StepPlan &P, float pipe_ms)
     const uint32_t c1 = P.c1;
     HIPCHK(hipStreamSynchronize(C.st));
     float a = pipe_ms, b = 0, c = 0;
-    if (pipe_ms < 0) HIPCHK(hipEventElapsedTime(&a, C.ev[0], C.ev[1]));
-    HIPCHK(hipEventElapsedTime(&b, C.ev[1], C.ev[2]));
-    HIPCHK(hipEventElapsedTime(&c, C.ev[3], C.ev[4]));
+    if (pipe_ms < 0) HIPCHK(hipEventElapsedTime(&a, P.ev[0], P.ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, P.ev[1], P.ev[2]));
+    HIPCHK(hipEventElapsedTime(&c, P.ev[3], P.ev[4]));
     C.tm.match_parse_ms += a; C.tm.match_parse_launches++;
     C.tm.rans_ms += b + c; C.tm.rans_launches++;
     C.tm.total_ms += a + b + c;
@@ -648,7 +723,7 @@ int refresh_stats(Ctx &C)
                 P.prof[17] / n, P.prof[16] / n, P.prof[25] / n, P.prof[19] / n, P.prof[18] / n, P.prof[21] / n, P.prof[20] / n, P.prof[23] / n, P.prof[24] / n, P.prof[22] / n);
         fprintf(stderr, "finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
                 P.prof[0], n / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
-        fprintf(stderr, "table: %llu positions emitted, %llu applications of a descent with more than twelve record-setters; parser: %llu steps (%.1f positions each), %.2f attempts per step (%.0f cycles of the chain wave per attempt), (%llu) probe rounds %llu, steps done again %llu\n",
+        fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
@@ -656,13 +731,25 @@ int refresh_stats(Ctx &C)
         if (P.prof[88]) fprintf(stderr, "finder sections (cycles/position, profile build): predict %.0f, own loads %.0f, HT rows %.0f, candidates + jobs %.0f, record + RK256 %.0f, "
                                 "BT4 results (wait included) %.0f, verify %.0f, commit %.0f\n", P.prof[88] / n, P.prof[89] / n, P.prof[90] / n, P.prof[91] / n, P.prof[92] / n,
                                 P.prof[93] / n, P.prof[94] / n, P.prof[95] / n);
-        if (P.prof[44]) fprintf(stderr, "table stage, cycles/position summed over the seven emitter waves (profile build): applying pairs %.0f, emitting %.0f, waiting for records %.0f, for their stores %.0f\n",
-                                P.prof[44] / n, P.prof[45] / n, P.prof[46] / n, P.prof[47] / n);
-        if (P.prof[57]) {
-            const double steps = (double)(P.prof[13] ? P.prof[13] : 1), nodes = (double)(P.prof[60] ? P.prof[60] : 1);
-            fprintf(stderr, "parser chain wave (profile build): per attempt of a step: start (merge, snapshot) %.0f, chain %.0f (%.0f cycles per node, %.1f nodes), waiting for the other waves %.0f, decide %.0f cycles; "
-                            "nodes on a rare path (edges longer than the window, handed-over probe edges) %llu of %llu\n",
-                    P.prof[56] / steps, P.prof[57] / steps, P.prof[57] / nodes, nodes / steps, P.prof[58] / steps, P.prof[59] / steps, P.prof[61], P.prof[60]);
+        if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position, profile build): gather %.0f, scan %.0f, emit %.0f\n", P.prof[44] / n, P.prof[45] / n, P.prof[46] / n);
+        if (P.prof[32]) {
+            const double np = (double)(P.prof[13] ? P.prof[13] : 1);
+            fprintf(stderr, "parser, cycles per pass (profile build): relax waves %.0f %.0f %.0f, probe wave %.0f (of it: sets that changed %.0f, mask fills %.0f), update %.0f, "
+                            "barrier waits per wave %.0f %.0f %.0f %.0f; block end %.0f cycles/position\n",
+                    P.prof[32] / np, P.prof[33] / np, P.prof[34] / np, P.prof[35] / np, P.prof[43] / np, P.prof[41] / np, P.prof[40] / np,
+                    P.prof[36] / np, P.prof[37] / np, P.prof[38] / np, P.prof[39] / np, P.prof[42] / n);
+            fprintf(stderr, "parser, cycles per pass by wave 0..7 (profile build): work");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[64 + w] / np);
+            fprintf(stderr, " | barrier wait");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[72 + w] / np);
+            fprintf(stderr, " | update");
+            for (int w = 0; w < 8; w++) fprintf(stderr, " %.0f", P.prof[80 + w] / np);
+            fprintf(stderr, "\n");
+            const double nbk = (double)(P.prof[8] ? P.prof[8] : 1);
+            fprintf(stderr, "parser loader wave, cycles per block set-up: block size + barrier %.0f, re-list %.0f, own edges %.0f, all edges %.0f, literal scan + clear + barrier %.0f\n",
+                    P.prof[56] / nbk, P.prof[57] / nbk, P.prof[58] / nbk, P.prof[59] / nbk, P.prof[60] / nbk);
+            fprintf(stderr, "parser wave 0, cycles per pass: relax %.0f, probe %.0f, clear %.0f | update: keys + cost scan %.0f, membership %.0f, winner sets %.0f, rest %.0f\n",
+                    P.prof[48] / np, P.prof[49] / np, P.prof[50] / np, P.prof[51] / np, P.prof[52] / np, P.prof[53] / np, P.prof[54] / np);
         }
     }
     if (C.workers) {
@@ -988,6 +1075,8 @@ int block_ctx_init(Ctx &c, int device, int64_t worker_blocks, int64_t batch)
     c.opt_workers = 1; c.opt_worker_blocks = worker_blocks; c.opt_batch = batch; c.opt_worker_threads = g_ctx.opt_block_threads;        // (block mode: a stream has few worker CUs, every lane of them takes bins)
     HIPCHK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
     for (auto &ev : c.ev) HIPCHK(hipEventCreate(&ev));
+    for (auto &ev : c.ev_b) HIPCHK(hipEventCreate(&ev));
+    c.double_sets = true;
     c.inited = true;
     return 0;
 }
@@ -995,6 +1084,7 @@ void block_ctx_destroy(Ctx &c)
 {
     free_stream_buffers(c);
     for (auto &ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    for (auto &ev : c.ev_b) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     if (c.st) { (void)hipStreamDestroy(c.st); c.st = nullptr; }
     c.inited = false;
 }
@@ -1004,11 +1094,16 @@ void block_ctx_destroy(Ctx &c)
 namespace {
 void blocks_close()
 {
+    // (a round may still be queued or on the device -- an abandoned set, a failed step: every device wait is bounded)
+    for (auto &st : g_group_st) (void)hipStreamSynchronize(st);
+    for (auto &j : g_jobs) if (j.c.st) (void)hipStreamSynchronize(j.c.st);
+    (void)hipGetLastError();
+    cur().rounds = DevState::Rounds{};
     for (auto &j : g_jobs) { j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
     g_jobs.clear();
     if (cur().blocks_pool) { (void)hipFree(cur().blocks_pool); cur().blocks_pool = nullptr; }
     for (auto &st : g_group_st) (void)hipStreamDestroy(st);
-    for (auto &ev : g_group_ev) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+    for (auto &ev : g_group_ev) for (auto &e : ev) (void)hipEventDestroy(e);
     g_group_st.clear(); g_group_ev.clear();
     if (g_pack_host) (void)hipHostFree(g_pack_host);
     if (g_pack_dev) (void)hipFree(g_pack_dev);
@@ -1096,7 +1191,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
             m.opt_workers = 1; m.opt_worker_blocks = wb; m.opt_batch = batch; m.opt_worker_threads = C.opt_block_threads; m.opt_tbits_max = tbits_max; m.cu_count = C.cu_count;
             m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min; m.opt_tbits_per = C.opt_tbits_per;
             Pool mp; mp.measuring = true;
-            m.pool = &mp;
+            m.pool = &mp; m.double_sets = true;
             uint8_t *fake_out = nullptr;
             const int rc = stream_begin(m, g_blocks_src + g_jobs[i].lo, g_jobs[i].n, hist_bits_req, (void *)(uintptr_t)16, g_jobs[i].bound);
             (void)fake_out;
@@ -1124,14 +1219,19 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     });
     for (auto &j : g_jobs) if (j.rc) { const int rc = j.rc; blocks_close(); return rc; }
     const int rc = [&]() -> int {
-        HIPCHK(hipHostMalloc(&g_pack_host, stream2_pack_size(), hipHostMallocDefault));
-        HIPCHK(hipMalloc(&g_pack_dev, stream2_pack_size()));
-        const uint32_t ngroups = (nblocks + stream2_pack_capacity() - 1) / stream2_pack_capacity();
-        for (uint32_t gi = 0; gi < ngroups; gi++) {
-            hipStream_t st; std::array<hipEvent_t, 2> ev;
-            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            HIPCHK(hipEventCreate(&ev[0])); HIPCHK(hipEventCreate(&ev[1]));
-            g_group_st.push_back(st); g_group_ev.push_back(ev);
+        HIPCHK(hipHostMalloc(&g_pack_host, 2 * stream2_pack_size(), hipHostMallocDefault));      // (one per launch set)
+        HIPCHK(hipMalloc(&g_pack_dev, 2 * stream2_pack_size()));
+        {   // the HIP stream of the shared launches: of higher priority than the streams' own, i.e. on a hardware queue apart
+            int lo_p = 0, hi_p = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            hipStream_t st;
+            HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi_p));
+            g_group_st.push_back(st);
+        }
+        for (uint32_t qi = 0; qi < 2; qi++) {
+            std::array<hipEvent_t, 3> ev;
+            for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+            g_group_ev.push_back(ev);
         }
         return 0;
     }();
@@ -1164,37 +1264,61 @@ static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_tot
     hipEvent_t e0 = C.ev[5], e1 = C.ev[6];
     HIPCHK(hipEventRecord(e0, C.st));
     HIPCHK(hipStreamSynchronize(C.st));
-    std::vector<uint32_t> left(nj);
-    for (size_t i = 0; i < nj; i++) {
-        left[i] = g_jobs[i].c.g.nchunks - g_jobs[i].c.next_chunk;
-        if (max_chunks_per_block && left[i] > max_chunks_per_block) left[i] = max_chunks_per_block;
-    }
-    // Rounds in lockstep: every unfinished stream advances by one batch, and the streams of a round share persistent
-    // launches (groups of up to stream_pack_capacity() streams per launch, all launches of a round in flight together)
-    const uint32_t cap = stream2_pack_capacity();
-    std::vector<StepPlan> plan(nj);
-    for (;;) {
-        std::vector<uint32_t> act;
-        for (size_t i = 0; i < nj; i++) if (left[i]) act.push_back((uint32_t)i);
-        if (act.empty()) break;
-        for (uint32_t i : act) { const int rc = step_pre(g_jobs[i].c, left[i], plan[i]); if (rc) return rc; }
-        const uint32_t ngroups = ((uint32_t)act.size() + cap - 1) / cap;
-        const uint32_t per_group = ((uint32_t)act.size() + ngroups - 1) / ngroups;
-        if (ngroups > g_group_st.size()) return set_err(NLZM_HIP_E_ARG, "too many stream groups");
-        for (uint32_t gi = 0; gi < ngroups; gi++) {
-            const uint32_t lo = gi * per_group, hi = lo + per_group < act.size() ? lo + per_group : (uint32_t)act.size();
-            hipStream_t gs = g_group_st[gi];
-            for (uint32_t k = lo; k < hi; k++) {
-                Ctx &c = g_jobs[act[k]].c;
-                HIPCHK(hipStreamWaitEvent(gs, c.ev[6], 0));            // its pre-pass is done
-                fill_stream2_args(g_pack_host, k - lo, c.g, plan[act[k]].G, plan[act[k]].V, plan[act[k]].c0, plan[act[k]].c1);
-            }
-            HIPCHK(hipEventRecord(g_group_ev[gi][0], gs));
-            HIPCHK(hipMemcpyAsync(g_pack_dev, g_pack_host, stream2_pack_size(), hipMemcpyHostToDevice, gs));
-            launch_pipeline2_multi(g_pack_dev, hi - lo, (uint32_t)g_blocks_wb, gs);
-            HIPCHK(hipEventRecord(g_group_ev[gi][1], gs));
-            for (uint32_t k = lo; k < hi; k++) HIPCHK(hipStreamWaitEvent(g_jobs[act[k]].c.st, g_group_ev[gi][1], 0));
+    // Rounds: every unfinished stream advances by one launch's worth, and the streams of a round share ONE persistent launch.
+    // The rounds overlap: while launch r is on the device (on the 224 CUs its workgroups hold), the pre-pass kernels of round
+    // r + 1 run on the CUs that are left, launch r + 1 is queued behind launch r, and the host waits for launch r only to code
+    // and gather its frames -- which then runs beside launch r + 1.  (Measured before, 32 streams: 115-140 ms of pre-pass
+    // and frame coding between two launches of 580 ms.)  A round's launch is bracketed by round_open_kernel (progress words)
+    // and round_close_kernel (what the host checks, copied aside): both on the launch's HIP stream, which has a hardware queue
+    // of its own (a stream of higher priority), so that nothing of the other streams queues behind a persistent launch.
+    // A call that has collected its share leaves the next round QUEUED (sized like its own rounds) for the next call to collect:
+    // the device does not idle between the calls of a caller that steps through the set.
+    if (nj > stream2_pack_capacity()) return set_err(NLZM_HIP_E_ARG, "too many streams for one launch");
+    DevState::Rounds &R = cur().rounds;
+    hipStream_t gs = g_group_st[0];
+    for (auto &p : R.plan) if (p.size() != nj) p.assign(nj, StepPlan{});
+    const uint32_t kAll = 0xFFFFFFFFu;
+    std::vector<uint32_t> quota(nj, max_chunks_per_block ? max_chunks_per_block : kAll);       // chunks this call still collects, per stream
+    auto queue_round = [&](uint32_t q, bool in_call) -> int {      // pre-passes of the round's streams, then its launch
+        std::vector<uint32_t> &act = R.act[q];
+        act.clear();
+        std::vector<uint32_t> todo(nj, 0);
+        for (size_t i = 0; i < nj; i++) {
+            const Ctx &c = g_jobs[i].c;
+            const uint32_t rem = c.g.nchunks - c.pre_chunk;
+            const uint32_t want = in_call ? quota[i] : (max_chunks_per_block ? max_chunks_per_block : kAll);
+            todo[i] = rem < want ? rem : want;
+            if (todo[i]) act.push_back((uint32_t)i);
         }
+        if (act.empty()) return 0;
+        for (uint32_t i : act) { const int rc = step_pre(g_jobs[i].c, todo[i], R.plan[q][i], true); if (rc) return rc; }
+        uint8_t *ph = (uint8_t *)g_pack_host + (size_t)q * stream2_pack_size(), *pd = (uint8_t *)g_pack_dev + (size_t)q * stream2_pack_size();
+        for (uint32_t k = 0; k < act.size(); k++) {
+            Ctx &c = g_jobs[act[k]].c;
+            const StepPlan &P = R.plan[q][act[k]];
+            HIPCHK(hipStreamWaitEvent(gs, P.ev[6], 0));                 // its pre-pass is done
+            fill_stream2_args(ph, k, c.g, P.G, P.V, P.c0, P.c1, P.snap);
+        }
+        HIPCHK(hipMemcpyAsync(pd, ph, stream2_pack_size(), hipMemcpyHostToDevice, gs));
+        launch_round_open(pd, (uint32_t)act.size(), gs);
+        HIPCHK(hipEventRecord(g_group_ev[q][0], gs));
+        launch_pipeline2_multi(pd, (uint32_t)act.size(), (uint32_t)g_blocks_wb, gs);
+        HIPCHK(hipEventRecord(g_group_ev[q][1], gs));
+        launch_round_close(pd, (uint32_t)act.size(), gs);
+        HIPCHK(hipEventRecord(g_group_ev[q][2], gs));
+        return 0;
+    };
+    if (!R.have) {
+        const int rc = queue_round(R.q, true);
+        if (rc) return rc;
+        R.have = !R.act[R.q].empty();
+    }
+    while (R.have) {
+        const uint32_t q = R.q;
+        bool more = false;              // does this call collect another round after this one?
+        for (uint32_t i : R.act[q]) { const uint32_t nb = R.plan[q][i].nb; if (quota[i] != kAll) quota[i] -= nb < quota[i] ? nb : quota[i]; }
+        for (size_t i = 0; i < nj; i++) more |= quota[i] && g_jobs[i].c.pre_chunk < g_jobs[i].c.g.nchunks;
+        { const int rc = queue_round(q ^ 1, more); if (rc) return rc; }
         {   // (every stream of the round is looked at, so that the first failure is reported with its own diagnostics)
             int first_rc = 0;
             char first_msg[sizeof g_err] = "";
@@ -1207,18 +1331,22 @@ static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_tot
                     snprintf(first_msg, sizeof first_msg, "block %u: %.*s", i, (int)sizeof first_msg - 32, g_err);
                 }
             };
-            for (uint32_t i : act) note(i, step_post_issue(g_jobs[i].c, plan[i]));
-            for (uint32_t i : act) if (!rcs[i]) note(i, step_post_check(g_jobs[i].c, plan[i]));
-            for (uint32_t i : act) if (!rcs[i]) note(i, step_post_done(g_jobs[i].c, plan[i], 0.0f));
+            for (uint32_t i : R.act[q]) {
+                const hipError_t e = hipStreamWaitEvent(g_jobs[i].c.st, g_group_ev[q][2], 0);
+                note(i, e == hipSuccess ? step_post_issue(g_jobs[i].c, R.plan[q][i]) : set_err(NLZM_HIP_E_NODEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(e)));
+            }
+            for (uint32_t i : R.act[q]) if (!rcs[i]) note(i, step_post_check(g_jobs[i].c, R.plan[q][i]));
+            for (uint32_t i : R.act[q]) if (!rcs[i]) note(i, step_post_done(g_jobs[i].c, R.plan[q][i], 0.0f));
             if (first_rc) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, first_msg, sizeof g_err); return first_rc; }
         }
-        for (uint32_t gi = 0; gi < ngroups; gi++) {
+        {
             float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, g_group_ev[gi][0], g_group_ev[gi][1]));
-            const uint32_t lo = gi * per_group, hi = lo + per_group < act.size() ? lo + per_group : (uint32_t)act.size();
-            for (uint32_t k = lo; k < hi; k++) { Ctx &c = g_jobs[act[k]].c; c.tm.match_parse_ms += ms; c.tm.total_ms += ms; }
+            HIPCHK(hipEventElapsedTime(&ms, g_group_ev[q][0], g_group_ev[q][1]));
+            for (uint32_t i : R.act[q]) { Ctx &c = g_jobs[i].c; c.tm.match_parse_ms += ms; c.tm.total_ms += ms; }
         }
-        for (uint32_t i : act) left[i] -= plan[i].nb;
+        R.q = q ^ 1;
+        R.have = !R.act[q ^ 1].empty();
+        if (!more) break;               // (what is queued now is the next call's first round)
     }
     HIPCHK(hipEventRecord(e1, C.st));
     HIPCHK(hipStreamSynchronize(C.st));
@@ -1245,8 +1373,8 @@ int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, u
     for_blocks((uint32_t)g_jobs.size(), [&](uint32_t, BlockJob &j) { j.rc = stream_finish(j.c, &j.len); });
     if (C.opt_report) {
         // which stage limits a stream under load: smallest / median / largest over the streams, cycles per position
-        static const char *const what[8] = { "finder total", "finder waiting", "  of it for BT4 results", "table updater total", "table updater waiting",
-                                             "parser total", "parser waiting (records)", "parser chain" };
+        static const char *const what[8] = { "finder total", "finder waiting", "  of it for BT4 results", "table stage total", "table stage waiting",
+                                             "parser total", "parser waiting (records)", "parser passes" };
         fprintf(stderr, "block set of %zu streams, %lld worker CUs each -- per stream, cycles per position (min / median / max over the streams):\n", g_jobs.size(), (long long)g_blocks_wb);
         for (int k = 0; k < 8; k++) {
             std::vector<double> v;

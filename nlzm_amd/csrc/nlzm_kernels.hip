@@ -12,6 +12,7 @@
 //   gather_frames_kernel concatenates the frames into the output stream.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstddef>
 #include <stdint.h>
 
 #include "nlzm_core.h"
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::G
     const uint32_t local = (b % 8 == 0 && b / 8 < kV2Roles && gridDim.x > 16) ? b / 8 : (gridDim.x > 16 ? kV2Roles + (b - before) : b);
     pipeline2_roles(g, G, V, c0, c1, local, gridDim.x - kV2Roles);
 }
-struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; };
+struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; v2::RoundSnap *snap; };
 constexpr uint32_t kMaxStreams2PerLaunch = 64;          // (the pack lives in device memory: the kernel-argument segment holds 4 KB)
 __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args *__restrict__ pack, uint32_t bps)
 {
@@ -930,6 +931,37 @@ __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args 
 #undef NLZM_GLOBAL_PTR
     pipeline2_roles(a.g, a.G, a.V, a.c0, a.c1, local, bps - kV2Roles);
 }
+// Either side of a shared launch whose successor is queued before the host has looked at it (nlzm_hip.cpp, blocks_step_impl):
+// round_open sets every stream's progress words to the launch's first position (what step_pre's copy does for a launch of its own),
+// round_close copies aside what the host checks afterwards -- the next launch resets and advances the originals.
+#define NLZM_G(T, x) ((__attribute__((address_space(1))) T *)(unsigned long long)(x))       // (pointers read from memory: global ones, not flat)
+__global__ __launch_bounds__(256) void round_open_kernel(const Stream2Args *__restrict__ pack)
+{
+    const Stream2Args &a = pack[blockIdx.x];
+    auto *w = NLZM_G(uint32_t, a.V.hx);
+    const uint32_t a0 = a.G.batch_a0;
+    constexpr uint32_t kWords = sizeof(v2::Hx) / 4;
+    for (uint32_t i = threadIdx.x; i < kWords; i += 256) {
+        uint32_t v = 0;
+        if (i == offsetof(v2::Hx, f_pos) / 4 || i == offsetof(v2::Hx, t_pos) / 4 || i == offsetof(v2::Hx, t_out) / 4 || i == offsetof(v2::Hx, p_pos) / 4 ||
+            i == offsetof(v2::Hx, p_seg) / 4 || i == offsetof(v2::Hx, p_seg) / 4 + 1) v = a0;         // (p_seg = a0 << 32 | a0)
+        w[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void round_close_kernel(const Stream2Args *__restrict__ pack)
+{
+    const Stream2Args &a = pack[blockIdx.x];
+    const auto *w = NLZM_G(const uint32_t, a.V.hx);
+    auto *o = NLZM_G(uint32_t, a.snap);
+    constexpr uint32_t kHead = offsetof(v2::RoundSnap, hx) / 4;
+    for (uint32_t i = threadIdx.x; i < sizeof(v2::Hx) / 4; i += 256) o[kHead + i] = w[i];
+    if (threadIdx.x == 0) {
+        const auto *ps = NLZM_G(const uint32_t, a.G.persist);
+        o[0] = ps[offsetof(Persist, error) / 4]; o[1] = ps[offsetof(Persist, next_chunk) / 4];
+        o[2] = a.G.abort_word ? *NLZM_G(const uint32_t, a.G.abort_word) : 0u; o[3] = 0;
+    }
+}
+#undef NLZM_G
 
 // ---------------------------------------------------------------------------
 // frame coder.  One workgroup (256 threads) per frame.
@@ -1045,10 +1077,18 @@ void launch_pipeline2(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, u
 unsigned long long stream2_pack_size() { return sizeof(Stream2Args) * kMaxStreams2PerLaunch; }
 uint32_t stream2_pack_capacity() { return kMaxStreams2PerLaunch; }
 uint32_t pipeline2_role_blocks() { return kV2Roles; }
-void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1)
+void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1, v2::RoundSnap *snap)
 {
     Stream2Args &a = ((Stream2Args *)host_pack)[i];
-    a.g = g; a.G = G; a.V = V; a.c0 = c0; a.c1 = c1;
+    a.g = g; a.G = G; a.V = V; a.c0 = c0; a.c1 = c1; a.snap = snap;
+}
+void launch_round_open(const void *dev_pack, uint32_t nstreams, hipStream_t st)
+{
+    hipLaunchKernelGGL(round_open_kernel, dim3(nstreams), dim3(256), 0, st, (const Stream2Args *)dev_pack);
+}
+void launch_round_close(const void *dev_pack, uint32_t nstreams, hipStream_t st)
+{
+    hipLaunchKernelGGL(round_close_kernel, dim3(nstreams), dim3(256), 0, st, (const Stream2Args *)dev_pack);
 }
 // dev_pack: the streams' arguments in device memory (stream2_pack_size() bytes, filled with fill_stream2_args on the host)
 void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st)

@@ -57,6 +57,8 @@ struct Hx {                                     // progress words, one 128-byte 
     alignas(128) uint32_t dbg[4][32];           // per stage (0 finder, 1 table, 2 parser): where it was when it left because of an error
 };
 enum : uint32_t { kStFinder = 11, kStTable = 12, kStParser = 13 };
+// What the host looks at after a launch, copied aside on the device when the next launch is already queued behind it (block mode)
+struct RoundSnap { uint32_t error, next_chunk, aborted, pad; Hx hx; };
 
 struct GlobalsV2 {
     uint32_t *ft;                               // [kFtRing][kFtStride]
@@ -1111,29 +1113,16 @@ constexpr unsigned long long kKeyNone = ~0ull;
 constexpr uint32_t kRankLit = 255, kRankProbe = 64;
 constexpr uint32_t kSrcNone = 0x1FFF;
 constexpr uint32_t kPW = 8;                     // waves of the stage.  A node has up to 32 sampled edges, nearly always fewer than 16:
-#ifndef NLZM_EDGE_SPLIT
-#define NLZM_EDGE_SPLIT 1
-#endif
-#if NLZM_EDGE_SPLIT == 0
-constexpr uint32_t kEdgesPerWave = 5;           //   (round 3) waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
-                                                //   ahead), waves 0..3 four of the rare ones each and make the explicit probe of rep slot w
+constexpr uint32_t kEdgesPerWave = 5;           //   waves 4..6 relax five of the first fifteen each, wave 7 the sixteenth (it also loads the records
+                                                //   ahead), waves 0..3 four of the rare ones each and make the explicit probe of rep slot w.
+                                                //   (Round 4 dealt the rare edges to waves 4..7 instead, the probe waves being a pass's critical
+                                                //   path: no difference at 300 MB, 80.6 s both ways -- rare edges cost nothing where they are.)
 NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
 {
     if (w < 4) return j < 4 ? 16 + w + 4 * j : kMaxEdges;
     if (w < 7) return (w - 4) + 3 * j;
     return j == 0 ? 15u : kMaxEdges;
 }
-#else
-// The probe waves 0..3 are a pass's critical path (relax 890 + probe 775 cycles against 1,100 of the others, which then wait
-// 650 at the barrier): they keep two of the rare edges each (16..23), waves 4..6 take two more (24..29), wave 7 the last two.
-constexpr uint32_t kEdgesPerWave = 7;
-NLZM_HD uint32_t edge_of(uint32_t w, uint32_t j)    // sampled edge j of wave w (kMaxEdges: none)
-{
-    if (w < 4) return j < 2 ? 16 + w + 4 * j : kMaxEdges;
-    if (w < 7) return j < 5 ? (w - 4) + 3 * j : 24 + (w - 4) + 3 * (j - 5);
-    return j == 0 ? 15u : (j < 3 ? 29 + j : kMaxEdges);
-}
-#endif
 constexpr uint32_t kParserThreads = 64 * kPW;
 constexpr uint32_t kStagePos = 128;             // table records kept ahead in LDS: positions ...
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
@@ -1548,6 +1537,31 @@ struct Parser {
         link = src | (len << 13) | (cmd << 22) | (idx << 24);
     }
 
+    // the loader wave: how many nodes the block at node b0 gets (sh[0]), and this stage's progress word
+    XW_FN void decide_block(uint32_t seg_a, uint32_t b0, uint32_t max_parse)
+    {
+        const uint32_t i = xw::lane();
+        const uint32_t a_first = seg_a + b0;
+        if (!stage_need(a_first)) err = kErrInternal + 100;
+        uint32_t nb = umin(64u, max_parse - b0);
+        uint32_t sh_hi = staged_hi();
+        if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) < 0) {
+            // A block costs about the same whatever its size: when this stage has caught up with the table stage, it
+            // gives it a moment (bounded: the finder may be waiting for this stage's word) rather than run on a few nodes
+            const unsigned long long tg = xw::tick();
+            for (uint32_t round = 0; round < kGatherRounds; round++) {      // (a step waits for the loads of the one before)
+                pump(a_first);
+                sh_hi = staged_hi();
+                if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) >= 0) break;
+            }
+            acc(kAccWait, xw::tick() - tg);
+        }
+        if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
+        nb = xw::test_cut(nb);                              // (identity on the device; the simulation cuts blocks at random here, as
+                                                            //  the device does when this stage catches up with the table stage)
+        if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; xw::st_agent(&V.hx->p_pos, a_first); }
+    }
+
     // ---- one parse segment: nodes 0.. of positions seg_a.. (every thread of the stage); returns its length, the path
     // in cmdlist (ncmds entries, end first)
     XW_FN uint32_t parse_segment(uint32_t seg_a, uint32_t max_parse, uint32_t &ncmds)
@@ -1577,6 +1591,7 @@ struct Parser {
         }
         uint32_t end_p = 1, end_open = 1, b0 = 0;
         uint32_t seg_len = 0;
+        bool decided = false;
         if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
         {
             // A position without any match is a segment of its own (more than half of all segments are): its node has no
@@ -1643,29 +1658,14 @@ struct Parser {
                 seg_len = b0;
                 break;
             }
-            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come)
-            if (w == kPW - 1) {
-                const uint32_t a_first = seg_a + b0;
-                if (!stage_need(a_first)) err = kErrInternal + 100;
-                uint32_t nb = umin(64u, max_parse - b0);
-                uint32_t sh_hi = staged_hi();
-                if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) < 0) {
-                    // A block costs about the same whatever its size: when this stage has caught up with the table stage, it
-                    // gives it a moment (bounded: the finder may be waiting for this stage's word) rather than run on a few nodes
-                    const unsigned long long tg = xw::tick();
-                    for (uint32_t round = 0; round < kGatherRounds; round++) {      // (a step waits for the loads of the one before)
-                        pump(a_first);
-                        sh_hi = staged_hi();
-                        if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) >= 0) break;
-                    }
-                    acc(kAccWait, xw::tick() - tg);
-                }
-                if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
-                nb = xw::test_cut(nb);                              // (identity on the device; the simulation cuts blocks at random here, as
-                                                                    //  the device does when this stage catches up with the table stage)
-                if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; xw::st_agent(&V.hx->p_pos, a_first); }
+            // ---- the block: nodes b0 .. b0+nb-1 whose records are out (the first one is inside the segment: it will come).
+            // Its size is the loader wave's decision -- made at the end of the block before, beside the merge of that block's
+            // edges and in front of ITS last barrier, whenever the segment goes on (decided); here only for a segment's first block.
+            if (!decided) {
+                if (w == kPW - 1) decide_block(seg_a, b0, max_parse);
+                xw::block_sync();
             }
-            xw::block_sync();
+            decided = false;
             const unsigned long long q1 = ptick();
             const uint32_t nb = L()->sh[0];
             if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
@@ -1807,11 +1807,14 @@ struct Parser {
                     }
                 }
                 const unsigned long long k0b = ptick();
-                // the buffers of the next pass
-                for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
-                if (w == 0) L()->reach[nbuf][i] = sreach;
+                // the buffers of the next pass.  (Pass 0 relaxes nothing and its update reads the keys of finished blocks only:
+                // the set-up has cleared mcur[1] and stored reach[1], and the set-up's barrier stands for this one.)
+                if (pass > 0) {
+                    for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
+                    if (w == 0) L()->reach[nbuf][i] = sreach;
+                }
                 const unsigned long long k1 = ptick();
-                xw::block_sync();
+                if (pass > 0) xw::block_sync();
                 const unsigned long long k2 = ptick();
                 // ---- update: every node of the block from the keys (the same in every wave)
                 unsigned long long kin = kKeyNone;
@@ -1912,6 +1915,8 @@ struct Parser {
                 if (new_end > end_open) end_open = new_end;
                 end_p = new_end;
                 b0 += nb;
+                decided = !(b0 == end_p || b0 >= max_parse);        // (the same in every thread)
+                if (decided && w == kPW - 1) decide_block(seg_a, b0, max_parse);
                 xw::block_sync();
             }
             t_fin += ptick() - e0;

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round evidence, run on the GPU box through gpurun:  bash tests/evidence_run.sh r03
+# Round evidence, run on the GPU box through gpurun:  bash tests/evidence_run.sh r04
 # (stage accounting of three configurations, the profile build's per-section numbers, block mode; then the rocprofv3 passes
 #  of tests/prof_run.sh.  The parity suite and the whole-stream bench line are separate calls: they take 12 and 10 minutes.)
-R=${1:-r03}
+R=${1:-r04}
 mkdir -p gpurun_out
+bash tests/build_prof.sh      # the profile library does not travel with the snapshot (.gpurunignore): built here
 {
   echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1   (3 MB of text, -window:20; product library)"
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 3e6 20 1 2>&1
@@ -13,7 +14,7 @@ mkdir -p gpurun_out
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 20e6 28 1 2>&1
   echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1   (300 MB of text, -window:28: depth)"
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1 2>&1
-  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_blocks.py 8 20 32   (32 independent blocks of 8 MB in flight)"
-  NLZM_WAIT_PRINT=1 python tests/gpu_blocks.py 8 20 32 2>&1 | grep -v "^cycles\|^finder\|^table\|^worker\|^parser" 
+  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 batch_chunks=16   (independent blocks of 17 MB in flight: per-stream accounting)"
+  NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 batch_chunks=16 2>&1
 } > gpurun_out/${R}_wave_accounting.txt
 bash tests/prof_run.sh $R > gpurun_out/${R}_prof_run.log 2>&1; tail -2 gpurun_out/${R}_prof_run.log
