@@ -1128,8 +1128,8 @@ constexpr uint32_t kStagePos = 128;             // table records kept ahead in L
 constexpr uint32_t kStageEdges = 16;            // ... the first sampled edges of each (the rest, rare, is read from the ring)
 constexpr uint32_t kStageQ = 2 + kStageEdges;   // 8-byte words per staged record: header, edges, the mask of samples with a new distance
 constexpr uint32_t kGatherNodes = 32, kGatherRounds = 3;   // a block waits this many loader steps for this many records before it runs shorter
-constexpr uint32_t kPumpLoads = 4;              // loads in flight per lane of the loader wave ...
-constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: twelve records a step
+constexpr uint32_t kPumpLoads = 8;              // loads in flight per lane of the loader wave (4: 55-node blocks at 300 MB, the stage ran out of staged records; 8: 62) ...
+constexpr uint32_t kPumpRecs = 64 / kStageQ;    // ... each for the words of three records: twenty-four records a step
 constexpr uint32_t kInf = 0x3FFFFFFFu;
 constexpr uint32_t kSpan = 64 + kMatchMax + 2;  // nodes a block's edges can end at
 
@@ -1690,11 +1690,17 @@ struct Parser {
             // distances are looked up in.
             const uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
             const unsigned long long *srec = staged(a);
-            const unsigned long long hd = inb ? srec[0] : 0ull;
+            // (every LDS word a lane may need is requested before the first one is looked at -- one round trip, not one per
+            //  dependent condition; a lane outside the block reads some staged record and drops it)
+            const unsigned long long hd_w = srec[0], w1_w = srec[1], wu_w = srec[kStageQ - 1];
+            unsigned long long sv[kEdgesPerWave];
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) { const uint32_t k = edge_of(w, j); sv[j] = srec[1 + (k < kStageEdges ? k : 0u)]; }
+            const unsigned long long hd = inb ? hd_w : 0ull;
             const uint32_t ne = (uint32_t)hd & 63u, lit = ((uint32_t)hd >> 8) & 0xFFu;
-            const uint32_t uniq = ne ? (uint32_t)srec[kStageQ - 1] : 0u;
+            const uint32_t uniq = ne ? (uint32_t)wu_w : 0u;
             const uint32_t nd = (uint32_t)__builtin_popcount(uniq);
-            const uint32_t max_len = ne ? ((uint32_t)(srec[1] >> 32) & 0x1FFu) : 0u;
+            const uint32_t max_len = ne ? ((uint32_t)(w1_w >> 32) & 0x1FFu) : 0u;
             const uint32_t sreach = inb ? node + max_len : 0u;                      // :1550
             uint32_t ed[kEdgesPerWave], ea[kEdgesPerWave];          // this wave's edges of the node (distance; length | price words)
 #pragma unroll
@@ -1705,7 +1711,7 @@ struct Parser {
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                 const uint32_t k = edge_of(w, j);
-                er[j] = k < ne ? (k < kStageEdges ? srec[1 + k] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
+                er[j] = k < ne ? (k < kStageEdges ? sv[j] : xw::ld_agent64((const unsigned long long *)(rec + kTpEdges + 2 * k))) : 0ull;
             }
             const unsigned long long q3 = ptick();
             uint32_t dd[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };            // the node's first eight distinct valid distances (probe waves)
@@ -1723,15 +1729,23 @@ struct Parser {
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
             const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
             if (w == 0 && i == nb - 1) { L()->sh[6] = lit; L()->sh[10] = litw; }   // (the literal edge into node b0 + nb: its byte, its price)
+            uint32_t lpv[kEdgesPerWave], spv[kEdgesPerWave];       // (the price words of all edges requested, then used: as above)
+#pragma unroll
+            for (uint32_t j = 0; j < kEdgesPerWave; j++) {
+                const uint32_t at = (uint32_t)(er[j] >> 32);
+                const uint32_t lv = (at >> 31) ? (at >> 9) & 0x1FFu : 0u, slot = (at >> 31) ? (at >> 18) & 63u : 0u;
+                lpv[j] = L()->len_price[lv];
+                spv[j] = L()->slot_price[umin(lv, 3) * 64 + slot];
+            }
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) {
                 const uint32_t k = edge_of(w, j);
                 if (k < ne) L()->edge_d[(a & 511u) * kMaxEdges + k] = (uint32_t)er[j];
                 const uint32_t at = (uint32_t)(er[j] >> 32);
                 if (at >> 31) {
-                    const uint32_t tl = at & 0x1FFu, lv = (at >> 9) & 0x1FFu, slot = (at >> 18) & 63u, nx = (at >> 24) & 31u;
-                    const uint32_t lp = L()->len_price[lv];
-                    const uint32_t wd = lp + (nx << 5) + L()->slot_price[umin(lv, 3) * 64 + slot];     // (+ pc_dict: :1208-1251)
+                    const uint32_t tl = at & 0x1FFu, nx = (at >> 24) & 31u;
+                    const uint32_t lp = lpv[j];
+                    const uint32_t wd = lp + (nx << 5) + spv[j];     // (+ pc_dict: :1208-1251)
                     ed[j] = (uint32_t)er[j];
                     ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
                 }
@@ -1923,12 +1937,23 @@ struct Parser {
         }
         xw::block_sync();
         // backtrack (:1633-1650): node indices of the path, end first
+        // (A walk through LDS is one dependent round trip per command, 130-200 cycles each with seven waves at the barrier below.
+        //  Here the links of the 64 nodes from `cur` down come with ONE read -- lane l: node cur - l -- and the path through
+        //  them is followed by register reads; the lanes of the nodes on it then write their places in the list together.)
         if (w == 0) {
-            uint32_t n = 0, cur = seg_len;
+            uint32_t n = 0, cur = xw::readfirst(seg_len);
             while (cur != 0) {
-                if (i == 0) L()->cmdlist()[n] = (uint16_t)cur;
-                n++;
-                cur = xw::readfirst(L()->node_link[cur]) & 0x1FFFu;
+                const uint32_t top = cur;
+                const uint32_t lnk = i <= top ? L()->node_link[top - i] & 0x1FFFu : 0u;
+                unsigned long long on = 0;                          // bit l: node top - l is on the path
+                uint32_t l = 0;
+                do {
+                    on |= 1ull << l;
+                    cur = xw::readlane(lnk, l);                     // (the source of node top - l: always a node before it)
+                    l = top - cur;
+                } while (cur != 0 && l < 64);
+                if ((on >> i) & 1ull) L()->cmdlist()[n + (uint32_t)__builtin_popcountll(on & ((1ull << i) - 1ull))] = (uint16_t)(top - i);
+                n += (uint32_t)__builtin_popcountll(on);
             }
             if (i == 0) L()->ncmds = n;
         }
