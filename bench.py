@@ -170,7 +170,7 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
     block alone, which `check` verifies against tests/golden/blocks_1g.json when all the steps were run."""
     per = -(-n // k)
     B = BLOCKS_BATCH                    # (chunks of every block per shared launch.  The launches of consecutive rounds are queued back
-    nlzm_amd.set_option("batch_chunks", B)      #  to back, so their length matters little: 6 / 8 / 12 / 16 chunks 88.9 / 89.8 / 88.7 / 89.6 MB/s, profiles/r04_block_mode.txt)
+    nlzm_amd.set_option("block_batch_chunks", B)    #  to back, so their length matters little: 6 / 8 / 12 / 16 chunks 88.9 / 89.8 / 88.7 / 89.6 MB/s, profiles/r04_block_mode.txt)
     nb_launch = -(-(-(-per // CHUNK)) // B)
     per_step = max(1, -(-nb_launch // STEPS_PER_STREAM)) * B
     geo = nlzm_amd.geometry(per, WINDOW)

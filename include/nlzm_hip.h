@@ -191,8 +191,10 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
 /* key: "workers" (only 1: BT4 runs on per-head worker lanes), "batch_chunks" (chunks per persistent launch), "worker_blocks" (worker CUs of a stream, default 60),
  * "worker_threads" (bin-taking lanes per worker CU, 64..512, default 128), "hot_waves" (waves per worker CU that take a hot
  * BT4 bin each, 0..6, default 2), "hot_min" (positions per launch from which a bin counts as hot, default 8192);
- * block mode: "block_worker_threads" (default 256) and "block_hot_waves" (default 4), the same two for the streams of a block set
- * (their worker CUs are few: the count follows from the number of streams); "stage_report" (1: the stages' cycle accounting of
+ * block mode: "block_worker_threads" (default 320) and "block_hot_waves" (default 3), the same two for the streams of a block set
+ * (their worker CUs are few: the count follows from the number of streams), "block_batch_chunks" (chunks of every stream per
+ * shared launch, default 8); "prefilter_bits_per_position" (log2 of the pre-filter table's entries per input position, default 4);
+ * "stage_report" (1: the stages' cycle accounting of
  * every finished stream, and of a block set per stream, on stderr).  There are no environment knobs.
  * None of them changes a byte of the output.  The options are read when a stream or a block set is opened
  * (nlzm_hip_stream_begin, nlzm_hip_blocks_begin, nlzm_hip_feed_begin, the one-call entries): what is open keeps what it was opened with.

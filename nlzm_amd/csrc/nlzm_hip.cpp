@@ -110,6 +110,8 @@ struct Ctx {
     int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
     int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
                                             // (profiles/r04_block_mode.txt): under load a stream waits for the serial chains of its busiest heads
+    int64_t opt_block_batch = 8;            // block mode: chunks of every stream per shared launch (the rounds overlap, so their length matters little --
+                                            // 6 / 8 / 12 / 16 chunks: 88.9 / 89.8 / 88.7 / 89.6 MB/s; the pool holds 2.3 KB per position of a launch and stream)
     int64_t opt_tbits_per = 4;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
@@ -952,6 +954,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "block_hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "block_hot_waves out of range"); C.opt_block_hot_waves = value; return 0; }
     if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
+    if (!strcmp(key, "block_batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "block_batch_chunks out of range"); C.opt_block_batch = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
 }
@@ -1156,7 +1159,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
     // Every stream holds its own tables and hand-off arrays: the pre-filter table (4 << t_bits bytes) and the per-launch
     // arrays (about 2.2 KB per position of a launch) are sized so that all streams fit the free memory.
-    int64_t tbits_max = 32, batch = C.opt_batch;
+    int64_t tbits_max = 32, batch = C.opt_block_batch;
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));

@@ -717,9 +717,10 @@ struct Finder {
 constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
 
 #ifndef NLZM_KTW
-#define NLZM_KTW 3
+#define NLZM_KTW 4
 #endif
-constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn
+constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn (a block of 64 positions takes a wave ~100,000 cycles:
+                                                // three waves were busy 530 of 618 cycles per position at 300 MB, four 416 of 614; 156 KB of LDS)
 struct TWave {
     unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
     uint32_t recs[64 * kFtStride];              // the block's finder records

@@ -14,7 +14,7 @@ bash tests/build_prof.sh      # the profile library does not travel with the sna
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 20e6 28 1 2>&1
   echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1   (300 MB of text, -window:28: depth)"
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1 2>&1
-  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 batch_chunks=16   (independent blocks of 17 MB in flight: per-stream accounting)"
-  NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 batch_chunks=16 2>&1
+  echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 block_batch_chunks=8   (independent blocks of 17 MB in flight: per-stream accounting)"
+  NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 block_batch_chunks=8 2>&1
 } > gpurun_out/${R}_wave_accounting.txt
 bash tests/prof_run.sh $R > gpurun_out/${R}_prof_run.log 2>&1; tail -2 gpurun_out/${R}_prof_run.log

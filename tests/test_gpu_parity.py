@@ -214,14 +214,14 @@ def test_block_mode_options_are_invisible(gpu):
     want = gpu.compress_blocks(data, 8, 20)
     try:
         for opts in ({"block_worker_threads": 512, "block_hot_waves": 0}, {"block_worker_threads": 128, "block_hot_waves": 6},
-                     {"prefilter_bits_per_position": 0}, {"prefilter_bits_per_position": 6, "batch_chunks": 3}):
+                     {"prefilter_bits_per_position": 0}, {"prefilter_bits_per_position": 6, "block_batch_chunks": 3}):
             for k, v in opts.items():
                 gpu.set_option(k, v)
             assert gpu.compress_blocks(data, 8, 20) == want, opts
-            for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "batch_chunks": 32}.items():
+            for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "block_batch_chunks": 8}.items():
                 gpu.set_option(k, v)
     finally:
-        for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "batch_chunks": 32}.items():
+        for k, v in {"block_worker_threads": 320, "block_hot_waves": 3, "prefilter_bits_per_position": 4, "block_batch_chunks": 8}.items():
             gpu.set_option(k, v)
     # the single-stream path with a sparse and a dense table
     one = gpu.compress(data[:2_000_000], 20)
