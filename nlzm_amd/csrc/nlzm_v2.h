@@ -1445,11 +1445,20 @@ struct Parser {
     // The segment is within 264 of its forced cut (:1469): the sampled lengths of position a change with the smaller
     // max_len (:1545, :1558-1560).  Re-listed from the position's front into its ring record (lanes = samples; the
     // record is this stage's until p_pos passes it).
-    XW_FN void resample(uint32_t a, uint32_t max_len)
+    // (its parts, so that a block's re-listings overlap: the first 64 entries of the NEXT position's front are requested before
+    //  this one's are used, the header comes from the staged copy, and the stores are waited for once, by the caller -- 300 MB
+    //  of text runs every segment into the forced cut, and a re-listing of its own was three round trips to HBM with the other
+    //  seven waves at the barrier behind it)
+    XW_FN unsigned long long resample_front(uint32_t a) const
+    {
+        const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
+        return xw::ld_agent64((const unsigned long long *)(fo + 2 * xw::lane()));      // (beyond the front's size: whatever the slot holds, not looked at)
+    }
+    XW_FN void resample(uint32_t a, uint32_t max_len, unsigned long long ev0)
     {
         acc(kAccRedo, 1);
         uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
-        const unsigned long long h = xw::readfirst64(xw::ld_agent64((const unsigned long long *)rec));
+        const unsigned long long h = xw::readfirst64(staged(a)[0]);
         const uint32_t fn = (uint32_t)(h >> 32);
         const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
         uint32_t step = (max_len - kMatchMin) >> 4;
@@ -1458,12 +1467,19 @@ struct Parser {
         uint32_t ne = 0;
         if (max_len >= kMatchMin) ne = (max_len - kMatchMin) / step + 1;
         uint32_t d = 0, valid = 0;
+        {   // the last entry of the front (smallest end) that still has >= tl bytes: lane j holds entry j, walked by register reads
+            const uint32_t tl = k < ne ? max_len - k * step : 0xFFFFFFFFu;
+            for (uint32_t j0 = 0; j0 < fn; j0 += 64) {
+                const uint32_t cnt = umin(64u, fn - j0);
+                const unsigned long long ev = j0 == 0 ? ev0 : (k < cnt ? xw::ld_agent64((const unsigned long long *)(fo + 2 * (j0 + k))) : 0ull);
+                for (uint32_t jj = 0; jj < cnt; jj++) {
+                    const unsigned long long e = xw::readlane64(ev, jj);
+                    if ((uint32_t)e >= tl) d = (uint32_t)(e >> 32);
+                }
+            }
+        }
         if (k < ne) {
             const uint32_t tl = max_len - k * step;
-            for (uint32_t j = 0; j < fn; j++) {                     // the last entry (smallest end) that still has >= tl bytes
-                const unsigned long long e = xw::ld_agent64((const unsigned long long *)(fo + 2 * j));
-                if ((uint32_t)e >= tl) d = (uint32_t)(e >> 32);
-            }
             const uint32_t mm = match_min(d);
             uint32_t nx, ex;
             const uint32_t slot = dist_slot(d - 1, nx, ex);
@@ -1482,6 +1498,21 @@ struct Parser {
             xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
             L()->stage[(a & (kStagePos - 1)) * kStageQ] = (h & ~63ull) | ne;
             L()->stage[(a & (kStagePos - 1)) * kStageQ + kStageQ - 1] = uniq;
+        }
+    }
+    // the positions first + j of `m`, position first + j with max_len_of lane j's value
+    XW_FN void resample_all(unsigned long long m, uint32_t first, uint32_t max_len_of, bool undo)
+    {
+        if (!m) return;
+        uint32_t j = (uint32_t)__builtin_ctzll(m);
+        unsigned long long ev = resample_front(first + j);
+        while (m) {
+            m &= m - 1;
+            const uint32_t jn = m ? (uint32_t)__builtin_ctzll(m) : j;
+            const unsigned long long evn = m ? resample_front(first + jn) : 0ull;
+            resample(first + j, xw::readlane(max_len_of, j), ev);
+            if (undo) acc(kAccUndo, 1);
+            j = jn; ev = evn;
         }
         xw::drain();
     }
@@ -1677,10 +1708,7 @@ struct Parser {
                 if (w == kPW - 1) {
                     const uint32_t h0 = inb ? (uint32_t)staged(a)[0] : 0u;
                     const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
-                    for (unsigned long long m = xw::ballot(inb && ml > max_parse - node); m; m &= m - 1) {
-                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                        resample(seg_a + b0 + j, max_parse - (b0 + j));
-                    }
+                    resample_all(xw::ballot(inb && ml > max_parse - node), seg_a + b0, max_parse - node, false);
                 }
                 xw::block_sync();
             }
@@ -1778,18 +1806,33 @@ struct Parser {
                     r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
                     dirty = lv && r != cr;
                     if (xw::any(dirty)) {
+                        // (the bytes of a distance not measured yet are requested before the test whether a sampled edge has met it:
+                        //  the test takes ~1,000 cycles of LDS reads and compares, the load's latency passes behind it; a few loads in vain)
+                        if (dirty && mr != r && pcap > 0 && r < seg_q + node) px = load64u(G.in + a - r);
                         bool met = false;
 #pragma unroll
                         for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
                         if (xw::any(dirty && nd > 8)) {
-                            if (dirty && nd > 8) {
-                                for (uint32_t um = uniq; um; um &= um - 1)
-                                    met = met || L()->edge_d[(a & 511u) * kMaxEdges + (uint32_t)__builtin_ctz(um)] == r;
+                            // the distinct distances beyond the eight in registers: from LDS, four requested at a time (one at a time is
+                            // a round trip per distance, in every pass, on the waves a pass waits for)
+                            uint32_t um = (dirty && nd > 8) ? uniq : 0u;
+#pragma unroll
+                            for (uint32_t z = 0; z < 8; z++) um &= um - 1;
+                            while (xw::any(um != 0)) {
+                                uint32_t v[4];
+                                bool on[4];
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; t++) {
+                                    on[t] = um != 0;
+                                    v[t] = L()->edge_d[(a & 511u) * kMaxEdges + (um ? (uint32_t)__builtin_ctz(um) : 0u)];
+                                    um &= um - 1;
+                                }
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; t++) met = met || (on[t] && v[t] == r);
                             }
                         }
                         wnt = dirty && !met && r < seg_q + node;                                        // :1601
                         fresh = wnt && mr != r && pcap > 0;
-                        if (fresh) px = load64u(G.in + a - r);
                     }
                 }
                 if (pass > 0 && lv) {
@@ -1906,11 +1949,7 @@ struct Parser {
                     const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
                     uint32_t full = umin((h0 >> 16) & 0x1FFu, chunk_left - node);
                     if (full < kMatchMin) full = 0;
-                    for (unsigned long long m = xw::ballot(inb && i >= istar && ml != full); m; m &= m - 1) {
-                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                        resample(seg_a + b0 + j, xw::readlane(full, j));
-                        acc(kAccUndo, 1);
-                    }
+                    resample_all(xw::ballot(inb && i >= istar && ml != full), seg_a + b0, full, true);
                 }
             } else {
                 // the nodes the block has made reachable: its edges that end beyond it become their keys (merged with what earlier
