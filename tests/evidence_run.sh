@@ -14,6 +14,8 @@ bash tests/build_prof.sh      # the profile library does not travel with the sna
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 20e6 28 1 2>&1
   echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1   (300 MB of text, -window:28: depth)"
   NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1 2>&1
+  echo; echo "# the same with the profile build"
+  NLZM_LIB=nlzm_amd/libnlzm_hip_prof.so NLZM_WAIT_PRINT=1 python tests/gpu_one.py 300e6 28 1 2>&1
   echo; echo "# NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 block_batch_chunks=8   (independent blocks of 17 MB in flight: per-stream accounting)"
   NLZM_WAIT_PRINT=1 python tests/gpu_curve.py 17 28 1,8,32 block_batch_chunks=8 2>&1
 } > gpurun_out/${R}_wave_accounting.txt
