@@ -370,9 +370,6 @@ def main():
     if args.block_streams > 0:
         del d_out
         torch.cuda.empty_cache()
-        # (a new, tiny stream: the library lets go of the 1e9-byte stream's device buffers -- 16 GiB of pre-filter table, the BT4
-        #  tree, a launch's hand-off arrays -- before the block set is opened and `begin_s` is taken)
-        nlzm_amd.compress(corpus.syn_text(4096), 20)
         blocks = blocks_leg(lib, torch, dev, d_in, n, args.block_streams, B, args.steps, args.warmup,
                             check=(world == 1 and data_kind == "synthetic"))
         if world > 1:

@@ -194,6 +194,9 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
  * block mode: "block_worker_threads" (default 320) and "block_hot_waves" (default 3), the same two for the streams of a block set
  * (their worker CUs are few: the count follows from the number of streams), "block_batch_chunks" (chunks of every stream per
  * shared launch, default 8); "prefilter_bits_per_position" (log2 of the pre-filter table's entries per input position, default 4);
+ * "keep_block_pool" (default 1: the one device allocation of a block set is kept when the set is closed and used again by the
+ * next set that fits -- the driver clears freed device memory, and an allocation made soon after a large one was freed waits for it;
+ * 0 releases it, as nlzm_hip_shutdown does);
  * "stage_report" (1: the stages' cycle accounting of
  * every finished stream, and of a block set per stream, on stderr).  There are no environment knobs.
  * None of them changes a byte of the output.  The options are read when a stream or a block set is opened

@@ -76,7 +76,7 @@ int set_err(int code, const char *fmt, ...)
                            "%s failed: %s", #expr, hipGetErrorString(e_));                        \
     } while (0)
 
-void blocks_close();         // defined with the block-set entry points
+void blocks_close(bool drop_pool = false);         // defined with the block-set entry points
 
 inline uint32_t clampu(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -113,6 +113,8 @@ struct Ctx {
     int64_t opt_block_batch = 8;            // block mode: chunks of every stream per shared launch (the rounds overlap, so their length matters little --
                                             // 6 / 8 / 12 / 16 chunks: 88.9 / 89.8 / 88.7 / 89.6 MB/s; the pool holds 2.3 KB per position of a launch and stream)
     int64_t opt_tbits_per = 4;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
+    int64_t opt_keep_pool = 1;              // block mode keeps its one allocation when a set is closed: the driver clears freed device memory, and an allocation
+                                            // made soon after a large one was freed waits for that -- opening 32 streams took 0.12 s or 4.5 s (tests/gpu_begin_probe.py)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -236,7 +238,8 @@ struct DevState {
     char err[sizeof g_err] = "";                    // the last error raised by a thread that works for this state
     Ctx ctx;                                        // the context behind the single-stream entry points
     std::vector<BlockJob> jobs;                     // the open block set (nlzm_hip_blocks_begin .. _finish)
-    uint8_t *blocks_pool = nullptr;                 // ... and the one allocation all its streams' buffers lie in
+    uint8_t *blocks_pool = nullptr;                 // ... and the one allocation all its streams' buffers lie in: kept between block sets
+    size_t blocks_pool_size = 0;                    //     (option keep_block_pool) and used again by the next set that fits
     std::vector<hipStream_t> group_st;              // one HIP stream and an event pair per shared launch of a round
     std::vector<std::array<hipEvent_t, 3>> group_ev;   // per launch set: launch begins / ends / its results are copied aside
     void *pack_host = nullptr, *pack_dev = nullptr; // the streams' launch arguments of a round: pinned host copy, device copy
@@ -820,7 +823,7 @@ static void dev_shutdown(DevState &D)
     if (!C.inited) return;
     DevState *keep = t_dev;
     t_dev = &D;
-    blocks_close();
+    blocks_close(true);
     t_dev = keep;
     if (D.feed.pin[0] || D.feed.st) { for (int k = 0; k < 2; k++) { if (D.feed.pin[k]) (void)hipHostFree(D.feed.pin[k]); if (D.feed.ev[k]) (void)hipEventDestroy(D.feed.ev[k]); }
                                       if (D.feed.st) (void)hipStreamDestroy(D.feed.st); D.feed = DevState::Feed{}; }
@@ -954,6 +957,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "block_hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "block_hot_waves out of range"); C.opt_block_hot_waves = value; return 0; }
     if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
+    if (!strcmp(key, "keep_block_pool")) { C.opt_keep_pool = value != 0; if (!value && g_jobs.empty()) blocks_close(true); return 0; }
     if (!strcmp(key, "block_batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "block_batch_chunks out of range"); C.opt_block_batch = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown option %s", key);
@@ -1095,7 +1099,7 @@ void block_ctx_destroy(Ctx &c)
 }  // namespace
 
 namespace {
-void blocks_close()
+void blocks_close(bool drop_pool)
 {
     // (a round may still be queued or on the device -- an abandoned set, a failed step: every device wait is bounded)
     for (auto &st : g_group_st) (void)hipStreamSynchronize(st);
@@ -1104,7 +1108,7 @@ void blocks_close()
     cur().rounds = DevState::Rounds{};
     for (auto &j : g_jobs) { j.d_out = nullptr; if (j.c.inited) block_ctx_destroy(j.c); }
     g_jobs.clear();
-    if (cur().blocks_pool) { (void)hipFree(cur().blocks_pool); cur().blocks_pool = nullptr; }
+    if (cur().blocks_pool && (drop_pool || !g_ctx.opt_keep_pool)) { (void)hipFree(cur().blocks_pool); cur().blocks_pool = nullptr; cur().blocks_pool_size = 0; }
     for (auto &st : g_group_st) (void)hipStreamDestroy(st);
     for (auto &ev : g_group_ev) for (auto &e : ev) (void)hipEventDestroy(e);
     g_group_st.clear(); g_group_ev.clear();
@@ -1163,6 +1167,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        free_b += cur().blocks_pool_size;               // (the allocation kept from the set before is this set's to use)
         const double per_stream = 0.85 * (double)free_b / nblocks;
         Geom g0;
         make_geom(per_fixed ? per_fixed : (n + nblocks - 1) / nblocks, hist_bits_req, g0);
@@ -1204,7 +1209,11 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         }
         size_t total = 0;
         for (size_t v : need) total += v;
-        if (hipMalloc(&cur().blocks_pool, total) != hipSuccess) { blocks_close(); return set_err(NLZM_HIP_E_NOMEM, "block set: %zu bytes for %u streams", total, nblocks); }
+        if (cur().blocks_pool && cur().blocks_pool_size < total) { (void)hipFree(cur().blocks_pool); cur().blocks_pool = nullptr; cur().blocks_pool_size = 0; }
+        if (!cur().blocks_pool) {
+            if (hipMalloc(&cur().blocks_pool, total) != hipSuccess) { cur().blocks_pool = nullptr; blocks_close(); return set_err(NLZM_HIP_E_NOMEM, "block set: %zu bytes for %u streams", total, nblocks); }
+            cur().blocks_pool_size = total;
+        }
         size_t at = 0;
         for (uint32_t i = 0; i < nblocks; i++) {
             g_jobs[i].pool.base = cur().blocks_pool + at; g_jobs[i].pool.size = need[i]; g_jobs[i].pool.used = 0; g_jobs[i].pool.measuring = false;

@@ -207,6 +207,60 @@ def test_blocks_in_flight_on_one_gpu(gpu, nblocks, hb):
     assert shard.split_streams(b"".join(got)) == got
 
 
+def test_blocks_stepwise_with_a_round_queued_ahead(gpu):
+    """nlzm_hip_blocks_step with a chunk limit returns what has been coded and leaves the next round queued on the device
+    (the rounds of a block set overlap).  Stepping through a ragged set in small steps must give the streams of the one-call
+    form; a set abandoned with a round still queued must leave the library usable."""
+    import ctypes as C
+
+    lib = gpu.load_library()
+    hip = C.CDLL("libamdhip64.so")                              # (the runtime the library is linked against: device buffers for the test)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    data = corpus.mixed(5_000_000, corpus.SEED + 41)
+    k, hb = 5, 20                                               # (blocks of 1,000,000 bytes: 9 chunks of 122,368 each at -window:20)
+    want = gpu.compress_blocks(data, k, hb)
+    cap = int(lib.nlzm_hip_compress_bound(data.size)) + k * (16 + 131072)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_in), data.size + 512) == 0 and hip.hipMalloc(C.byref(d_out), cap) == 0
+    assert hip.hipMemset(d_in, 0, data.size + 512) == 0 and hip.hipMemcpy(d_in, data.ctypes.data, data.size, 1) == 0
+    done, fin, ms = C.c_uint64(0), C.c_int(0), C.c_double(0)
+    gpu.set_option("block_batch_chunks", 2)
+    try:
+        # abandoned after two steps: a round is queued behind the one just collected
+        assert lib.nlzm_hip_blocks_begin(d_in, data.size, k, hb) == 0, lib.nlzm_hip_last_error().decode()
+        for _ in range(2):
+            assert lib.nlzm_hip_blocks_step(2, C.byref(done), C.byref(fin), C.byref(ms)) == 0, lib.nlzm_hip_last_error().decode()
+        assert 0 < done.value < data.size and not fin.value
+        lib.nlzm_hip_blocks_abandon()
+        # stepped through to the end, steps of three chunks over launches of two (a step = two rounds, the second one short)
+        assert lib.nlzm_hip_blocks_begin(d_in, data.size, k, hb) == 0, lib.nlzm_hip_last_error().decode()
+        steps, last = 0, 0
+        while not fin.value:
+            assert lib.nlzm_hip_blocks_step(3, C.byref(done), C.byref(fin), C.byref(ms)) == 0, lib.nlzm_hip_last_error().decode()
+            assert done.value > last
+            last = done.value
+            steps += 1
+            assert steps < 50
+        assert done.value == data.size and steps >= 3
+        lens = (C.c_uint64 * k)()
+        total = C.c_uint64(0)
+        assert lib.nlzm_hip_blocks_finish(d_out, cap, lens, C.byref(total)) == 0, lib.nlzm_hip_last_error().decode()
+        host = np.empty(total.value, dtype=np.uint8)
+        assert hip.hipMemcpy(host.ctypes.data, d_out, total.value, 2) == 0
+        pos = 0
+        for i in range(k):
+            assert host[pos: pos + int(lens[i])].tobytes() == want[i], f"block {i}"
+            pos += int(lens[i])
+    finally:
+        gpu.set_option("block_batch_chunks", 8)
+        lib.nlzm_hip_blocks_abandon()
+        hip.hipFree(d_in); hip.hipFree(d_out)
+    assert gpu.compress(data[:300_000], hb) == oracle_py.compress(data[:300_000], hb)      # (the single-stream path after it)
+
+
 def test_block_mode_options_are_invisible(gpu):
     """How a block set's worker CUs are used (bin-taking lanes, hot-bin waves), how dense the pre-filter table is and how many
     chunks a launch takes must not change a byte of any stream."""
