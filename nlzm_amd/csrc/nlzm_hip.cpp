@@ -252,7 +252,6 @@ struct DevState {
     struct Rounds {
         bool have = false;                          // round `q` is queued (pre-passes and launch) and not collected yet
         uint32_t q = 0;
-        uint32_t last_max = 0;
         std::vector<StepPlan> plan[2];
         std::vector<uint32_t> act[2];
     } rounds;

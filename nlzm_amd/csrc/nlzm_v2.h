@@ -1753,7 +1753,7 @@ struct Parser {
                     um &= um - 1;
                 }
             }
-            if (w == 0) L()->reach[1][i] = sreach;
+            if (w == 4) L()->reach[1][i] = sreach;                   // (the relax waves have the time: the probe waves are what a block waits for)
             const unsigned long long q4 = ptick();
             const uint32_t litw = inb ? pc_lit + price(kCtxLitHi, lit >> 4) + price(kCtxLitLo + (lit >> 4), lit & 15) : 0u;   // :1418-1426
             const uint32_t S = xw::scan_add(litw) - litw;           // price of the literals of nodes b0 .. b0+i-1
@@ -1779,7 +1779,7 @@ struct Parser {
                     ea[j] = tl | (wd << 9) | (lp << 21);        // wd < 4096, lp < 2048
                 }
             }
-            for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
+            if (w >= 4) for (uint32_t t = tid - 256u; t < kSpan; t += 256u) L()->mcur[1][(b0 + t) & 511u] = kKeyNone;
             xw::block_sync();
             if (w == 0) acc(kAccSetup, xw::tick() - ts);
             t_q[0] += q1 - q0; t_q[1] += q2 - q1; t_q[2] += q3 - q2; t_q[3] += q4 - q3; t_q[4] += ptick() - q4;
@@ -1868,8 +1868,8 @@ struct Parser {
                 // the buffers of the next pass.  (Pass 0 relaxes nothing and its update reads the keys of finished blocks only:
                 // the set-up has cleared mcur[1] and stored reach[1], and the set-up's barrier stands for this one.)
                 if (pass > 0) {
-                    for (uint32_t t = tid; t < kSpan; t += kParserThreads) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;
-                    if (w == 0) L()->reach[nbuf][i] = sreach;
+                    if (w >= 4) for (uint32_t t = tid - 256u; t < kSpan; t += 256u) L()->mcur[nbuf][(b0 + t) & 511u] = kKeyNone;     // (the relax waves: see the set-up)
+                    if (w == 4) L()->reach[nbuf][i] = sreach;
                 }
                 const unsigned long long k1 = ptick();
                 if (pass > 0) xw::block_sync();
