@@ -1521,11 +1521,22 @@ struct Parser {
     // Every lane compares for itself, eight bytes a round: `own` holds the eight bytes at a (loaded once per block), `first` the
     // eight bytes at a - r (requested by the caller ahead of time, so that their latency passes behind other work).
     // Nearly every probe ends inside its first eight bytes; the others go on round by round.
-    XW_FN uint32_t probe_finish(bool want, uint32_t a, uint32_t r, uint32_t c, unsigned long long own, unsigned long long first)
+    // (`own2` / `first2`: the eight bytes behind them, requested with them -- a match of eight bytes and more is common enough (a
+    //  third of the passes with a new distance had one) that the second round, a dependent round trip to HBM on the waves a pass
+    //  waits for, is worth sixteen bytes a request)
+    XW_FN uint32_t probe_finish(bool want, uint32_t a, uint32_t r, uint32_t c, unsigned long long own, unsigned long long first,
+                                unsigned long long own2, unsigned long long first2)
     {
         uint32_t len = 0;
         bool open = want && c > 0;
         unsigned long long x = first, y = own;
+        if (open) {                                                 // the first eight bytes; the second eight are at hand
+            const unsigned long long d = x ^ y;
+            const uint32_t nb = d ? (uint32_t)__builtin_ctzll(d) >> 3 : 8u;
+            len += umin(nb, c - len);
+            if (nb < 8 || len >= c) open = false;
+        }
+        x = first2; y = own2;
         for (;;) {
             if (open) {
                 const unsigned long long d = x ^ y;
@@ -1645,7 +1656,8 @@ struct Parser {
                     uint32_t l = 0;
                     if (xw::any(want)) {
                         const unsigned long long yo = want ? load64u(G.in + seg_a + i) : 0ull, xo = want ? load64u(G.in + seg_a + i - r) : 0ull;
-                        l = probe_finish(want, seg_a + i, r, pcap, yo, xo);
+                        const unsigned long long yo2 = want ? load64u(G.in + seg_a + i + 8) : 0ull, xo2 = want ? load64u(G.in + seg_a + i + 8 - r) : 0ull;
+                        l = probe_finish(want, seg_a + i, r, pcap, yo, xo, yo2, xo2);
                     }
                     if (want) { counted = l + (l < pcap); n_cmp += counted; }
                     const unsigned long long okm = xw::ballot(want && l >= match_min(r));
@@ -1713,6 +1725,7 @@ struct Parser {
                 xw::block_sync();
             }
             const unsigned long long own8 = (w < 4 && inb) ? load64u(G.in + a) : 0ull;     // (probe waves: the bytes at the node's position, on their way during the set-up)
+            const unsigned long long own16 = (w < 4 && inb) ? load64u(G.in + a + 8) : 0ull;
             const unsigned long long q2 = ptick();
             // ---- set-up: the block's records, from the stage.  Every wave: the node's header, its distinct distances (for
             // the probes' "already met" test) and the wave's own edges; their distances also go into the ring the winners'
@@ -1801,14 +1814,14 @@ struct Parser {
                 // measured anew is decided first and its bytes are requested, so that they arrive behind the relaxation
                 bool dirty = false, wnt = false, fresh = false;
                 uint32_t r = 0;
-                unsigned long long px = 0;
+                unsigned long long px = 0, px2 = 0;
                 if (pass > 0 && w < 4) {
                     r = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
                     dirty = lv && r != cr;
                     if (xw::any(dirty)) {
                         // (the bytes of a distance not measured yet are requested before the test whether a sampled edge has met it:
                         //  the test takes ~1,000 cycles of LDS reads and compares, the load's latency passes behind it; a few loads in vain)
-                        if (dirty && mr != r && pcap > 0 && r < seg_q + node) px = load64u(G.in + a - r);
+                        if (dirty && mr != r && pcap > 0 && r < seg_q + node) { px = load64u(G.in + a - r); px2 = load64u(G.in + a + 8 - r); }
                         bool met = false;
 #pragma unroll
                         for (uint32_t z = 0; z < 8; z++) met = met || dd[z] == r;
@@ -1852,7 +1865,7 @@ struct Parser {
                 const unsigned long long k0a = ptick();
                 if (pass > 0 && w < 4) {
                     if (xw::any(dirty)) {
-                        if (xw::any(fresh)) { const uint32_t l = probe_finish(fresh, a, r, pcap, own8, px); if (fresh) { mr = r; ml = l; } }
+                        if (xw::any(fresh)) { const uint32_t l = probe_finish(fresh, a, r, pcap, own8, px, own16, px2); if (fresh) { mr = r; ml = l; } }
                         if (wnt && mr != r) { mr = r; ml = 0; }     // (nothing to compare: no room for a match)
                         if (dirty) {
                             cr = r; want = wnt; pw = 0; pt = 0;
