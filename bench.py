@@ -83,11 +83,11 @@ def algorithmic_bytes_lines(st: dict) -> int:
 
 
 def csrc_sha16() -> str:
-    """what the library is built from (tests/prof_summarise.py records the same over the profiled tree)"""
+    """the KERNEL sources (headers and .hip: what the counters of a launch depend on; the host file only queues launches) --
+    tests/prof_summarise.py records the same over the profiled tree"""
     import glob
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.hip"))
-                    + glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.cpp"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nlzm_amd", "csrc", "*.hip"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -1616,6 +1616,8 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
                 const Ctx &o = g_dev0.ctx; Ctx &c = P.D.ctx;
                 c.opt_batch = o.opt_batch; c.opt_worker_blocks = o.opt_worker_blocks; c.opt_worker_threads = o.opt_worker_threads;
                 c.opt_hot_waves = o.opt_hot_waves; c.opt_hot_min = o.opt_hot_min; c.opt_report = o.opt_report;
+                c.opt_block_threads = o.opt_block_threads; c.opt_block_hot_waves = o.opt_block_hot_waves; c.opt_block_batch = o.opt_block_batch;
+                c.opt_tbits_per = o.opt_tbits_per;
             }
             HIPCHK(hipMalloc(&P.d_in, P.n + 512));
             HIPCHK(hipMalloc(&P.d_out, P.bound));
