@@ -1900,7 +1900,10 @@ struct Parser {
                 const unsigned long long nkey = litwin ? (((unsigned long long)nc << 32) | ((node - 1) << 8) | kRankLit) : kin;
                 const unsigned long long u1 = ptick();
                 // membership: a node is inside while some edge of the nodes before it reaches it (:1486, :1550-1554)
-                const uint32_t rlive = (lv && pass > 0) ? L()->reach[buf][i] : 0u;     // (a node's reach counts once it was inside: it has relaxed its edges)
+                // (pass 0: the reach of the SAMPLED edges does not depend on the prices -- max_len is the table's (:1550) -- and the
+                //  first node that no node before it reaches is where the unconditional prefix maximum stops covering, so the
+                //  block's membership is known before anything is relaxed; only a probe's reach (:1608-1612) is found on the way)
+                const uint32_t rlive = pass == 0 ? sreach : (lv ? L()->reach[buf][i] : 0u);     // (a node's reach counts once it was inside: it has relaxed its edges)
                 const uint32_t pm = xw::scan_max(rlive);
                 const uint32_t before = umax(xw::lane_below(pm, 0u), end_p);
                 const bool inside = inb && node < before;
