@@ -98,6 +98,13 @@ int nlzm_hip_stream_finish(uint64_t *dst_len);
 
 int nlzm_hip_get_stats(nlzm_hip_stats *out);
 int nlzm_hip_get_timing(nlzm_hip_timing *out);
+/* Diagnostic counters of the pipeline stages for the last stream (what "stage_report" prints, by name): cycles are summed over the
+ * stream's launches, e.g. "parser_total_cycles", "parser_wait_cycles", "parser_pass_cycles", "parser_passes", "parser_blocks",
+ * "finder_total_cycles", "finder_wait_cycles", "finder_bt_wait_cycles", "table_total_cycles", "table_wait_cycles", "helper_jobs",
+ * "helper_taken", "helper_taken_nodes", "helper_wait_cycles", "worker_call_cycles", "worker_call_tests", "worker_calls",
+ * "hot_bin_calls", "positions".  No reference counterpart (the reference prints a progress line, NLZM.cpp:1861-1864); bench.py's
+ * latency bound and the tests read them. */
+int nlzm_hip_get_counter(const char *key, uint64_t *value);
 
 /* ---- stage: frame coder, replaces CodeFrame::Flush (NLZM.cpp:590-640) ------ */
 
@@ -197,6 +204,8 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
  * "keep_block_pool" (default 1: the one device allocation of a block set is kept when the set is closed and used again by the
  * next set that fits -- the driver clears freed device memory, and an allocation made soon after a large one was freed waits for it;
  * 0 releases it, as nlzm_hip_shutdown does);
+ * "parser_helper" (default 1: a stream gets a helper parser workgroup -- one CU more -- that parses the back of every segment that is cut
+ * at 4,096 positions while the parser stage parses its front; "block_parser_helper", default 0, the same for the streams of a block set);
  * "stage_report" (1: the stages' cycle accounting of
  * every finished stream, and of a block set per stream, on stderr).  There are no environment knobs.
  * None of them changes a byte of the output.  The options are read when a stream or a block set is opened

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "nlzm_hip_blocks_begin", "nlzm_hip_blocks_step", "nlzm_hip_blocks_finish", "nlzm_hip_blocks_abandon",
     "nlzm_hip_compress_blocks_dev", "nlzm_hip_compress_blocks", "nlzm_hip_compress_blocks_multi",
     "nlzm_hip_feed_begin", "nlzm_hip_feed", "nlzm_hip_feed_output", "nlzm_hip_feed_finish", "nlzm_hip_feed_end",
-    "nlzm_hip_block_placement",
+    "nlzm_hip_block_placement", "nlzm_hip_get_counter",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
     lib.nlzm_hip_stream_finish.argtypes = [u64p]
     lib.nlzm_hip_get_stats.argtypes = [C.POINTER(Stats)]
     lib.nlzm_hip_get_timing.argtypes = [C.POINTER(Timing)]
+    lib.nlzm_hip_get_counter.argtypes = [C.c_char_p, u64p]
     lib.nlzm_hip_rans_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_uint64, C.c_void_p]
     lib.nlzm_hip_find_matches.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -226,6 +227,13 @@ def stats() -> dict:
     s = Stats()
     _chk(load_library().nlzm_hip_get_stats(C.byref(s)))
     return s.as_dict()
+
+
+def counter(key: str) -> int:
+    """A diagnostic counter of the pipeline stages for the last stream (nlzm_hip_get_counter)."""
+    v = C.c_uint64(0)
+    _chk(load_library().nlzm_hip_get_counter(key.encode(), C.byref(v)))
+    return int(v.value)
 
 
 def timing() -> dict:

@@ -260,7 +260,43 @@ def block_set(size: int, seed: int = SEED) -> np.ndarray:
     return np.concatenate([syn_text(per, seed + 100 + i) for i in range(32)])
 
 
-_GENS = {"syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def dense_text(size: int, seed: int = SEED) -> np.ndarray:
+    """Text over a vocabulary of 40 words: after a few kilobytes every position lies inside some match, so that nearly every
+    parse segment runs into the forced cut at 4,096 positions (NLZM.cpp:1469) -- what 300 MB of ordinary text look like to the
+    parser at -window:28, in a few hundred kilobytes (the helper parser's cases: DESIGN.md section 11)."""
+    rng = np.random.default_rng(seed ^ 0xDE75E)
+    vocab = _vocab(rng, 40)
+    p = 1.0 / np.arange(1, 41) ** 0.9
+    cdf = np.cumsum(p / p.sum())
+    out = np.empty(size, dtype=np.uint8)
+    pos = 0
+    while pos < size:
+        b = _text_block(rng, vocab, cdf, min(1 << 20, size - pos))
+        k = min(len(b), size - pos)
+        out[pos:pos + k] = b[:k]
+        pos += k
+    return out
+
+
+def dense_breaks(size: int, seed: int = SEED) -> np.ndarray:
+    """dense_text with a natural segment end every 1,500 - 9,000 bytes: three bytes that occur nowhere else (no match spans them), so
+    that segments of every length follow segments that were cut -- among them ones that end inside the last 264 + 64 positions in front
+    of a forced cut, where records were re-listed for a cut that then does not happen (the helper parser's give-up and drop paths)."""
+    rng = np.random.default_rng(seed ^ 0xB4EA45)
+    out = dense_text(size, seed)
+    pos = int(rng.integers(1500, 9000))
+    k = 0
+    while pos + 3 < size:
+        out[pos] = 0x80 + (k % 120); out[pos + 1] = 0x80 + ((k // 120) % 120); out[pos + 2] = 0x80 + ((k * 7) % 120)
+        k += 1
+        # (often close to a multiple of 4,096 behind the last break: a segment that ends just in front of, or just behind, a forced cut)
+        step = int(rng.integers(1500, 9000))
+        if rng.random() < 0.5: step = 4096 * int(rng.integers(1, 3)) + int(rng.integers(-330, 40))
+        pos += max(step, 200)
+    return out
+
+
+_GENS = {"dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

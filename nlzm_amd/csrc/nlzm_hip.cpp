@@ -115,10 +115,14 @@ struct Ctx {
     int64_t opt_tbits_per = 4;              // log2 of the pre-filter table's entries per input position (capped by window + 5 and 32 bits)
     int64_t opt_keep_pool = 1;              // block mode keeps its one allocation when a set is closed: the driver clears freed device memory, and an allocation
                                             // made soon after a large one was freed waits for that -- opening 32 streams took 0.12 s or 4.5 s (tests/gpu_begin_probe.py)
+    int64_t opt_helper = 1;                 // a helper parser workgroup (nlzm_v2.h, HelpBox): 1 CU more per stream.  The streams of a block
+    int64_t opt_block_helper = 0;           // set run without one unless "block_parser_helper" says otherwise (a stream of a full device waits for its BT4 results)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
     uint32_t run_worker_blocks = 0, run_worker_threads = 0;
+    unsigned long long prof_last[128] = {}; // of the last finished stream: Persist::prof and the worker lanes' counters (nlzm_hip_get_counter)
+    WorkerCounters wc_last{};
     double acct[8] = {};                    // of the last finished stream, cycles per position: finder total / wait / of it for BT4, table total / wait, parser total / wait / passes
 
 
@@ -153,6 +157,7 @@ struct Ctx {
     // three-stage pipeline (nlzm_v2.h): hand-off rings, progress words, stage state
     uint32_t *v2_ft = nullptr, *v2_tp = nullptr, *v2_tf = nullptr, *v2_state = nullptr;
     v2::Hx *v2_hx = nullptr;
+    v2::HelpBox *v2_hb = nullptr;
     v2::Hx hx_host;
 
     // capture (stage tests)
@@ -287,11 +292,11 @@ void free_stream_buffers(Ctx &C)
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
                      C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
                      C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo, C.hot_of_bin, C.hot_list, C.hot_undo,
-                     C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx };
+                     C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx, C.v2_hb };
     if (!C.pooled) for (void *p : ptrs) if (p) (void)hipFree(p);
     C.pooled = false;
     C.alt = Ctx::LaunchSet{}; C.snap = nullptr; C.set_idx = 0;      // (a second launch set only ever comes from a pool)
-    C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr;
+    C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr; C.v2_hb = nullptr;
     C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
     C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = C.hot_of_bin = C.hot_list = nullptr; C.hot_undo = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
@@ -464,6 +469,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     DEVALLOC(C.v2_tf, (size_t)v2::kTpRing * v2::kTfStride * 4);
     DEVALLOC(C.v2_state, sizeof(v2::StateV2));
     DEVALLOC(C.v2_hx, sizeof(v2::Hx));
+    if (C.opt_helper) DEVALLOC(C.v2_hb, sizeof(v2::HelpBox));
     DEVFILL(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
 
     if (C.double_sets) {
@@ -563,7 +569,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
         h.f_pos = h.t_pos = h.t_out = h.p_pos = (uint32_t)a0;
         h.p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         if (!ahead) HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
-        P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state;
+        P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state; P.V.hb = C.v2_hb;
         G.progress = &C.v2_hx->f_pos;
     }
     HIPCHK(hipEventRecord(P.ev[6], C.st));
@@ -715,6 +721,7 @@ int refresh_stats(Ctx &C)
     s.nice_positions = P.cnt.nice_positions; s.segments = P.cnt.segments; s.n_literal = P.cnt.n_literal;
     s.n_dict = P.cnt.n_dict; s.n_rep = P.cnt.n_rep; s.rans_syms = P.cnt.rans_syms; s.bit_ops = P.cnt.bit_ops;
     s.frames = P.cnt.frames; s.shifts = P.cnt.shifts; s.uncertain_positions = P.cnt.uncertain_positions;
+    memcpy(C.prof_last, P.prof, sizeof C.prof_last);
     {
         const double n = (double)(P.cnt.positions ? P.cnt.positions : 1);
         C.acct[0] = P.prof[17] / n; C.acct[1] = P.prof[16] / n; C.acct[2] = P.prof[25] / n; C.acct[3] = P.prof[19] / n; C.acct[4] = P.prof[18] / n;
@@ -732,6 +739,11 @@ int refresh_stats(Ctx &C)
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "parser: waited for its record loader %llu times, the table stage %.0f positions ahead on average then\n", P.prof[26], (double)P.prof[27] / (double)(P.prof[26] ? P.prof[26] : 1));
+        if (P.prof[96] || P.prof[100])
+            fprintf(stderr, "helper parser: %llu jobs posted, %llu taken over (%llu nodes = %.1f %% of the positions), the parser stage waited %.0f cycles per position for it; "
+                            "helper: %llu jobs seen, %llu done, %llu blocks (%.2f passes each), waited %.0f cycles per position for records\n",
+                    P.prof[96], P.prof[97], P.prof[98], 100.0 * P.prof[98] / n, P.prof[99] / n, P.prof[100], P.prof[101], P.prof[102],
+                    (double)P.prof[103] / (double)(P.prof[102] ? P.prof[102] : 1), P.prof[104] / n);
         if (P.prof[88]) fprintf(stderr, "finder sections (cycles/position, profile build): predict %.0f, own loads %.0f, HT rows %.0f, candidates + jobs %.0f, record + RK256 %.0f, "
                                 "BT4 results (wait included) %.0f, verify %.0f, commit %.0f\n", P.prof[88] / n, P.prof[89] / n, P.prof[90] / n, P.prof[91] / n, P.prof[92] / n,
                                 P.prof[93] / n, P.prof[94] / n, P.prof[95] / n);
@@ -761,6 +773,7 @@ int refresh_stats(Ctx &C)
         HIPCHK(hipMemcpy(&wc, C.wcnt, sizeof wc, hipMemcpyDeviceToHost));
         s.bt_calls += wc.bt_calls; s.bt_tests += wc.bt_tests; s.cmp_bytes += wc.cmp_bytes;
         C.last_dry_runs = wc.dry_runs; C.last_flag_waits = wc.flag_waits;
+        C.wc_last = wc;
         if (C.opt_report)
             fprintf(stderr, "worker lanes: %llu calls made with their fate open (at and behind a position not decided yet), %llu decisions that took calls back, %llu calls made again for it\n",
                     wc.dry_runs, wc.spec_calls, wc.spec_good);
@@ -924,6 +937,27 @@ int nlzm_hip_get_stats(nlzm_hip_stats *out)
     return 0;
 }
 
+int nlzm_hip_get_counter(const char *key, uint64_t *value)
+{
+    Ctx &C = g_ctx;
+    if (!key || !value) return set_err(NLZM_HIP_E_ARG, "null argument");
+    if (C.open) { const int rc = refresh_stats(C); if (rc) return rc; }
+    static const struct { const char *name; int idx; } kProf[] = {
+        { "finder_blocks", 0 }, { "table_blocks", 6 }, { "parser_blocks", 8 }, { "parser_passes", 13 },
+        { "finder_wait_cycles", 16 }, { "finder_total_cycles", 17 }, { "table_wait_cycles", 18 }, { "table_total_cycles", 19 },
+        { "parser_wait_cycles", 20 }, { "parser_total_cycles", 21 }, { "parser_emit_cycles", 22 }, { "parser_setup_cycles", 23 }, { "parser_pass_cycles", 24 },
+        { "finder_bt_wait_cycles", 25 },
+        { "helper_jobs", 96 }, { "helper_taken", 97 }, { "helper_taken_nodes", 98 }, { "helper_wait_cycles", 99 }, { "helper_jobs_done", 101 }, { "helper_blocks", 102 }, { "helper_passes", 103 },
+    };
+    for (const auto &e : kProf) if (!strcmp(key, e.name)) { *value = C.prof_last[e.idx]; return 0; }
+    if (!strcmp(key, "worker_call_cycles")) { *value = C.wc_last.call_cycles; return 0; }
+    if (!strcmp(key, "worker_call_tests")) { *value = C.wc_last.call_tests; return 0; }
+    if (!strcmp(key, "worker_calls")) { *value = C.wc_last.bt_calls; return 0; }
+    if (!strcmp(key, "hot_bin_calls")) { *value = C.wc_last.hot_calls; return 0; }
+    if (!strcmp(key, "positions")) { *value = C.stats.positions; return 0; }
+    return set_err(NLZM_HIP_E_ARG, "unknown counter %s", key);
+}
+
 int nlzm_hip_get_timing(nlzm_hip_timing *out)
 {
     Ctx &C = g_ctx;
@@ -956,6 +990,8 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "block_hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "block_hot_waves out of range"); C.opt_block_hot_waves = value; return 0; }
     if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
+    if (!strcmp(key, "parser_helper")) { C.opt_helper = value != 0; return 0; }
+    if (!strcmp(key, "block_parser_helper")) { C.opt_block_helper = value != 0; return 0; }
     if (!strcmp(key, "keep_block_pool")) { C.opt_keep_pool = value != 0; if (!value && g_jobs.empty()) blocks_close(true); return 0; }
     if (!strcmp(key, "block_batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "block_batch_chunks out of range"); C.opt_block_batch = value; return 0; }
     if (!strcmp(key, "batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "batch_chunks out of range"); C.opt_batch = value; return 0; }
@@ -1154,11 +1190,13 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     HIPCHK(hipGetDeviceProperties(&prop, C.device));
     // (a spare CU per stream while there is room for it; every workgroup of the launch has a CU of its own either way:
     //  at most CUs / 4 streams -- three stage CUs and one worker CU each -- which is 64 on an MI355X)
-    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - (int64_t)pipeline2_role_blocks();
+    // (the helper parser's workgroup leaves at once where the streams run without one: it takes no CU then)
+    const int64_t roles_live = (int64_t)pipeline2_role_blocks() - (C.opt_block_helper ? 0 : 1);
+    int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - roles_live;
     if (wb > 1 && nblocks > 1) wb--;
     if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;
     if (wb < 1) return set_err(NLZM_HIP_E_ARG, "%u streams do not fit %d CUs (at most %d)", nblocks, prop.multiProcessorCount,
-                               prop.multiProcessorCount / (int)(pipeline2_role_blocks() + 1));
+                               prop.multiProcessorCount / (int)(roles_live + 1));
     g_blocks_wb = wb; g_blocks_n = n; g_blocks_src = (const uint8_t *)d_src; g_blocks_hist = hist_bits_req;
     // Every stream holds its own tables and hand-off arrays: the pre-filter table (4 << t_bits bytes) and the per-launch
     // arrays (about 2.2 KB per position of a launch) are sized so that all streams fit the free memory.
@@ -1196,7 +1234,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
             Ctx m;                                  // (a scratch context: options as the streams will have them)
             m.inited = true; m.device = device; m.st = C.st;
             m.opt_workers = 1; m.opt_worker_blocks = wb; m.opt_batch = batch; m.opt_worker_threads = C.opt_block_threads; m.opt_tbits_max = tbits_max; m.cu_count = C.cu_count;
-            m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min; m.opt_tbits_per = C.opt_tbits_per;
+            m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min; m.opt_tbits_per = C.opt_tbits_per; m.opt_helper = C.opt_block_helper;
             Pool mp; mp.measuring = true;
             m.pool = &mp; m.double_sets = true;
             uint8_t *fake_out = nullptr;
@@ -1222,7 +1260,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     for_blocks(nblocks, [&](uint32_t i, BlockJob &j) {
         j.rc = block_ctx_init(j.c, device, wb, batch);
         j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
-        j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min; j.c.opt_tbits_per = C.opt_tbits_per;
+        j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min; j.c.opt_tbits_per = C.opt_tbits_per; j.c.opt_helper = C.opt_block_helper;
         j.c.pool = &j.pool;
         if (!j.rc) j.rc = dev_alloc(j.c, &j.d_out, j.bound);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
@@ -1617,7 +1655,7 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
                 c.opt_batch = o.opt_batch; c.opt_worker_blocks = o.opt_worker_blocks; c.opt_worker_threads = o.opt_worker_threads;
                 c.opt_hot_waves = o.opt_hot_waves; c.opt_hot_min = o.opt_hot_min; c.opt_report = o.opt_report;
                 c.opt_block_threads = o.opt_block_threads; c.opt_block_hot_waves = o.opt_block_hot_waves; c.opt_block_batch = o.opt_block_batch;
-                c.opt_tbits_per = o.opt_tbits_per;
+                c.opt_tbits_per = o.opt_tbits_per; c.opt_helper = o.opt_helper; c.opt_block_helper = o.opt_block_helper;
             }
             HIPCHK(hipMalloc(&P.d_in, P.n + 512));
             HIPCHK(hipMalloc(&P.d_out, P.bound));

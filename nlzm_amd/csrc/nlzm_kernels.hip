@@ -891,26 +891,28 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
 // worker lanes.  512-thread blocks with > 80 KB of LDS: one block per CU; the grid is kept below the CU count, so every
 // block is resident at once (the stages wait on each other through progress words in HBM).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kV2Roles = 3;
+constexpr uint32_t kV2Roles = 4;                // finder, table, parser, helper parser (leaves at once where a stream has no HelpBox)
 __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1,
                                                 uint32_t local_block, uint32_t wblocks)
 {
     if (local_block < kV2Roles) {
         // finder: one wave; table: kTW waves, a block each; parser: kPW waves on the same block
-        if (threadIdx.x >= (local_block == 2 ? v2::kParserThreads : (local_block == 1 ? 64u * v2::kTW : 64u))) return;
+        if (threadIdx.x >= (local_block >= 2 ? v2::kParserThreads : (local_block == 1 ? 64u * v2::kTW : 64u))) return;
         if (local_block == 0) { v2::Finder r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else if (local_block == 1) { v2::Table r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
-        else { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
+        else if (local_block == 2) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
+        else if (V.hb) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run_helper(c0); }
     } else {
         worker_role(g, G, c0, c1, wblocks, local_block - kV2Roles);
     }
 }
 __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::GlobalsV2 V, uint32_t c0, uint32_t c1)
 {
-    // blocks 0, 8, 16 are the three stages: workgroups go to the XCDs round-robin, so they share XCD 0 (and its L2)
+    // blocks 0, 8, 16, 24 are the stages: workgroups go to the XCDs round-robin, so they share XCD 0 (and its L2)
     const uint32_t b = blockIdx.x;
+    const bool spread = gridDim.x > 8 * (kV2Roles - 1);                                   // (a small grid: the first blocks are the stages)
     const uint32_t before = b ? (b + 7) / 8 < kV2Roles ? (b + 7) / 8 : kV2Roles : 0u;     // stage blocks below b
-    const uint32_t local = (b % 8 == 0 && b / 8 < kV2Roles && gridDim.x > 16) ? b / 8 : (gridDim.x > 16 ? kV2Roles + (b - before) : b);
+    const uint32_t local = (b % 8 == 0 && b / 8 < kV2Roles && spread) ? b / 8 : (spread ? kV2Roles + (b - before) : b);
     pipeline2_roles(g, G, V, c0, c1, local, gridDim.x - kV2Roles);
 }
 struct Stream2Args { Geom g; Globals G; v2::GlobalsV2 V; uint32_t c0, c1; v2::RoundSnap *snap; };
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args 
     NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs);
     NLZM_GLOBAL_PTR(a.G.bt_flag); NLZM_GLOBAL_PTR(a.G.unc); NLZM_GLOBAL_PTR(a.G.bin_off); NLZM_GLOBAL_PTR(a.G.bin_pos); NLZM_GLOBAL_PTR(a.G.abort_word);
     NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt); NLZM_GLOBAL_PTR(a.G.bt_undo); NLZM_GLOBAL_PTR(a.G.hot_of_bin); NLZM_GLOBAL_PTR(a.G.hot_list); NLZM_GLOBAL_PTR(a.G.hot_undo);
-    NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state);
+    NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state); NLZM_GLOBAL_PTR(a.V.hb);
 #undef NLZM_GLOBAL_PTR
     pipeline2_roles(a.g, a.G, a.V, a.c0, a.c1, local, bps - kV2Roles);
 }

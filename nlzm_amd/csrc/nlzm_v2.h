@@ -52,6 +52,11 @@ struct Hx {                                     // progress words, one 128-byte 
     alignas(128) uint32_t t_out;                // table: parser records of positions < t_out are written
     alignas(128) uint32_t p_pos;                // parser: records of positions < p_pos are consumed
     alignas(128) unsigned long long p_seg;      // parser: segment start << 32 | positions below this lie in that segment
+    // helper parser (HelpBox below)
+    alignas(128) uint32_t h_job;                // parser: number of the job in the HelpBox (0: none yet, kHelpExit: the launch is over)
+    alignas(128) uint32_t h_verdict;            // parser: job << 2 | 1 taken over, 2 dropped
+    alignas(128) unsigned long long h_prog;     // helper: job << 32 | nodes it knows to be inside the segment << 16 | nodes final (HelpBox arrays valid below)
+    alignas(128) uint32_t h_state;              // helper: job << 2 | 1 done (seg_len, end_rep valid), 2 given up
     alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves (the FIRST code stays: raise())
     uint32_t err_info[7];                       // of the stage that raised it: stage (11 finder, 12 table, 13 parser), wait site, position, what it saw
     alignas(128) uint32_t dbg[4][32];           // per stage (0 finder, 1 table, 2 parser): where it was when it left because of an error
@@ -60,12 +65,41 @@ enum : uint32_t { kStFinder = 11, kStTable = 12, kStParser = 13 };
 // What the host looks at after a launch, copied aside on the device when the next launch is already queued behind it (block mode)
 struct RoundSnap { uint32_t error, next_chunk, aborted, pad; Hx hx; };
 
+// ---- helper parser: a second parser workgroup that parses the BACK of a long segment while the parser stage parses its front.
+// Under the same prices two parses of a segment differ only in where they started, and the recurrence forgets its start: a parse
+// begun at node kHelpStart as if the segment began there (cost 0, the rep set of the segment start) has, a few hundred nodes on,
+// the true state of every node up to ONE cost offset.  The parser stage checks exactly that when it gets to the first block border
+// behind kHelpStart + kHelpWarm: the 264 nodes in front of the border are all the sources an edge into a later node can have
+// (:737); if on them the helper's costs minus its own are one constant and the rep sets are equal, every candidate of every later
+// node is shifted by that constant in the helper's parse -- same winners under strict '>' and the (source, rank) order, same rep
+// sets -- and it takes the helper's nodes over instead of computing them.  Otherwise it goes on by itself.  Measured on the CPU
+// (oracle/stale_probe.c, profiles/r05_parser_go_nogo.txt): 85 - 92 % of such frontiers agree 576 nodes after the start.
+constexpr uint32_t kHelpStart = 1792;           // the helper's first node (a segment that is cut at 4,096: the front 2,400 nodes stay with the parser stage)
+constexpr uint32_t kHelpWarm = 576;             // nodes the helper has behind it where the frontiers are compared
+constexpr uint32_t kHelpExit = 0xFFFFFFFFu;
+struct HelpBox {
+    // parser -> helper: the job (valid once Hx::h_job carries its number)
+    uint32_t seg_a, chunk_left, base, pad0, rep[4];
+    alignas(16) uint16_t price[kNumCtx * 16];
+    alignas(16) uint16_t len_price[kMatchMax + 8];
+    alignas(16) uint16_t slot_price[4 * 64];
+    // helper -> parser: per node (valid below Hx::h_prog's count): the emitter's words, the cost, the rep set, the bytes the node's final probes compared
+    alignas(16) uint32_t link[kParseMax + 2], delta[kParseMax + 2], cost[kParseMax + 2], rep_of[(kParseMax + 2) * 4], cmpw[4][kParseMax + 2];
+    uint32_t seg_len, end_rep[4];               // (valid with Hx::h_state "done")
+    // the helper's own: records it has re-listed for the segment's forced cut (position a at [(a & 511) * kTpStride]).  The ring's records
+    // are the parser stage's to change -- the helper runs ahead of it on a guess, and a record cut short for a segment that then ends
+    // elsewhere (or whose job is dropped) would be the next segment's wrong table.
+    alignas(16) uint32_t relist[512 * kTpStride];
+};
+constexpr unsigned long long kStagedOwn = 0x80000000ull;   // helper: bit of a staged record's header -- its edges beyond the staged sixteen are in HelpBox::relist
+
 struct GlobalsV2 {
     uint32_t *ft;                               // [kFtRing][kFtStride]
     uint32_t *tp;                               // [kTpRing][kTpStride]
     uint32_t *tf;                               // [kTpRing][kTfStride]
     Hx *hx;
     uint32_t *state;                            // StateV2 (survives between launches)
+    HelpBox *hb;                                // null: no helper parser
 };
 
 // stage state that survives between launches (HBM)
@@ -1153,8 +1187,10 @@ struct PLds {
     uint32_t ncmds;
     uint32_t bitbuf[64];                        // raw bits of a batch of commands (wave 7)
     uint32_t dbgw[4];                           // error dump: the segment being parsed, its block, the node count so far
-    unsigned long long acc[11];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back
+    unsigned long long acc[15];                 // cycles waited / emitting / in block set-up / in passes; blocks, passes, records re-listed, put back; helper jobs posted / taken over, nodes taken over, cycles waited for the helper
     unsigned long long fpm[4];                  // single-literal runs: per probe wave, the positions where its rep slot found a match
+    uint32_t ncost[512];                        // cost of the final nodes (ring like nrep: the frontier the helper's parse is compared on)
+    uint32_t hj[4];                             // helper: 0 jobs posted in this launch, 1 this segment gets a job, 2 / 3 results of the take-over steps
     uint32_t stg[5];                            // loader wave: records requested up to / written up to this position, (2 unused), records of the last step; 4: records staged up to here
     unsigned long long stage[kStagePos * kStageQ];  // the table stage's records of the positions from the current block on, loaded ahead
                                                 //   by wave kPW-1 (position a at [((a - launch start) & 127) * kStageQ])
@@ -1172,6 +1208,10 @@ struct Parser {
     uint32_t t_out_seen;
     uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
+    bool is_helper = false;         // this workgroup is the helper parser (run_helper)
+    bool prev_cut = false;          // the last segment was cut at 4,096 positions (:1469): the next one most likely is, and gets a helper job
+    uint32_t myjob = 0;             // helper: the job it works on
+    uint32_t hstop = 0;             // helper: 1 the job was dropped, 2 it gives the job up
     // wave kPW-1: the loader of the record stage (8-byte words counted from the launch's first position)
     uint32_t pend_t;                            // (what the loads of the last step were for, how far the stage is complete: L()->stg)
     unsigned long long pend_v[kPumpLoads];
@@ -1183,7 +1223,7 @@ struct Parser {
     uint32_t n_cmp;                             // (per lane and launch: well below 2^32)
     unsigned long long t_s[7] = {}, t_q[5] = {};
     // the stage's accounting lives in LDS (L()->acc: it is touched once a block or less, and scalar registers are short)
-    enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccNeed, kAccAhead, kAccN };
+    enum { kAccWait, kAccEmit, kAccSetup, kAccPass, kAccBlocks, kAccPasses, kAccRedo, kAccUndo, kAccTotal, kAccNeed, kAccAhead, kAccJobs, kAccTaken, kAccTakenNodes, kAccHelpWait, kAccN };
     XW_FN void acc(uint32_t k, unsigned long long v) { if (xw::lane() == 0) xw::lds_add64(&L()->acc[k], v); }
     unsigned long long t_work = 0, t_bar = 0, t_upd = 0, t_fill = 0, t_fin = 0, t_dirty = 0;     // profile build: this wave's push / probe work, barrier waits, update, mask fills, block end
 #ifdef NLZM_PROFILE
@@ -1414,7 +1454,21 @@ struct Parser {
         pend_t = xw::ld_agent(&V.hx->t_out);
         if (i == 0) { L()->stg[0] = st_req + n; L()->stg[1] = st_wr; L()->stg[3] = n; L()->stg[4] = st_wr; }
     }
-    // until the record of position a is staged (false: another stage failed, or the wait timed out)
+    // the loader goes on at position a (what is staged or on its way is dropped): a segment's back was taken over from the helper, or a
+    // helper job starts in the middle of a segment
+    XW_FN void pump_seek(uint32_t a)
+    {
+        if (xw::lane() == 0) { L()->stg[0] = a; L()->stg[1] = a; L()->stg[3] = 0; L()->stg[4] = a; }
+        xw::wave_sync();
+    }
+    // helper: has the parser stage dropped the job (or posted another one, or ended the launch)?
+    XW_FN bool helper_cancelled() const
+    {
+        const uint32_t j = xw::readfirst(xw::ld_agent(&V.hx->h_job)), v = xw::readfirst(xw::ld_agent(&V.hx->h_verdict));
+        xw::after_poll();
+        return j != myjob || v == ((myjob << 2) | 2u);
+    }
+    // until the record of position a is staged (false: another stage failed, the wait timed out, or -- helper -- the job was dropped)
     XW_FN bool stage_need(uint32_t a)
     {
         if ((int32_t)(staged_hi() - (a + 1)) >= 0) return true;
@@ -1426,6 +1480,7 @@ struct Parser {
             if ((int32_t)(staged_hi() - (a + 1)) >= 0) break;
             if ((++spins & 63u) == 0) {
                 if (xw::readfirst(xw::ld_agent(&V.hx->err))) { ok = false; break; }
+                if (is_helper && helper_cancelled()) { hstop = 1; ok = false; break; }
 #ifndef NLZM_SIM
                 if (xw::clock100() - t0 > 3000000000ull) {            // 30 s
                     if (xw::lane() == 0) raise(V.hx, kErrTimeout * 100 + 4, kStParser, 4, a, staged_hi(), t_out_seen);
@@ -1457,7 +1512,7 @@ struct Parser {
     XW_FN void resample(uint32_t a, uint32_t max_len, unsigned long long ev0)
     {
         acc(kAccRedo, 1);
-        uint32_t *rec = V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        uint32_t *rec = is_helper ? V.hb->relist + (a & 511u) * kTpStride : V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
         const unsigned long long h = xw::readfirst64(staged(a)[0]);
         const uint32_t fn = (uint32_t)(h >> 32);
         const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
@@ -1496,7 +1551,7 @@ struct Parser {
         if (k == 0) {
             xw::st_agent64((unsigned long long *)rec, (h & ~63ull) | ne);
             xw::st_agent64((unsigned long long *)(rec + kTpUniq), uniq);
-            L()->stage[(a & (kStagePos - 1)) * kStageQ] = (h & ~63ull) | ne;
+            L()->stage[(a & (kStagePos - 1)) * kStageQ] = (h & ~63ull) | ne | (is_helper ? kStagedOwn : 0ull);
             L()->stage[(a & (kStagePos - 1)) * kStageQ + kStageQ - 1] = uniq;
         }
     }
@@ -1585,7 +1640,8 @@ struct Parser {
     {
         const uint32_t i = xw::lane();
         const uint32_t a_first = seg_a + b0;
-        if (!stage_need(a_first)) err = kErrInternal + 100;
+        if (is_helper && helper_cancelled()) { hstop = 1; err = kErrInternal + 100; }
+        else if (!stage_need(a_first)) err = kErrInternal + 100;
         uint32_t nb = umin(64u, max_parse - b0);
         uint32_t sh_hi = staged_hi();
         if ((int32_t)(sh_hi - (a_first + umin(nb, kGatherNodes))) < 0) {
@@ -1602,7 +1658,113 @@ struct Parser {
         if ((int32_t)(sh_hi - (a_first + nb)) < 0) nb = sh_hi - a_first;
         nb = xw::test_cut(nb);                              // (identity on the device; the simulation cuts blocks at random here, as
                                                             //  the device does when this stage catches up with the table stage)
-        if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; xw::st_agent(&V.hx->p_pos, a_first); }
+        if (i == 0) { L()->sh[0] = nb; L()->sh[4] = err; L()->dbgw[1] = b0; if (!is_helper) xw::st_agent(&V.hx->p_pos, a_first); }
+    }
+
+    // ---- helper parser, the parser stage's side (every thread of the stage) ---------------------------------------------------
+    // A job: the segment's start, how far the chunk goes, the rebase offset, the model's rep set and the price tables as this stage
+    // has just built them (3.4 KB), then the job's number.
+    XW_FN void post_job(uint32_t seg_a, uint32_t chunk_left)
+    {
+        HelpBox *hb = V.hb;
+        const uint32_t tid = xw::thread();
+        const uint32_t *pw = (const uint32_t *)L()->price, *lw = (const uint32_t *)L()->len_price, *sw = (const uint32_t *)L()->slot_price;
+        for (uint32_t k = tid; k < kNumCtx * 8; k += kParserThreads) xw::st_agent((uint32_t *)hb->price + k, pw[k]);
+        if (tid < (kMatchMax + 8) / 2) xw::st_agent((uint32_t *)hb->len_price + tid, lw[tid]);
+        if (tid >= 256 && tid < 256 + 128) xw::st_agent((uint32_t *)hb->slot_price + (tid - 256), sw[tid - 256]);
+        if (tid == 0) {
+            xw::st_agent(&hb->seg_a, seg_a); xw::st_agent(&hb->chunk_left, chunk_left); xw::st_agent(&hb->base, base);
+            xw::st_agent(&hb->rep[0], rep0); xw::st_agent(&hb->rep[1], rep1); xw::st_agent(&hb->rep[2], rep2); xw::st_agent(&hb->rep[3], rep3);
+        }
+        xw::drain();
+        xw::block_sync();
+        if (tid == 0) {
+            const uint32_t job = L()->hj[0] + 1;
+            L()->hj[0] = job;
+            xw::st_agent(&V.hx->h_job, job);
+            acc(kAccJobs, 1);
+        }
+    }
+    // This stage's nodes below b0 are final; the helper started at node kHelpStart.  Returns the segment's length if the helper's
+    // nodes from b0 on were taken over (links in node_link / node_delta, the rep set after the segment in sh[12..15], the loader at
+    // the segment's end), 0 if this stage has to go on by itself.
+    XW_FN uint32_t take_over(uint32_t seg_a, uint32_t b0)
+    {
+        HelpBox *hb = V.hb;
+        const uint32_t tid = xw::thread(), w = xw::wave();
+        const uint32_t job = L()->hj[0], V0 = b0 - 1;               // (hj[0]: written in front of many barriers)
+        // 1. is the helper beyond node V0?  It started when this stage did, 576 nodes in front of V0: if not, something held it up
+        // (records it had to wait for) -- a short wait, then the job is dropped.
+        if (w == 0) {                                               // (the wave polls as one: readfirst)
+            bool there = false;
+            for (uint32_t spins = 0; spins < 256 && !there; spins++) {
+                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&V.hx->h_prog));
+                there = (uint32_t)(pg >> 32) == job && ((uint32_t)pg & 0xFFFFu) > V0;
+                if (!there) { if ((xw::readfirst(xw::ld_agent(&V.hx->h_state)) >> 2) == job) break; xw::pause(); }    // (given up: it will not get there)
+            }
+            xw::after_poll();
+            if (tid == 0) { L()->hj[2] = there ? 1u : 0u; L()->hj[3] = 0; }
+        }
+        xw::block_sync();
+        bool ok = L()->hj[2] != 0;
+        // 2. the frontier: nodes V0 - 263 .. V0 (all of them the helper's: V0 - 263 > kHelpStart)
+        if (ok) {
+            if (tid < kMatchMax) {
+                const uint32_t t = V0 - tid;
+                const uint32_t off = xw::ld_agent(&hb->cost[V0]) - L()->ncost[V0 & 511u];
+                const uint32_t hc = xw::ld_agent(&hb->cost[t]);
+                const uint32_t h0 = xw::ld_agent(&hb->rep_of[t * 4]), h1 = xw::ld_agent(&hb->rep_of[t * 4 + 1]), h2 = xw::ld_agent(&hb->rep_of[t * 4 + 2]), h3 = xw::ld_agent(&hb->rep_of[t * 4 + 3]);
+                const uint32_t *mr = L()->nrep + (t & 511u) * 4;
+                if (hc - L()->ncost[t & 511u] != off || h0 != mr[0] || h1 != mr[1] || h2 != mr[2] || h3 != mr[3]) xw::lds_or(&L()->hj[3], 1u);
+            }
+            xw::block_sync();
+            ok = L()->hj[3] == 0;
+        }
+        if (tid == 0) xw::st_agent(&V.hx->h_verdict, (job << 2) | (ok ? 1u : 2u));
+        if (!ok) { xw::block_sync(); return 0; }
+        // 3. until the helper is through: what it has found to be inside the segment is this stage's word to the finder stage now
+        // (a nice region that starts there waits for it, :1529)
+        if (w == 0) {
+            const unsigned long long t0 = xw::clock100(), tw0 = xw::tick();
+            uint32_t res = 0, cover = 0, spins = 0;
+            for (;;) {
+                const uint32_t st = xw::readfirst(xw::ld_agent(&V.hx->h_state));
+                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&V.hx->h_prog));
+                if ((uint32_t)(pg >> 32) == job) {
+                    const uint32_t cv = (uint32_t)(pg >> 16) & 0xFFFFu;
+                    if (cv > cover) { cover = cv; if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + cv)); }
+                }
+                if ((st >> 2) == job) { res = (st & 3u) == 1u ? 1u : 0u; break; }
+                if ((++spins & 63u) == 0) {
+                    if (xw::readfirst(xw::ld_agent(&V.hx->err))) break;
+#ifndef NLZM_SIM
+                    if (xw::clock100() - t0 > 3000000000ull) { if (tid == 0) raise(V.hx, kErrTimeout * 100 + 6, kStParser, 6, seg_a, (uint32_t)pg, st); break; }
+#else
+                    (void)t0;
+#endif
+                }
+                xw::pause();
+            }
+            xw::after_poll();
+            if (tid == 0) L()->hj[2] = res;
+            acc(kAccHelpWait, xw::tick() - tw0);
+        }
+        xw::block_sync();
+        if (!L()->hj[2]) { xw::block_sync(); return 0; }            // (given up behind the comparison: a segment that ends inside its last 264 + 64 nodes)
+        // 4. its nodes
+        const uint32_t seg_len = xw::ld_agent(&hb->seg_len);
+        for (uint32_t t = b0 + tid; t <= seg_len; t += kParserThreads) {
+            L()->node_link[t] = xw::ld_agent(&hb->link[t]); L()->node_delta[t] = xw::ld_agent(&hb->delta[t]);
+            if (t < seg_len) n_cmp += xw::ld_agent(&hb->cmpw[0][t]) + xw::ld_agent(&hb->cmpw[1][t]) + xw::ld_agent(&hb->cmpw[2][t]) + xw::ld_agent(&hb->cmpw[3][t]);
+        }
+        if (tid == 0) {                                             // (uniform addresses: a per-lane one is computed early, kept, and spilled)
+            L()->sh[12] = xw::ld_agent(&hb->end_rep[0]); L()->sh[13] = xw::ld_agent(&hb->end_rep[1]);
+            L()->sh[14] = xw::ld_agent(&hb->end_rep[2]); L()->sh[15] = xw::ld_agent(&hb->end_rep[3]);
+        }
+        if (w == kPW - 1) pump_seek(seg_a + seg_len);
+        if (tid == 0) { acc(kAccTaken, 1); acc(kAccTakenNodes, seg_len + 1 - b0); }
+        xw::block_sync();
+        return seg_len;
     }
 
     // ---- one parse segment: nodes 0.. of positions seg_a.. (every thread of the stage); returns its length, the path
@@ -1614,13 +1776,21 @@ struct Parser {
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
+        const uint32_t hs = is_helper ? kHelpStart : 0u;            // the node this workgroup starts at (the helper: as if the segment began there)
         // A segment starts at seg_a: said BEFORE this stage asks for the position's record.  The finder stage may be waiting
         // for exactly this word at seg_a (a nice region that starts where the segment before was cut at 4,096 positions,
         // :1469: no edge spans the cut, so nothing else tells it) and the record of seg_a comes only after it.
-        if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
+        if (tid == 0 && !is_helper) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + 1));
         if (w == kPW - 1) {                                         // (meanwhile: the first node's record, staged)
-            if (!stage_need(seg_a)) err = kErrInternal + 100;
-            if (i == 0) L()->sh[4] = err;
+            if (!stage_need(seg_a + hs)) err = kErrInternal + 100;
+            // Does this segment get a helper job?  One that can run into the forced cut (:1469), after one that did, if the helper is idle.
+            bool want_help = false;
+            if (V.hb && !is_helper && chunk_left >= kParseMax && prev_cut) {
+                const uint32_t posted = xw::readfirst(xw::lds_ld(&L()->hj[0]));
+                want_help = posted == 0 || (xw::readfirst(xw::ld_agent(&V.hx->h_state)) >> 2) == posted;
+                xw::after_poll();
+            }
+            if (i == 0) { L()->sh[4] = err; L()->hj[1] = want_help ? 1u : 0u; }
         }
         seg_tables(tab_dirty);                                      // (tab_dirty is the same in every wave: run_chunk, run)
         tab_dirty = false;
@@ -1628,15 +1798,15 @@ struct Parser {
         // node 0 (:1472-1482)
         if (tid == 0) {
             L()->dbgw[0] = seg_a; L()->dbgw[1] = 0; L()->dbgw[2] = max_parse;
-            L()->mprev[0] = ((unsigned long long)kSrcNone << 8) | kRankLit;
-            L()->mprev[1] = kKeyNone;
-            L()->node_link[0] = kSrcNone;
+            L()->mprev[hs & 511u] = ((unsigned long long)kSrcNone << 8) | kRankLit;
+            L()->mprev[(hs + 1) & 511u] = kKeyNone;
+            L()->node_link[hs] = kSrcNone;
         }
-        uint32_t end_p = 1, end_open = 1, b0 = 0;
+        uint32_t end_p = hs + 1, end_open = hs + 1, b0 = hs;
         uint32_t seg_len = 0;
         bool decided = false;
         if (L()->sh[4]) { err = kErrInternal + 100; return 0; }
-        {
+        if (!is_helper) {
             // A position without any match is a segment of its own (more than half of all segments are): its node has no
             // sampled edge, and if none of the four rep probes finds anything (:1598-1628) the only command is the literal.
             // Literals leave the rep set alone and prices do not matter here, so a RUN of such positions is found at once
@@ -1686,6 +1856,8 @@ struct Parser {
                 }
             }
         }
+        bool help = !is_helper && L()->hj[1] != 0;                   // (written in front of seg_tables' barrier: the same in every thread)
+        if (help) post_job(seg_a, chunk_left);
         while (!seg_len) {
             const unsigned long long ts = xw::tick();
             const unsigned long long q0 = ptick();
@@ -1698,6 +1870,7 @@ struct Parser {
                     if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[9];      // the byte of position b0 - 1
                     L()->node_link[b0] = link; L()->node_delta[b0] = delta;
                     L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3;    // the model's rep set after the segment
+                    if (is_helper) { xw::st_agent(&V.hb->link[b0], link); xw::st_agent(&V.hb->delta[b0], delta); }
                 }
                 seg_len = b0;
                 break;
@@ -1735,6 +1908,7 @@ struct Parser {
             // (every LDS word a lane may need is requested before the first one is looked at -- one round trip, not one per
             //  dependent condition; a lane outside the block reads some staged record and drops it)
             const unsigned long long hd_w = srec[0], w1_w = srec[1], wu_w = srec[kStageQ - 1];
+            if (is_helper && (hd_w & kStagedOwn)) rec = V.hb->relist + (a & 511u) * kTpStride;      // (re-listed by this workgroup: its own copy)
             unsigned long long sv[kEdgesPerWave];
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) { const uint32_t k = edge_of(w, j); sv[j] = srec[1 + (k < kStageEdges ? k : 0u)]; }
@@ -1950,17 +2124,30 @@ struct Parser {
                     L()->node_link[node] = link; L()->node_delta[node] = delta;
                     uint32_t *dr = L()->nrep + (node & 511u) * 4;
                     dr[0] = r0; dr[1] = r1; dr[2] = r2; dr[3] = r3;
+                    L()->ncost[node & 511u] = c;
                     if (i == istar) { L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3; }   // (the segment's last node, if it ends here)
+                    if (is_helper) {                                // what the parser stage compares and takes over (sc1 stores, drained in front of the barrier below)
+                        HelpBox *hb = V.hb;
+                        xw::st_agent(&hb->link[node], link); xw::st_agent(&hb->delta[node], delta); xw::st_agent(&hb->cost[node], c);
+                        xw::st_agent128(&hb->rep_of[node * 4], r0, r1, r2, r3);
+                    }
                 }
                 if (i == nb - 1) L()->sh[11] = c;
             }
             if (w < 4 && i < done && want) n_cmp += ml + (ml < pcap);  // bytes the final probe of this slot looked at (counter parity)
+            if (is_helper) {
+                if (w < 4 && inb) xw::st_agent(&V.hb->cmpw[w][node], (i < done && want) ? ml + (ml < pcap) : 0u);
+                if (w < 4) xw::drain();
+            }
             xw::block_sync();
             if (istar < nb) {
                 seg_len = b0 + istar;                               // the segment ends inside the block
                 // The positions after it belong to the next segment, whose cut is elsewhere: what was re-listed for this
                 // segment's forced cut goes back to the full sampling (:1545 with the new max_parse).
-                if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax && w == kPW - 1) {
+                // (the helper does not put records back -- its segment is only the parser stage's guess until that stage has compared
+                //  the frontiers: it gives the job up, and the parser stage ends the segment itself)
+                if (is_helper && b0 + nb + kMatchMax > max_parse && max_parse == kParseMax) hstop = 2;
+                else if (b0 + nb + kMatchMax > max_parse && max_parse == kParseMax && w == kPW - 1) {
                     const uint32_t h0 = (inb && i >= istar) ? (uint32_t)staged(a)[0] : 0u;
                     const uint32_t ml = (h0 & 63u) ? ((uint32_t)(staged(a)[1] >> 32) & 0x1FFu) : 0u;
                     uint32_t full = umin((h0 >> 16) & 0x1FFu, chunk_left - node);
@@ -1981,17 +2168,39 @@ struct Parser {
                     }
                     L()->mprev[t & 511u] = k;
                 }
-                if (tid == 0 && new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
+                if (tid == 0) {
+                    if (is_helper) xw::st_agent64(&V.hx->h_prog, ((unsigned long long)myjob << 32) | (new_end << 16) | (b0 + nb));   // (the nodes' stores: drained in front of the barrier above)
+                    else if (new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
+                }
                 if (new_end > end_open) end_open = new_end;
                 end_p = new_end;
                 b0 += nb;
                 decided = !(b0 == end_p || b0 >= max_parse);        // (the same in every thread)
                 if (decided && w == kPW - 1) decide_block(seg_a, b0, max_parse);
                 xw::block_sync();
+                // the first block border behind the helper's warm-up: are its nodes the ones this stage would compute?
+                if (help && b0 > kHelpStart + kHelpWarm) {
+                    help = false;
+                    seg_len = take_over(seg_a, b0);                 // (0: no -- this stage goes on by itself)
+                }
             }
             t_fin += ptick() - e0;
         }
         xw::block_sync();
+        if (is_helper) {                                            // (no path, no emission: the parser stage's, if it takes the nodes over)
+            if (tid == 0 && !hstop) {
+                HelpBox *hb = V.hb;
+                xw::st_agent(&hb->seg_len, seg_len);
+                xw::st_agent(&hb->end_rep[0], L()->sh[12]); xw::st_agent(&hb->end_rep[1], L()->sh[13]);
+                xw::st_agent(&hb->end_rep[2], L()->sh[14]); xw::st_agent(&hb->end_rep[3], L()->sh[15]);
+                xw::drain();
+                xw::st_agent64(&V.hx->h_prog, ((unsigned long long)myjob << 32) | (seg_len << 16) | (seg_len + 1));
+            }
+            ncmds = 0;
+            return seg_len;
+        }
+        if (help && tid == 0) xw::st_agent(&V.hx->h_verdict, (L()->hj[0] << 2) | 2u);     // (the segment ended in front of the helper's nodes: dropped)
+        prev_cut = seg_len == kParseMax;
         // backtrack (:1633-1650): node indices of the path, end first
         // (A walk through LDS is one dependent round trip per command, 130-200 cycles each with seven waves at the barrier below.
         //  Here the links of the 64 nodes from `cur` down come with ONE read -- lane l: node cur - l -- and the path through
@@ -2085,10 +2294,13 @@ struct Parser {
         pend_t = t_out_seen;                                        // (as if t_out had been read before the table stage started)
         n_eq_fill = n_eq_rounds = 0; n_cmp = 0;
         if (tid < kAccN) L()->acc[tid] = 0;
+        if (tid < 4) L()->hj[tid] = 0;
+        prev_cut = false;
         xw::block_sync();
         if (tid == 0) L()->acc[kAccTotal] = 0ull - xw::tick();
         uint32_t ci = c0;
         for (; ci < c1 && !err; ci++) run_chunk(ci);
+        if (V.hb && tid == 0) xw::st_agent(&V.hx->h_job, kHelpExit);      // (the helper leaves)
         xw::block_sync();
 #ifdef NLZM_PROFILE
         if (xw::lane() == 0 && xw::wave() == kPW - 1) for (int z = 0; z < 5; z++) xw::atomic_add64_agent(&P->prof[56 + z], t_q[z]);
@@ -2120,6 +2332,7 @@ struct Parser {
                 auto add = [](unsigned long long *q, unsigned long long v) __attribute__((always_inline)) { xw::atomic_add64_agent(q, v); };
                 add(&pr[8], L()->acc[kAccBlocks]); add(&pr[13], L()->acc[kAccPasses]); add(&pr[14], L()->acc[kAccUndo]); add(&pr[26], L()->acc[kAccNeed]); add(&pr[27], L()->acc[kAccAhead]);
                 add(&pr[9], L()->cnt.stale_ht); add(&pr[10], L()->cnt.stale_rk); add(&pr[11], L()->acc[kAccRedo]);
+                add(&pr[96], L()->acc[kAccJobs]); add(&pr[97], L()->acc[kAccTaken]); add(&pr[98], L()->acc[kAccTakenNodes]); add(&pr[99], L()->acc[kAccHelpWait]);
                 Counters &c = P->cnt;
                 const Counters &lc = L()->cnt;
                 add(&c.n_literal, lc.n_literal); add(&c.n_dict, lc.n_dict); add(&c.n_rep, lc.n_rep); add(&c.segments, lc.segments);
@@ -2134,6 +2347,74 @@ struct Parser {
                 }
                 if ((err || xe) && G.abort_word) xw::st_agent(G.abort_word, 1u);
             }
+        }
+    }
+
+    // ---- the helper parser's workgroup: jobs of the parser stage until that stage ends the launch ---------------------------------
+    XW_FN void run_helper(uint32_t c0)
+    {
+        is_helper = true;
+        HelpBox *hb = V.hb;
+        const uint32_t tid = xw::thread();
+        for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
+        err = 0; tab_dirty = false; myjob = 0;
+        t_out_seen = (uint32_t)((unsigned long long)c0 * g.chunk_size);
+        if (tid < 5) L()->stg[tid] = (tid == 3 || tid == 2) ? 0u : t_out_seen;
+        pend_t = t_out_seen;
+        n_eq_fill = n_eq_rounds = 0; n_cmp = 0;
+        if (tid < kAccN) L()->acc[tid] = 0;
+        if (tid < 16) L()->sh[tid] = 0;
+        xw::block_sync();
+        for (;;) {
+            // the next job
+            if (xw::wave() == 0) {                                  // (the wave polls as one)
+                uint32_t j, spins = 0;
+                for (;;) {
+                    j = xw::readfirst(xw::ld_agent(&V.hx->h_job));
+                    if (j != myjob) break;
+                    if ((++spins & 15u) == 0 && xw::readfirst(xw::ld_agent(&V.hx->err))) { j = kHelpExit; break; }
+                    xw::pause_long();
+                }
+                xw::after_poll();
+                if (tid == 0) L()->hj[2] = j;
+            }
+            xw::block_sync();
+            const uint32_t job = L()->hj[2];
+            if (job == kHelpExit) break;
+            myjob = job; hstop = 0; err = 0;
+            const uint32_t seg_a = xw::ld_agent(&hb->seg_a), chunk_left = xw::ld_agent(&hb->chunk_left);
+            base = xw::ld_agent(&hb->base);
+            rep0 = xw::ld_agent(&hb->rep[0]); rep1 = xw::ld_agent(&hb->rep[1]); rep2 = xw::ld_agent(&hb->rep[2]); rep3 = xw::ld_agent(&hb->rep[3]);
+            {
+                uint32_t *pw = (uint32_t *)L()->price, *lw = (uint32_t *)L()->len_price, *sw = (uint32_t *)L()->slot_price;
+                for (uint32_t k = tid; k < kNumCtx * 8; k += kParserThreads) pw[k] = xw::ld_agent((const uint32_t *)hb->price + k);
+                if (tid < (kMatchMax + 8) / 2) lw[tid] = xw::ld_agent((const uint32_t *)hb->len_price + tid);
+                if (tid >= 256 && tid < 256 + 128) sw[tid - 256] = xw::ld_agent((const uint32_t *)hb->slot_price + (tid - 256));
+            }
+            if (xw::wave() == kPW - 1) pump_seek(seg_a + kHelpStart);
+            if (tid == 0) { L()->sh[4] = 0; acc(kAccJobs, 1); }
+            xw::block_sync();
+            uint32_t ncmds = 0;
+            const uint32_t len = parse_segment(seg_a, chunk_left, ncmds);
+            xw::block_sync();
+            if (tid == 0) {
+                // done: every node up to the segment's end is in the box; given up: the job was dropped, or this workgroup cannot end the segment
+                const bool done = len != 0 && !err && !hstop;
+                xw::st_agent(&V.hx->h_state, (job << 2) | (done ? 1u : 2u));
+                if (done) acc(kAccTaken, 1);
+                L()->sh[4] = 0;
+                L()->hj[3] = xw::ld_agent(&V.hx->err) ? 1u : 0u;        // (another stage failed: leave)
+            }
+            xw::block_sync();
+            if (L()->hj[3]) break;
+            err = 0;
+        }
+        xw::block_sync();
+        if (tid == 0) {
+            unsigned long long *pr = G.persist->prof;
+            xw::atomic_add64_agent(&pr[100], L()->acc[kAccJobs]); xw::atomic_add64_agent(&pr[101], L()->acc[kAccTaken]);
+            xw::atomic_add64_agent(&pr[102], L()->acc[kAccBlocks]); xw::atomic_add64_agent(&pr[103], L()->acc[kAccPasses]);
+            xw::atomic_add64_agent(&pr[104], L()->acc[kAccWait]);
         }
     }
 };

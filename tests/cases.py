@@ -40,12 +40,18 @@ CASES = [
     ("text_2m_w15", "syn_text", 2_000_000, 13, 15),
     ("chains_150k_w17", "chains", 150_000, 14, 17),
     ("cutnice_60k_w17", "cutnice", 60_000, 15, 17),
+    # the helper parser's cases: nearly every segment cut at 4,096 positions, as on deep text; and segments of
+    # every length behind cut ones, some ending inside the 264 + 64 positions in front of a forced cut
+    ("dense_150k_w17", "dense_text", 150_000, 16, 17),
+    ("denseb_250k_w18", "dense_breaks", 250_000, 17, 18),
 ]
 
 # larger cases: checked on the GPU box against the oracle run live (and golden sha)
 BIG_CASES = [
     ("text_3m_w20", "syn_text", 3_000_000, 0, 20),
     ("mixed_3m_w20", "mixed", 3_152_896, 0, 20),
+    ("dense_3m_w20", "dense_text", 3_000_000, 18, 20),
+    ("denseb_6m_w22", "dense_breaks", 6_000_000, 19, 22),
 ]
 
 

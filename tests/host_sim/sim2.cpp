@@ -250,7 +250,8 @@ static void role_entry(void *p)
     const uint32_t b = xw::block_index();
     if (b == 0) { if (xw::wave() == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else if (b == 1) { if (xw::wave() < v2::kTW) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
-    else if (xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); }
+    else if (b == 2) { if (xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
+    else if (A.V.hb && xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run_helper(A.c0); }
 }
 
 int main(int argc, char **argv)
@@ -307,12 +308,17 @@ int main(int argc, char **argv)
     v2::Hx *hx = (v2::Hx *)aligned_alloc(128, sizeof(v2::Hx));
     v2::StateV2 S; memset(&S, 0, sizeof S);
     A.V.ft = ft.data(); A.V.tp = tp.data(); A.V.tf = tf.data(); A.V.hx = hx; A.V.state = (uint32_t *)&S;
+    // the helper parser (NLZM_SIM_HELPER=0: without it)
+    std::vector<uint32_t> hbmem(sizeof(v2::HelpBox) / 4 + 4);
+    junk(hbmem);
+    const bool with_helper = !(getenv("NLZM_SIM_HELPER") && atoi(getenv("NLZM_SIM_HELPER")) == 0);
+    A.V.hb = with_helper ? (v2::HelpBox *)(((uintptr_t)hbmem.data() + 15) & ~(uintptr_t)15) : nullptr;
 
     SimPrefilter pf; SimWorkers wk; std::vector<uint8_t> unc; std::vector<uint32_t> ready, pairs, flag;
     uint32_t abort_word = 0; WorkerCounters wc = {};
     unsigned long long unc_total = 0;
     pf.init(g.wbits, (unsigned long long)(g.nchunks / nlaunch + 2) * g.chunk_size); wk.g = g; wk.G = &G; g_workers = &wk;
-    unsigned long long lds_bytes[3] = { sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds) };
+    unsigned long long lds_bytes[4] = { sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds), sizeof(v2::PLds) };
     printf("LDS: finder %zu, table %zu, parser %zu bytes\n", sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds));
     for (uint32_t r = 0; r < nlaunch; r++) {
         const uint32_t c0 = (uint32_t)((unsigned long long)g.nchunks * r / nlaunch), c1 = (uint32_t)((unsigned long long)g.nchunks * (r + 1) / nlaunch);
@@ -332,7 +338,7 @@ int main(int argc, char **argv)
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;
-        xw::launch(3, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
+        xw::launch(4, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
         wk.finish();
         if (P.error || hx->err) { printf("sim error %u / %u (info %u %u)\n", P.error, hx->err, P.error_info[0], P.error_info[1]); return 1; }
         if (g_ref.bad) break;
@@ -351,6 +357,8 @@ int main(int argc, char **argv)
            P.prof[0], np / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
     printf("table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block, mask fills %llu, probe rounds %llu, re-sampled %llu (put back %llu)\n",
            P.prof[6], P.prof[7], P.prof[8], np / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11], P.prof[14]);
+    printf("helper parser: %llu jobs posted, %llu taken over (%llu nodes), parser waited %llu sweeps for it; helper: %llu jobs seen, %llu done, %llu blocks\n",
+           P.prof[96], P.prof[97], P.prof[98], P.prof[99], P.prof[100], P.prof[101], P.prof[102]);
     printf("workers: uncertain marks %llu (%.2f%%), dry runs %llu\n", unc_total, 100.0 * unc_total / np, wk.dry);
     const int bad = g_ref.bad || c.bad || (g_stop_chunk != 0xFFFFFFFFu ? 0 : 1) * (P.cnt.positions != st.positions || P.cnt.nice_positions != st.nice_positions ||
                     P.cnt.segments != st.segments || P.cnt.bt_tests != st.bt_tests || P.cnt.bt_calls != st.bt_calls ||

@@ -113,6 +113,30 @@ def test_batching_is_invisible(gpu):
     gpu.set_option("batch_chunks", 32)
 
 
+def test_helper_parser_is_invisible_and_used(gpu):
+    """The helper parser (a second parser workgroup on the back of every segment that is cut at 4,096 positions, NLZM.cpp:1469; taken
+    over by the parser stage when the 264-node frontiers agree up to one cost offset: DESIGN.md section 11) must not change a byte or
+    a counter -- and must actually take nodes over on inputs whose segments are long: text of a small vocabulary, the same with
+    natural segment ends at every distance from a forced cut, and at several launch sizes (a job never spans a launch)."""
+    for kind, size, hb, seed in (("dense_text", 2_000_000, 20, 41), ("dense_breaks", 3_000_000, 19, 42), ("syn_text", 1_500_000, 18, 43)):
+        data = corpus.make(kind, size, corpus.SEED + seed)
+        want = oracle_py.compress(data, hb, want_stats=True)
+        try:
+            for helper, batch in ((1, 32), (0, 32), (1, 1), (1, 3)):
+                gpu.set_option("parser_helper", helper); gpu.set_option("batch_chunks", batch)
+                assert gpu.compress(data, hb) == want[0], (kind, helper, batch)
+                st = gpu.stats()
+                for k in ("cmp_bytes", "bt_calls", "bt_tests", "positions", "nice_positions", "segments", "n_literal", "n_dict", "n_rep"):
+                    assert st[k] == (want[1]["cmp_bytes_needed"] if k == "cmp_bytes" else want[1][k]), (k, kind, helper, batch)
+                jobs, taken, nodes = gpu.counter("helper_jobs"), gpu.counter("helper_taken"), gpu.counter("helper_taken_nodes")
+                if not helper:
+                    assert jobs == 0 and taken == 0
+                elif kind != "syn_text":
+                    assert jobs >= 50 and taken >= jobs // 3 and nodes >= 1000 * taken, (kind, batch, jobs, taken, nodes)
+        finally:
+            gpu.set_option("parser_helper", 1); gpu.set_option("batch_chunks", 32)
+
+
 def test_worker_lanes_and_hot_bin_waves_are_invisible(gpu):
     """How the BT4 calls are spread over lanes and waves must not change a byte or a counter (MatchFinderBT::FindAndUpdate,
     NLZM.cpp:978-1022, is serial per hash head): a wave for nearly every bin (threshold forced down to 4 and 64 positions per

@@ -54,3 +54,24 @@ def test_forced_cuts_and_block_sizes(sim, env, tmp_path):
     r = subprocess.run([sim, str(p), str(case[4]), "1", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "put back 0)" not in r.stdout, "the case no longer exercises the put-back path"
+
+
+@pytest.mark.parametrize("name,env,launches", [("dense_150k_w17", {}, 1), ("dense_150k_w17", {"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}, 3),
+                                               ("denseb_250k_w18", {"NLZM_SIM_POISON": "5"}, 2)])
+def test_helper_parser_takes_segments_over(sim, name, env, launches, tmp_path):
+    """The helper parser (nlzm_v2.h HelpBox): segments that are cut at 4,096 positions get a second workgroup that
+    parses their back from node 1,792; the parser stage compares the 264-node frontier and takes the helper's nodes over -- streams,
+    tables and every counter must still be the oracle's, and the case must exercise the take-over (and, with breaks, the drop / give-up
+    paths: segments that end inside the re-listed zone in front of a forced cut)."""
+    case = next(c for c in cases.CASES if c[0] == name)
+    p = tmp_path / "in.bin"
+    cases.make_case(case).tofile(p)
+    r = subprocess.run([sim, str(p), str(case[4]), "2", str(launches)], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
+    assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    line = next(l for l in r.stdout.splitlines() if l.startswith("helper parser:"))
+    posted, taken = int(line.split()[2]), int(line.split()[5])
+    assert posted >= 5 and taken >= 3, line
+    # ... and without the helper the same streams
+    r0 = subprocess.run([sim, str(p), str(case[4]), "2", str(launches)], capture_output=True, text=True, timeout=1500,
+                        env=dict(os.environ, NLZM_SIM_HELPER="0", **env))
+    assert r0.returncode == 0 and ": OK" in r0.stdout, r0.stdout[-2000:] + r0.stderr[-2000:]
