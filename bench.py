@@ -82,6 +82,57 @@ def algorithmic_bytes_lines(st: dict) -> int:
             + 128 * st["ht_rows"] + 64 * st["rk_probes"] + 64 * st["rk_inserts"])
 
 
+STAGE_COUNTERS = ("positions", "finder_total_cycles", "finder_wait_cycles", "finder_bt_wait_cycles", "table_total_cycles", "table_wait_cycles",
+                  "parser_total_cycles", "parser_wait_cycles", "parser_pass_cycles", "parser_setup_cycles", "parser_emit_cycles", "parser_passes",
+                  "parser_blocks", "helper_jobs", "helper_taken", "helper_taken_nodes", "helper_wait_cycles", "worker_call_cycles",
+                  "worker_call_tests", "worker_calls", "hot_bin_calls")
+# machine constants measured in rounds 3 - 5, cycles
+LAT_BARRIER, LAT_LDS, LAT_ISSUE, LAT_L2, LAT_HBM = 250, 130, 4.5, 700, 1500
+
+
+def stage_counters() -> dict:
+    return {k: nlzm_amd.counter(k) for k in STAGE_COUNTERS}
+
+
+def latency_bound(c0: dict, c1: dict) -> dict:
+    """The bound that applies to this path (the HBM roof never will): the three pipelined stages of the persistent kernel are chains of
+    dependent round trips, and the slowest one sets the rate.  Per stage the busy cycles per position (total - waiting) over the timed
+    launches, from the kernel's own counters; for the parser stage the floor of its pass loop from the machine constants of DESIGN.md
+    section 9 -- a pass cannot take less than one workgroup barrier, one dependent LDS atomic and one dependent LDS read, the
+    four DPP scans of the update (6 steps x 2 dependent instructions each) and one ds_bpermute round trip; for BT4 the measured lane
+    cycles per test against one L2 / HBM round trip."""
+    d = {k: c1[k] - c0[k] for k in STAGE_COUNTERS}
+    n = max(1, d["positions"])
+    per = lambda k: d[k] / n
+    blocks, passes = max(1, d["parser_blocks"]), max(1, d["parser_passes"])
+    own_nodes = n - d["helper_taken_nodes"]                  # nodes the parser stage computed itself (the rest: taken over from the helper)
+    pass_floor = LAT_BARRIER + 2 * LAT_LDS + 4 * 6 * 2 * LAT_ISSUE + LAT_LDS
+    stages = {
+        "finder": {"total": round(per("finder_total_cycles"), 1), "busy": round(per("finder_total_cycles") - per("finder_wait_cycles"), 1),
+                   "waiting_for_bt4_results": round(per("finder_bt_wait_cycles"), 1)},
+        "table": {"total": round(per("table_total_cycles"), 1), "busy": round(per("table_total_cycles") - per("table_wait_cycles"), 1)},
+        "parser": {"total": round(per("parser_total_cycles"), 1),
+                   "busy": round(per("parser_total_cycles") - per("parser_wait_cycles") - per("helper_wait_cycles"), 1),
+                   "waiting_for_records": round(per("parser_wait_cycles"), 1), "waiting_for_helper": round(per("helper_wait_cycles"), 1),
+                   "passes": round(per("parser_pass_cycles"), 1), "block_setup": round(per("parser_setup_cycles"), 1), "emission": round(per("parser_emit_cycles"), 1),
+                   "passes_per_block": round(passes / blocks, 2), "nodes_per_block": round(own_nodes / blocks, 1), "cycles_per_pass": round(d["parser_pass_cycles"] / passes),
+                   "helper": {"jobs": d["helper_jobs"], "taken_over": d["helper_taken"], "share_of_positions": round(d["helper_taken_nodes"] / n, 4)}},
+    }
+    # what a stage cannot wait away: its busy cycles; for the finder also the BT4 results it stands in front of
+    load = {"finder": stages["finder"]["busy"] + stages["finder"]["waiting_for_bt4_results"], "table": stages["table"]["busy"], "parser": stages["parser"]["busy"]}
+    slowest = max(load, key=load.get)
+    achieved = max(stages[s]["total"] for s in stages)
+    bound = passes * pass_floor / n                          # the parser stage's pass loop at its floor, per position of the stream
+    tests = max(1, d["worker_call_tests"])
+    return {"unit": "cycles per position", "achieved": round(achieved, 1), "slowest_stage": slowest, "load": {k: round(v, 1) for k, v in load.items()},
+            "stages": stages,
+            "bound": round(bound, 1), "achieved_over_bound": round(achieved / bound, 2) if bound else None,
+            "bound_model": f"parser passes x ({LAT_BARRIER} barrier + 3 x {LAT_LDS} LDS / bpermute round trips + 48 dependent scan instructions x {LAT_ISSUE}) "
+                           f"= {pass_floor:.0f} cycles per pass, {passes / blocks:.2f} passes per block of {own_nodes / blocks:.1f} nodes",
+            "bt4": {"lane_cycles_per_test": round(d["worker_call_cycles"] / tests), "l2_round_trip": LAT_L2, "hbm_round_trip": LAT_HBM,
+                    "calls_by_hot_bin_waves": round(d["hot_bin_calls"] / max(1, d["worker_calls"]), 4)}}
+
+
 def csrc_sha16() -> str:
     """the KERNEL sources (headers and .hip: what the counters of a launch depend on; the host file only queues launches) --
     tests/prof_summarise.py records the same over the profiled tree"""
@@ -109,6 +160,13 @@ class CpuBaseline:
         cores = sorted(os.sched_getaffinity(0))
         self.pins = [cores[len(cores) // 2], cores[len(cores) // 2 + 1 if len(cores) > 2 else 0]]
         self.taskset = shutil.which("taskset")
+        # (this process, the HIP runtime's threads and the block leg's host threads stay off the two cores the reference runs on)
+        try:
+            rest = set(cores) - set(self.pins)
+            if len(rest) >= 2 and os.path.exists(self.ref):
+                os.sched_setaffinity(0, rest)
+        except OSError:
+            pass
         if os.path.exists(self.ref):
             self.tmp = tempfile.TemporaryDirectory()
             for k, n in enumerate((self.deep_n, self.shallow_n)):
@@ -181,6 +239,10 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
     if lib.nlzm_hip_blocks_begin(d_in.data_ptr(), n, k, WINDOW):
         return dict(out, error=lib.nlzm_hip_last_error().decode())
     out["begin_s"] = round(time.perf_counter() - t_b0, 2)
+    try:
+        out["pool_bytes"] = nlzm_amd.counter("block_pool_bytes")       # the set's ONE device allocation (kept for the next set)
+    except nlzm_amd.NlzmError:
+        pass
     done, fin, ms = C.c_uint64(0), C.c_int(0), C.c_double(0)
     for _ in range(warmup):
         if lib.nlzm_hip_blocks_step(per_step, C.byref(done), C.byref(fin), C.byref(ms)):
@@ -212,6 +274,11 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
         return dict(out, error=lib.nlzm_hip_last_error().decode())
     out["finish_s"] = round(time.perf_counter() - t_f0, 2)
     out["stream_bytes"] = int(total.value)
+    # everything from opening the set to the gathered streams: begin (the first set of a process pays one large hipMalloc), the warm-up
+    # steps, the timed steps, finish -- `value` above is the timed steps alone
+    wall = time.perf_counter() - t_b0
+    out["wall_s"] = round(wall, 2)
+    out["wall_value"] = round(n / 1e6 / wall, 4)
     gold_path = os.path.join(ROOT, "tests", "golden", "blocks_1g.json")
     out["bit_exact"] = None
     if check and os.path.exists(gold_path):
@@ -309,6 +376,7 @@ def main():
             step()
     torch.cuda.synchronize()
     st0, tm0 = nlzm_amd.stats(), nlzm_amd.timing()
+    sc0 = stage_counters()
     in0, out0 = in_done.value, out_done.value
 
     if world > 1:
@@ -330,6 +398,7 @@ def main():
     dt = time.perf_counter() - t0
 
     st1, tm1 = nlzm_amd.stats(), nlzm_amd.timing()
+    sc1 = stage_counters()
     mine = torch.tensor([in_done.value - in0, dt], dtype=torch.float64, device=dev)
     if world > 1:
         allv = [torch.zeros_like(mine) for _ in range(world)]
@@ -404,7 +473,9 @@ def main():
             "config": {
                 "workload": f"enwik9 stand-in: {STREAM_BYTES} B stream, -window:{WINDOW}"
                             + (f" split into {world} independent blocks of {n} B, one per GPU (RCCL world size {dist.get_world_size()}, window "
-                               f"{nlzm_amd.geometry(n, WINDOW)['hist_bits']} after the reference's auto-shrink)" if world > 1 else "")
+                               f"{nlzm_amd.geometry(n, WINDOW)['hist_bits']} after the reference's auto-shrink; rank r's block is its own seeded text "
+                               f"syn_text({n}, SEED + r) -- the same kind and amount of work as byte range r of the 1e9-byte stand-in, not those bytes; "
+                               f"its reference stream is in tests/golden/gpus.json)" if world > 1 else "")
                             + f"; step = {per_step} launches of {B} chunks ({per_step * B * CHUNK} B) of the stream; timed: bytes "
                               f"[{first_b}, {last_b}) of {n}" + (", i.e. to the end of the stream" if fin.value else " (a prefix: fewer than 25 steps were asked for)"),
                 "window_bits": WINDOW, "batch_chunks": B, "launches_per_step": per_step, "bytes_timed": int(total_in),
@@ -422,12 +493,14 @@ def main():
                          "b_min_bytes_per_launch": int((d["in_bytes_step"] + d["out_bytes_step"]) / launches),
                          "algorithmic_bytes_per_input_byte": round(algorithmic_bytes(d) / max(1, d["in_bytes_step"]), 2),
                          "algorithmic_bytes_line_granular": int(algorithmic_bytes_lines(d) / launches),
-                         "frac_line_granular": round(algorithmic_bytes_lines(d) / launches / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 8) if k_ms > 0 else 0.0},
+                         "frac_line_granular": round(algorithmic_bytes_lines(d) / launches / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 8) if k_ms > 0 else 0.0,
+                         "latency_bound": latency_bound(sc0, sc1)},
             "kernel_ms": {"prep": round(tm1["prep_ms"] - tm0["prep_ms"], 3),
                           "match_parse": round(tm1["match_parse_ms"] - tm0["match_parse_ms"], 3),
                           "rans_gather": round(tm1["rans_ms"] - tm0["rans_ms"], 3)},
             "counters": d,
         }
+        res["roofline"]["latency_bound"]["bt4"]["tests_per_call"] = round(d["bt_tests"] / max(1, d["bt_calls"]), 1)
         if bit_exact is False:
             errors.append("the stream differs from the reference's")
         # HBM traffic of the same command, measured in separate rocprofv3 --pmc passes (tests/prof_run.sh) and

@@ -60,6 +60,9 @@ typedef struct nlzm_hip_timing {
 
 /* Select the device and create the library's stream.  Fails (NLZM_HIP_E_NODEVICE)
  * when there is no GPU: there is no CPU fallback behind this ABI. */
+/* nlzm_hip_init sets GPU_MAX_HW_QUEUES=16 in the process environment unless the caller has set it (block mode runs the small kernels of 32
+ * streams beside one persistent launch; with the HIP runtime's default of 4 hardware queues they serialise: ~70 instead of ~100 MB/s).  The
+ * runtime reads the variable at the process's FIRST HIP call: a host program that uses HIP before nlzm_hip_init must export it itself. */
 int nlzm_hip_init(int device);
 void nlzm_hip_shutdown(void);
 const char *nlzm_hip_last_error(void);
@@ -203,7 +206,8 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
  * shared launch, default 8); "prefilter_bits_per_position" (log2 of the pre-filter table's entries per input position, default 4);
  * "keep_block_pool" (default 1: the one device allocation of a block set is kept when the set is closed and used again by the
  * next set that fits -- the driver clears freed device memory, and an allocation made soon after a large one was freed waits for it;
- * 0 releases it, as nlzm_hip_shutdown does);
+ * 0 releases it, as nlzm_hip_shutdown does; the kept allocation is what the set needed -- up to 0.85 of the device's free memory --
+ * and is given back by itself when any other allocation of the library, e.g. a single stream's, fails for lack of memory);
  * "parser_helper" (default 1: a stream gets a helper parser workgroup -- one CU more -- that parses the back of every segment that is cut
  * at 4,096 positions while the parser stage parses its front; "block_parser_helper", default 0, the same for the streams of a block set);
  * "stage_report" (1: the stages' cycle accounting of

@@ -222,6 +222,9 @@ void lower(char *v) { for (; *v; v++) *v = (char)(*v | 0x20); }
 int main(int argc, char **argv)
 {
     printf("NLZM 1.03 - Written by Nauful (MI355X/gfx950 build)\n");
+    // (-blocks:k runs k streams' kernels side by side: the HIP runtime needs more than its default of 4 hardware queues for that, and reads
+    //  the variable at the first HIP call -- nlzm_hip_init sets it too, this is for a main that touches HIP before it)
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     crc_init();
     uint32_t hist_bits = 22;                                                      // :2071
     uint32_t nblocks = 1;                           // -blocks:k (not in the reference): k independent streams, back to back

@@ -77,6 +77,7 @@ int set_err(int code, const char *fmt, ...)
     } while (0)
 
 void blocks_close(bool drop_pool = false);         // defined with the block-set entry points
+bool idle_block_pool_dropped();                    // no block set open and its kept allocation still there: frees it, true (defined there too)
 
 inline uint32_t clampu(uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -117,6 +118,8 @@ struct Ctx {
                                             // made soon after a large one was freed waits for that -- opening 32 streams took 0.12 s or 4.5 s (tests/gpu_begin_probe.py)
     int64_t opt_helper = 1;                 // a helper parser workgroup (nlzm_v2.h, HelpBox): 1 CU more per stream.  The streams of a block
     int64_t opt_block_helper = 0;           // set run without one unless "block_parser_helper" says otherwise (a stream of a full device waits for its BT4 results)
+    int64_t opt_multi_same = 0;             // test only ("multi_allow_same_device"): nlzm_hip_compress_blocks_multi accepts a device twice, so that its
+                                            // threads, device states and gather loop run with two parts on a box with one GPU
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -206,7 +209,11 @@ void swap_sets(Ctx &C)
 template <class T> int dev_alloc(Ctx &C, T **p, size_t bytes)
 {
     if (!C.pool) {
-        const hipError_t e = hipMalloc((void **)p, bytes);
+        hipError_t e = hipMalloc((void **)p, bytes);
+        if (e == hipErrorOutOfMemory && idle_block_pool_dropped()) {    // (the allocation a closed block set left behind: given back, once, for this one)
+            (void)hipGetLastError();
+            e = hipMalloc((void **)p, bytes);
+        }
         if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? NLZM_HIP_E_NOMEM : NLZM_HIP_E_NODEVICE, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         return 0;
     }
@@ -737,6 +744,9 @@ int refresh_stats(Ctx &C)
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
+        fprintf(stderr, "table: blocks in which some position's front had more than 8 / 12 / 16 / 20 / 24 / %u entries at some step of the scan: %.2f / %.2f / %.2f / %.3f / %.3f / %.3f %%\n",
+                v2::kFrCap, 100.0 * P.prof[105] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[106] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[107] / (P.prof[6] ? P.prof[6] : 1),
+                100.0 * P.prof[108] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[109] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[7] / (P.prof[6] ? P.prof[6] : 1));
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "parser: waited for its record loader %llu times, the table stage %.0f positions ahead on average then\n", P.prof[26], (double)P.prof[27] / (double)(P.prof[26] ? P.prof[26] : 1));
         if (P.prof[96] || P.prof[100])
@@ -747,7 +757,8 @@ int refresh_stats(Ctx &C)
         if (P.prof[88]) fprintf(stderr, "finder sections (cycles/position, profile build): predict %.0f, own loads %.0f, HT rows %.0f, candidates + jobs %.0f, record + RK256 %.0f, "
                                 "BT4 results (wait included) %.0f, verify %.0f, commit %.0f\n", P.prof[88] / n, P.prof[89] / n, P.prof[90] / n, P.prof[91] / n, P.prof[92] / n,
                                 P.prof[93] / n, P.prof[94] / n, P.prof[95] / n);
-        if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position, profile build): gather %.0f, scan %.0f, emit %.0f\n", P.prof[44] / n, P.prof[45] / n, P.prof[46] / n);
+        if (P.prof[44]) fprintf(stderr, "table stage sections (cycles/position summed over the waves, profile build): gather %.0f, scan %.0f, waiting for the carry %.0f, carry merge (the part in block order) %.0f, records %.0f\n",
+                                P.prof[44] / n, P.prof[45] / n, P.prof[47] / n, P.prof[46] / n, P.prof[55] / n);
         if (P.prof[32]) {
             const double np = (double)(P.prof[13] ? P.prof[13] : 1);
             fprintf(stderr, "parser, cycles per pass (profile build): relax waves %.0f %.0f %.0f, probe wave %.0f (of it: sets that changed %.0f, mask fills %.0f), update %.0f, "
@@ -808,6 +819,12 @@ static void dev_shutdown(DevState &D);
 static int dev_init(DevState &D, int device)
 {
     Ctx &C = D.ctx;
+    // Block mode queues the pre-pass kernels and frame coders of 32 streams beside a persistent launch, each stream on a HIP stream of its
+    // own: with the runtime's default of 4 hardware queues they would line up behind one another.  The runtime reads the variable when it
+    // starts, i.e. at this process's first HIP call -- ours, unless the host program has made one already (then it has to export
+    // GPU_MAX_HW_QUEUES=16 itself: include/nlzm_hip.h).  A value the caller has set is left alone.  Set, never read: the library has no
+    // environment knobs of its own.
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return set_err(NLZM_HIP_E_NODEVICE, "no HIP device (%s)", hipGetErrorString(e));
@@ -955,6 +972,7 @@ int nlzm_hip_get_counter(const char *key, uint64_t *value)
     if (!strcmp(key, "worker_calls")) { *value = C.wc_last.bt_calls; return 0; }
     if (!strcmp(key, "hot_bin_calls")) { *value = C.wc_last.hot_calls; return 0; }
     if (!strcmp(key, "positions")) { *value = C.stats.positions; return 0; }
+    if (!strcmp(key, "block_pool_bytes")) { *value = cur().blocks_pool_size; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown counter %s", key);
 }
 
@@ -991,6 +1009,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
     if (!strcmp(key, "parser_helper")) { C.opt_helper = value != 0; return 0; }
+    if (!strcmp(key, "multi_allow_same_device")) { C.opt_multi_same = value != 0; return 0; }
     if (!strcmp(key, "block_parser_helper")) { C.opt_block_helper = value != 0; return 0; }
     if (!strcmp(key, "keep_block_pool")) { C.opt_keep_pool = value != 0; if (!value && g_jobs.empty()) blocks_close(true); return 0; }
     if (!strcmp(key, "block_batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "block_batch_chunks out of range"); C.opt_block_batch = value; return 0; }
@@ -1134,6 +1153,16 @@ void block_ctx_destroy(Ctx &c)
 }  // namespace
 
 namespace {
+// "keep_block_pool" keeps a closed set's one allocation (most of the device's memory for the bench's set) for the next set; anything
+// else that then cannot allocate -- a single stream, a feed, find_matches -- takes it back here instead of failing with NOMEM.
+bool idle_block_pool_dropped()
+{
+    if (!g_jobs.empty() || !cur().blocks_pool) return false;
+    (void)hipFree(cur().blocks_pool);
+    cur().blocks_pool = nullptr; cur().blocks_pool_size = 0;
+    return true;
+}
+
 void blocks_close(bool drop_pool)
 {
     // (a round may still be queued or on the device -- an abandoned set, a failed step: every device wait is bounded)
@@ -1620,9 +1649,10 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
 {
     if (!devices || !ndev || !blocks_per_dev || (!src && n) || !dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
     if (ndev > 64) return set_err(NLZM_HIP_E_ARG, "more than 64 devices");
-    for (uint32_t i = 0; i < ndev; i++)
-        for (uint32_t k = 0; k < i; k++)
-            if (devices[i] == devices[k]) return set_err(NLZM_HIP_E_ARG, "device %d is listed twice", devices[i]);
+    if (!g_dev0.ctx.opt_multi_same)
+        for (uint32_t i = 0; i < ndev; i++)
+            for (uint32_t k = 0; k < i; k++)
+                if (devices[i] == devices[k]) return set_err(NLZM_HIP_E_ARG, "device %d is listed twice", devices[i]);
     const uint64_t nb_total = (uint64_t)ndev * blocks_per_dev;
     const uint64_t per = n ? (n + nb_total - 1) / nb_total : 1;
     struct Part {
@@ -1638,6 +1668,16 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
     std::vector<Part> parts(ndev);
     int dev_before = -1;
     (void)hipGetDevice(&dev_before);                // (the caller's current device is put back on the way out)
+    // the caller's pages pinned for the uploads when the driver allows it (a pageable copy goes through a bounce buffer): the whole
+    // range once, page-aligned, before the threads start -- their parts share pages
+    bool pinned_all = false;
+    uint8_t *pin_lo = nullptr; size_t pin_len = 0;
+    if (n) {
+        const uintptr_t pg = 4096, lo = (uintptr_t)src & ~(pg - 1), hi = ((uintptr_t)src + n + pg - 1) & ~(pg - 1);
+        pin_lo = (uint8_t *)lo; pin_len = (size_t)(hi - lo);
+        pinned_all = hipHostRegister(pin_lo, pin_len, hipHostRegisterPortable) == hipSuccess;
+        if (!pinned_all) (void)hipGetLastError();
+    }
     auto run_part = [&](uint32_t i) {
         Part &P = parts[i];
         t_dev = &P.D;
@@ -1661,14 +1701,8 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
             HIPCHK(hipMalloc(&P.d_out, P.bound));
             HIPCHK(hipMemset(P.d_in + P.n, 0, 512));
             const auto t0 = std::chrono::steady_clock::now();
-            if (P.n) {
-                // (the caller's pages pinned for the upload when the driver allows it: a pageable copy goes through a bounce buffer)
-                P.pinned = hipHostRegister((void *)(src + P.lo), P.n, hipHostRegisterDefault) == hipSuccess;
-                if (!P.pinned) (void)hipGetLastError();
-                const hipError_t e = hipMemcpy(P.d_in, src + P.lo, P.n, hipMemcpyHostToDevice);
-                if (P.pinned) (void)hipHostUnregister((void *)(src + P.lo));
-                HIPCHK(e);
-            }
+            P.pinned = pinned_all;
+            if (P.n) HIPCHK(hipMemcpy(P.d_in, src + P.lo, P.n, hipMemcpyHostToDevice));
             const auto t1 = std::chrono::steady_clock::now();
             P.D.blocks_per = per;
             rc = nlzm_hip_compress_blocks_dev(P.d_in, P.n, blocks_per_dev, hist_bits_req, P.d_out, P.bound, P.blens.data(), &P.len);
@@ -1684,6 +1718,7 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
         for (uint32_t i = 0; i < ndev; i++) th.emplace_back(run_part, i);
         for (auto &t : th) t.join();
     }
+    if (pinned_all) (void)hipHostUnregister(pin_lo);
     int rc = 0;
     uint64_t total = 0;
     for (auto &P : parts) { if (P.rc && !rc) { rc = P.rc; std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, P.msg, sizeof g_err); } total += P.len; }
@@ -1696,24 +1731,39 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
             HIPCHK(hipSetDevice(root));
             if (ndev == 1) { HIPCHK(hipMemcpy(dst, parts[0].d_out, total, hipMemcpyDeviceToHost)); return 0; }
             HIPCHK(hipMalloc(&d_all, total ? total : 1));
+            // GPU to GPU: directly over the link where the root may address the device's memory (xGMI inside a node), else staged by the
+            // runtime; which it was is reported.  Every copy is queued before any is waited for; events on the root's stream time them.
+            std::vector<hipEvent_t> ev(2 * parts.size(), nullptr);
+            std::vector<int> enabled_here;
             uint64_t off = 0;
-            for (auto &P : parts) {
-                // GPU to GPU: directly over the link where the root may address the device's memory (xGMI inside a node),
-                // else staged by the runtime; which it was is reported
+            int grc = 0;
+            for (size_t k = 0; k < parts.size() && !grc; k++) {
+                Part &P = parts[k];
                 if (P.device != root) {
                     int can = 0;
                     if (hipDeviceCanAccessPeer(&can, root, P.device) == hipSuccess && can) {
                         const hipError_t e = hipDeviceEnablePeerAccess(P.device, 0);
                         P.direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                        if (e == hipSuccess) enabled_here.push_back(P.device);
                         (void)hipGetLastError();
                     }
                 } else P.direct = true;
-                const auto g0 = std::chrono::steady_clock::now();
-                if (P.len) HIPCHK(hipMemcpyPeerAsync(d_all + off, root, P.d_out, P.device, P.len, nullptr));
-                HIPCHK(hipDeviceSynchronize());
-                P.gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
+                if (hipEventCreate(&ev[2 * k]) != hipSuccess || hipEventCreate(&ev[2 * k + 1]) != hipSuccess) { grc = set_err(NLZM_HIP_E_NODEVICE, "hipEventCreate failed"); break; }
+                (void)hipEventRecord(ev[2 * k], nullptr);
+                if (P.len && hipMemcpyPeerAsync(d_all + off, root, P.d_out, P.device, P.len, nullptr) != hipSuccess)
+                    grc = set_err(NLZM_HIP_E_NODEVICE, "gather from device %d failed: %s", P.device, hipGetErrorString(hipGetLastError()));
+                (void)hipEventRecord(ev[2 * k + 1], nullptr);
                 off += P.len;
             }
+            if (!grc && hipDeviceSynchronize() != hipSuccess) grc = set_err(NLZM_HIP_E_NODEVICE, "gather failed: %s", hipGetErrorString(hipGetLastError()));
+            for (size_t k = 0; k < parts.size(); k++) {
+                float ms = 0;
+                if (!grc && ev[2 * k] && ev[2 * k + 1] && hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) parts[k].gather_ms = ms;
+                if (ev[2 * k]) (void)hipEventDestroy(ev[2 * k]);
+                if (ev[2 * k + 1]) (void)hipEventDestroy(ev[2 * k + 1]);
+            }
+            for (int d : enabled_here) (void)hipDeviceDisablePeerAccess(d);     // (only what this call enabled: the caller's settings stay)
+            if (grc) return grc;
             HIPCHK(hipMemcpy(dst, d_all, total, hipMemcpyDeviceToHost));
             return 0;
         }();

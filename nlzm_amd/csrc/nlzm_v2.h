@@ -748,13 +748,21 @@ struct Finder {
 // e >= p + 2 -- an associative merge, computed for the 64 positions of a block by a parallel prefix scan.
 // (The one entry whose end moves with p, the top entry while it keeps extending :1503-1512, arrives from the finder
 // stage as a fresh pair per position.)
-constexpr uint32_t kFrCap = 32;                 // entries a lane's front may have on the scan path
+// (Round 5 measured the fronts at 300 MB of text at -window:28: some position of a block holds more than 8 entries at some step of
+//  the scan in 42 % of the blocks, more than 12 in 0.23 %, more than 16 in 0.002 % -- with 16 entries a wave's two front buffers are
+//  16 KB instead of 32 KB and seven waves fit the CU's LDS where four did.)
+#ifndef NLZM_FRCAP
+#define NLZM_FRCAP 16
+#endif
+constexpr uint32_t kFrCap = NLZM_FRCAP;         // entries a lane's front may have on the scan path
 
 #ifndef NLZM_KTW
-#define NLZM_KTW 4
+#define NLZM_KTW 7
 #endif
 constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn (a block of 64 positions takes a wave ~100,000 cycles:
-                                                // three waves were busy 530 of 618 cycles per position at 300 MB, four 416 of 614; 156 KB of LDS)
+                                                // three waves were busy 530 of 618 cycles per position at 300 MB, four 416 of 614 with the whole tail of a
+                                                // block in block order; round 5, only the carry merge in order: 4 / 5 / 6 / 7 waves 506 / 483 / 483 / 483 --
+                                                // from five waves on the stage is no longer what the pipeline waits for; 151 KB of LDS with seven)
 struct TWave {
     unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
     uint32_t recs[64 * kFtStride];              // the block's finder records
@@ -767,7 +775,8 @@ struct TLds {
     uint32_t carry_n;
     uint32_t turn;                              // blocks are taken in turn: the wave whose sequence number this is cuts the next block
     uint32_t cursor;                            // first position not yet in a block
-    uint32_t carry_seq;                         // ... and finished in that order: the block with this sequence number takes the carry
+    uint32_t carry_seq;                         // ... and take the carry in that order: the block with this sequence number merges it into its fronts
+    uint32_t emit_seq;                          // ... and publish their records in that order (t_out): the block with this sequence number, once it has written them
     uint32_t stop;
 };
 
@@ -782,7 +791,8 @@ struct Table {
     uint32_t err;
     uint32_t p_pos_seen;
     unsigned long long n_blocks, n_slow, t_wait;
-    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0;     // profile build: gather, scan, carry + emit, wait for the carry
+    unsigned long long n_fr8 = 0, n_fr12 = 0, n_fr16 = 0, n_fr20 = 0, n_fr24 = 0;      // blocks in which some lane's front exceeded 8 / 12 / 16 / 20 / 24 entries at some step
+    unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;     // profile build: gather, scan, carry merge (in block order), wait for the carry, records
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
 #else
@@ -956,7 +966,7 @@ struct Table {
         }
         const unsigned long long q1 = ptick();
         // prefix scan: after the step with offset D lane i holds the front of the pairs of lanes (i - 2D, i]
-        uint32_t cur = 0;
+        uint32_t cur = 0, cmax = cnt;                               // (cmax: the largest front this lane holds at any step -- the histogram below)
         for (uint32_t D = 1; D < 64; D <<= 1) {
             xw::wave_sync();
             const uint32_t ocnt = xw::shfl_up(cnt, D);
@@ -967,11 +977,13 @@ struct Table {
             else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
             if (nn == kNone) { W->overflow = 1; nn = 0; }
             cnt = nn;
+            cmax = umax(cmax, cnt);
             cur ^= 1;
         }
         xw::wave_sync();
         const unsigned long long q2 = ptick();
         // ---- from here on in block order: the front carried into the block
+        if (G.cap_words && !wait_lds(&L->emit_seq, seq)) { err = 1; return; }     // (stage test tap: one list, appended to in position order -- whole blocks in turn)
         if (!wait_lds(&L->carry_seq, seq)) { err = 1; return; }
         const unsigned long long q3 = ptick();
         const uint32_t cn = xw::readfirst(L->carry_n);
@@ -983,24 +995,38 @@ struct Table {
         }
         xw::wave_sync();
         n_blocks++;
-        if (xw::readfirst(W->overflow)) slow_block(a0, n, a1, la_end);
+        cmax = umax(cmax, fn == kNone ? 0u : fn);
+        n_fr8 += xw::any(cmax > 8); n_fr12 += xw::any(cmax > 12); n_fr16 += xw::any(cmax > 16); n_fr20 += xw::any(cmax > 20); n_fr24 += xw::any(cmax > 24);
+        // Only the merge with the carried front has to happen in block order: the next block may take its carry -- this block's last
+        // front -- as soon as that exists, and the records (the bulk of what is left: the sampled lengths of 64 positions) are written
+        // beside the next block's merge.  (Round 4 kept the whole tail in order: 435 of a block's ~1,500 cycles per position, profile
+        // build, were serial -- the stage stood at 420 - 440 however many waves it had.)
+        const bool slow = xw::readfirst(W->overflow) != 0;
+        if (slow) slow_block(a0, n, a1, la_end);
         else {
-            if (in_blk) emit(a, a1, lit, fin_f, fn);
-            if (G.cap_words) {
-                for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
-            }
-#ifdef NLZM_SIM
-            if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
-#endif
-            // carry out: the last position's front
+            // carry out: the last position's front (every lane has finished its merge with the old one: wave_sync above)
             const uint32_t last_n = xw::readlane(fn, n - 1);
             for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = W->fr[cur ^ 1][(n - 1) * kFrCap + k];
             if (i == 0) L->carry_n = last_n;
         }
-        xw::drain();
         xw::wave_sync();
-        if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->carry_seq, seq + 1); }
-        tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += ptick() - q3;
+        if (i == 0) xw::lds_st(&L->carry_seq, seq + 1);
+        const unsigned long long q4 = ptick();
+        if (!slow) {
+            if (in_blk) emit(a, a1, lit, fin_f, fn);
+#ifdef NLZM_SIM
+            if (in_blk) sim_on_front(G.hook_user, a, fin_f, fn);
+#endif
+        }
+        xw::drain();
+        // the records are out: said in block order (t_out covers every position below it)
+        if (!wait_lds(&L->emit_seq, seq)) { err = 1; return; }
+        if (!slow && G.cap_words) {                                 // (stage test tap: appends to one list, so in order too)
+            for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
+        }
+        xw::wave_sync();
+        if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->emit_seq, seq + 1); }
+        tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += q4 - q3; tt4 += ptick() - q4;
     }
 
     // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
@@ -1051,7 +1077,7 @@ struct Table {
         if (w == 0) {
             const uint32_t cn = xw::readfirst(S->front_n);
             for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
-            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->stop = 0; }
+            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->emit_seq = 0; L->stop = 0; }
         }
         xw::block_sync();
         err = 0; n_blocks = n_slow = 0; t_wait = 0;
@@ -1093,8 +1119,10 @@ struct Table {
         if (i == 0) {       // accounting: summed over the waves
             unsigned long long *pr = G.persist->prof;
             xw::atomic_add64_agent(&pr[6], n_blocks); xw::atomic_add64_agent(&pr[7], n_slow);
+            xw::atomic_add64_agent(&pr[105], n_fr8); xw::atomic_add64_agent(&pr[106], n_fr12); xw::atomic_add64_agent(&pr[107], n_fr16);
+            xw::atomic_add64_agent(&pr[108], n_fr20); xw::atomic_add64_agent(&pr[109], n_fr24);
             xw::atomic_add64_agent(&pr[44], tt0); xw::atomic_add64_agent(&pr[45], tt1);
-            xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3);
+            xw::atomic_add64_agent(&pr[46], tt2); xw::atomic_add64_agent(&pr[47], tt3); xw::atomic_add64_agent(&pr[55], tt4);
             if (w == 0) { xw::atomic_add64_agent(&pr[18], t_wait); xw::atomic_add64_agent(&pr[19], xw::tick() - t_start); }
         }
         if (w == 0) {
