@@ -127,6 +127,7 @@ struct WorkerCounters {
     unsigned long long stuck_lanes, stuck_pos_inv;  // lanes that left while waiting for a decision (a launch that failed); ~(smallest such position)
     unsigned long long hot_bins, hot_calls;         // hot bins over all launches; calls made by their waves
     unsigned long long spec_calls, spec_good;       // decisions "skip" that took calls back; calls behind the skipped position that were made again
+    unsigned long long hot_steps, hot_blocked_dry, hot_blocked_risky;   // hot bins' waves: steps; steps in which the next call could not start (a call without stores on its way / a risky assumption open)
 };
 
 // Everything the master needs from HBM.

@@ -748,6 +748,8 @@ int refresh_stats(Ctx &C)
                 v2::kFrCap, 100.0 * P.prof[105] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[106] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[107] / (P.prof[6] ? P.prof[6] : 1),
                 100.0 * P.prof[108] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[109] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[7] / (P.prof[6] ? P.prof[6] : 1));
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
+        fprintf(stderr, "finder: blocks that had to wait for a worker result: %llu (%.0f cycles each); late results of hot bins' waves %llu, late results at lane 0 (the position the block before was cut at) %llu\n",
+                P.prof[112], (double)P.prof[25] / (double)(P.prof[112] ? P.prof[112] : 1), P.prof[110], P.prof[111]);
         fprintf(stderr, "parser: waited for its record loader %llu times, the table stage %.0f positions ahead on average then\n", P.prof[26], (double)P.prof[27] / (double)(P.prof[26] ? P.prof[26] : 1));
         if (P.prof[96] || P.prof[100])
             fprintf(stderr, "helper parser: %llu jobs posted, %llu taken over (%llu nodes = %.1f %% of the positions), the parser stage waited %.0f cycles per position for it; "
@@ -790,6 +792,9 @@ int refresh_stats(Ctx &C)
                     wc.dry_runs, wc.spec_calls, wc.spec_good);
         if (C.opt_report && C.hot_max)
             fprintf(stderr, "hot bins (a wave each): %llu over all launches, %llu of %llu calls made by their waves\n", wc.hot_bins, wc.hot_calls, wc.bt_calls);
+        if (C.opt_report && C.hot_max && wc.hot_steps)
+            fprintf(stderr, "hot bins' waves: %llu steps (%.1f per call); the next call could not start in %.1f %% of them (a call without its stores on its way) + %.1f %% (an assumed \"skip\" behind a \"call\" still open); lanes: %llu turns spent waiting for a decision\n",
+                    wc.hot_steps, (double)wc.hot_steps / (wc.hot_calls ? wc.hot_calls : 1), 100.0 * wc.hot_blocked_dry / wc.hot_steps, 100.0 * wc.hot_blocked_risky / wc.hot_steps, wc.flag_waits);
         if (C.opt_report && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));

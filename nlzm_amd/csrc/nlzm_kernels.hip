@@ -157,7 +157,9 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     uint32_t *off = off_all + (unsigned long long)blockIdx.x * (nheads + 1);
     uint32_t *cur = cur_all + (unsigned long long)blockIdx.x * nheads;
     // an entry: the position, and its BT4 head with the pre-filter's mark in bit 31 (what a worker lane needs to start the call:
-    // one load instead of a chain of three)
+    // one load instead of a chain of three), the mark of the position before in bit 30 and of the position behind in bit 29 (what the
+    // lane assumes about a decision that is not in yet; the array has 16 bytes of slack behind the launch's last position, whose
+    // "position behind" is whatever stands there: an assumption, never a result)
     uint32_t *pos = pos_all + (unsigned long long)blockIdx.x * g.chunk_size * 2;
     const unsigned long long chunk_abs = (unsigned long long)ci * g.chunk_size;
     const unsigned long long remain = g.n - chunk_abs;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
                 const uint32_t at = first + rank;
                 const uint32_t a = (uint32_t)chunk_abs + p;
                 pos[2 * at] = a;
-                pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u) | ((a > batch_a0 && unc[a - batch_a0 - 1]) ? 0x40000000u : 0u);
+                pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u) | ((a > batch_a0 && unc[a - batch_a0 - 1]) ? 0x40000000u : 0u) | (unc[a - batch_a0 + 1] ? 0x20000000u : 0u);
             }
         }
         return;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
             const uint32_t a = (uint32_t)chunk_abs + p;
             pos[2 * at] = a;
             // (bit 30: the position before is marked as well -- what a worker lane assumes about an undecided position)
-            pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u) | ((a > batch_a0 && unc[a - batch_a0 - 1]) ? 0x40000000u : 0u);
+            pos[2 * at + 1] = hfull | (unc[a - batch_a0] ? 0x80000000u : 0u) | ((a > batch_a0 && unc[a - batch_a0 - 1]) ? 0x40000000u : 0u) | (unc[a - batch_a0 + 1] ? 0x20000000u : 0u);
         }
         __syncthreads();
         if (ok && !after) cur[h] = at + 1;
@@ -454,6 +456,9 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
 //    wave stops starting calls, lets the calls in flight finish, takes the stores of every call behind the position
 //    back, latest first, takes back or makes the position's own, and goes on behind it.
 // ---------------------------------------------------------------------------
+#ifndef NLZM_RISKY_AHEAD
+#define NLZM_RISKY_AHEAD 0
+#endif
 constexpr uint32_t kPending = 0xFFFFFFFEu;      // (no position: stream_begin refuses inputs of 0xFFFF0000 bytes and more)
 __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t bin, uint32_t hot_index)
 {
@@ -485,8 +490,10 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     bool last_skip = false;         // (wave-uniform) the bin's latest decision was "skip"
     LaneSink sink{ (uint32_t *)&g_v2_lds + threadIdx.x, nullptr };
     unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_open = 0, n_back = 0, n_redo = 0;
+    unsigned long long n_steps = 0, n_blk_dry = 0, n_blk_risky = 0;
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0, prog_seen = 0, steps = 0;
+    uint32_t behind_risky = 0;      // (wave-uniform) calls started while a risky assumption is open
     bool fail = false;
 
     for (;;) {
@@ -536,16 +543,25 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         //  to read: nothing starts until it has ended.)
         // (An undecided position assumed to be skipped although the bin's last decision was "call" is wrong one time in eight,
         //  and a wrong assumption costs every call behind it: nothing starts behind such a position until it is decided.)
-        const bool dry_on_its_way = __any((st == kStart || st == kRun) && dry) || __any(und && risky);
+        // (Round 5: ... but ONE call may -- the finder stage nearly always needs the bin's next position right behind such a decision, and
+        //  with nothing started it stood there for a whole call, 138,000 cycles a time: two thirds of its waits for worker results at
+        //  300 MB were a hot bin's.  Seven times in eight the call stands; the eighth it is the one call that is taken back.)
+        const bool risky_open = __any(und && risky);
+        if (!risky_open) behind_risky = 0;
+        const bool dry_on_its_way = __any((st == kStart || st == kRun) && dry) || (risky_open && behind_risky >= NLZM_RISKY_AHEAD);
         if (!rec && !dry_on_its_way && have_pe && free_m) { start_lane = (uint32_t)__builtin_ctzll(free_m); have_pe = false; }
+        n_steps++;
+        if (!rec && have_pe && free_m && dry_on_its_way) {             // (diagnostics: steps in which the next call could not start for one of the two reasons)
+            if (__any((st == kStart || st == kRun) && dry)) n_blk_dry++; else n_blk_risky++;
+        }
         if (lane == start_lane) {
-            a = (uint32_t)pe; hidx = (uint32_t)(pe >> 32) & 0x3FFFFFFFu;
+            a = (uint32_t)pe; hidx = (uint32_t)(pe >> 32) & 0x1FFFFFFFu;
             max_len = umin(la_end - a, kMatchMax);
-            marked = (pe >> 63) != 0; dry = (pe >> 62) == 3u;           // (without stores: if it turns out to be undecided)
+            marked = (pe >> 63) != 0; dry = (pe >> 61) == 7u;           // (without stores: if it turns out to be undecided.  Assumed to be skipped: marked like both its neighbours -- see worker_role)
             seq = seq_next; binidx = i0 - 1;
             st = kStart;
         }
-        if (start_lane < 64) seq_next++;
+        if (start_lane < 64) { seq_next++; if (risky_open) behind_risky++; }
         // ---- the next entry of the bin (requested a step ahead of its use); the chunk is left when no call is in flight
         if (!have_pe && more && !rec) {
             for (;;) {
@@ -696,14 +712,20 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
         atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
         atomicAdd(&G.wcnt->hot_calls, n_calls);
+        atomicAdd(&G.wcnt->hot_steps, n_steps); atomicAdd(&G.wcnt->hot_blocked_dry, n_blk_dry); atomicAdd(&G.wcnt->hot_blocked_risky, n_blk_risky);
     }
 }
 
 // A worker lane.  Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it.
 //
 // Whether BT4 runs at a position the pre-filter marked is the finder stage's decision, and the lane is usually there first.
-// It does not wait.  It assumes the decision -- "skip" if the position before is marked as well (inside a long repeat: 97 %
-// of those are skipped), "call" otherwise (99.98 % are called; measured on 300 MB of text) -- and goes
+// It does not wait.  It assumes the decision -- "skip" if the positions before AND behind it are marked as well (inside a long
+// repeat), "call" otherwise -- and goes
+// (Until round 5 the position before alone decided the assumption: right for 97 % of those, and the 3 % were one position per long
+//  repeat -- its LAST marked one, where the carried match has dropped below 64 bytes (:1514) and BT4 runs again: 520,000 wrong
+//  assumptions in 300 MB of text, each a take-back, the calls behind it made again and the finder stage waiting for them.  A marked
+//  position is a 65-gram that occurred before: the run's first and last position are called, the ones between skipped --
+//  tests/host_sim/sim2 NLZM_SIM_RULES=1 tabulates the four cases: 9,203 / 220 / 220 / 5 called, 0 / 5 / 5 / 28,390 skipped.)
 // on with the next positions of its bin, up to kAhead calls whose fate is open.  A call assumed to happen is made, every
 // store noting what it replaced; one assumed not to happen is made without its stores, which are noted instead.  The first
 // open call is an undecided position; its RESULT does not depend on its own decision and goes out at once.  The results of
@@ -817,7 +839,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                     if (i0 >= e0) { if (!nq) { c++; loaded = false; } }      // (open calls: the chunk is left when they are settled)
                     else {
                         const unsigned long long pe = *(const unsigned long long *)(pos + 2 * i0);
-                        ja = (uint32_t)pe; jh = (uint32_t)(pe >> 32) & 0x3FFFFFFFu; jlen = umin(la_end - ja, kMatchMax);
+                        ja = (uint32_t)pe; jh = (uint32_t)(pe >> 32) & 0x1FFFFFFFu; jlen = umin(la_end - ja, kMatchMax);
                         jinfo = (i0 << 1) | (uint32_t)(pe >> 63);
                         i0++;
                         if (pe >> 63) {
@@ -825,7 +847,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             // regions, :1529): act on it; otherwise the call is made with its fate open
                             const uint32_t f = LaneIO::ld_agent(G.bt_flag + (ja - G.batch_a0));
                             job = f == kFlagSkip ? 0u : ((f == kFlagCall && !nq) ? 1u : 2u);
-                            if (f != kFlagCall && ((pe >> 62) & 1u)) jinfo |= 1u << 28;         // (the position before is marked too: assumed to be skipped)
+                            if (f != kFlagCall && ((pe >> 61) & 3u) == 3u) jinfo |= 1u << 28;   // (the positions before AND behind are marked too: assumed to be skipped)
                         } else job = nq ? 2u : 1u;
                     }
                 }

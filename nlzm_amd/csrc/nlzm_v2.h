@@ -202,7 +202,7 @@ struct Finder {
     uint32_t dbg_a = 0;         // start of the block being evaluated (error dump)
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long t_wait, t_wait_bt = 0, t_total;
-    uint32_t n_late_unc = 0, n_late_other = 0;
+    uint32_t n_late_unc = 0, n_late_other = 0, n_late_hot = 0, n_late_first = 0, n_late_blocks = 0;
     unsigned long long t_f[8] = {};             // profile build: cycles per section of block()
 #ifdef NLZM_PROFILE
     XW_FN unsigned long long ptick() const { return xw::tick(); }
@@ -529,6 +529,12 @@ struct Finder {
                     const unsigned long long late = xw::ballot(!(w0 & kBtReady));
                     n_late_unc += (uint32_t)__builtin_popcountll(late & xw::ballot(unc));
                     n_late_other += (uint32_t)__builtin_popcountll(late & ~xw::ballot(unc));
+                    if (late) {         // ... of a hot bin's wave or of a lane; lane 0 of the block (the position a block was cut at) or a later one
+                        const bool hot = G.hot_of_bin && bt_wait && !(w0 & kBtReady) && G.hot_of_bin[(hash4(v4) >> g.bt_shift) % G.nheads] != 0;
+                        n_late_hot += (uint32_t)__builtin_popcountll(xw::ballot(hot));
+                        n_late_first += (uint32_t)(late & 1ull);
+                        n_late_blocks++;
+                    }
                 }
                 if (!xw::any(!(w0 & kBtReady))) {
                     xw::after_poll();
@@ -723,6 +729,7 @@ struct Finder {
             xw::atomic_add64_agent(&pr[12], n_cut5);
             xw::atomic_add64_agent(&pr[16], t_wait); xw::atomic_add64_agent(&pr[17], xw::tick() - t_start); xw::atomic_add64_agent(&pr[25], t_wait_bt);
             xw::atomic_add64_agent(&pr[28], n_late_unc); xw::atomic_add64_agent(&pr[29], n_late_other);
+            xw::atomic_add64_agent(&pr[110], n_late_hot); xw::atomic_add64_agent(&pr[111], n_late_first); xw::atomic_add64_agent(&pr[112], n_late_blocks);
 #ifdef NLZM_PROFILE
             for (int z = 0; z < 8; z++) xw::atomic_add64_agent(&pr[88 + z], t_f[z]);
 #endif

@@ -340,6 +340,17 @@ int main(int argc, char **argv)
         A.c0 = c0; A.c1 = c1;
         xw::launch(4, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
         wk.finish();
+        {   // how well do the marks of the neighbours predict the finder stage's decision at a marked position?  (NLZM_SIM_RULES=1)
+            static unsigned long long tab[2][2][2] = {};   // [prev marked][next marked][decision skip]
+            const unsigned long long cnt = a1 - a0;
+            for (unsigned long long i = 0; i < cnt; i++) {
+                if (!unc[i] || !flag[i]) continue;
+                tab[i > 0 && unc[i - 1]][i + 1 < cnt && unc[i + 1]][flag[i] == kFlagSkip]++;
+            }
+            if (getenv("NLZM_SIM_RULES") && r + 1 == nlaunch)
+                for (int p = 0; p < 2; p++) for (int q = 0; q < 2; q++)
+                    printf("marked positions with prev %s, next %s: decided call %llu, skip %llu\n", p ? "marked" : "unmarked", q ? "marked" : "unmarked", tab[p][q][0], tab[p][q][1]);
+        }
         if (P.error || hx->err) { printf("sim error %u / %u (info %u %u)\n", P.error, hx->err, P.error_info[0], P.error_info[1]); return 1; }
         if (g_ref.bad) break;
         if (getenv("NLZM_SIM_MAX_LAUNCH") && r + 1 >= (uint32_t)atoi(getenv("NLZM_SIM_MAX_LAUNCH"))) { g_stop_chunk = c1; break; }
