@@ -253,6 +253,40 @@ def cutnice(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
+def xml_like(size: int, seed: int = SEED) -> np.ndarray:
+    """Markup shaped like a wiki dump (what enwik8 / enwik9 are): <page> records with a title, numeric ids, a timestamp, a contributor and
+    a text body of Zipf words with [[links]], ''emphasis'' and {{templates}} -- fixed tag strings that repeat every few hundred bytes at
+    slowly varying distances (rep-distance commands, NLZM.cpp:1253-1272, 1344-1367), runs of digits, and free text in between."""
+    rng = np.random.default_rng(seed ^ 0x3C3F786D)
+    flat, starts, lens = _vocab(rng, 8000)
+    words = [bytes(flat[s:s + l]) for s, l in zip(starts, lens)]
+    p = 1.0 / np.arange(1, len(words) + 1) ** 1.05
+    cdf = np.cumsum(p / p.sum())
+    parts, total, pid = [], 0, 1000
+    while total < size:
+        nw = int(rng.integers(20, 400))
+        tok = np.searchsorted(cdf, rng.random(nw), side="right")
+        body = []
+        for t in tok:
+            w = words[min(int(t), len(words) - 1)]
+            r = rng.random()
+            if r < 0.04: w = b"[[" + w + b"]]"
+            elif r < 0.06: w = b"''" + w + b"''"
+            elif r < 0.07: w = b"{{" + w + b"|" + words[int(rng.integers(0, 50))] + b"}}"
+            elif r < 0.09: w = w + b".\n"
+            body.append(w)
+        pid += int(rng.integers(1, 40))
+        ts = b"20%02d-%02d-%02dT%02d:%02d:%02dZ" % (int(rng.integers(1, 7)), int(rng.integers(1, 13)), int(rng.integers(1, 29)),
+                                                    int(rng.integers(0, 24)), int(rng.integers(0, 60)), int(rng.integers(0, 60)))
+        rec = (b"  <page>\n    <title>" + b" ".join(words[int(x)] for x in rng.integers(0, 3000, size=int(rng.integers(1, 4)))) + b"</title>\n    <id>%d</id>\n"
+               b"    <revision>\n      <id>%d</id>\n      <timestamp>" % (pid, pid * 7 + int(rng.integers(0, 1000))) + ts + b"</timestamp>\n"
+               b"      <contributor>\n        <username>" + words[int(rng.integers(0, 500))] + b"</username>\n        <id>%d</id>\n      </contributor>\n"
+               b"      <text xml:space=\"preserve\">" % int(rng.integers(1, 99999)) + b" ".join(body) + b"</text>\n    </revision>\n  </page>\n")
+        parts.append(rec)
+        total += len(rec)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8)[:size].copy()
+
+
 # ---- real text: source files that are part of the image (the same on the build container and on the GPU boxes) ------------------
 REAL_ROOTS = [("/usr/lib/python3.10", (".py",)), ("/usr/lib/python3/dist-packages", (".py",)), ("/opt/rocm/include", (".h", ".hpp")),
               ("/usr/include", (".h", ".hpp")), ("/usr/local/lib/python3.10/dist-packages", (".py", ".pyi", ".h", ".hpp", ".rst"))]
@@ -335,7 +369,7 @@ def dense_breaks(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
-_GENS = {"real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+_GENS = {"xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

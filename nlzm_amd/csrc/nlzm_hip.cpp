@@ -476,7 +476,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     DEVALLOC(C.v2_tf, (size_t)v2::kTpRing * v2::kTfStride * 4);
     DEVALLOC(C.v2_state, sizeof(v2::StateV2));
     DEVALLOC(C.v2_hx, sizeof(v2::Hx));
-    if (C.opt_helper) DEVALLOC(C.v2_hb, sizeof(v2::HelpBox));
+    if (C.opt_helper) DEVALLOC(C.v2_hb, v2::kHelpers * sizeof(v2::HelpBox));
     DEVFILL(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
 
     if (C.double_sets) {
@@ -1225,7 +1225,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
     // (a spare CU per stream while there is room for it; every workgroup of the launch has a CU of its own either way:
     //  at most CUs / 4 streams -- three stage CUs and one worker CU each -- which is 64 on an MI355X)
     // (the helper parser's workgroup leaves at once where the streams run without one: it takes no CU then)
-    const int64_t roles_live = (int64_t)pipeline2_role_blocks() - (C.opt_block_helper ? 0 : 1);
+    const int64_t roles_live = (int64_t)pipeline2_role_blocks() - (C.opt_block_helper ? 0 : (int64_t)v2::kHelpers);
     int64_t wb = prop.multiProcessorCount / (int64_t)nblocks - roles_live;
     if (wb > 1 && nblocks > 1) wb--;
     if (wb > C.opt_worker_blocks) wb = C.opt_worker_blocks;

@@ -913,7 +913,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
 // worker lanes.  512-thread blocks with > 80 KB of LDS: one block per CU; the grid is kept below the CU count, so every
 // block is resident at once (the stages wait on each other through progress words in HBM).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kV2Roles = 4;                // finder, table, parser, helper parser (leaves at once where a stream has no HelpBox)
+constexpr uint32_t kV2Roles = 3 + v2::kHelpers; // finder, table, parser, helper parsers (these leave at once where a stream has no HelpBox)
 __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G, const v2::GlobalsV2 &V, uint32_t c0, uint32_t c1,
                                                 uint32_t local_block, uint32_t wblocks)
 {
@@ -923,14 +923,14 @@ __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G,
         if (local_block == 0) { v2::Finder r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else if (local_block == 1) { v2::Table r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else if (local_block == 2) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
-        else if (V.hb) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run_helper(c0); }
+        else if (V.hb) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run_helper(c0, local_block - 3); }
     } else {
         worker_role(g, G, c0, c1, wblocks, local_block - kV2Roles);
     }
 }
 __global__ __launch_bounds__(512) void pipeline2_kernel(Geom g, Globals G, v2::GlobalsV2 V, uint32_t c0, uint32_t c1)
 {
-    // blocks 0, 8, 16, 24 are the stages: workgroups go to the XCDs round-robin, so they share XCD 0 (and its L2)
+    // blocks 0, 8, 16, 24, 32 are the stages: workgroups go to the XCDs round-robin, so they share XCD 0 (and its L2)
     const uint32_t b = blockIdx.x;
     const bool spread = gridDim.x > 8 * (kV2Roles - 1);                                   // (a small grid: the first blocks are the stages)
     const uint32_t before = b ? (b + 7) / 8 < kV2Roles ? (b + 7) / 8 : kV2Roles : 0u;     // stage blocks below b

@@ -53,10 +53,12 @@ struct Hx {                                     // progress words, one 128-byte 
     alignas(128) uint32_t p_pos;                // parser: records of positions < p_pos are consumed
     alignas(128) unsigned long long p_seg;      // parser: segment start << 32 | positions below this lie in that segment
     // helper parser (HelpBox below)
-    alignas(128) uint32_t h_job;                // parser: number of the job in the HelpBox (0: none yet, kHelpExit: the launch is over)
-    alignas(128) uint32_t h_verdict;            // parser: job << 2 | 1 taken over, 2 dropped
-    alignas(128) unsigned long long h_prog;     // helper: job << 32 | nodes it knows to be inside the segment << 16 | nodes final (HelpBox arrays valid below)
-    alignas(128) uint32_t h_state;              // helper: job << 2 | 1 done (seg_len, end_rep valid), 2 given up
+    alignas(128) uint32_t h_job;                // parser: number of the job in the HelpBox (0: none yet, kHelpExit: the launch is over); every helper takes it
+    struct alignas(128) HelpWords {             // per helper, a line each:
+        alignas(128) uint32_t verdict;          //   whoever drops the helper's job (the parser stage, or the helper in front of it): job << 2 | 2
+        alignas(128) unsigned long long prog;   //   helper: job << 32 | nodes it knows to be inside the segment << 16 | nodes final (HelpBox arrays valid below)
+        alignas(128) uint32_t state;            //   helper: job << 2 | 1 done (seg_len, end_rep valid), 2 given up
+    } hw[2];
     alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves (the FIRST code stays: raise())
     uint32_t err_info[7];                       // of the stage that raised it: stage (11 finder, 12 table, 13 parser), wait site, position, what it saw
     alignas(128) uint32_t dbg[4][32];           // per stage (0 finder, 1 table, 2 parser): where it was when it left because of an error
@@ -67,15 +69,25 @@ struct RoundSnap { uint32_t error, next_chunk, aborted, pad; Hx hx; };
 
 // ---- helper parser: a second parser workgroup that parses the BACK of a long segment while the parser stage parses its front.
 // Under the same prices two parses of a segment differ only in where they started, and the recurrence forgets its start: a parse
-// begun at node kHelpStart as if the segment began there (cost 0, the rep set of the segment start) has, a few hundred nodes on,
+// begun at a node s0 (help_start) as if the segment began there (cost 0, the rep set of the segment start) has, a few hundred nodes on,
 // the true state of every node up to ONE cost offset.  The parser stage checks exactly that when it gets to the first block border
-// behind kHelpStart + kHelpWarm: the 264 nodes in front of the border are all the sources an edge into a later node can have
+// behind s0 + kHelpWarm: the 264 nodes in front of the border are all the sources an edge into a later node can have
 // (:737); if on them the helper's costs minus its own are one constant and the rep sets are equal, every candidate of every later
 // node is shifted by that constant in the helper's parse -- same winners under strict '>' and the (source, rank) order, same rep
 // sets -- and it takes the helper's nodes over instead of computing them.  Otherwise it goes on by itself.  Measured on the CPU
 // (oracle/stale_probe.c, profiles/r05_parser_go_nogo.txt): 85 - 92 % of such frontiers agree 576 nodes after the start.
-constexpr uint32_t kHelpStart = 1792;           // the helper's first node (a segment that is cut at 4,096: the front 2,400 nodes stay with the parser stage)
-constexpr uint32_t kHelpWarm = 576;             // nodes the helper has behind it where the frontiers are compared
+// There are kHelpers of them, each starting further back; a helper is to the helper behind it what the parser stage is to the first: it
+// compares that helper's frontier with its own states (true up to ITS offset, if it is itself taken over) and takes its nodes over, so that
+// what the parser stage takes from the first helper is the rest of the segment.
+#ifndef NLZM_HELPERS
+#define NLZM_HELPERS 2
+#endif
+constexpr uint32_t kHelpers = NLZM_HELPERS;     // (1 or 2)
+static_assert(kHelpers >= 1 && kHelpers <= 2, "Hx::hw holds two helpers' words");
+// helper k's first node (a segment that is cut at 4,096: one helper -- the front 2,400 nodes stay with the parser stage, the helper has
+// 1,792 .. 4,096; two -- 1,900 / 1,280 .. 3,100 / 2,496 .. 4,096; the helpers further back wait for their records longer)
+NLZM_HD uint32_t help_start(uint32_t k) { return kHelpers == 1 ? 1792u : (k == 0 ? 1280u : 2496u); }
+constexpr uint32_t kHelpWarm = 576;             // nodes a helper has behind it where the frontiers are compared
 constexpr uint32_t kHelpExit = 0xFFFFFFFFu;
 struct HelpBox {
     // parser -> helper: the job (valid once Hx::h_job carries its number)
@@ -99,7 +111,7 @@ struct GlobalsV2 {
     uint32_t *tf;                               // [kTpRing][kTfStride]
     Hx *hx;
     uint32_t *state;                            // StateV2 (survives between launches)
-    HelpBox *hb;                                // null: no helper parser
+    HelpBox *hb;                                // [kHelpers] (the job's parameters and prices in the first); null: no helper parsers
 };
 
 // stage state that survives between launches (HBM)
@@ -216,6 +228,19 @@ struct Finder {
         if (xw::lane() == 0) raise(V.hx, code, kStFinder, site, pos, x0, x1);
     }
 
+    // A block's records are stored at its end; the progress word that covers them may only follow when they have landed (payload, then
+    // flag).  Waiting for that at the block's end cost a round trip to memory per block with nothing else to do; the word is now written
+    // in the middle of the NEXT block (in front of its wait for the worker lanes' results), where the stores have long landed -- and in
+    // front of anything else this stage may wait for, since the stages behind it may be what that wait depends on.
+    uint32_t pend_fpos = 0;         // nonzero: records up to here are stored, f_pos does not say so yet
+    XW_FN void flush_fpos()
+    {
+        if (!pend_fpos) return;
+        xw::drain();
+        if (xw::lane() == 0) xw::st_agent(&V.hx->f_pos, pend_fpos);
+        pend_fpos = 0;
+    }
+
     // The growing top entry (distance s_d): find where it stops matching, as far as `limit` (:1507-1509).
     XW_FN void slider_look(uint32_t limit)
     {
@@ -259,6 +284,7 @@ struct Finder {
             // spans a0 (the table of a0 - 1 reaches 64 further) or has ended a segment exactly there.
             if (a0 == (uint32_t)((unsigned long long)(a0 / g.chunk_size) * g.chunk_size)) seg_s = a0;   // a chunk starts a segment (:1802)
             else {
+                flush_fpos();                                       // (the parser stage may need the block before to get there)
                 const unsigned long long tw = xw::tick();
                 const unsigned long long t0 = xw::clock100();
                 uint32_t spins = 0;
@@ -518,6 +544,7 @@ struct Finder {
         }
         const bool bt_wait = bt_call && i < cut_bin;
         uint32_t bt_n = 0;
+        flush_fpos();                                               // (the block before: its records have landed by now)
         if (xw::any(bt_wait)) {
             const unsigned long long tw = xw::tick();
             const unsigned long long t0 = xw::clock100();
@@ -647,8 +674,7 @@ struct Finder {
             for (uint32_t d = 32; d; d >>= 1) c += xw::shfl(c, i ^ d);
             n_cmp += xw::readfirst(c);
         }
-        xw::drain();
-        if (i == 0) xw::st_agent(&V.hx->f_pos, a0 + m);
+        pend_fpos = a0 + m;                                         // (said by flush_fpos)
         xw::trace(2, a0, n, m, reach, s_active, s_d, s_end);
         {
             const unsigned long long f8 = ptick();
@@ -700,6 +726,7 @@ struct Finder {
                 dbg_a = a;
                 // ring space: the table stage must have consumed position a + n - kFtRing
                 if ((int32_t)(a + n - t_pos_seen - kFtRing) > 0) {
+                    flush_fpos();
                     const unsigned long long tw = xw::tick();
                     if (!wait_word_ge(&V.hx->t_pos, a + n - kFtRing, V.hx, 1)) { err = kErrInternal + 100; break; }
                     t_pos_seen = xw::readfirst(xw::ld_agent(&V.hx->t_pos));
@@ -708,6 +735,7 @@ struct Finder {
                 a += block(a, n, a1, la_end);
             }
         }
+        flush_fpos();
         xw::wave_sync();
         for (uint32_t k = i; k < 4096; k += 64) G.ht2[k] = L->ht2[k];
         for (uint32_t k = i; k < ht3_rows; k += 64) G.ht3[k] = L->ht3[k];
@@ -1243,7 +1271,8 @@ struct Parser {
     uint32_t t_out_seen;
     uint32_t nsegs;                 // segments the last parse_segment() call covered (a run of single-literal segments: several)
     bool tab_dirty;
-    bool is_helper = false;         // this workgroup is the helper parser (run_helper)
+    bool is_helper = false;         // this workgroup is a helper parser (run_helper)
+    uint32_t hrole = 0;             // 0: the parser stage; k + 1: helper k.  Helper hrole is the first one this workgroup may take over from
     bool prev_cut = false;          // the last segment was cut at 4,096 positions (:1469): the next one most likely is, and gets a helper job
     uint32_t myjob = 0;             // helper: the job it works on
     uint32_t hstop = 0;             // helper: 1 the job was dropped, 2 it gives the job up
@@ -1499,7 +1528,7 @@ struct Parser {
     // helper: has the parser stage dropped the job (or posted another one, or ended the launch)?
     XW_FN bool helper_cancelled() const
     {
-        const uint32_t j = xw::readfirst(xw::ld_agent(&V.hx->h_job)), v = xw::readfirst(xw::ld_agent(&V.hx->h_verdict));
+        const uint32_t j = xw::readfirst(xw::ld_agent(&V.hx->h_job)), v = xw::readfirst(xw::ld_agent(&V.hx->hw[hrole - 1].verdict));
         xw::after_poll();
         return j != myjob || v == ((myjob << 2) | 2u);
     }
@@ -1547,7 +1576,7 @@ struct Parser {
     XW_FN void resample(uint32_t a, uint32_t max_len, unsigned long long ev0)
     {
         acc(kAccRedo, 1);
-        uint32_t *rec = is_helper ? V.hb->relist + (a & 511u) * kTpStride : V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
+        uint32_t *rec = is_helper ? V.hb[hrole - 1].relist + (a & 511u) * kTpStride : V.tp + (unsigned long long)(a & (kTpRing - 1)) * kTpStride;
         const unsigned long long h = xw::readfirst64(staged(a)[0]);
         const uint32_t fn = (uint32_t)(h >> 32);
         const uint32_t *fo = V.tf + (unsigned long long)(a & (kTpRing - 1)) * kTfStride;
@@ -1701,7 +1730,7 @@ struct Parser {
     // has just built them (3.4 KB), then the job's number.
     XW_FN void post_job(uint32_t seg_a, uint32_t chunk_left)
     {
-        HelpBox *hb = V.hb;
+        HelpBox *hb = V.hb;                                         // (the first box holds the job for every helper)
         const uint32_t tid = xw::thread();
         const uint32_t *pw = (const uint32_t *)L()->price, *lw = (const uint32_t *)L()->len_price, *sw = (const uint32_t *)L()->slot_price;
         for (uint32_t k = tid; k < kNumCtx * 8; k += kParserThreads) xw::st_agent((uint32_t *)hb->price + k, pw[k]);
@@ -1720,29 +1749,31 @@ struct Parser {
             acc(kAccJobs, 1);
         }
     }
-    // This stage's nodes below b0 are final; the helper started at node kHelpStart.  Returns the segment's length if the helper's
-    // nodes from b0 on were taken over (links in node_link / node_delta, the rep set after the segment in sh[12..15], the loader at
-    // the segment's end), 0 if this stage has to go on by itself.
-    XW_FN uint32_t take_over(uint32_t seg_a, uint32_t b0)
+    // This workgroup's nodes below b0 are final; helper k started at node help_start(k).  Returns the segment's length if that helper's
+    // nodes from b0 on were taken over -- the parser stage: links in node_link / node_delta, the rep set after the segment in sh[12..15],
+    // the loader at the segment's end; a helper: the nodes copied into its own box, for whoever takes IT over -- and 0 if this workgroup
+    // has to go on by itself.
+    XW_FN uint32_t take_over(uint32_t seg_a, uint32_t b0, uint32_t k)
     {
-        HelpBox *hb = V.hb;
+        HelpBox *hb = V.hb + k;
+        Hx::HelpWords *hw = &V.hx->hw[k];
         const uint32_t tid = xw::thread(), w = xw::wave();
-        const uint32_t job = L()->hj[0], V0 = b0 - 1;               // (hj[0]: written in front of many barriers)
-        // 1. is the helper beyond node V0?  It started when this stage did, 576 nodes in front of V0: if not, something held it up
-        // (records it had to wait for) -- a short wait, then the job is dropped.
+        const uint32_t job = is_helper ? myjob : L()->hj[0], V0 = b0 - 1;      // (hj[0]: written in front of many barriers)
+        // 1. is the helper beyond node V0?  It started when this workgroup did, 576 nodes in front of V0: if not, something held it up
+        // (records it had to wait for) -- a short wait, then its job is dropped.
         if (w == 0) {                                               // (the wave polls as one: readfirst)
             bool there = false;
             for (uint32_t spins = 0; spins < 256 && !there; spins++) {
-                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&V.hx->h_prog));
+                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&hw->prog));
                 there = (uint32_t)(pg >> 32) == job && ((uint32_t)pg & 0xFFFFu) > V0;
-                if (!there) { if ((xw::readfirst(xw::ld_agent(&V.hx->h_state)) >> 2) == job) break; xw::pause(); }    // (given up: it will not get there)
+                if (!there) { if ((xw::readfirst(xw::ld_agent(&hw->state)) >> 2) == job) break; xw::pause(); }    // (given up: it will not get there)
             }
             xw::after_poll();
             if (tid == 0) { L()->hj[2] = there ? 1u : 0u; L()->hj[3] = 0; }
         }
         xw::block_sync();
         bool ok = L()->hj[2] != 0;
-        // 2. the frontier: nodes V0 - 263 .. V0 (all of them the helper's: V0 - 263 > kHelpStart)
+        // 2. the frontier: nodes V0 - 263 .. V0 (all of them the helper's: V0 - 263 > help_start(k))
         if (ok) {
             if (tid < kMatchMax) {
                 const uint32_t t = V0 - tid;
@@ -1755,23 +1786,33 @@ struct Parser {
             xw::block_sync();
             ok = L()->hj[3] == 0;
         }
-        if (tid == 0) xw::st_agent(&V.hx->h_verdict, (job << 2) | (ok ? 1u : 2u));
-        if (!ok) { xw::block_sync(); return 0; }
-        // 3. until the helper is through: what it has found to be inside the segment is this stage's word to the finder stage now
-        // (a nice region that starts there waits for it, :1529)
+        if (!ok) {
+            if (tid == 0) xw::st_agent(&hw->verdict, (job << 2) | 2u);
+            xw::block_sync();
+            return 0;
+        }
+        // 3. until the helper is through: what it has found to be inside the segment is the parser stage's word to the finder stage now
+        // (a nice region that starts there waits for it, :1529); a helper passes it on in its own progress word
         if (w == 0) {
             const unsigned long long t0 = xw::clock100(), tw0 = xw::tick();
             uint32_t res = 0, cover = 0, spins = 0;
             for (;;) {
-                const uint32_t st = xw::readfirst(xw::ld_agent(&V.hx->h_state));
-                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&V.hx->h_prog));
+                const uint32_t st = xw::readfirst(xw::ld_agent(&hw->state));
+                const unsigned long long pg = xw::readfirst64(xw::ld_agent64(&hw->prog));
                 if ((uint32_t)(pg >> 32) == job) {
                     const uint32_t cv = (uint32_t)(pg >> 16) & 0xFFFFu;
-                    if (cv > cover) { cover = cv; if (tid == 0) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + cv)); }
+                    if (cv > cover) {
+                        cover = cv;
+                        if (tid == 0) {
+                            if (is_helper) xw::st_agent64(&V.hx->hw[hrole - 1].prog, ((unsigned long long)myjob << 32) | (cv << 16) | b0);
+                            else xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + cv));
+                        }
+                    }
                 }
                 if ((st >> 2) == job) { res = (st & 3u) == 1u ? 1u : 0u; break; }
                 if ((++spins & 63u) == 0) {
                     if (xw::readfirst(xw::ld_agent(&V.hx->err))) break;
+                    if (is_helper && helper_cancelled()) { hstop = 1; break; }
 #ifndef NLZM_SIM
                     if (xw::clock100() - t0 > 3000000000ull) { if (tid == 0) raise(V.hx, kErrTimeout * 100 + 6, kStParser, 6, seg_a, (uint32_t)pg, st); break; }
 #else
@@ -1785,19 +1826,33 @@ struct Parser {
             acc(kAccHelpWait, xw::tick() - tw0);
         }
         xw::block_sync();
-        if (!L()->hj[2]) { xw::block_sync(); return 0; }            // (given up behind the comparison: a segment that ends inside its last 264 + 64 nodes)
+        if (!L()->hj[2]) {                                          // (given up behind the comparison: a segment that ends inside its last 264 + 64 nodes)
+            if (tid == 0) xw::st_agent(&hw->verdict, (job << 2) | 2u);
+            xw::block_sync();
+            return 0;
+        }
         // 4. its nodes
         const uint32_t seg_len = xw::ld_agent(&hb->seg_len);
-        for (uint32_t t = b0 + tid; t <= seg_len; t += kParserThreads) {
-            L()->node_link[t] = xw::ld_agent(&hb->link[t]); L()->node_delta[t] = xw::ld_agent(&hb->delta[t]);
-            if (t < seg_len) n_cmp += xw::ld_agent(&hb->cmpw[0][t]) + xw::ld_agent(&hb->cmpw[1][t]) + xw::ld_agent(&hb->cmpw[2][t]) + xw::ld_agent(&hb->cmpw[3][t]);
+        if (is_helper) {
+            HelpBox *own = V.hb + (hrole - 1);
+            for (uint32_t t = b0 + tid; t <= seg_len; t += kParserThreads) {
+                xw::st_agent(&own->link[t], xw::ld_agent(&hb->link[t])); xw::st_agent(&own->delta[t], xw::ld_agent(&hb->delta[t]));
+                if (t < seg_len)
+                    for (uint32_t q = 0; q < 4; q++) xw::st_agent(&own->cmpw[q][t], xw::ld_agent(&hb->cmpw[q][t]));
+            }
+            xw::drain();
+        } else {
+            for (uint32_t t = b0 + tid; t <= seg_len; t += kParserThreads) {
+                L()->node_link[t] = xw::ld_agent(&hb->link[t]); L()->node_delta[t] = xw::ld_agent(&hb->delta[t]);
+                if (t < seg_len) n_cmp += xw::ld_agent(&hb->cmpw[0][t]) + xw::ld_agent(&hb->cmpw[1][t]) + xw::ld_agent(&hb->cmpw[2][t]) + xw::ld_agent(&hb->cmpw[3][t]);
+            }
+            if (w == kPW - 1) pump_seek(seg_a + seg_len);
         }
         if (tid == 0) {                                             // (uniform addresses: a per-lane one is computed early, kept, and spilled)
             L()->sh[12] = xw::ld_agent(&hb->end_rep[0]); L()->sh[13] = xw::ld_agent(&hb->end_rep[1]);
             L()->sh[14] = xw::ld_agent(&hb->end_rep[2]); L()->sh[15] = xw::ld_agent(&hb->end_rep[3]);
+            acc(kAccTaken, 1); acc(kAccTakenNodes, seg_len + 1 - b0);
         }
-        if (w == kPW - 1) pump_seek(seg_a + seg_len);
-        if (tid == 0) { acc(kAccTaken, 1); acc(kAccTakenNodes, seg_len + 1 - b0); }
         xw::block_sync();
         return seg_len;
     }
@@ -1811,7 +1866,7 @@ struct Parser {
         max_parse = umin(max_parse, kParseMax);
         const uint32_t i = xw::lane(), w = xw::wave(), tid = xw::thread();
         const uint32_t seg_q = seg_a - base;
-        const uint32_t hs = is_helper ? kHelpStart : 0u;            // the node this workgroup starts at (the helper: as if the segment began there)
+        const uint32_t hs = is_helper ? help_start(hrole - 1) : 0u; // the node this workgroup starts at (a helper: as if the segment began there)
         // A segment starts at seg_a: said BEFORE this stage asks for the position's record.  The finder stage may be waiting
         // for exactly this word at seg_a (a nice region that starts where the segment before was cut at 4,096 positions,
         // :1469: no edge spans the cut, so nothing else tells it) and the record of seg_a comes only after it.
@@ -1822,7 +1877,8 @@ struct Parser {
             bool want_help = false;
             if (V.hb && !is_helper && chunk_left >= kParseMax && prev_cut) {
                 const uint32_t posted = xw::readfirst(xw::lds_ld(&L()->hj[0]));
-                want_help = posted == 0 || (xw::readfirst(xw::ld_agent(&V.hx->h_state)) >> 2) == posted;
+                want_help = true;                                   // (every helper has to be through with the job before)
+                for (uint32_t k = 0; k < kHelpers; k++) want_help = want_help && (posted == 0 || (xw::readfirst(xw::ld_agent(&V.hx->hw[k].state)) >> 2) == posted);
                 xw::after_poll();
             }
             if (i == 0) { L()->sh[4] = err; L()->hj[1] = want_help ? 1u : 0u; }
@@ -1891,8 +1947,10 @@ struct Parser {
                 }
             }
         }
-        bool help = !is_helper && L()->hj[1] != 0;                   // (written in front of seg_tables' barrier: the same in every thread)
-        if (help) post_job(seg_a, chunk_left);
+        // (helpers: the parser stage has posted the job to all of them; a helper may take over from the ones behind it)
+        bool help = is_helper || L()->hj[1] != 0;                   // (written in front of seg_tables' barrier: the same in every thread)
+        uint32_t next_help = hrole;                                 // the first helper this workgroup has not tried to take over from
+        if (help && !is_helper) post_job(seg_a, chunk_left);
         while (!seg_len) {
             const unsigned long long ts = xw::tick();
             const unsigned long long q0 = ptick();
@@ -1905,7 +1963,7 @@ struct Parser {
                     if (((uint32_t)k & 0xFFu) == kRankLit) delta = L()->sh[9];      // the byte of position b0 - 1
                     L()->node_link[b0] = link; L()->node_delta[b0] = delta;
                     L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3;    // the model's rep set after the segment
-                    if (is_helper) { xw::st_agent(&V.hb->link[b0], link); xw::st_agent(&V.hb->delta[b0], delta); }
+                    if (is_helper) { xw::st_agent(&V.hb[hrole - 1].link[b0], link); xw::st_agent(&V.hb[hrole - 1].delta[b0], delta); }
                 }
                 seg_len = b0;
                 break;
@@ -1943,7 +2001,7 @@ struct Parser {
             // (every LDS word a lane may need is requested before the first one is looked at -- one round trip, not one per
             //  dependent condition; a lane outside the block reads some staged record and drops it)
             const unsigned long long hd_w = srec[0], w1_w = srec[1], wu_w = srec[kStageQ - 1];
-            if (is_helper && (hd_w & kStagedOwn)) rec = V.hb->relist + (a & 511u) * kTpStride;      // (re-listed by this workgroup: its own copy)
+            if (is_helper && (hd_w & kStagedOwn)) rec = V.hb[hrole - 1].relist + (a & 511u) * kTpStride;      // (re-listed by this workgroup: its own copy)
             unsigned long long sv[kEdgesPerWave];
 #pragma unroll
             for (uint32_t j = 0; j < kEdgesPerWave; j++) { const uint32_t k = edge_of(w, j); sv[j] = srec[1 + (k < kStageEdges ? k : 0u)]; }
@@ -2162,7 +2220,7 @@ struct Parser {
                     L()->ncost[node & 511u] = c;
                     if (i == istar) { L()->sh[12] = r0; L()->sh[13] = r1; L()->sh[14] = r2; L()->sh[15] = r3; }   // (the segment's last node, if it ends here)
                     if (is_helper) {                                // what the parser stage compares and takes over (sc1 stores, drained in front of the barrier below)
-                        HelpBox *hb = V.hb;
+                        HelpBox *hb = V.hb + (hrole - 1);
                         xw::st_agent(&hb->link[node], link); xw::st_agent(&hb->delta[node], delta); xw::st_agent(&hb->cost[node], c);
                         xw::st_agent128(&hb->rep_of[node * 4], r0, r1, r2, r3);
                     }
@@ -2171,7 +2229,7 @@ struct Parser {
             }
             if (w < 4 && i < done && want) n_cmp += ml + (ml < pcap);  // bytes the final probe of this slot looked at (counter parity)
             if (is_helper) {
-                if (w < 4 && inb) xw::st_agent(&V.hb->cmpw[w][node], (i < done && want) ? ml + (ml < pcap) : 0u);
+                if (w < 4 && inb) xw::st_agent(&V.hb[hrole - 1].cmpw[w][node], (i < done && want) ? ml + (ml < pcap) : 0u);
                 if (w < 4) xw::drain();
             }
             xw::block_sync();
@@ -2204,7 +2262,7 @@ struct Parser {
                     L()->mprev[t & 511u] = k;
                 }
                 if (tid == 0) {
-                    if (is_helper) xw::st_agent64(&V.hx->h_prog, ((unsigned long long)myjob << 32) | (new_end << 16) | (b0 + nb));   // (the nodes' stores: drained in front of the barrier above)
+                    if (is_helper) xw::st_agent64(&V.hx->hw[hrole - 1].prog, ((unsigned long long)myjob << 32) | (new_end << 16) | (b0 + nb));   // (the nodes' stores: drained in front of the barrier above)
                     else if (new_end != end_p) xw::st_agent64(&V.hx->p_seg, ((unsigned long long)seg_a << 32) | (seg_a + new_end));
                 }
                 if (new_end > end_open) end_open = new_end;
@@ -2213,10 +2271,10 @@ struct Parser {
                 decided = !(b0 == end_p || b0 >= max_parse);        // (the same in every thread)
                 if (decided && w == kPW - 1) decide_block(seg_a, b0, max_parse);
                 xw::block_sync();
-                // the first block border behind the helper's warm-up: are its nodes the ones this stage would compute?
-                if (help && b0 > kHelpStart + kHelpWarm) {
-                    help = false;
-                    seg_len = take_over(seg_a, b0);                 // (0: no -- this stage goes on by itself)
+                // the first block border behind the next helper's warm-up: are its nodes the ones this workgroup would compute?
+                if (help && next_help < kHelpers && !seg_len && !(b0 == end_p || b0 >= max_parse) && b0 > help_start(next_help) + kHelpWarm) {
+                    seg_len = take_over(seg_a, b0, next_help);      // (0: no -- this workgroup goes on by itself, and may try the helper behind that one)
+                    next_help++;
                 }
             }
             t_fin += ptick() - e0;
@@ -2224,17 +2282,18 @@ struct Parser {
         xw::block_sync();
         if (is_helper) {                                            // (no path, no emission: the parser stage's, if it takes the nodes over)
             if (tid == 0 && !hstop) {
-                HelpBox *hb = V.hb;
+                HelpBox *hb = V.hb + (hrole - 1);
                 xw::st_agent(&hb->seg_len, seg_len);
                 xw::st_agent(&hb->end_rep[0], L()->sh[12]); xw::st_agent(&hb->end_rep[1], L()->sh[13]);
                 xw::st_agent(&hb->end_rep[2], L()->sh[14]); xw::st_agent(&hb->end_rep[3], L()->sh[15]);
                 xw::drain();
-                xw::st_agent64(&V.hx->h_prog, ((unsigned long long)myjob << 32) | (seg_len << 16) | (seg_len + 1));
+                xw::st_agent64(&V.hx->hw[hrole - 1].prog, ((unsigned long long)myjob << 32) | (seg_len << 16) | (seg_len + 1));
             }
             ncmds = 0;
             return seg_len;
         }
-        if (help && tid == 0) xw::st_agent(&V.hx->h_verdict, (L()->hj[0] << 2) | 2u);     // (the segment ended in front of the helper's nodes: dropped)
+        if (help && tid == 0)                                       // (whatever a helper is still doing for this segment: dropped)
+            for (uint32_t k = 0; k < kHelpers; k++) xw::st_agent(&V.hx->hw[k].verdict, (L()->hj[0] << 2) | 2u);
         prev_cut = seg_len == kParseMax;
         // backtrack (:1633-1650): node indices of the path, end first
         // (A walk through LDS is one dependent round trip per command, 130-200 cycles each with seven waves at the barrier below.
@@ -2386,10 +2445,10 @@ struct Parser {
     }
 
     // ---- the helper parser's workgroup: jobs of the parser stage until that stage ends the launch ---------------------------------
-    XW_FN void run_helper(uint32_t c0)
+    XW_FN void run_helper(uint32_t c0, uint32_t k)
     {
-        is_helper = true;
-        HelpBox *hb = V.hb;
+        is_helper = true; hrole = k + 1;
+        HelpBox *hb = V.hb;                                         // (the job's parameters and prices: the first box)
         const uint32_t tid = xw::thread();
         for (uint32_t k = tid; k < sizeof(Counters) / 8; k += kParserThreads) ((unsigned long long *)&L()->cnt)[k] = 0;
         err = 0; tab_dirty = false; myjob = 0;
@@ -2426,7 +2485,7 @@ struct Parser {
                 if (tid < (kMatchMax + 8) / 2) lw[tid] = xw::ld_agent((const uint32_t *)hb->len_price + tid);
                 if (tid >= 256 && tid < 256 + 128) sw[tid - 256] = xw::ld_agent((const uint32_t *)hb->slot_price + (tid - 256));
             }
-            if (xw::wave() == kPW - 1) pump_seek(seg_a + kHelpStart);
+            if (xw::wave() == kPW - 1) pump_seek(seg_a + help_start(k));
             if (tid == 0) { L()->sh[4] = 0; acc(kAccJobs, 1); }
             xw::block_sync();
             uint32_t ncmds = 0;
@@ -2435,7 +2494,7 @@ struct Parser {
             if (tid == 0) {
                 // done: every node up to the segment's end is in the box; given up: the job was dropped, or this workgroup cannot end the segment
                 const bool done = len != 0 && !err && !hstop;
-                xw::st_agent(&V.hx->h_state, (job << 2) | (done ? 1u : 2u));
+                xw::st_agent(&V.hx->hw[k].state, (job << 2) | (done ? 1u : 2u));
                 if (done) acc(kAccTaken, 1);
                 L()->sh[4] = 0;
                 L()->hj[3] = xw::ld_agent(&V.hx->err) ? 1u : 0u;        // (another stage failed: leave)

@@ -44,6 +44,8 @@ CASES = [
     # every length behind cut ones, some ending inside the 264 + 64 positions in front of a forced cut
     ("dense_150k_w17", "dense_text", 150_000, 16, 17),
     ("denseb_250k_w18", "dense_breaks", 250_000, 17, 18),
+    # markup shaped like the wiki dumps the reference's README quotes (enwik8 / enwik9): fixed tags at slowly varying distances, digit runs
+    ("xml_400k_w19", "xml_like", 400_000, 20, 19),
 ]
 
 # larger cases: checked on the GPU box against the oracle run live (and golden sha)
@@ -52,6 +54,7 @@ BIG_CASES = [
     ("mixed_3m_w20", "mixed", 3_152_896, 0, 20),
     ("dense_3m_w20", "dense_text", 3_000_000, 18, 20),
     ("denseb_6m_w22", "dense_breaks", 6_000_000, 19, 22),
+    ("xml_5m_w23", "xml_like", 5_000_000, 21, 23),
 ]
 
 

@@ -251,7 +251,7 @@ static void role_entry(void *p)
     if (b == 0) { if (xw::wave() == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else if (b == 1) { if (xw::wave() < v2::kTW) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else if (b == 2) { if (xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
-    else if (A.V.hb && xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run_helper(A.c0); }
+    else if (A.V.hb && xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run_helper(A.c0, b - 3); }
 }
 
 int main(int argc, char **argv)
@@ -309,7 +309,7 @@ int main(int argc, char **argv)
     v2::StateV2 S; memset(&S, 0, sizeof S);
     A.V.ft = ft.data(); A.V.tp = tp.data(); A.V.tf = tf.data(); A.V.hx = hx; A.V.state = (uint32_t *)&S;
     // the helper parser (NLZM_SIM_HELPER=0: without it)
-    std::vector<uint32_t> hbmem(sizeof(v2::HelpBox) / 4 + 4);
+    std::vector<uint32_t> hbmem(v2::kHelpers * sizeof(v2::HelpBox) / 4 + 4);
     junk(hbmem);
     const bool with_helper = !(getenv("NLZM_SIM_HELPER") && atoi(getenv("NLZM_SIM_HELPER")) == 0);
     A.V.hb = with_helper ? (v2::HelpBox *)(((uintptr_t)hbmem.data() + 15) & ~(uintptr_t)15) : nullptr;
@@ -318,7 +318,7 @@ int main(int argc, char **argv)
     uint32_t abort_word = 0; WorkerCounters wc = {};
     unsigned long long unc_total = 0;
     pf.init(g.wbits, (unsigned long long)(g.nchunks / nlaunch + 2) * g.chunk_size); wk.g = g; wk.G = &G; g_workers = &wk;
-    unsigned long long lds_bytes[4] = { sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds), sizeof(v2::PLds) };
+    unsigned long long lds_bytes[5] = { sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds), sizeof(v2::PLds), sizeof(v2::PLds) };
     printf("LDS: finder %zu, table %zu, parser %zu bytes\n", sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds));
     for (uint32_t r = 0; r < nlaunch; r++) {
         const uint32_t c0 = (uint32_t)((unsigned long long)g.nchunks * r / nlaunch), c1 = (uint32_t)((unsigned long long)g.nchunks * (r + 1) / nlaunch);
@@ -338,7 +338,7 @@ int main(int argc, char **argv)
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;
-        xw::launch(4, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
+        xw::launch(3 + v2::kHelpers, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
         wk.finish();
         {   // how well do the marks of the neighbours predict the finder stage's decision at a marked position?  (NLZM_SIM_RULES=1)
             static unsigned long long tab[2][2][2] = {};   // [prev marked][next marked][decision skip]
