@@ -113,6 +113,18 @@ struct FrameMeta {
 // whose stride is the worst case (one pair per test, <= 256 tests, :777): 2 KiB per position, sized for HBM, so no allocator
 // and no overflow path exists.
 constexpr uint32_t kBtMaxPairs = 256;
+// A position's reservation in bt_pairs may be shorter than that (Globals::bt_pstride pairs; block mode: 32, a single stream: all 256): pair k
+// >= bt_pstride of a position then lives in an EXTENSION block of kBtMaxPairs - bt_pstride pairs taken from the launch's arena (bt_ext) by
+// an atomic increment of its cursor at the position's first such pair; the block's index + 1 is word 14 of the record (0: none).  32 streams
+// of a block set reserved 64 GB of pair lists for a dozen pairs at four positions in ten.
+template <class IO>
+NLZM_HD uint32_t *bt_pair_ptr(uint32_t *pairs, uint32_t pstride, uint32_t *ext, uint32_t *ext_cur, uint32_t ext_cap, uint32_t &ext_idx, uint32_t k)
+{
+    if (k < pstride) return pairs + 2 * k;
+    if (!ext_idx) ext_idx = IO::atomic_inc(ext_cur) + 1;
+    if (ext_idx > ext_cap) return nullptr;              // the arena is used up: the caller fails the launch (never silently)
+    return ext + (unsigned long long)(ext_idx - 1) * (2 * (kBtMaxPairs - pstride)) + 2 * (k - pstride);
+}
 constexpr uint32_t kBtReady = 0x80000000u;
 constexpr uint32_t kBtTag = 0x80000000u;
 constexpr uint32_t kFlagCall = 1, kFlagSkip = 2;
@@ -148,7 +160,11 @@ struct Globals {
     uint32_t workers;           // 0: BT4 runs inside the master workgroup
     uint32_t batch_a0;          // absolute position of the first byte of this launch
     uint32_t *bt_ready;         // [(a - batch_a0) * kBtRec]
-    uint32_t *bt_pairs;         // [(a - batch_a0) * 2 * kBtMaxPairs]
+    uint32_t *bt_pairs;         // [(a - batch_a0) * 2 * bt_pstride]
+    uint32_t bt_pstride;        // pairs reserved per position in bt_pairs (kBtMaxPairs: every pair fits, no extension blocks)
+    uint32_t *bt_ext;           // extension blocks of kBtMaxPairs - bt_pstride pairs
+    uint32_t *bt_ext_cur;       // blocks taken in this launch (reset with the stages' progress words)
+    uint32_t bt_ext_cap;        // blocks there are
     uint32_t *bt_flag;          // [a - batch_a0] master -> worker: kFlagCall / kFlagSkip
     const uint8_t *unc;         // [a - batch_a0] 1: whether BT4 runs at `a` is the master's call
     const uint32_t *bin_off;    // [chunk - chunk0][nheads + 1]
@@ -303,24 +319,16 @@ struct ResultSink {
     uint32_t count, best;
     uint32_t best_d = 0;
     uint32_t d0 = 0, l0 = 0, d1 = 0, l1 = 0, d2 = 0, l2 = 0, d3 = 0, l3 = 0;      // the first four record-setters, kept until the call is over
-    NLZM_HD void operator()(uint32_t d, uint32_t l)
-    {
-        if (!pairs || l <= best) return;    // only record-setters change the table
-        best = l; best_d = d;
-        // (selects: a branch per slot becomes ONE indexed access to the eight, in scratch)
-        const bool s0 = count == 0, s1 = count == 1, s2 = count == 2, s3 = count == 3;
-        d0 = s0 ? d : d0; l0 = s0 ? l : l0; d1 = s1 ? d : d1; l1 = s1 ? l : l1;
-        d2 = s2 ? d : d2; l2 = s2 ? l : l2; d3 = s3 ? d : d3; l3 = s3 ? l : l3;
-        if (count >= 4) { IO::st_agent(pairs + 2 * count, d); IO::st_agent(pairs + 2 * count + 1, l); }
-        count++;
-    }
+    const struct BtView *view = nullptr;    // (where pairs beyond the position's reservation go)
+    uint32_t ext_idx = 0;
+    NLZM_HD void operator()(uint32_t d, uint32_t l);
     // the record: quads 1..3, then quad 0 (pairs beyond the record are in memory before it)
     NLZM_HD void publish(uint32_t *rec, uint32_t tests)
     {
         if (count > 4) IO::drain();
         IO::st_quad(rec + 4, d0, l0, d1, kBtTag);
         IO::st_quad(rec + 8, l1, d2, l2, kBtTag);
-        IO::st_quad(rec + 12, d3, l3, 0u, kBtTag);
+        IO::st_quad(rec + 12, d3, l3, ext_idx, kBtTag);
         IO::st_quad(rec, kBtReady | (tests << 9) | count, best_d, count ? best : 0u, 0u);
     }
 };
@@ -330,10 +338,31 @@ struct BtView {
     const uint8_t *in;
     uint32_t *heads, *tree, *ready, *pairs;
     uint32_t batch_a0, bt_shift, wmask, tmask;
+    uint32_t pstride = kBtMaxPairs;
+    uint32_t *ext = nullptr, *ext_cur = nullptr;
+    uint32_t ext_cap = 0;
+    uint32_t *fail_word = nullptr;          // set to 3 when the extension arena is used up (Globals::abort_word)
 };
 NLZM_HD BtView bt_view(const Geom &g, const Globals &G)
 {
-    return BtView{ G.in, G.bt_heads, G.bt_tree, G.bt_ready, G.bt_pairs, G.batch_a0, g.bt_shift, g.wmask, g.bt_tmask };
+    return BtView{ G.in, G.bt_heads, G.bt_tree, G.bt_ready, G.bt_pairs, G.batch_a0, g.bt_shift, g.wmask, g.bt_tmask,
+                   G.bt_pstride, G.bt_ext, G.bt_ext_cur, G.bt_ext_cap, G.abort_word };
+}
+template <class IO>
+NLZM_HD void ResultSink<IO>::operator()(uint32_t d, uint32_t l)
+{
+    if (!pairs || l <= best) return;    // only record-setters change the table
+    best = l; best_d = d;
+    // (selects: a branch per slot becomes ONE indexed access to the eight, in scratch)
+    const bool s0 = count == 0, s1 = count == 1, s2 = count == 2, s3 = count == 3;
+    d0 = s0 ? d : d0; l0 = s0 ? l : l0; d1 = s1 ? d : d1; l1 = s1 ? l : l1;
+    d2 = s2 ? d : d2; l2 = s2 ? l : l2; d3 = s3 ? d : d3; l3 = s3 ? l : l3;
+    if (count >= 4) {
+        uint32_t *q = bt_pair_ptr<IO>(pairs, view->pstride, view->ext, view->ext_cur, view->ext_cap, ext_idx, count);
+        if (q) { IO::st_agent(q, d); IO::st_agent(q + 1, l); }
+        else if (view->fail_word) IO::st_agent(view->fail_word, 3u);
+    }
+    count++;
 }
 
 // the dry run of an `unc` position with its stores noted down by `st`
@@ -343,7 +372,8 @@ NLZM_HD void worker_bt_dry(const BtView &B, uint32_t a, uint32_t max_len, unsign
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - B.batch_a0;
-    ResultSink<IO> sink{ B.pairs + bi * (2 * kBtMaxPairs), 0, 1 };
+    ResultSink<IO> sink{ B.pairs + bi * (2 * B.pstride), 0, 1 };
+    sink.view = &B;
     uint32_t tests = 0;
     const uint32_t h4 = head == kNone ? hash4(load32u(B.in + a)) : head << B.bt_shift;     // (only h4 >> bt_shift is used)
     bt_find_and_update_st(B.heads, B.tree, B.bt_shift, B.wmask, B.tmask, B.in, a, h4, max_len, cmp, sink, tests, st);
@@ -357,7 +387,8 @@ NLZM_HD void worker_bt_call(const BtView &B, uint32_t a, uint32_t max_len, bool 
 {
     LaneCmp cmp{ &cmp_bytes };
     const unsigned long long bi = a - B.batch_a0;
-    ResultSink<IO> sink{ publish ? B.pairs + bi * (2 * kBtMaxPairs) : nullptr, 0, 1 };
+    ResultSink<IO> sink{ publish ? B.pairs + bi * (2 * B.pstride) : nullptr, 0, 1 };
+    sink.view = &B;
     uint32_t tests = 0;
     const uint32_t h4 = head == kNone ? hash4(load32u(B.in + a)) : head << B.bt_shift;
     bt_find_and_update<kWrite>(B.heads, B.tree, B.bt_shift, B.wmask, B.tmask, B.in, a, h4, max_len, cmp, sink, tests);

@@ -36,7 +36,7 @@ void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t wo
 void launch_round_open(const void *dev_pack, uint32_t nstreams, hipStream_t st);
 void launch_round_close(const void *dev_pack, uint32_t nstreams, hipStream_t st);
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
-                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st);
+                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint32_t *hbuf2, uint8_t *c1, uint8_t *unc, hipStream_t st);
 unsigned long long worker_undo_bytes_per_lane();
 unsigned long long worker_hot_undo_bytes_per_wave();
 void launch_hot_select(const uint32_t *off, uint32_t nchunks, uint32_t nheads, uint32_t hmax, uint32_t min_count, uint32_t *hot_of_bin,
@@ -107,7 +107,7 @@ struct Ctx {
                                             // time than with all eight -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
     int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
-    int64_t opt_tbits_max = 32;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
+    int64_t opt_tbits_max = 34;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
     int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
     int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
                                             // (profiles/r04_block_mode.txt): under load a stream waits for the serial chains of its busiest heads
@@ -150,9 +150,10 @@ struct Ctx {
     uint32_t batch = 0;
     // worker mode
     bool workers = false;
-    uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
+    uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr, *pf_h2 = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
     uint32_t t_bits = 0, m_bits = 0, nheads = 0;
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
+    uint32_t *bt_ext = nullptr; uint32_t pstride = kBtMaxPairs, ext_cap = 0;       // pairs reserved per position; extension blocks for the rest
     uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr, *bt_undo = nullptr, *hot_of_bin = nullptr, *hot_list = nullptr;
     unsigned long long *hot_undo = nullptr;
     uint32_t hot_max = 0;
@@ -297,14 +298,14 @@ char *thread_err() { return t_dev ? t_dev->err : nullptr; }
 void free_stream_buffers(Ctx &C)
 {
     void *ptrs[] = { C.rkhash, C.ht2, C.ht3, C.rk_table, C.bt_heads, C.bt_tree, C.persist, C.syms, C.scratch,
-                     C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_c1, C.unc,
+                     C.bits, C.frames, C.fmeta, C.dst_off, C.own_in, C.own_dst, C.pf_T, C.pf_M, C.pf_h, C.pf_h2, C.pf_c1, C.unc,
                      C.bt_ready, C.bt_pairs, C.bt_flag, C.abort_word, C.bin_off, C.bin_cur, C.bin_pos, C.wcnt, C.bt_undo, C.hot_of_bin, C.hot_list, C.hot_undo,
-                     C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx, C.v2_hb };
+                     C.v2_ft, C.v2_tp, C.v2_tf, C.v2_state, C.v2_hx, C.v2_hb, C.bt_ext };
     if (!C.pooled) for (void *p : ptrs) if (p) (void)hipFree(p);
     C.pooled = false;
     C.alt = Ctx::LaunchSet{}; C.snap = nullptr; C.set_idx = 0;      // (a second launch set only ever comes from a pool)
     C.v2_ft = C.v2_tp = C.v2_tf = C.v2_state = nullptr; C.v2_hx = nullptr; C.v2_hb = nullptr;
-    C.pf_T = C.pf_M = C.pf_h = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr;
+    C.pf_T = C.pf_M = C.pf_h = C.pf_h2 = nullptr; C.pf_c1 = C.unc = nullptr; C.bt_ready = C.bt_pairs = nullptr; C.bt_ext = nullptr;
     C.bt_flag = C.abort_word = C.bin_off = C.bin_cur = C.bin_pos = C.bt_undo = C.hot_of_bin = C.hot_list = nullptr; C.hot_undo = nullptr; C.wcnt = nullptr;
     C.rkhash = C.ht2 = C.ht3 = C.rk_table = C.bt_heads = C.bt_tree = nullptr;
     C.persist = nullptr; C.syms = C.scratch = nullptr; C.bits = C.frames = nullptr; C.fmeta = nullptr;
@@ -429,7 +430,9 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     if (C.workers) {
         const unsigned long long bpos = (unsigned long long)C.batch * g.chunk_size;
         uint32_t lg = 1; while ((1ull << lg) < bpos) lg++;
-        C.t_bits = g.wbits + 5 > 32 ? 32 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
+        // (32 slots per window position: a slot taken by another 65-gram of the window is a false mark.  Up to 2^33 slots -- 32 GiB for the 1e9-byte
+        //  stream at -window:28, which had the 32-bit hash's 2^32 until round 5: 6 % false marks at depth instead of 3 %)
+        C.t_bits = g.wbits + 5 > 33 ? 33 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
         {   // (... and by the input: 2^tbits_per entries per position (default 16; the 1e9-byte stream at -window:28 has four, the cap): a denser table marks more
             //  positions as undecided -- 300 MB with four instead of eight entries per position waited twice as long for BT4 results;
             //  every entry is cleared when a stream begins, which is what opening a set of 32 blocks spent most of its time on)
@@ -444,11 +447,18 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         DEVFILL(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
         DEVFILL(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
         DEVALLOC(C.pf_h, bpos * 4);
+        DEVALLOC(C.pf_h2, bpos * 4);
         DEVALLOC(C.pf_c1, bpos);
         DEVALLOC(C.unc, bpos + 16);
         // hand-off arrays between workgroups (written with sc1 stores, read with sc1 loads: plain device memory)
         DEVALLOC(C.bt_ready, bpos * 4 * kBtRec);
-        DEVALLOC(C.bt_pairs, bpos * (2ull * kBtMaxPairs * 4));      // worst case, 2 KiB per position
+        // a position's pairs beyond the four in its record: the worst case (256 pairs, 2 KiB per position) reserved for a single stream; the
+        // streams of a block set reserve 32 pairs (256 bytes) and take extension blocks from an arena for the positions that have more
+        // (nlzm_core.h, bt_pair_ptr; a launch that uses the arena up fails with an error, it never drops a pair)
+        C.pstride = C.pool ? 32u : kBtMaxPairs;
+        C.ext_cap = C.pstride < kBtMaxPairs ? (uint32_t)(bpos / 64 + 1024) : 0u;
+        DEVALLOC(C.bt_pairs, bpos * (2ull * C.pstride * 4));
+        if (C.ext_cap) DEVALLOC(C.bt_ext, (size_t)C.ext_cap * (2ull * (kBtMaxPairs - C.pstride) * 4));
         DEVALLOC(C.bt_flag, bpos * 4);
         DEVALLOC(C.abort_word, 4);
         DEVALLOC(C.bin_off, (size_t)C.batch * (C.nheads + 1) * 4);
@@ -556,13 +566,14 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
     if (C.workers) {
         const unsigned long long cnt = a1 - a0;
         G.bt_ready = C.bt_ready; G.bt_pairs = C.bt_pairs; G.bt_flag = C.bt_flag; G.unc = C.unc;
+        G.bt_pstride = C.pstride; G.bt_ext = C.bt_ext; G.bt_ext_cap = C.ext_cap; G.bt_ext_cur = &C.v2_hx->ext_cur;
         G.bin_off = C.bin_off; G.bin_pos = C.bin_pos; G.nheads = C.nheads; G.wthreads = C.run_worker_threads;
         G.abort_word = C.abort_word; G.wcnt = C.wcnt; G.bt_undo = C.bt_undo;
         HIPCHK(hipMemsetAsync(C.bt_ready, 0, cnt * 4 * kBtRec, C.st));
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
         HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
         HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
-        launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h,
+        launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h, C.pf_h2,
                          C.pf_c1, C.unc, C.st);
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
         if (C.hot_max) {
@@ -642,6 +653,8 @@ int step_post_check(Ctx &C, const StepPlan &P)
                        h.dbg[2][0], h.dbg[2][1], h.dbg[2][2], h.dbg[2][3], h.dbg[2][4], h.dbg[2][5], h.dbg[2][6],
                        wc.stuck_lanes, wc.stuck_lanes ? (uint32_t)~(uint32_t)wc.stuck_pos_inv : 0u);
     }
+    if (aborted == 3) return set_err(NLZM_HIP_E_KERNEL, "the extension arena of the BT4 pair lists (%u blocks per launch) was used up in chunks [%u,%u): more positions with over %u "
+                                     "record-setters than a block set reserves for", C.ext_cap, c0, c1, C.pstride);
     if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
     if (Pst.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", Pst.next_chunk, c1);
     unsigned long long pos = C.out_pos;

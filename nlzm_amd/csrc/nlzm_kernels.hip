@@ -22,7 +22,10 @@ namespace nlzm {
 
 // LDS image of the three-stage pipeline (nlzm_v2.h): every block of pipeline2_kernel has ONE role, so the roles share
 // the bytes.  A file-scope __shared__ object: every access is a ds_* instruction.
-constexpr uint32_t kAhead = 3;                      // calls a worker lane may have made whose fate is not decided yet
+#ifndef NLZM_AHEAD
+#define NLZM_AHEAD 3
+#endif
+constexpr uint32_t kAhead = NLZM_AHEAD;             // calls a worker lane may have made whose fate is not decided yet
 constexpr uint32_t kEntryWords = 16;                // LDS words per such call: eight of record-setters, eight of bookkeeping
 union V2Lds {
     v2::FLds f; v2::TLds t; v2::PLds p;
@@ -79,12 +82,19 @@ __global__ __launch_bounds__(256) void rk_hash_kernel(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPfLen = 65;
 constexpr uint32_t kPfMul = 0x9E3779B1u, kPfMul2 = 0x85EBCA77u;
+// the table's slot of a 65-gram: up to 2^32 slots from its 32-bit hash; more (a window of 2^28 positions wants 2^33: one slot in 32 taken,
+// and every slot that is taken by another 65-gram of the window is a false mark) from a second hash beside it
+__device__ __forceinline__ unsigned long long pf_slot(uint32_t h, uint32_t h2, uint32_t t_bits)
+{
+    if (t_bits <= 32) return (h * kPfMul) >> (32 - t_bits);
+    return ((((unsigned long long)h2 << 32) | h) * 0x9E3779B97F4A7C15ull) >> (64 - t_bits);
+}
 
 __global__ __launch_bounds__(256) void prefilter_hash_kernel(const uint8_t *__restrict__ in, unsigned long long n,
                                                              uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
                                                              uint32_t m_bits, const uint32_t *__restrict__ T,
                                                              uint32_t *__restrict__ M, uint32_t *__restrict__ hbuf,
-                                                             uint8_t *__restrict__ c1)
+                                                             uint32_t *__restrict__ hbuf2, uint8_t *__restrict__ c1)
 {
     __shared__ uint8_t tile[1024 + kPfLen + 15];
     const unsigned long long blk0 = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 1024;
@@ -98,16 +108,16 @@ __global__ __launch_bounds__(256) void prefilter_hash_kernel(const uint8_t *__re
         const uint32_t o = threadIdx.x + 256u * k;
         const unsigned long long a = blk0 + o;
         if (a >= a1) continue;
-        uint32_t h = 0;
+        uint32_t h = 0, h2 = 0;
         const bool ok = a + kPfLen <= n;
         if (ok) {
 #pragma unroll 13
-            for (uint32_t j = 0; j < kPfLen; j++) h = (h + tile[o + j]) * 0x2F0FD693u;
+            for (uint32_t j = 0; j < kPfLen; j++) { h = (h + tile[o + j]) * 0x2F0FD693u; h2 = (h2 ^ tile[o + j]) * 0x01000193u + 0x7F4A7C15u; }
         }
-        hbuf[a - a0] = h;
+        hbuf[a - a0] = h; hbuf2[a - a0] = h2;
         uint8_t f = 0;
         if (ok) {
-            const uint32_t t = T[(h * kPfMul) >> (32 - t_bits)];
+            const uint32_t t = T[pf_slot(h, h2, t_bits)];
             f = t != 0 && (uint32_t)a - (t - 1) <= wmask;
             atomicMin(&M[(h * kPfMul2) >> (32 - m_bits)], (uint32_t)a);
         }
@@ -133,12 +143,13 @@ __global__ __launch_bounds__(256) void prefilter_mark_kernel(unsigned long long 
 
 __global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long long n, uint32_t a0, uint32_t a1, uint32_t t_bits,
                                                                uint32_t m_bits, uint32_t *__restrict__ T,
-                                                               uint32_t *__restrict__ M, const uint32_t *__restrict__ hbuf)
+                                                               uint32_t *__restrict__ M, const uint32_t *__restrict__ hbuf,
+                                                               const uint32_t *__restrict__ hbuf2)
 {
     const unsigned long long a = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (a >= a1 || a + kPfLen > n) return;
     const uint32_t h = hbuf[a - a0];
-    atomicMax(&T[(h * kPfMul) >> (32 - t_bits)], (uint32_t)a + 1);
+    atomicMax(&T[pf_slot(h, hbuf2[a - a0], t_bits)], (uint32_t)a + 1);
     M[(h * kPfMul2) >> (32 - m_bits)] = kNone;
 }
 
@@ -317,6 +328,7 @@ struct LaneIO {
     {
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    static __device__ __forceinline__ uint32_t atomic_inc(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     // every write-through store of this wave has completed (inline asm: the compiler
     // may not drop or move it, cf. guide "Compiler hazard")
     static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -343,11 +355,16 @@ struct LaneSink {
     uint32_t *slot;         // LDS: this call's eight words (stride 512: the lanes' words interleave)
     uint32_t *pairs;        // bt_pairs of the position
     uint32_t count = 0, best = 1, best_d = 0;
-    __device__ __forceinline__ void operator()(uint32_t d, uint32_t l)
+    uint32_t ext_idx = 0;   // the position's extension block + 1 (pairs beyond its reservation in bt_pairs: nlzm_core.h, bt_pair_ptr)
+    __device__ __forceinline__ void put(const BtView &B, uint32_t d, uint32_t l)
     {
         best = l; best_d = d;
         if (count < 4) { slot[(2 * count) * 512] = d; slot[(2 * count + 1) * 512] = l; }
-        else { LaneIO::st_agent(pairs + 2 * count, d); LaneIO::st_agent(pairs + 2 * count + 1, l); }
+        else {
+            uint32_t *q = bt_pair_ptr<LaneIO>(pairs, B.pstride, B.ext, B.ext_cur, B.ext_cap, ext_idx, count);
+            if (q) { LaneIO::st_agent(q, d); LaneIO::st_agent(q + 1, l); }
+            else LaneIO::st_agent(B.fail_word, 3u);                 // (the launch fails: nlzm_hip.cpp reports the arena)
+        }
         count++;
     }
     __device__ __forceinline__ void publish(uint32_t *rec, uint32_t tests) const
@@ -357,7 +374,7 @@ struct LaneSink {
         const uint32_t d2 = count > 2 ? slot[4 * 512] : 0u, l2 = count > 2 ? slot[5 * 512] : 0u, d3 = count > 3 ? slot[6 * 512] : 0u, l3 = count > 3 ? slot[7 * 512] : 0u;
         LaneIO::st_quad(rec + 4, d0, l0, d1, kBtTag);
         LaneIO::st_quad(rec + 8, l1, d2, l2, kBtTag);
-        LaneIO::st_quad(rec + 12, d3, l3, 0u, kBtTag);
+        LaneIO::st_quad(rec + 12, d3, l3, ext_idx, kBtTag);
         LaneIO::st_quad(rec, kBtReady | (tests << 9) | count, best_d, count ? best : 0u, 0u);
     }
 };
@@ -407,7 +424,7 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
         if (full) l = max_len;
         cb += (l - init) + (full ? 0u : 1u);
         const uint32_t pl = (uint32_t)pp, pr = (uint32_t)(pp >> 32), d = a - sp;
-        if (l >= match_min(d) && l > sink.best) sink(d, l);         // :996-998; only record-setters change the table
+        if (l >= match_min(d) && l > sink.best) sink.put(B, d, l);  // :996-998; only record-setters change the table
         if (full) {                                                 // :1000-1004
             if (!dry) { B.tree[pend_l] = pl; B.tree[pend_r] = pr; }
             if (keep) {
@@ -477,6 +494,8 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     unsigned long long *const undo = NLZM_AS_GLOBAL(unsigned long long, p6) + ((unsigned long long)hot_index * 64 + lane) * kUndoCap;
 #undef NLZM_AS_GLOBAL
     const uint32_t batch_a0 = q0, wmask = q2, tmask = q3;
+    BtView Bx{ in, heads, tree, ready, pairs, batch_a0, 0u, wmask, tmask };         // (for LaneSink::put: where a position's later pairs go)
+    Bx.pstride = G.bt_pstride; Bx.ext = G.bt_ext; Bx.ext_cur = G.bt_ext_cur; Bx.ext_cap = G.bt_ext_cap; Bx.fail_word = G.abort_word;
     enum : uint32_t { kIdle = 0, kStart = 1, kRun = 2, kHeld = 3 };
     // the bin's entries, in order (wave-uniform)
     uint32_t c = c0, i0 = 0, e0 = 0, la_end = 0, seq_next = 1;
@@ -612,7 +631,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             if (go) {
                 sp = v_word;                                        // :983
                 pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0;
-                sink.count = 0; sink.best = 1; sink.best_d = 0; sink.pairs = pairs + (unsigned long long)(a - batch_a0) * (2 * kBtMaxPairs);
+                sink.count = 0; sink.best = 1; sink.best_d = 0; sink.ext_idx = 0; sink.pairs = pairs + (unsigned long long)(a - batch_a0) * (2 * Bx.pstride);
                 published = false;
                 undo[0] = (0x80000000u | hidx) | ((unsigned long long)(dry ? a : sp) << 32);
                 nu = 1;
@@ -652,7 +671,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 tests++;
                 cb += (l - init) + (full ? 0u : 1u);
                 const uint32_t d = a - sp;
-                if (l >= match_min(d) && l > sink.best) sink(d, l);         // :996-998
+                if (l >= match_min(d) && l > sink.best) sink.put(Bx, d, l);  // :996-998
                 if (full) { fin_now = true; fin_l = pl; fin_r = pr; }       // :1000-1004
                 else {
                     // :1006-1017.  The slot taken is marked before the store that makes its node reachable for later calls.
@@ -754,8 +773,9 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
     // (re-typed as global pointers: accesses through pointers of unknown kind would be flat ones)
 #define NLZM_AS_GLOBAL(T, x) ((T *)(__attribute__((address_space(1))) T *)(x))
-    const BtView B{ NLZM_AS_GLOBAL(const uint8_t, p0), NLZM_AS_GLOBAL(uint32_t, p1), NLZM_AS_GLOBAL(uint32_t, p2), NLZM_AS_GLOBAL(uint32_t, p3),
-                    NLZM_AS_GLOBAL(uint32_t, p4), q0, q1, q2, q3 };
+    BtView B{ NLZM_AS_GLOBAL(const uint8_t, p0), NLZM_AS_GLOBAL(uint32_t, p1), NLZM_AS_GLOBAL(uint32_t, p2), NLZM_AS_GLOBAL(uint32_t, p3),
+              NLZM_AS_GLOBAL(uint32_t, p4), q0, q1, q2, q3 };
+    B.pstride = G.bt_pstride; B.ext = G.bt_ext; B.ext_cur = G.bt_ext_cur; B.ext_cap = G.bt_ext_cap; B.fail_word = G.abort_word;   // (touched at a position's fifth pair and later: rare)
     uint32_t *const undo_base = NLZM_AS_GLOBAL(uint32_t, (unsigned long long)G.bt_undo) + (unsigned long long)gl * (kAhead * kUndoCap * 2);
 #undef NLZM_AS_GLOBAL
     bool active = gl < G.nheads && !(G.hot_of_bin && G.hot_of_bin[gl < G.nheads ? gl : 0]);        // (a hot bin has a wave of its own)
@@ -789,7 +809,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                         if (!nq) break;
                         e = my + (first * kEntryWords) * 512;
                         const uint32_t ea = e[kWa * 512], einfo = e[kWinfo * 512];
-                        LaneSink sk{ e, B.pairs + (unsigned long long)(ea - B.batch_a0) * (2 * kBtMaxPairs), e[kWcount * 512], e[kWbest * 512], e[kWbestd * 512] };
+                        LaneSink sk{ e, B.pairs + (unsigned long long)(ea - B.batch_a0) * (2 * B.pstride), e[kWcount * 512] & 0x1FFu, e[kWbest * 512], e[kWbestd * 512], e[kWcount * 512] >> 9 };
                         sk.publish(B.ready + (unsigned long long)(ea - B.batch_a0) * kBtRec, e[kWtests * 512]);
                         if (einfo & 1u) {                           // a marked position: the new oldest, unless its decision is in too, and as assumed
                             head_a = ea;
@@ -872,7 +892,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
             const unsigned long long bi = ja - B.batch_a0;
             const uint32_t slot = first + nq >= kAhead ? first + nq - kAhead : first + nq;     // (job 1: nq = 0, any slot will do)
             uint32_t *e = my + (slot * kEntryWords) * 512;
-            LaneSink sink{ e, B.pairs + bi * (2 * kBtMaxPairs) };
+            LaneSink sink{ e, B.pairs + bi * (2 * B.pstride) };
             uint32_t tests = 0, cmpb = 0, nu = 0;
             bt_descent(B, ja, jh, jlen, job == 2, (jinfo >> 28) & 1u, undo_base + slot * (kUndoCap * 2), nu, sink, tests, cmpb);
             if (job == 1) {
@@ -881,7 +901,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                 n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += tests;
             } else {
                 if (!nq) { sink.publish(B.ready + bi * kBtRec, tests); head_a = ja; t_wait0 = 0; idle = 0; }    // (the oldest: its result stands whatever is decided)
-                e[kWa * 512] = ja; e[kWtests * 512] = tests; e[kWcmp * 512] = cmpb; e[kWcount * 512] = sink.count;
+                e[kWa * 512] = ja; e[kWtests * 512] = tests; e[kWcmp * 512] = cmpb; e[kWcount * 512] = sink.count | (sink.ext_idx << 9);
                 e[kWbest * 512] = sink.best; e[kWbestd * 512] = sink.best_d; e[kWundo * 512] = nu; e[kWinfo * 512] = jinfo;
                 nq++; n_open++;
             }
@@ -948,7 +968,7 @@ __global__ __launch_bounds__(512) void pipeline2_multi_kernel(const Stream2Args 
 #define NLZM_GLOBAL_PTR(p) p = (decltype(p))(__attribute__((address_space(1))) std::remove_pointer_t<decltype(p)> *)(unsigned long long)(p)
     NLZM_GLOBAL_PTR(a.G.in); NLZM_GLOBAL_PTR(a.G.rkhash); NLZM_GLOBAL_PTR(a.G.ht2); NLZM_GLOBAL_PTR(a.G.ht3); NLZM_GLOBAL_PTR(a.G.rk_table);
     NLZM_GLOBAL_PTR(a.G.bt_heads); NLZM_GLOBAL_PTR(a.G.bt_tree); NLZM_GLOBAL_PTR(a.G.persist); NLZM_GLOBAL_PTR(a.G.syms); NLZM_GLOBAL_PTR(a.G.bits);
-    NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs);
+    NLZM_GLOBAL_PTR(a.G.fmeta); NLZM_GLOBAL_PTR(a.G.cap_words); NLZM_GLOBAL_PTR(a.G.cap_used); NLZM_GLOBAL_PTR(a.G.bt_ready); NLZM_GLOBAL_PTR(a.G.bt_pairs); NLZM_GLOBAL_PTR(a.G.bt_ext); NLZM_GLOBAL_PTR(a.G.bt_ext_cur);
     NLZM_GLOBAL_PTR(a.G.bt_flag); NLZM_GLOBAL_PTR(a.G.unc); NLZM_GLOBAL_PTR(a.G.bin_off); NLZM_GLOBAL_PTR(a.G.bin_pos); NLZM_GLOBAL_PTR(a.G.abort_word);
     NLZM_GLOBAL_PTR(a.G.progress); NLZM_GLOBAL_PTR(a.G.wcnt); NLZM_GLOBAL_PTR(a.G.bt_undo); NLZM_GLOBAL_PTR(a.G.hot_of_bin); NLZM_GLOBAL_PTR(a.G.hot_list); NLZM_GLOBAL_PTR(a.G.hot_undo);
     NLZM_GLOBAL_PTR(a.V.ft); NLZM_GLOBAL_PTR(a.V.tp); NLZM_GLOBAL_PTR(a.V.tf); NLZM_GLOBAL_PTR(a.V.hx); NLZM_GLOBAL_PTR(a.V.state); NLZM_GLOBAL_PTR(a.V.hb);
@@ -1122,14 +1142,14 @@ void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t wo
 }
 
 void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
-                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint8_t *c1, uint8_t *unc, hipStream_t st)
+                      uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint32_t *hbuf2, uint8_t *c1, uint8_t *unc, hipStream_t st)
 {
     if (a1 <= a0) return;
     const uint32_t cnt = a1 - a0;
     hipLaunchKernelGGL(prefilter_hash_kernel, dim3((cnt + 1023) / 1024), dim3(256), 0, st, in, n, a0, a1, wmask, t_bits, m_bits,
-                       T, M, hbuf, c1);
+                       T, M, hbuf, hbuf2, c1);
     hipLaunchKernelGGL(prefilter_mark_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, m_bits, M, hbuf, c1, unc);
-    hipLaunchKernelGGL(prefilter_insert_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, t_bits, m_bits, T, M, hbuf);
+    hipLaunchKernelGGL(prefilter_insert_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, t_bits, m_bits, T, M, hbuf, hbuf2);
 }
 
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,

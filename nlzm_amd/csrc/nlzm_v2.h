@@ -59,6 +59,7 @@ struct Hx {                                     // progress words, one 128-byte 
         alignas(128) unsigned long long prog;   //   helper: job << 32 | nodes it knows to be inside the segment << 16 | nodes final (HelpBox arrays valid below)
         alignas(128) uint32_t state;            //   helper: job << 2 | 1 done (seg_len, end_rep valid), 2 given up
     } hw[2];
+    alignas(128) uint32_t ext_cur;              // worker lanes: extension blocks of pair lists taken in this launch (Globals::bt_ext_cur)
     alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves (the FIRST code stays: raise())
     uint32_t err_info[7];                       // of the stage that raised it: stage (11 finder, 12 table, 13 parser), wait site, position, what it saw
     alignas(128) uint32_t dbg[4][32];           // per stage (0 finder, 1 table, 2 parser): where it was when it left because of an error
@@ -890,9 +891,12 @@ struct Table {
                 if (n >= cap) return kNone;
                 out[n++] = fr_key(a + l, d);
             }
-            const uint32_t *pairs = G.bt_pairs + bi * (2 * kBtMaxPairs);
+            const uint32_t *pairs = G.bt_pairs + bi * (2 * G.bt_pstride);
+            // (pairs beyond the position's reservation: in the extension block whose index + 1 is the record's word 14)
+            const uint32_t *extp = cnt > G.bt_pstride ? G.bt_ext + (unsigned long long)(bw[14] - 1) * (2 * (kBtMaxPairs - G.bt_pstride)) : pairs;
             for (uint32_t k = 4; k < cnt; k++) {
-                const uint32_t d = xw::ld_agent(pairs + 2 * k), l = xw::ld_agent(pairs + 2 * k + 1);
+                const uint32_t *q = k < G.bt_pstride ? pairs + 2 * k : extp + 2 * (k - G.bt_pstride);
+                const uint32_t d = xw::ld_agent(q), l = xw::ld_agent(q + 1);
                 if (l >= cap_len) continue;
                 if (n >= cap) return kNone;
                 out[n++] = fr_key(a + l, d);

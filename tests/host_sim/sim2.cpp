@@ -26,6 +26,7 @@ struct HostIO {
     static uint32_t ld_agent(const uint32_t *p) { return *p; }
     static void drain() {}
     static void st_quad(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+    static uint32_t atomic_inc(uint32_t *p) { return (*p)++; }
 };
 
 static void make_geom(uint64_t n, uint32_t hist_bits_req, uint32_t nlaunch, Geom &g)
@@ -327,14 +328,20 @@ int main(int argc, char **argv)
         unsigned long long a1 = (unsigned long long)c1 * g.chunk_size; if (a1 > (unsigned long long)n) a1 = n;
         pf.run(in.data(), (unsigned long long)n, (uint32_t)a0, (uint32_t)a1, g.wmask, unc);
         for (unsigned long long i = 0; i < a1 - a0; i++) unc_total += unc[i];
-        ready.assign((a1 - a0 + 1) * (size_t)kBtRec, 0); pairs.resize((size_t)(a1 - a0 + 1) * 2 * kBtMaxPairs); junk(pairs); flag.assign(a1 - a0 + 1, 0);
+        // (NLZM_SIM_PSTRIDE=k: k pairs reserved per position, the rest in extension blocks -- the block sets' layout)
+        const uint32_t pstride = getenv("NLZM_SIM_PSTRIDE") ? (uint32_t)atoi(getenv("NLZM_SIM_PSTRIDE")) : kBtMaxPairs;
+        static std::vector<uint32_t> ext;
+        const uint32_t ext_cap = pstride < kBtMaxPairs ? (uint32_t)((a1 - a0) + 64) : 0u;
+        ext.resize((size_t)ext_cap * 2 * (kBtMaxPairs - pstride) + 2); junk(ext);
+        G.bt_pstride = pstride; G.bt_ext = ext.data(); G.bt_ext_cap = ext_cap; G.bt_ext_cur = &hx->ext_cur;
+        ready.assign((a1 - a0 + 1) * (size_t)kBtRec, 0); pairs.resize((size_t)(a1 - a0 + 1) * 2 * pstride); junk(pairs); flag.assign(a1 - a0 + 1, 0);
         G.workers = 1; G.batch_a0 = (uint32_t)a0; G.bt_ready = ready.data(); G.bt_pairs = pairs.data(); G.bt_flag = flag.data(); G.unc = unc.data();
         G.nheads = 1u << (32 - g.bt_shift);
         G.abort_word = &abort_word; G.wcnt = &wc;
         wk.build((uint32_t)a0, (uint32_t)a1);
         wk.eager_mode = use_workers == 2;
+        memset(hx, 0, sizeof *hx);                      // (before the eager worker lanes: the extension blocks' cursor is one of its words)
         if (use_workers == 2) wk.eager();
-        memset(hx, 0, sizeof *hx);
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;

@@ -43,11 +43,12 @@ def test_stages_match_oracle_rebased_duplicates(sim, name, tmp_path):
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}])
+@pytest.mark.parametrize("env", [{"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}, {"NLZM_SIM_PSTRIDE": "5", "NLZM_SIM_POISON": "4"}])
 def test_forced_cuts_and_block_sizes(sim, env, tmp_path):
     """Segments that run into the forced cut at 4,096 positions or end just before it (records re-listed for the cut, and
     put back when the segment ends early); with the parser's blocks cut at random and every buffer the kernel does not
-    initialise itself full of junk, as both are on the device."""
+    initialise itself full of junk, as both are on the device.  Second variant: five pairs reserved per position in bt_pairs and the
+    rest of a position's BT4 pairs in extension blocks of the launch's arena (the layout of a block set's streams, nlzm_core.h)."""
     case = next(c for c in cases.CASES if c[0] == "chains_150k_w17")
     p = tmp_path / "in.bin"
     cases.make_case(case).tofile(p)
