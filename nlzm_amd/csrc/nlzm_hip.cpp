@@ -99,7 +99,10 @@ struct Ctx {
     // options
     int64_t opt_workers = 1;
     int64_t opt_batch = 32;
-    int64_t opt_worker_blocks = 60;         // + the three stage blocks: a quarter of the 256 CUs, one 512-thread block per CU.  Measured (profiles/
+    int64_t opt_worker_blocks = 240;        // + the stage blocks, one 512-thread block per CU.  Round 5: with the serial half at 400 - 460 cycles per position the
+                                            // number of worker CUs matters again at depth -- a lane's bin holds the heads h with h % lanes equal, a long call of one
+                                            // head holds up the positions of the others, and the finder stage waits: the whole 1e9-byte stream with 60 / 240
+                                            // worker CUs 459 / 412 cycles per position (BT4 results waited for: 173 / 127), 300 MB 399 / 396.  Round 3 had measured (profiles/
                                             // r03_worker_cu_sweep.log): 240 / 120 / 60 / 30 / 16 / 8 worker CUs give 3.71 / 3.72 / 3.72 / 3.70 / 3.70 / 3.63 MB/s
                                             // at 150 MB depth and 240 / 60 / 32 the same at 20 MB and 300 MB -- the lanes are there for latency, and the hot
                                             // bins have waves of their own; 60 leaves a margin and three quarters of the device to other streams

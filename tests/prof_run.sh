@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for one round (run on the GPU box through gpurun):
 #   bash tests/prof_run.sh r02
 # kernel trace + stats of the bench command, then two separate PMC passes (never combined with traces).
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$R

@@ -414,7 +414,7 @@ def test_multi_device_entry_with_two_parts_on_one_gpu(gpu):
                 lo, hi = shard.block_range(data.size, 2 * m, i)
                 assert stream == oracle_py.compress(data[lo:hi], 19), (m, i)
     finally:
-        gpu.set_option("multi_allow_same_device", 0); gpu.set_option("worker_blocks", 60)
+        gpu.set_option("multi_allow_same_device", 0); gpu.set_option("worker_blocks", 240)
     with pytest.raises(nlzm_amd.NlzmError):
         gpu.compress_blocks_multi(data, [0, 0], 1, 19)          # (listed twice without the option: refused)
 
