@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long lon
 __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ in, Geom g, uint32_t c0,
                                                    uint32_t nheads /* = bins */, uint32_t *__restrict__ off_all,
                                                    uint32_t *__restrict__ cur_all, uint32_t *__restrict__ pos_all,
-                                                   const uint8_t *__restrict__ unc, uint32_t batch_a0)
+                                                   const uint8_t *__restrict__ unc, uint32_t batch_a0, uint32_t lds_bins)
 {
     const uint32_t ci = c0 + blockIdx.x;
     uint32_t *off = off_all + (unsigned long long)blockIdx.x * (nheads + 1);
@@ -200,9 +200,10 @@ __global__ __launch_bounds__(1024) void bin_kernel(const uint8_t *__restrict__ i
     for (uint32_t h = lo; h < hi; h++) { const uint32_t v = off[h]; off[h] = run; cur[h] = run; run += v; }
     __syncthreads();
     // stable scatter, 1024 positions at a time
-    constexpr uint32_t kBinsInLds = 12288;
-    __shared__ uint32_t lcur[kBinsInLds];
-    if (nheads <= kBinsInLds) {
+    // (the cursors' LDS is sized by the launch: 4 bytes per bin, up to 36,864 bins = 144 KB -- 240 worker CUs x 128 lanes are 30,720 bins, which
+    //  the 48 KB of round 4 did not hold: the comparison path below took 6 ms per launch instead of 1.3)
+    extern __shared__ uint32_t lcur[];
+    if (nheads <= lds_bins) {
         // The cursors live in LDS.  A wave ranks its 64 positions among those of the same bin (one round of ballots per distinct
         // bin in the wave); the waves then take their places in the bins one after the other, which keeps a bin's positions
         // ascending -- 16 short steps per 1024 positions instead of a 1024-step comparison loop per position.
@@ -1156,7 +1157,11 @@ void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks,
                 uint32_t *pos, const uint8_t *unc, uint32_t batch_a0, hipStream_t st)
 {
     if (!nchunks) return;
-    hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), 0, st, in, g, c0, nheads, off, cur, pos, unc, batch_a0);
+    constexpr uint32_t kBinsInLdsMax = 36864;
+    const uint32_t lds_bins = nheads <= kBinsInLdsMax ? nheads : 0u;
+    // (more than the default 64 KB of dynamic LDS has to be allowed for the function, on the current device)
+    (void)hipFuncSetAttribute((const void *)bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kBinsInLdsMax * 4));
+    hipLaunchKernelGGL(bin_kernel, dim3(nchunks), dim3(1024), lds_bins * 4, st, in, g, c0, nheads, off, cur, pos, unc, batch_a0, lds_bins);
 }
 
 void launch_hot_select(const uint32_t *off, uint32_t nchunks, uint32_t nheads, uint32_t hmax, uint32_t min_count, uint32_t *hot_of_bin,

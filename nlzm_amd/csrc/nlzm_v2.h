@@ -418,14 +418,22 @@ struct Finder {
         uint32_t cl[3] = { 0, 0, 0 };
         L->njobs = 0;
         xw::wave_sync();
+        // (the sixteen bytes of all three candidates are requested before any of them is looked at: ONE round trip to memory for the block --
+        //  with the second eight bytes requested only behind a first eight that matched, a block paid up to six dependent ones)
+        unsigned long long cx0[3], cx1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            cx0[k] = cd[k] ? load64u(cur - cd[k]) : 0ull;
+            cx1[k] = cd[k] ? load64u(cur - cd[k] + 8) : 0ull;
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             if (!cd[k]) continue;
-            const unsigned long long x0 = load64u(cur - cd[k]) ^ own0;
+            const unsigned long long x0 = cx0[k] ^ own0;
             uint32_t l;
             if (x0) l = (uint32_t)__builtin_ctzll(x0) >> 3;
             else {
-                const unsigned long long x1 = load64u(cur - cd[k] + 8) ^ own1;
+                const unsigned long long x1 = cx1[k] ^ own1;
                 l = x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
             }
             if (l >= cap) l = cap;
@@ -552,7 +560,10 @@ struct Finder {
             uint32_t spins = 0;
             if (bt_wait) xw::need_bt(G.hook_user, a);
             for (;;) {
-                uint32_t w0 = bt_wait ? xw::ld_agent(G.bt_ready + bi * kBtRec) : kBtReady;
+                // (quad 0 of the record in one load: the ready word and the longest pair behind it -- they were two dependent round trips)
+                xw::u32x4 q0 = { kBtReady, 0u, 0u, 0u };
+                if (bt_wait) q0 = xw::ld_agent128(G.bt_ready + bi * kBtRec);
+                const uint32_t w0 = q0.x;
                 if (spins == 0) {       // (accounting: whose results are not there when the block asks first)
                     const unsigned long long late = xw::ballot(!(w0 & kBtReady));
                     n_late_unc += (uint32_t)__builtin_popcountll(late & xw::ballot(unc));
@@ -569,7 +580,7 @@ struct Finder {
                     if (bt_wait) {
                         bt_n = w0 & 0x1FFu;
                         if (bt_n) {
-                            const uint32_t d = xw::ld_agent(G.bt_ready + bi * kBtRec + 1), l = xw::ld_agent(G.bt_ready + bi * kBtRec + 2);   // (quad 0: with the ready word)
+                            const uint32_t d = q0.y, l = q0.z;
                             if (l >= cap) od = umin(od, d); else ec = umax(ec, a + l);
                         }
                     }

@@ -107,6 +107,16 @@ XW_FN void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t
     const u4 v = { a, b, c, d };
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"((__attribute__((address_space(1))) uint32_t *)p), "v"(v) : "memory");
 }
+// sixteen bytes (16-byte aligned) in ONE sc1 load: a record quad as its writer's one store left it (the wait is part of it: the compiler
+// does not count an asm load)
+struct u32x4 { uint32_t x, y, z, w; };
+XW_FN u32x4 ld_agent128(const uint32_t *p)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"((const __attribute__((address_space(1))) uint32_t *)p) : "memory");
+    return u32x4{ v.x, v.y, v.z, v.w };
+}
 XW_FN void atomic_or_agent(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 XW_FN void atomic_add64_agent(unsigned long long *p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // *p = v if *p == expect; returns what was there
@@ -237,6 +247,8 @@ inline uint32_t ld_agent(const uint32_t *p) { return *(volatile const uint32_t *
 inline void st_agent64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline unsigned long long ld_agent64(const unsigned long long *p) { return *(volatile const unsigned long long *)p; }
 inline void st_agent128(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+struct u32x4 { uint32_t x, y, z, w; };
+inline u32x4 ld_agent128(const uint32_t *p) { const volatile uint32_t *q = p; return u32x4{ q[0], q[1], q[2], q[3] }; }
 inline void atomic_or_agent(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_add64_agent(unsigned long long *p, unsigned long long v) { *p += v; }
 inline uint32_t cas_agent(uint32_t *p, uint32_t expect, uint32_t v) { const uint32_t o = *p; if (o == expect) *p = v; return o; }
