@@ -234,6 +234,10 @@ struct Finder {
     // in the middle of the NEXT block (in front of its wait for the worker lanes' results), where the stores have long landed -- and in
     // front of anything else this stage may wait for, since the stages behind it may be what that wait depends on.
     uint32_t pend_fpos = 0;         // nonzero: records up to here are stored, f_pos does not say so yet
+    // the own loads of the block that starts at pf_a0, requested when the block before it ended
+    uint32_t pf_a0 = kNone, pf_rkh = 0;
+    unsigned long long pf_own0 = 0, pf_own1 = 0;
+    uint8_t pf_unc = 0;
     XW_FN void flush_fpos()
     {
         if (!pend_fpos) return;
@@ -338,13 +342,23 @@ struct Finder {
         }
 
         const unsigned long long f1 = ptick();
-        // ---- loads that the position alone addresses
+        // ---- loads that the position alone addresses: requested at the END of the block before (its cut fixes this block's first position), so
+        // that their round trip passes behind that block's commit and this block's prediction; the RK256 slot, which hangs on the hash, goes out
+        // at once and is used after the HT rows
         uint32_t v4 = 0;
         unsigned long long own0 = 0, own1 = 0;
-        if (in_blk) { own0 = load64u(cur); own1 = load64u(cur + 8); v4 = (uint32_t)own0; }
-        const uint32_t rkh = rk_call ? G.rkhash[a] : 0u;
+        uint32_t rkh = 0;
+        bool unc = false;
+        if (pf_a0 == a0) {
+            if (in_blk) { own0 = pf_own0; own1 = pf_own1; v4 = (uint32_t)own0; }
+            rkh = rk_call ? pf_rkh : 0u;
+            unc = in_blk && G.workers && pf_unc != 0;
+        } else {
+            if (in_blk) { own0 = load64u(cur); own1 = load64u(cur + 8); v4 = (uint32_t)own0; }
+            rkh = rk_call ? G.rkhash[a] : 0u;
+            unc = in_blk && G.workers && G.unc[bi] != 0;
+        }
         uint32_t rkv = rk_call ? G.rk_table[rkh >> g.rk_shift] : 0u;
-        const bool unc = in_blk && G.workers && G.unc[bi] != 0;
         const bool bt_call = call_full && avail >= 4 && G.workers;
 
         const unsigned long long f2 = ptick();
@@ -687,6 +701,16 @@ struct Finder {
             n_cmp += xw::readfirst(c);
         }
         pend_fpos = a0 + m;                                         // (said by flush_fpos)
+        // the next block's own loads (same chunk: same lookahead end)
+        pf_a0 = kNone;
+        if (a0 + m < a1) {
+            pf_a0 = a0 + m;
+            const uint32_t na = pf_a0 + i;
+            const bool nin = na < a1;
+            pf_own0 = nin ? load64u(G.in + na) : 0ull; pf_own1 = nin ? load64u(G.in + na + 8) : 0ull;
+            pf_rkh = (nin && la_end - na >= 256) ? G.rkhash[na] : 0u;
+            pf_unc = (nin && G.workers) ? G.unc[(unsigned long long)(na - G.batch_a0)] : (uint8_t)0;
+        }
         xw::trace(2, a0, n, m, reach, s_active, s_d, s_end);
         {
             const unsigned long long f8 = ptick();
@@ -749,8 +773,9 @@ struct Finder {
         }
         flush_fpos();
         xw::wave_sync();
-        for (uint32_t k = i; k < 4096; k += 64) G.ht2[k] = L->ht2[k];
-        for (uint32_t k = i; k < ht3_rows; k += 64) G.ht3[k] = L->ht3[k];
+        // (opaque: or the 64 store addresses are computed when the launch begins, kept through it, and one of them spilled)
+        for (uint32_t k = xw::opaque(i); k < 4096; k += 64) G.ht2[k] = L->ht2[k];
+        for (uint32_t k = xw::opaque(i); k < ht3_rows; k += 64) G.ht3[k] = L->ht3[k];
         if (i == 0) {
             P->reb_base = base;
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
