@@ -289,7 +289,10 @@ def xml_like(size: int, seed: int = SEED) -> np.ndarray:
 
 # ---- real text: source files that are part of the image (the same on the build container and on the GPU boxes) ------------------
 REAL_ROOTS = [("/usr/lib/python3.10", (".py",)), ("/usr/lib/python3/dist-packages", (".py",)), ("/opt/rocm/include", (".h", ".hpp")),
-              ("/usr/include", (".h", ".hpp")), ("/usr/local/lib/python3.10/dist-packages", (".py", ".pyi", ".h", ".hpp", ".rst"))]
+              ("/usr/include", (".h", ".hpp"))] + [
+    # (the installed packages that the build container and the GPU boxes both have, named one by one: the container holds more)
+    ("/usr/local/lib/python3.10/dist-packages/" + pkg, (".py", ".pyi", ".h", ".hpp", ".rst"))
+    for pkg in ("torch", "sympy", "pandas", "scipy", "plotly", "triton", "numpy", "sqlalchemy", "matplotlib", "networkx", "pygments", "fontTools", "libcst")]
 
 
 def real_text(size: int, seed: int = SEED) -> np.ndarray:

@@ -22,6 +22,9 @@ namespace nlzm {
 
 // LDS image of the three-stage pipeline (nlzm_v2.h): every block of pipeline2_kernel has ONE role, so the roles share
 // the bytes.  A file-scope __shared__ object: every access is a ds_* instruction.
+#ifndef NLZM_LPW
+#define NLZM_LPW 64
+#endif
 #ifndef NLZM_AHEAD
 #define NLZM_AHEAD 3
 #endif
@@ -756,15 +759,21 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
 // Per call, in LDS (interleaved by thread): the first four record-setters and what the lane needs to publish or drop it.
 __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t wblocks, uint32_t wblock)
 {
-    if (threadIdx.x >= G.wthreads) {
+    // The bin-taking lanes sit on the first NLZM_LPW lanes of the block's first waves: the lanes of a wave run their calls in lockstep, so a
+    // lane that gets something to do waits for the longest call its wave is busy with -- the fewer lanes share a wave, the shorter.
+    constexpr uint32_t kLpw = NLZM_LPW;
+    const uint32_t lane_waves = (G.wthreads + kLpw - 1) / kLpw;
+    if ((threadIdx.x >> 6) >= lane_waves) {
         // the waves behind the bin-taking lanes: one hot bin each (hot bin k: wave k / wblocks of worker block k % wblocks)
         if (!G.hot_list) return;
-        const uint32_t k = ((threadIdx.x - G.wthreads) >> 6) * wblocks + wblock;
+        const uint32_t k = ((threadIdx.x >> 6) - lane_waves) * wblocks + wblock;
         if (k >= G.hot_list[0]) return;
         worker_role_hot(g, G, c0, c1, G.hot_list[1 + k], k);
         return;
     }
-    const uint32_t gl = wblock * G.wthreads + threadIdx.x;
+    const uint32_t lane_in_block = (threadIdx.x >> 6) * kLpw + (threadIdx.x & 63u);
+    const bool takes_bin = (threadIdx.x & 63u) < kLpw && lane_in_block < G.wthreads;
+    const uint32_t gl = wblock * G.wthreads + (takes_bin ? lane_in_block : 0u);
     // What a descent touches, as values of this role (made opaque): left as kernel arguments, the compiler re-loads them
     // from the argument segment inside the test loop -- two 64-byte scalar loads and their waits per test -- rather than keep them.
     unsigned long long p0 = (unsigned long long)G.in, p1 = (unsigned long long)G.bt_heads, p2 = (unsigned long long)G.bt_tree,
@@ -779,7 +788,7 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
     B.pstride = G.bt_pstride; B.ext = G.bt_ext; B.ext_cur = G.bt_ext_cur; B.ext_cap = G.bt_ext_cap; B.fail_word = G.abort_word;   // (touched at a position's fifth pair and later: rare)
     uint32_t *const undo_base = NLZM_AS_GLOBAL(uint32_t, (unsigned long long)G.bt_undo) + (unsigned long long)gl * (kAhead * kUndoCap * 2);
 #undef NLZM_AS_GLOBAL
-    bool active = gl < G.nheads && !(G.hot_of_bin && G.hot_of_bin[gl < G.nheads ? gl : 0]);        // (a hot bin has a wave of its own)
+    bool active = takes_bin && gl < G.nheads && !(G.hot_of_bin && G.hot_of_bin[gl < G.nheads ? gl : 0]);        // (a hot bin has a wave of its own)
     uint32_t c = c0;
     bool loaded = false;
     uint32_t i0 = 0, e0 = 0;

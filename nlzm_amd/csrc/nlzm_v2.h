@@ -214,6 +214,7 @@ struct Finder {
     uint32_t err;
     uint32_t dbg_a = 0;         // start of the block being evaluated (error dump)
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
+    unsigned long long n_cmp_lane = 0;          // bytes compared, per lane
     unsigned long long t_wait, t_wait_bt = 0, t_total;
     uint32_t n_late_unc = 0, n_late_other = 0, n_late_hot = 0, n_late_first = 0, n_late_blocks = 0;
     unsigned long long t_f[8] = {};             // profile build: cycles per section of block()
@@ -695,11 +696,7 @@ struct Finder {
         n_ht += (unsigned long long)__builtin_popcountll(xw::ballot(fin && ht_call));
         n_rkp += (unsigned long long)__builtin_popcountll(xw::ballot(fin && rk_probe));
         n_rki += (unsigned long long)__builtin_popcountll(xw::ballot(fin && rk_call && (q & 255u) == 0));
-        {
-            uint32_t c = fin ? cmpb : 0u;
-            for (uint32_t d = 32; d; d >>= 1) c += xw::shfl(c, i ^ d);
-            n_cmp += xw::readfirst(c);
-        }
+        n_cmp_lane += fin ? cmpb : 0u;                              // (summed over the lanes once, when the launch ends: six dependent shuffles per block otherwise)
         pend_fpos = a0 + m;                                         // (said by flush_fpos)
         // the next block's own loads (same chunk: same lookahead end)
         pf_a0 = kNone;
@@ -772,6 +769,8 @@ struct Finder {
             }
         }
         flush_fpos();
+        for (uint32_t d = 32; d; d >>= 1) n_cmp_lane += xw::shfl64(n_cmp_lane, i ^ d);
+        n_cmp += xw::readfirst64(n_cmp_lane);
         xw::wave_sync();
         // (opaque: or the 64 store addresses are computed when the launch begins, kept through it, and one of them spilled)
         for (uint32_t k = xw::opaque(i); k < 4096; k += 64) G.ht2[k] = L->ht2[k];
