@@ -92,7 +92,8 @@ def load_library() -> C.CDLL:
     lib.nlzm_hip_stream_finish.argtypes = [u64p]
     lib.nlzm_hip_get_stats.argtypes = [C.POINTER(Stats)]
     lib.nlzm_hip_get_timing.argtypes = [C.POINTER(Timing)]
-    lib.nlzm_hip_get_counter.argtypes = [C.c_char_p, u64p]
+    if hasattr(lib, "nlzm_hip_get_counter"):       # (absent from older diagnostic builds loaded through NLZM_LIB)
+        lib.nlzm_hip_get_counter.argtypes = [C.c_char_p, u64p]
     lib.nlzm_hip_rans_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_uint64, C.c_void_p]
     lib.nlzm_hip_find_matches.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p,

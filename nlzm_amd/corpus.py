@@ -372,7 +372,39 @@ def dense_breaks(size: int, seed: int = SEED) -> np.ndarray:
     return out
 
 
-_GENS = {"xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def u16_cut(size: int, seed: int = SEED) -> np.ndarray:
+    """Matches that RK256 finds where its compare is ended by the uint16 length parameter (NLZM.cpp:760, :1096) after 90 - 257 bytes:
+    `la_end - p` is then just above 65,536, which happens at the chunk offsets 56,840 - 57,007 of every chunk (chunk_size 122,368, feed
+    122,633).  Such an entry is shorter than the match it stands for, and when it is the table's longest entry the next position extends
+    it again (:1503-1512) -- real text does this once in ~100 MB.  For RK256 to be the finder that meets the match, BT4
+    must be off (a nice region of ANOTHER match A that is still >= 64 long where the match B begins) and the HT rows stale (the matches
+    are over four symbols only: every 2- and 3-gram was seen a few bytes ago).  Per trial t: source B = Y + Z in chunk 0 at a place that
+    puts one of its 256-aligned RK windows on the wanted position, source A = X + Y in chunk 1 (placed so that none of ITS aligned windows
+    lies inside the match: RK256 would carry A over the hit and not probe, :1090), target X + Y + Z in chunk t + 2 so that B's window falls on
+    an offset of the zone, 12 / 20 / 28 bytes behind the start of Y: A has 88 / 80 / 72 bytes left there (nice, and shorter than what the
+    uint16 leaves of B), and the position is a multiple of 8 from the target's start, where its segment begins (between the matches the
+    bytes match nothing, every segment is one literal) -- nice positions call the finders at every eighth position of the segment (:1514)."""
+    C, FEED = 122_368, 122_633
+    rng = np.random.default_rng(seed ^ 0x16C07)
+    sym = np.frombuffer(b"acgt", dtype=np.uint8)
+    out = rng.integers(0, 256, size=size, dtype=np.uint8)
+    trials = min(max(0, size // C - 3), 48)
+    for t in range(trials):
+        X = sym[rng.integers(0, 4, size=300)]; Y = sym[rng.integers(0, 4, size=100)]; Z = sym[rng.integers(0, 4, size=900)]
+        cap = 90 + (t * 37) % 168                           # what the uint16 leaves of the lookahead at the hit
+        hit = (t + 2) * C + (FEED - 65_536 - cap)           # absolute position of the RK256 hit
+        lead = 12 + 8 * (t % 3)                             # ... that many bytes behind the start of Y in the target
+        tgt = hit - lead - 300
+        win = 256 * (40 + 8 * t)                            # B's window (256-aligned start, chunk 0: every position calls there)
+        src_b = win - lead
+        src_a = C + 2048 + 1024 * t + 56                    # (A's aligned windows start 200 bytes into the match: none has 256 bytes of it)
+        out[src_b:src_b + 1000] = np.concatenate([Y, Z])
+        out[src_a:src_a + 400] = np.concatenate([X, Y])
+        out[tgt:tgt + 1300] = np.concatenate([X, Y, Z])
+    return out
+
+
+_GENS = {"u16_cut": u16_cut, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

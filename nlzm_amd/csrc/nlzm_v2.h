@@ -209,6 +209,7 @@ struct Finder {
     uint32_t reach;             // largest absolute end of a closed table entry
     uint32_t s_active, s_d, s_end, s_seen;
     uint32_t rk_from, rk_to, rk_len, rk_end;
+    uint32_t rk_cut = 0;        // the carried RK256 match is shorter than the bytes agree: the uint16 length parameter ended its compare (:760, :1096)
     uint32_t prev_nice, seg_s;
     uint32_t t_pos_seen;
     uint32_t err;
@@ -515,9 +516,18 @@ struct Finder {
         }
 
         // ---- RK256 (:1055-1113)
+        // An RK256 entry whose compare the uint16 length parameter ended (`la_end - p` just above a multiple of 65,536: chunk offsets 56,833 - 57,080
+        // at 122,368-byte chunks) is SHORTER than the bytes agree.  Where it is the table's longest entry, the next position extends it again
+        // (:1503-1512 extends delta[max_len], whatever found it): it becomes the growing top entry.  Where something longer stands in the table
+        // it is an ordinary closed entry.  Decided below, when the ends of everything else at this lane are known.
+        uint32_t so_d = 0, so_end = 0;                      // this lane's entry of that kind: distance, absolute end (0: none)
+        auto add_soft = [&](uint32_t d, uint32_t l) __attribute__((always_inline)) {
+            st[2 + 2 * np] = d; st[3 + 2 * np] = l; np++;
+            if (a + l > so_end || (a + l == so_end && d < so_d)) { so_d = d; so_end = a + l; }
+        };
         if (rk_call && rk_act) {
             const uint32_t d = rk_to - rk_from, l = rk_len - (q - rk_to);
-            if (l >= match_min(d)) add_pair(d, umin(l, kMatchMax));
+            if (l >= match_min(d)) { if (rk_cut && l < cap) add_soft(d, l); else add_pair(d, umin(l, kMatchMax)); }
         }
         // an aligned insert (:1109-1112) of an earlier lane rewrites the slot this lane read: cut there
         uint32_t cut_slot = 64;
@@ -532,7 +542,7 @@ struct Finder {
         }
         if (rk_dropped) cmpb += rk_l16 + 1;                             // (the bytes the reference's compare looked at)
         uint32_t cut_ev = 64, ev_d = 0, ev_l = 0;
-        bool ev_ok = false;
+        bool ev_ok = false, ev_cut = false;
         {   // the first candidate that is left is measured by the whole wave (up to 65,535 bytes: uint16 parameter, :760, :1096)
             const unsigned long long evm = xw::ballot(rk_cand && !rk_dropped);
             if (evm) {
@@ -543,9 +553,10 @@ struct Finder {
                 cut_ev = k + 1;
                 ev_ok = l >= keff && l >= match_min(kd);                        // :1099-1105 (state taken over below if lane k is final)
                 ev_d = kd; ev_l = l;
+                ev_cut = l == kav;                                              // (no mismatch: the uint16 ended it)
                 if (i == k) {
                     cmpb += l + (l < kav);
-                    if (ev_ok) add_pair(kd, umin(l, kMatchMax));
+                    if (ev_ok) { if (ev_cut && l < cap) add_soft(kd, l); else add_pair(kd, umin(l, kMatchMax)); }
                 }
             }
         }
@@ -623,10 +634,18 @@ struct Finder {
 
         const unsigned long long f6 = ptick();
         // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
-        const uint32_t pm = xw::scan_max(in_blk ? ec : 0u);                     // inclusive prefix max of the closed ends
+        const uint32_t pm = xw::scan_max(in_blk ? umax(ec, so_end) : 0u);       // inclusive prefix max of the closed ends
         uint32_t before = umax(xw::lane_below(pm, 0u), reach);
         if (i >= jc && s_active) before = umax(before, s_end);                  // the former top entry, closed
         const bool nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
+        // a cut-short RK256 entry that is longer than everything else in this lane's table grows from the next position on (the lanes in front of
+        // the first such lane hold theirs as closed entries: `before` is right for it).  As long as another entry: which of the two the table's
+        // end holds hangs on their distances (:835-852 keeps the smaller), and the other one's is not known here -- not met so far; refused.
+        const bool so_free = in_blk && so_end != 0 && od == kNone && !s_sliding;
+        const bool so_top = so_free && so_end > umax(before, ec);
+        const bool so_tie = so_free && so_end == umax(before, ec);
+        const unsigned long long stm = xw::ballot(so_top);
+        const uint32_t js = stm ? (uint32_t)__builtin_ctzll(stm) : 64u;
         const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
         const uint32_t cut_nice = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
         // a match as long as the lookahead allows becomes the growing top entry, unless one with a smaller
@@ -635,7 +654,9 @@ struct Finder {
         const unsigned long long om = xw::ballot(in_blk && od != kNone && (!s_here || od < s_d));
         const uint32_t jo = om ? (uint32_t)__builtin_ctzll(om) : 64u;
         uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
+        m = umin(m, js + 1 > 64 ? 64u : js + 1);
         if (m == 0) { fail(kErrInternal, a0, 7); return 1; }
+        if (xw::any(i < m && so_tie)) { fail(kErrInternal, a0, 9); return 1; }
         n_blocks++;
         if (m < n) {        // (why the block was cut; diagnostics)
             // (adds, not a chain of branches: the compiler turns the chain into ONE indexed access and the stage's state goes to scratch)
@@ -679,6 +700,7 @@ struct Finder {
             reach = umax(reach, pm_last);
             if (s_active && jc <= last) { reach = umax(reach, s_end); s_active = 0; }
             if (jo == last) { s_active = 1; s_d = xw::readlane(od, last); s_end = kNone; s_seen = a0 + last + xw::readlane(cap, last); }
+            else if (js == last) { s_active = 1; s_d = xw::readlane(so_d, last); s_end = kNone; s_seen = xw::readlane(so_end, last); }
             prev_nice = xw::readlane(nice_real ? 1u : 0u, last);
             const unsigned long long rkf = xw::ballot(fin && rk_call);
             if (rkf) rk_end = (a0 + (63u - (uint32_t)__builtin_clzll(rkf))) - base + 256;
@@ -686,7 +708,7 @@ struct Finder {
             // later position of the next epoch could look covered again)
             if (rk_len && xw::any(fin && rk_call && !rk_act)) rk_len = 0;
             if (ev_ok && cut_ev == m) {                                         // the RK candidate of lane m-1 was taken (:1102-1104)
-                rk_from = (a0 + last - base) - ev_d; rk_to = a0 + last - base; rk_len = ev_l;
+                rk_from = (a0 + last - base) - ev_d; rk_to = a0 + last - base; rk_len = ev_l; rk_cut = ev_cut ? 1u : 0u;
             }
         }
         // counters
@@ -731,6 +753,7 @@ struct Finder {
         s_end = xw::readfirst(S->s_end); s_seen = xw::readfirst(S->s_seen);
         prev_nice = xw::readfirst(S->prev_nice); seg_s = xw::readfirst(S->seg_s);
         rk_from = xw::readfirst(P->rk_from); rk_to = xw::readfirst(P->rk_to); rk_len = xw::readfirst(P->rk_len); rk_end = xw::readfirst(P->rk_end);
+        rk_cut = rk_len >> 31; rk_len &= 0x7FFFFFFFu;                       // (the length is at most 65,535)
         err = xw::readfirst(P->error);
         n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = n_blocks = 0;
         n_cut0 = n_cut1 = n_cut2 = n_cut3 = n_cut4 = n_cut5 = 0;
@@ -777,7 +800,7 @@ struct Finder {
         for (uint32_t k = xw::opaque(i); k < ht3_rows; k += 64) G.ht3[k] = L->ht3[k];
         if (i == 0) {
             P->reb_base = base;
-            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len; P->rk_end = rk_end;
+            P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len | (rk_cut << 31); P->rk_end = rk_end;
             S->reach = reach; S->s_active = s_active; S->s_d = s_d; S->s_end = s_end; S->s_seen = s_seen;
             S->prev_nice = prev_nice; S->seg_s = seg_s;
             // (every stage adds the counters it owns, with agent-scope atomics: the stages run on different CUs, in
@@ -821,7 +844,10 @@ struct Finder {
 // stage as a fresh pair per position.)
 // (Round 5 measured the fronts at 300 MB of text at -window:28: some position of a block holds more than 8 entries at some step of
 //  the scan in 42 % of the blocks, more than 12 in 0.23 %, more than 16 in 0.002 % -- with 16 entries a wave's two front buffers are
-//  16 KB instead of 32 KB and seven waves fit the CU's LDS where four did.)
+//  16 KB instead of 32 KB and seven waves fit the CU's LDS where four did.
+//  REAL text is different: positions with more than 16 (and more than 24) BT4 record-setters of their own are common there -- 6.8 % of
+//  its blocks went down the serial path with 16 entries, 2.9 % with 24.  Measured, same box: 24 entries x 5 waves against 16 x 7: real text 2,185 against 2,765
+//  cycles per position, the stand-in 421 against 388.)
 #ifndef NLZM_FRCAP
 #define NLZM_FRCAP 16
 #endif

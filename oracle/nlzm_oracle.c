@@ -533,6 +533,12 @@ uint32_t nlzm_oracle_rk_hash256(const uint8_t *w)
     return h;
 }
 
+/* (test diagnostics, not part of the algorithm: how often the uint16 cap of NLZM.cpp:760 -- not a mismatch, not the
+ *  lookahead, not the maximum length -- ended the compare of a match that was taken and is the table's longest entry.  Such
+ *  an entry grows again at the next position, :1503-1512; the generator corpus.u16_cut exists to make it happen.) */
+static uint64_t g_rk_u16_cuts;
+uint64_t nlzm_oracle_debug_rk_u16_cuts(void) { return g_rk_u16_cuts; }
+
 static void rk_find(enc_t *e, mtab_t *mt, uint32_t p)
 {
     rk_t *r = &e->rk;
@@ -567,6 +573,7 @@ static void rk_find(enc_t *e, mtab_t *mt, uint32_t p)
             if (l >= r->carry_len && l >= nlzm_oracle_match_min(p - sp)) {
                 mt_update(mt, p - sp, u32min(l, NLZM_MATCH_MAX));
                 r->carry_from = sp; r->carry_to = p; r->carry_len = l;
+                if (l == cap && l < u32min(e->la_end - p, NLZM_MATCH_MAX) && mt->max_len == l) g_rk_u16_cuts++;
             }
         }
     }

@@ -88,6 +88,11 @@ int nlzm_oracle_decompress(const uint8_t *src, uint64_t n,
 
 uint32_t nlzm_oracle_crc32(const uint8_t *p, uint64_t n, uint32_t crc);
 
+/* Test diagnostics: matches RK256 took whose compare the uint16 length parameter (NLZM.cpp:760) ended and that were the
+ * table's longest entry, summed over the process's compress calls so far (such an entry grows again at the next position,
+ * NLZM.cpp:1503-1512). */
+uint64_t nlzm_oracle_debug_rk_u16_cuts(void);
+
 /* Small pure functions exposed for known-answer tests. */
 const uint16_t *nlzm_oracle_log2_lut(void);                 /* 256 entries */
 uint32_t nlzm_oracle_match_min(uint32_t dist);

@@ -4,7 +4,7 @@ Each case is (name, generator kind, size, seed offset, window bits as given to t
 The edge cases are the ones SURVEY.md section 8c lists: empty input, < 2 KiB input (window
 shrinks below the decoder's minimum), exactly chunk_size +-1, EOF inside the 265-byte
 overlap, input > 2W (window rebases and the p >= W masking regime of HT/RK), long
-duplicated spans (RK carry, uint16 truncation), long runs (nice-length skip, BT4 early
+duplicated spans (RK carry, uint16 truncation -- and, corpus.u16_cut, a truncated entry that grows again), long runs (nice-length skip, BT4 early
 return), random bytes (expansion), segments that reach the forced cut at 4,096 positions or end
 just before it (the sampled lengths near the cut depend on the segment the position ends up in), a nice region that
 starts exactly at such a cut (round 2's block-mode stall: the finder stage waited for the parser's word on the segment,
@@ -46,6 +46,9 @@ CASES = [
     ("denseb_250k_w18", "dense_breaks", 250_000, 17, 18),
     # markup shaped like the wiki dumps the reference's README quotes (enwik8 / enwik9): fixed tags at slowly varying distances, digit runs
     ("xml_400k_w19", "xml_like", 400_000, 20, 19),
+    # RK256 matches whose compare the uint16 length parameter ends and that the next position extends again (NLZM.cpp:760, :1503-1512;
+    # corpus.u16_cut): the bug real text exposed in round 5, two or three of them here
+    ("u16cut_734k_w24", "u16_cut", 6 * 122_368 + 100, 22, 24),
 ]
 
 # larger cases: checked on the GPU box against the oracle run live (and golden sha)
@@ -55,6 +58,7 @@ BIG_CASES = [
     ("dense_3m_w20", "dense_text", 3_000_000, 18, 20),
     ("denseb_6m_w22", "dense_breaks", 6_000_000, 19, 22),
     ("xml_5m_w23", "xml_like", 5_000_000, 21, 23),
+    ("u16cut_4m_w24", "u16_cut", 35 * 122_368 + 5000, 23, 24),
 ]
 
 

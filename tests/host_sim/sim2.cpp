@@ -165,7 +165,10 @@ void xw::need_bt(void *, uint32_t a) { if (g_workers) g_workers->need(a); }
 void xw::trace(int what, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f, uint32_t g)
 {
     static const bool all = getenv("NLZM_SIM_TRACE") != nullptr, seg = getenv("NLZM_SIM_TRACE_SEG") != nullptr;
-    if (xw::lane() != 0) return;
+    // (NLZM_SIM_TRACE_LO / _HI: only the blocks that start in [lo, hi) -- a large input with one place of interest)
+    static const unsigned long long lo = getenv("NLZM_SIM_TRACE_LO") ? strtoull(getenv("NLZM_SIM_TRACE_LO"), nullptr, 10) : 0ull,
+                                    hi = getenv("NLZM_SIM_TRACE_HI") ? strtoull(getenv("NLZM_SIM_TRACE_HI"), nullptr, 10) : ~0ull;
+    if (xw::lane() != 0 || a < lo || a >= hi) return;
     if (what == 1 && seg) fprintf(stderr, "F region at %u: segment %u (cover %u)\n", a, b, c);
     if (what == 2 && all) fprintf(stderr, "F block a0 %u n %u m %u reach %u slider %u d %u end %u\n", a, b, c, d, e, f, g);
     if (what == 3 && all) fprintf(stderr, "T block a %u n %u\n", a, b);
@@ -189,16 +192,20 @@ struct RefTables {
     int bad = 0;
 };
 static RefTables g_ref;
+// (NLZM_SIM_CHECK_LO / _HI: the tables of the positions in [lo, hi) only -- a large input: the oracle's tables of every position would not fit)
+static unsigned long long g_check_lo = 0, g_check_hi = ~0ull;
 static void ref_on_pos(void *, uint64_t abs_pos, uint32_t max_len, const uint32_t *delta)
 {
     if (g_ref.off.size() != abs_pos) { printf("oracle positions out of order\n"); exit(2); }
     g_ref.off.push_back(g_ref.words.size());
+    if (abs_pos < g_check_lo || abs_pos >= g_check_hi) return;
     g_ref.words.push_back(max_len);
     for (uint32_t i = 2; i <= max_len; i++) g_ref.words.push_back(delta[i]);
 }
 void v2::Table::sim_on_front(void *, uint32_t a, const unsigned long long *f, uint32_t fn)
 {
     if (g_ref.bad) return;
+    if (a < g_check_lo || a >= g_check_hi) return;
     if (a >= g_ref.off.size()) { printf("table stage: position %u beyond the oracle's\n", a); g_ref.bad = 1; return; }
     const uint32_t *r = g_ref.words.data() + g_ref.off[a];
     const uint32_t max_len = r[0];
@@ -265,6 +272,8 @@ int main(int argc, char **argv)
     if (n && fread(in.data(), 1, (size_t)n, f) != (size_t)n) return 2;
     fclose(f);
     const uint32_t hb = (uint32_t)atoi(argv[2]);
+    if (getenv("NLZM_SIM_CHECK_LO")) g_check_lo = strtoull(getenv("NLZM_SIM_CHECK_LO"), nullptr, 10);
+    if (getenv("NLZM_SIM_CHECK_HI")) g_check_hi = strtoull(getenv("NLZM_SIM_CHECK_HI"), nullptr, 10);
     const int use_workers = argc > 3 ? atoi(argv[3]) : 1;
     const uint32_t nlaunch = argc > 4 ? (uint32_t)atoi(argv[4]) : 2;
 

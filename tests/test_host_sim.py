@@ -43,6 +43,26 @@ def test_stages_match_oracle_rebased_duplicates(sim, name, tmp_path):
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_rk_entry_cut_short_by_uint16_grows_again(sim, tmp_path):
+    """An RK256 match found where `la_end - p` is just above 65,536 is compared over (uint16)(la_end - p) bytes only (NLZM.cpp:760, :1096);
+    when that entry is the table's longest, the next position extends it again (:1503-1512).  The finder stage held such an entry for a
+    closed one until round 5 (real text meets it once in ~100 MB).  The case must contain the situation: the oracle
+    counts it."""
+    import ctypes
+    from tests import oracle_py
+    case = next(c for c in cases.CASES if c[0] == "u16cut_734k_w24")
+    data = cases.make_case(case)
+    L = oracle_py.lib()
+    L.nlzm_oracle_debug_rk_u16_cuts.restype = ctypes.c_uint64
+    n0 = L.nlzm_oracle_debug_rk_u16_cuts()
+    oracle_py.compress(data, case[4])
+    assert L.nlzm_oracle_debug_rk_u16_cuts() - n0 >= 2, "the case no longer contains a cut-short RK256 entry that is the table's longest"
+    p = tmp_path / "in.bin"
+    data.tofile(p)
+    r = subprocess.run([sim, str(p), str(case[4]), "2", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("env", [{"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}, {"NLZM_SIM_PSTRIDE": "5", "NLZM_SIM_POISON": "4"}])
 def test_forced_cuts_and_block_sizes(sim, env, tmp_path):
     """Segments that run into the forced cut at 4,096 positions or end just before it (records re-listed for the cut, and
