@@ -210,6 +210,9 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
  * and is given back by itself when any other allocation of the library, e.g. a single stream's, fails for lack of memory);
  * "parser_helper" (default 1: a stream gets a helper parser workgroup -- one CU more -- that parses the back of every segment that is cut
  * at 4,096 positions while the parser stage parses its front; "block_parser_helper", default 0, the same for the streams of a block set);
+ * "table_shape" (default 0: the table stage runs every launch with 16-entry fronts on seven waves or with 24-entry fronts on five, whichever the
+ * launch before it asked for -- the share of its blocks in which some position had more entries than the fronts hold decides; 1 / 2 fix the
+ * shape: source code runs ~20 % faster in the wide one, prose ~8 % faster in the narrow one);
  * "stage_report" (1: the stages' cycle accounting of
  * every finished stream, and of a block set per stream, on stderr).  There are no environment knobs.
  * None of them changes a byte of the output.  The options are read when a stream or a block set is opened

@@ -178,6 +178,8 @@ struct Globals {
     uint32_t *abort_word;       // nonzero: every role leaves its loops
     const uint32_t *progress;   // the finder stage's position (its decisions are what a worker lane may wait for)
     WorkerCounters *wcnt;
+    uint32_t table_shape;       // the table stage's shape (nlzm_v2.h): 0 by the data, 1 narrow fronts, 2 wide fronts
+    uint32_t launch_par;        // the stream's launch number & 1: a launch reads the shape from slot launch_par and leaves the next one's in the other
     void *hook_user;            // host simulation only
 };
 

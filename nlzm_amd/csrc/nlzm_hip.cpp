@@ -123,6 +123,8 @@ struct Ctx {
     int64_t opt_block_helper = 0;           // set run without one unless "block_parser_helper" says otherwise (a stream of a full device waits for its BT4 results)
     int64_t opt_multi_same = 0;             // test only ("multi_allow_same_device"): nlzm_hip_compress_blocks_multi accepts a device twice, so that its
                                             // threads, device states and gather loop run with two parts on a box with one GPU
+    int64_t opt_table_shape = 0;            // the table stage's shape ("table_shape"): 0 every launch in the shape the launch before it asked for (nlzm_v2.h, TLds), 1 always 16-entry
+                                            // fronts on seven waves, 2 always 24 entries on five
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -155,6 +157,7 @@ struct Ctx {
     bool workers = false;
     uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr, *pf_h2 = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
     uint32_t t_bits = 0, m_bits = 0, nheads = 0;
+    uint32_t v2_launch_no = 0;              // persistent launches of the open stream so far (its parity picks the table stage's shape slot)
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
     uint32_t *bt_ext = nullptr; uint32_t pstride = kBtMaxPairs, ext_cap = 0;       // pairs reserved per position; extension blocks for the rest
     uint32_t *bin_off = nullptr, *bin_cur = nullptr, *bin_pos = nullptr, *bt_undo = nullptr, *hot_of_bin = nullptr, *hot_list = nullptr;
@@ -491,6 +494,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     DEVALLOC(C.v2_hx, sizeof(v2::Hx));
     if (C.opt_helper) DEVALLOC(C.v2_hb, v2::kHelpers * sizeof(v2::HelpBox));
     DEVFILL(hipMemsetAsync(C.v2_state, 0, sizeof(v2::StateV2), C.st));
+    C.v2_launch_no = 0;
 
     if (C.double_sets) {
         if (!C.pool) return set_err(NLZM_HIP_E_ARG, "a second launch set needs a pool");
@@ -592,6 +596,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
         if (!ahead) HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
         P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state; P.V.hb = C.v2_hb;
         G.progress = &C.v2_hx->f_pos;
+        G.table_shape = (uint32_t)C.opt_table_shape; G.launch_par = (uint32_t)(C.v2_launch_no++ & 1u);
     }
     HIPCHK(hipEventRecord(P.ev[6], C.st));
     return 0;
@@ -760,8 +765,9 @@ int refresh_stats(Ctx &C)
         fprintf(stderr, "table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block (%.0f cycles per pass), mask fills %llu, probe rounds %llu, re-sampled %llu\n",
                 P.prof[6], P.prof[7], P.prof[8], n / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1),
                 (double)P.prof[24] / (double)(P.prof[13] ? P.prof[13] : 1), P.prof[9], P.prof[10], P.prof[11]);
-        fprintf(stderr, "table: blocks in which some position's front had more than 8 / 12 / 16 / 20 / 24 / %u entries at some step of the scan: %.2f / %.2f / %.2f / %.3f / %.3f / %.3f %%\n",
-                v2::kFrCap, 100.0 * P.prof[105] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[106] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[107] / (P.prof[6] ? P.prof[6] : 1),
+        fprintf(stderr, "table: %llu launches with %u-entry fronts on %u waves (the others: %u on %u), the shape changed %llu times\n", P.prof[114], v2::kFrCapWide, v2::kTWWide, v2::kFrCap, v2::kTW, P.prof[113]);
+        fprintf(stderr, "table: blocks in which some position's front had more than 8 / 12 / 16 / 20 / 24 / the launch's capacity of entries at some step of the scan: %.2f / %.2f / %.2f / %.3f / %.3f / %.3f %%\n",
+                100.0 * P.prof[105] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[106] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[107] / (P.prof[6] ? P.prof[6] : 1),
                 100.0 * P.prof[108] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[109] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[7] / (P.prof[6] ? P.prof[6] : 1));
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "finder: blocks that had to wait for a worker result: %llu (%.0f cycles each); late results of hot bins' waves %llu, late results at lane 0 (the position the block before was cut at) %llu\n",
@@ -984,7 +990,7 @@ int nlzm_hip_get_counter(const char *key, uint64_t *value)
         { "finder_blocks", 0 }, { "table_blocks", 6 }, { "parser_blocks", 8 }, { "parser_passes", 13 },
         { "finder_wait_cycles", 16 }, { "finder_total_cycles", 17 }, { "table_wait_cycles", 18 }, { "table_total_cycles", 19 },
         { "parser_wait_cycles", 20 }, { "parser_total_cycles", 21 }, { "parser_emit_cycles", 22 }, { "parser_setup_cycles", 23 }, { "parser_pass_cycles", 24 },
-        { "finder_bt_wait_cycles", 25 },
+        { "finder_bt_wait_cycles", 25 }, { "table_slow_blocks", 7 }, { "table_shape_changes", 113 }, { "table_wide_launches", 114 },
         { "helper_jobs", 96 }, { "helper_taken", 97 }, { "helper_taken_nodes", 98 }, { "helper_wait_cycles", 99 }, { "helper_jobs_done", 101 }, { "helper_blocks", 102 }, { "helper_passes", 103 },
     };
     for (const auto &e : kProf) if (!strcmp(key, e.name)) { *value = C.prof_last[e.idx]; return 0; }
@@ -1030,6 +1036,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "prefilter_bits_per_position")) { if (value < 0 || value > 8) return set_err(NLZM_HIP_E_ARG, "prefilter_bits_per_position out of range"); C.opt_tbits_per = value; return 0; }
     if (!strcmp(key, "stage_report")) { C.opt_report = value != 0; return 0; }
     if (!strcmp(key, "parser_helper")) { C.opt_helper = value != 0; return 0; }
+    if (!strcmp(key, "table_shape")) { if (value < 0 || value > 2) return set_err(NLZM_HIP_E_ARG, "table_shape out of range"); C.opt_table_shape = value; return 0; }
     if (!strcmp(key, "multi_allow_same_device")) { C.opt_multi_same = value != 0; return 0; }
     if (!strcmp(key, "block_parser_helper")) { C.opt_block_helper = value != 0; return 0; }
     if (!strcmp(key, "keep_block_pool")) { C.opt_keep_pool = value != 0; if (!value && g_jobs.empty()) blocks_close(true); return 0; }
@@ -1311,6 +1318,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         j.rc = block_ctx_init(j.c, device, wb, batch);
         j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
         j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min; j.c.opt_tbits_per = C.opt_tbits_per; j.c.opt_helper = C.opt_block_helper;
+        j.c.opt_table_shape = C.opt_table_shape;
         j.c.pool = &j.pool;
         if (!j.rc) j.rc = dev_alloc(j.c, &j.d_out, j.bound);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
@@ -1716,7 +1724,7 @@ int nlzm_hip_compress_blocks_multi(const int *devices, uint32_t ndev, uint32_t b
                 c.opt_batch = o.opt_batch; c.opt_worker_blocks = o.opt_worker_blocks; c.opt_worker_threads = o.opt_worker_threads;
                 c.opt_hot_waves = o.opt_hot_waves; c.opt_hot_min = o.opt_hot_min; c.opt_report = o.opt_report;
                 c.opt_block_threads = o.opt_block_threads; c.opt_block_hot_waves = o.opt_block_hot_waves; c.opt_block_batch = o.opt_block_batch;
-                c.opt_tbits_per = o.opt_tbits_per; c.opt_helper = o.opt_helper; c.opt_block_helper = o.opt_block_helper;
+                c.opt_tbits_per = o.opt_tbits_per; c.opt_helper = o.opt_helper; c.opt_block_helper = o.opt_block_helper; c.opt_table_shape = o.opt_table_shape;
             }
             HIPCHK(hipMalloc(&P.d_in, P.n + 512));
             HIPCHK(hipMalloc(&P.d_out, P.bound));

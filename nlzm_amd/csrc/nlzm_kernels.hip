@@ -948,8 +948,8 @@ __device__ __forceinline__ void pipeline2_roles(const Geom &g, const Globals &G,
                                                 uint32_t local_block, uint32_t wblocks)
 {
     if (local_block < kV2Roles) {
-        // finder: one wave; table: kTW waves, a block each; parser: kPW waves on the same block
-        if (threadIdx.x >= (local_block >= 2 ? v2::kParserThreads : (local_block == 1 ? 64u * v2::kTW : 64u))) return;
+        // finder: one wave; table: kTW or kTWWide waves (the shape the launch before chose), a block each; parser: kPW waves on the same block
+        if (threadIdx.x >= (local_block >= 2 ? v2::kParserThreads : (local_block == 1 ? 64u * v2::table_waves(((const v2::StateV2 *)V.state)->tb_wide[G.launch_par & 1u]) : 64u))) return;
         if (local_block == 0) { v2::Finder r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else if (local_block == 1) { v2::Table r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }
         else if (local_block == 2) { v2::Parser r; r.g = g; r.G = G; r.V = V; r.run(c0, c1); }

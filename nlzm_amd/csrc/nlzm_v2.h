@@ -124,6 +124,8 @@ struct StateV2 {
     // table: the front after the last position of the launch
     uint32_t front_n;
     uint32_t front[2 * kFrontMax];
+    uint32_t tb_wide[2];                        // the table stage's shape (0: narrow fronts, many waves; 1: wide fronts, fewer waves): launch k reads slot k & 1 and
+                                                // leaves the next launch's in the other (a wave that enters the kernel late must not meet the word its launch writes)
 };
 
 constexpr uint32_t kErrV2Front = 40;            // front overflow on the slow path (cannot happen: one entry per length)
@@ -848,25 +850,38 @@ struct Finder {
 //  REAL text is different: positions with more than 16 (and more than 24) BT4 record-setters of their own are common there -- 6.8 % of
 //  its blocks went down the serial path with 16 entries, 2.9 % with 24.  Measured, same box: 24 entries x 5 waves against 16 x 7: real text 2,185 against 2,765
 //  cycles per position, the stand-in 421 against 388.)
+// (Round 5, real text: 24 entries x 5 waves against 16 x 7, same box: real text 2,185 against 2,765 cycles per position, the stand-in 421 against 388.  Neither
+//  shape serves both, so the stage has BOTH and every launch runs in the one the launch before it asked for: the fronts live in one LDS arena that the waves
+//  divide among themselves by the shape, and the last wave to leave a launch looks at the share of blocks that went down the serial path.)
 #ifndef NLZM_FRCAP
 #define NLZM_FRCAP 16
 #endif
-constexpr uint32_t kFrCap = NLZM_FRCAP;         // entries a lane's front may have on the scan path
-
 #ifndef NLZM_KTW
 #define NLZM_KTW 7
 #endif
-constexpr uint32_t kTW = NLZM_KTW;              // waves of the stage: each takes whole blocks, in turn (a block of 64 positions takes a wave ~100,000 cycles:
+#ifndef NLZM_FRCAP_WIDE
+#define NLZM_FRCAP_WIDE 24
+#endif
+#ifndef NLZM_KTW_WIDE
+#define NLZM_KTW_WIDE 5
+#endif
+constexpr uint32_t kFrCap = NLZM_FRCAP, kFrCapWide = NLZM_FRCAP_WIDE;   // entries a lane's front may have on the scan path
+constexpr uint32_t kTW = NLZM_KTW, kTWWide = NLZM_KTW_WIDE;             // waves of the stage: each takes whole blocks, in turn (a block of 64 positions takes a wave ~100,000 cycles:
                                                 // three waves were busy 530 of 618 cycles per position at 300 MB, four 416 of 614 with the whole tail of a
                                                 // block in block order; round 5, only the carry merge in order: 4 / 5 / 6 / 7 waves 506 / 483 / 483 / 483 --
-                                                // from five waves on the stage is no longer what the pipeline waits for; 151 KB of LDS with seven)
+                                                // from five waves on the stage is no longer what the pipeline waits for)
+constexpr uint32_t kTWMax = kTW > kTWWide ? kTW : kTWWide;
+constexpr uint32_t kFrArena = (kTW * kFrCap > kTWWide * kFrCapWide ? kTW * kFrCap : kTWWide * kFrCapWide) * 2 * 64;     // 64-bit words: two buffers of 64 fronts per wave
+// a launch changes to the wide shape when more than 1 block in 64 took the serial path, and back when fewer than 1 in 512 did
+constexpr uint32_t kTbWidenShift = 6, kTbNarrowShift = 9;
+NLZM_HD uint32_t table_waves(uint32_t wide) { return wide ? kTWWide : kTW; }
 struct TWave {
-    unsigned long long fr[2][64 * kFrCap];      // key = end << 32 | ~distance, descending: end falls, distance falls
     uint32_t recs[64 * kFtStride];              // the block's finder records
     uint32_t overflow;
 };
 struct TLds {
-    TWave w[kTW];
+    unsigned long long arena[kFrArena];         // the waves' fronts: wave w, buffer b at (2w + b) * 64 * cap; key = end << 32 | ~distance, descending: end falls, distance falls
+    TWave w[kTWMax];
     unsigned long long carry[kFrontMax + 8];    // front after the last finished position
     unsigned long long tmp[2 * kFrontMax + 300];
     uint32_t carry_n;
@@ -875,6 +890,7 @@ struct TLds {
     uint32_t carry_seq;                         // ... and take the carry in that order: the block with this sequence number merges it into its fronts
     uint32_t emit_seq;                          // ... and publish their records in that order (t_out): the block with this sequence number, once it has written them
     uint32_t stop;
+    uint32_t left, sum_blocks, sum_slow;        // waves that have left the launch; their blocks, and those of them on the serial path
 };
 
 NLZM_HD unsigned long long fr_key(uint32_t e, uint32_t d) { return ((unsigned long long)e << 32) | (0xFFFFFFFFu - d); }
@@ -887,6 +903,8 @@ struct Table {
     GlobalsV2 V;
     uint32_t err;
     uint32_t p_pos_seen;
+    uint32_t fcap = kFrCap, nwaves = kTW;       // this launch's shape
+    XW_FN unsigned long long *fronts(uint32_t buf) const { return xw::lds<TLds>()->arena + (unsigned long long)(2 * xw::wave() + buf) * 64 * fcap; }
     unsigned long long n_blocks, n_slow, t_wait;
     unsigned long long n_fr8 = 0, n_fr12 = 0, n_fr16 = 0, n_fr20 = 0, n_fr24 = 0;      // blocks in which some lane's front exceeded 8 / 12 / 16 / 20 / 24 entries at some step
     unsigned long long tt0 = 0, tt1 = 0, tt2 = 0, tt3 = 0, tt4 = 0;     // profile build: gather, scan, carry merge (in block order), wait for the carry, records
@@ -1057,10 +1075,10 @@ struct Table {
         xw::wave_sync();
         const unsigned long long q0 = ptick();
         // the position's own pairs as a front
-        unsigned long long *mine = W->fr[0] + i * kFrCap;
+        unsigned long long *mine = fronts(0) + i * fcap;
         uint32_t cnt = 0;
         if (in_blk) {
-            cnt = gather(a, cap_len, r, mine, kFrCap);
+            cnt = gather(a, cap_len, r, mine, fcap);
             if (cnt == kNone) { W->overflow = 1; cnt = 0; }
             else cnt = sort_filter(mine, cnt);
         }
@@ -1070,10 +1088,10 @@ struct Table {
         for (uint32_t D = 1; D < 64; D <<= 1) {
             xw::wave_sync();
             const uint32_t ocnt = xw::shfl_up(cnt, D);
-            unsigned long long *dst = W->fr[cur ^ 1] + i * kFrCap;
-            const unsigned long long *own = W->fr[cur] + i * kFrCap;
+            unsigned long long *dst = fronts(cur ^ 1) + i * fcap;
+            const unsigned long long *own = fronts(cur) + i * fcap;
             uint32_t nn;
-            if (i >= D && in_blk) nn = merge(own, cnt, W->fr[cur] + (i - D) * kFrCap, ocnt, a + 1, dst, kFrCap);
+            if (i >= D && in_blk) nn = merge(own, cnt, fronts(cur) + (i - D) * fcap, ocnt, a + 1, dst, fcap);
             else { for (uint32_t k = 0; k < cnt; k++) dst[k] = own[k]; nn = cnt; }
             if (nn == kNone) { W->overflow = 1; nn = 0; }
             cnt = nn;
@@ -1087,10 +1105,10 @@ struct Table {
         if (!wait_lds(&L->carry_seq, seq)) { err = 1; return; }
         const unsigned long long q3 = ptick();
         const uint32_t cn = xw::readfirst(L->carry_n);
-        unsigned long long *fin_f = W->fr[cur ^ 1] + i * kFrCap;
+        unsigned long long *fin_f = fronts(cur ^ 1) + i * fcap;
         uint32_t fn = 0;
         if (in_blk) {
-            fn = merge(W->fr[cur] + i * kFrCap, cnt, L->carry, cn, a + 1, fin_f, kFrCap);
+            fn = merge(fronts(cur) + i * fcap, cnt, L->carry, cn, a + 1, fin_f, fcap);
             if (fn == kNone) { W->overflow = 1; fn = 0; }
         }
         xw::wave_sync();
@@ -1106,7 +1124,7 @@ struct Table {
         else {
             // carry out: the last position's front (every lane has finished its merge with the old one: wave_sync above)
             const uint32_t last_n = xw::readlane(fn, n - 1);
-            for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = W->fr[cur ^ 1][(n - 1) * kFrCap + k];
+            for (uint32_t k = i; k < last_n; k += 64) L->carry[k] = fronts(cur ^ 1)[(n - 1) * fcap + k];
             if (i == 0) L->carry_n = last_n;
         }
         xw::wave_sync();
@@ -1122,14 +1140,14 @@ struct Table {
         // the records are out: said in block order (t_out covers every position below it)
         if (!wait_lds(&L->emit_seq, seq)) { err = 1; return; }
         if (!slow && G.cap_words) {                                 // (stage test tap: appends to one list, so in order too)
-            for (uint32_t j = 0; j < n; j++) capture(a0 + j, W->fr[cur ^ 1] + j * kFrCap, xw::readlane(fn, j));
+            for (uint32_t j = 0; j < n; j++) capture(a0 + j, fronts(cur ^ 1) + j * fcap, xw::readlane(fn, j));
         }
         xw::wave_sync();
         if (i == 0) { xw::st_agent(&V.hx->t_out, a0 + n); xw::st_agent(&V.hx->t_pos, a0 + n); xw::lds_st(&L->emit_seq, seq + 1); }
         tt0 += q1 - q0; tt1 += q2 - q1; tt3 += q3 - q2; tt2 += q4 - q3; tt4 += ptick() - q4;
     }
 
-    // a block with a front of more than kFrCap entries: position by position (every lane runs the same loop; rare)
+    // a block with a front of more than fcap entries: position by position (every lane runs the same loop; rare)
     XW_FN void slow_block(uint32_t a0, uint32_t n, uint32_t a1, uint32_t la_end)
     {
         TLds *L = xw::lds<TLds>();
@@ -1174,16 +1192,18 @@ struct Table {
         const uint32_t a_first = (uint32_t)((unsigned long long)c0 * g.chunk_size);
         unsigned long long a_last = (unsigned long long)c1 * g.chunk_size;
         if (a_last > g.n) a_last = g.n;
+        const uint32_t wide = xw::readfirst(S->tb_wide[G.launch_par & 1u]);    // (what the launch before left; the kernel let nwaves waves in by the same word)
+        fcap = wide ? kFrCapWide : kFrCap; nwaves = table_waves(wide);
         if (w == 0) {
             const uint32_t cn = xw::readfirst(S->front_n);
             for (uint32_t k = i; k < cn; k += 64) L->carry[k] = fr_key(S->front[2 * k], S->front[2 * k + 1]);
-            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->emit_seq = 0; L->stop = 0; }
+            if (i == 0) { L->carry_n = cn; L->turn = 0; L->cursor = a_first; L->carry_seq = 0; L->emit_seq = 0; L->stop = 0; L->left = 0; L->sum_blocks = 0; L->sum_slow = 0; }
         }
         xw::block_sync();
         err = 0; n_blocks = n_slow = 0; t_wait = 0;
         const unsigned long long t_start = xw::tick();
         uint32_t p_seen = a_first, f_seen = a_first;
-        for (uint32_t seq = w; !err; seq += kTW) {
+        for (uint32_t seq = w; !err; seq += nwaves) {
             // ---- take the next block (in turn)
             const unsigned long long tw = xw::tick();
             if (!wait_lds(&L->turn, seq)) { err = 1; break; }
@@ -1229,6 +1249,21 @@ struct Table {
             const uint32_t on = xw::readfirst(L->carry_n);
             for (uint32_t k = i; k < on; k += 64) { S->front[2 * k] = fr_end(L->carry[k]); S->front[2 * k + 1] = fr_dist(L->carry[k]); }
             if (i == 0) S->front_n = on;
+        }
+        // the shape of the next launch: by the share of this launch's blocks that took the serial path (the last wave to leave sees every wave's count)
+        if (i == 0) { xw::lds_add(&L->sum_blocks, (uint32_t)n_blocks); xw::lds_add(&L->sum_slow, (uint32_t)n_slow); }
+        xw::wave_sync();                                        // (the counts, then the word that says they are there)
+        if (i == 0) {
+            if (xw::lds_inc(&L->left) + 1 == nwaves) {
+                const uint32_t nb = xw::lds_ld(&L->sum_blocks), ns = xw::lds_ld(&L->sum_slow);
+                uint32_t nxt = wide;
+                if (!wide && ns > (nb >> kTbWidenShift)) nxt = 1;
+                if (wide && ns < (nb >> kTbNarrowShift)) nxt = 0;
+                if (G.table_shape) nxt = G.table_shape - 1;        // (option `table_shape`: 1 narrow, 2 wide; 0: by the data)
+                S->tb_wide[(G.launch_par & 1u) ^ 1u] = nxt;
+                if (nxt != wide) xw::atomic_add64_agent(&G.persist->prof[113], 1ull);
+                if (wide) xw::atomic_add64_agent(&G.persist->prof[114], 1ull);
+            }
         }
     }
 };

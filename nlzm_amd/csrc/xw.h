@@ -140,6 +140,7 @@ XW_FN void lds_add64(unsigned long long *p, unsigned long long v)
 }
 XW_FN void lds_or(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_inc(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+XW_FN void lds_add(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_max(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 XW_FN uint32_t lds_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -258,6 +259,7 @@ inline void lds_min64(unsigned long long *p, unsigned long long v) { if (v < *p)
 inline void lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_inc(uint32_t *p) { return (*p)++; }
+inline void lds_add(uint32_t *p, uint32_t v) { *p += v; }
 inline void lds_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 inline void lds_st(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t lds_ld(const uint32_t *p) { return *(volatile const uint32_t *)p; }

@@ -257,7 +257,7 @@ static void role_entry(void *p)
     const LaunchArgs &A = *(const LaunchArgs *)p;
     const uint32_t b = xw::block_index();
     if (b == 0) { if (xw::wave() == 0) { v2::Finder r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
-    else if (b == 1) { if (xw::wave() < v2::kTW) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
+    else if (b == 1) { if (xw::wave() < v2::table_waves(((const v2::StateV2 *)A.V.state)->tb_wide[A.G.launch_par & 1u])) { v2::Table r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else if (b == 2) { if (xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run(A.c0, A.c1); } }
     else if (A.V.hb && xw::wave() < v2::kPW) { v2::Parser r; r.g = A.g; r.G = A.G; r.V = A.V; r.run_helper(A.c0, b - 3); }
 }
@@ -347,6 +347,7 @@ int main(int argc, char **argv)
         G.workers = 1; G.batch_a0 = (uint32_t)a0; G.bt_ready = ready.data(); G.bt_pairs = pairs.data(); G.bt_flag = flag.data(); G.unc = unc.data();
         G.nheads = 1u << (32 - g.bt_shift);
         G.abort_word = &abort_word; G.wcnt = &wc;
+        G.launch_par = r & 1u; G.table_shape = getenv("NLZM_SIM_TABLE_SHAPE") ? (uint32_t)atoi(getenv("NLZM_SIM_TABLE_SHAPE")) : 0u;
         wk.build((uint32_t)a0, (uint32_t)a1);
         wk.eager_mode = use_workers == 2;
         memset(hx, 0, sizeof *hx);                      // (before the eager worker lanes: the extension blocks' cursor is one of its words)
@@ -354,7 +355,7 @@ int main(int argc, char **argv)
         hx->f_pos = hx->t_pos = hx->t_out = hx->p_pos = (uint32_t)a0;
         hx->p_seg = ((unsigned long long)(uint32_t)a0 << 32) | (uint32_t)a0;
         A.c0 = c0; A.c1 = c1;
-        xw::launch(3 + v2::kHelpers, v2::kParserThreads > 64 * v2::kTW ? v2::kParserThreads : 64 * v2::kTW, lds_bytes, role_entry, &A);
+        xw::launch(3 + v2::kHelpers, v2::kParserThreads > 64 * v2::kTWMax ? v2::kParserThreads : 64 * v2::kTWMax, lds_bytes, role_entry, &A);
         wk.finish();
         {   // how well do the marks of the neighbours predict the finder stage's decision at a marked position?  (NLZM_SIM_RULES=1)
             static unsigned long long tab[2][2][2] = {};   // [prev marked][next marked][decision skip]
@@ -382,6 +383,7 @@ int main(int argc, char **argv)
     const double np = (double)(n ? n : 1);
     printf("finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
            P.prof[0], np / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
+    printf("table shape: %llu launches wide, changed %llu times\n", P.prof[114], P.prof[113]);
     printf("table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block, mask fills %llu, probe rounds %llu, re-sampled %llu (put back %llu)\n",
            P.prof[6], P.prof[7], P.prof[8], np / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11], P.prof[14]);
     printf("helper parser: %llu jobs posted, %llu taken over (%llu nodes), parser waited %llu sweeps for it; helper: %llu jobs seen, %llu done, %llu blocks\n",

@@ -159,6 +159,27 @@ def test_helper_parser_is_invisible_and_used(gpu):
             gpu.set_option("parser_helper", 1); gpu.set_option("batch_chunks", 32)
 
 
+def test_table_stage_shape_is_invisible_and_follows_the_data(gpu):
+    """The table stage's two shapes (16-entry fronts on seven waves, 24 on five: nlzm_v2.h TLds) must give the same bytes, forced or chosen launch by launch;
+    left alone it must go wide on source code (positions with more BT4 record-setters than 16 in one block out of ten) and stay narrow on the stand-in."""
+    src = corpus.make("real_text", 12_000_000)[4_000_000:]
+    txt = corpus.make("syn_text", 4_000_000, corpus.SEED + 51)
+    try:
+        for data, hb, wide_expected in ((src, 23, True), (txt, 22, False)):
+            want = oracle_py.compress(data, hb)
+            gpu.set_option("batch_chunks", 4)
+            for shape in (0, 1, 2):
+                gpu.set_option("table_shape", shape)
+                assert gpu.compress(data, hb) == want, (shape, hb)
+                wide, changes = gpu.counter("table_wide_launches"), gpu.counter("table_shape_changes")      # (of the stream that has just finished)
+                if shape == 0:
+                    assert (wide >= 4 and changes >= 1) if wide_expected else (wide == 0 and changes == 0), (hb, wide, changes)
+                else:
+                    assert (wide == 0) == (shape == 1), (shape, wide)
+    finally:
+        gpu.set_option("table_shape", 0); gpu.set_option("batch_chunks", 32)
+
+
 def test_worker_lanes_and_hot_bin_waves_are_invisible(gpu):
     """How the BT4 calls are spread over lanes and waves must not change a byte or a counter (MatchFinderBT::FindAndUpdate,
     NLZM.cpp:978-1022, is serial per hash head): a wave for nearly every bin (threshold forced down to 4 and 64 positions per

@@ -6,6 +6,7 @@ import subprocess
 
 import pytest
 
+from nlzm_amd import corpus
 from tests import cases
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -61,6 +62,26 @@ def test_rk_entry_cut_short_by_uint16_grows_again(sim, tmp_path):
     data.tofile(p)
     r = subprocess.run([sim, str(p), str(case[4]), "2", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_table_stage_changes_shape_on_real_text(sim, tmp_path):
+    """The table stage runs a launch with 16-entry fronts on seven waves or with 24-entry fronts on five, as the launch before it asked (nlzm_v2.h, TLds): source code
+    has positions with more BT4 record-setters than 16 in one block out of ten, the stand-ins in none.  400 KB of the image's own headers (corpus.real_text) in four
+    launches must go wide and stay exact; forced wide from the first launch as well."""
+    import hashlib
+    import json
+    gold = next(c for c in json.load(open(os.path.join(HERE, "golden", "real.json")))["cases"] if c["name"] == "real_30m_w24")
+    data = corpus.make("real_text", 30_000_000)
+    if hashlib.sha256(data.tobytes()).hexdigest() != gold["input_sha256"]:
+        pytest.skip("this machine's files are not the ones the fixture was made from")
+    p = tmp_path / "in.bin"
+    data[20_000_000:20_400_000].tofile(p)
+    for shape, want_wide in (("0", True), ("2", True)):
+        r = subprocess.run([sim, str(p), "20", "2", "4"], capture_output=True, text=True, timeout=900, env=dict(os.environ, NLZM_SIM_TABLE_SHAPE=shape))
+        assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        line = next(l for l in r.stdout.splitlines() if l.startswith("table shape:"))
+        wide, changed = int(line.split()[2]), int(line.split()[6])
+        assert (wide >= 2) == want_wide and (shape != "0" or changed >= 1), line
 
 
 @pytest.mark.parametrize("env", [{"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}, {"NLZM_SIM_PSTRIDE": "5", "NLZM_SIM_POISON": "4"}])
