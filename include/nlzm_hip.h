@@ -152,7 +152,10 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
  * queued back to back (the pre-pass kernels of the next round and the frame coder of the round before run beside a launch,
  * out of two sets of per-launch buffers), and a step that has delivered its max_chunks leaves the NEXT round of the same
  * size queued on the device for the next step to collect, so that the device does not idle between the calls: in_done_total
- * counts what has been collected.  A begin or step that fails has closed
+ * counts what has been collected (a step whose max_chunks is SMALLER than the step's before it still collects the round that one
+ * left queued, i.e. more than it asked for: max_chunks bounds what a step starts, not what it finds started).  d_src and the set's
+ * device buffers are therefore read and written between the calls too: the input must not change until finish or abandon.
+ * A begin or step that fails has closed
  * the set (every stream's buffers freed, nothing left queued that reads d_src): there is nothing to abandon then;
  * nlzm_hip_blocks_abandon() drops a set the caller does not want to finish. */
 int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req);

@@ -384,27 +384,46 @@ def u16_cut(size: int, seed: int = SEED) -> np.ndarray:
     an offset of the zone, 12 / 20 / 28 bytes behind the start of Y: A has 88 / 80 / 72 bytes left there (nice, and shorter than what the
     uint16 leaves of B), and the position is a multiple of 8 from the target's start, where its segment begins (between the matches the
     bytes match nothing, every segment is one literal) -- nice positions call the finders at every eighth position of the segment (:1514)."""
+    return _u16_cut(size, seed, tie=False)
+
+
+def _u16_cut(size: int, seed: int, tie: bool) -> np.ndarray:
     C, FEED = 122_368, 122_633
     rng = np.random.default_rng(seed ^ 0x16C07)
     sym = np.frombuffer(b"acgt", dtype=np.uint8)
     out = rng.integers(0, 256, size=size, dtype=np.uint8)
     trials = min(max(0, size // C - 3), 48)
     for t in range(trials):
-        X = sym[rng.integers(0, 4, size=300)]; Y = sym[rng.integers(0, 4, size=100)]; Z = sym[rng.integers(0, 4, size=900)]
-        cap = 90 + (t * 37) % 168                           # what the uint16 leaves of the lookahead at the hit
+        # tie: every second trial with B the NEARER source (it wins the table's end and grows).  B then lies behind A in the file, its Y is a
+        # nice region of its own, and RK256 stores B's window under its own start only if that is a multiple of 8 from the start of Y (:1084-1087
+        # store the CALLING position): lead 16 / 24 there, and X four bytes shorter so that the hit is a calling position of the target too
+        swap = tie and t % 2 == 1
+        xlen = 296 if swap else 300
+        X = sym[rng.integers(0, 4, size=300)][:xlen]; Y = sym[rng.integers(0, 4, size=100)]; Z = sym[rng.integers(0, 4, size=900)]
+        lead = 16 + 8 * ((t // 2) % 2) if swap else 12 + 8 * (t % 3)   # the hit lies that many bytes behind the start of Y in the target
+        cap = 100 - lead if tie else 90 + (t * 37) % 168    # what the uint16 leaves of the lookahead at the hit (tie: exactly what A has left)
         hit = (t + 2) * C + (FEED - 65_536 - cap)           # absolute position of the RK256 hit
-        lead = 12 + 8 * (t % 3)                             # ... that many bytes behind the start of Y in the target
-        tgt = hit - lead - 300
-        win = 256 * (40 + 8 * t)                            # B's window (256-aligned start, chunk 0: every position calls there)
+        tgt = hit - lead - xlen
+        # B's window: 256-aligned start, in a chunk where every position calls; A placed so that its aligned windows start 200 bytes
+        # into the match (none has 256 bytes of it)
+        b_chunk, a_chunk = (1, 0) if swap else (0, 1)
+        win = b_chunk * C + 256 * (40 + 8 * t) + (-(b_chunk * C)) % 256
         src_b = win - lead
-        src_a = C + 2048 + 1024 * t + 56                    # (A's aligned windows start 200 bytes into the match: none has 256 bytes of it)
+        src_a = a_chunk * C + 2048 + 1024 * t + 56 + (-(a_chunk * C)) % 256
         out[src_b:src_b + 1000] = np.concatenate([Y, Z])
-        out[src_a:src_a + 400] = np.concatenate([X, Y])
-        out[tgt:tgt + 1300] = np.concatenate([X, Y, Z])
+        out[src_a:src_a + xlen + 100] = np.concatenate([X, Y])
+        out[tgt:tgt + xlen + 1000] = np.concatenate([X, Y, Z])
     return out
 
 
-_GENS = {"u16_cut": u16_cut, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def u16_tie(size: int, seed: int = SEED) -> np.ndarray:
+    """u16_cut with the cut-short RK256 entry ending exactly where the nice match A ends: both are the table's longest entries, and the
+    one with the smaller distance is what the table's end holds (NLZM.cpp:835-852) -- only then does the next position extend the RK256
+    entry.  Trials alternate: A the nearer source (the entry stays as it is), B the nearer source (it grows)."""
+    return _u16_cut(size, seed, tie=True)
+
+
+_GENS = {"u16_cut": u16_cut, "u16_tie": u16_tie, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

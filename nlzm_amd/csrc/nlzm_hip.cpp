@@ -395,7 +395,10 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     C.batch = (uint32_t)(C.opt_batch < 1 ? 1 : C.opt_batch);
     if (C.batch > g.nchunks && g.nchunks) C.batch = g.nchunks;
     if (!C.batch) C.batch = 1;
-    {   // the per-launch arrays take about 2.3 KB per position of a launch: a launch that does not fit is cut down
+    C.pooled = C.pool != nullptr;       // (from here on: a stream_begin that fails midway must not hipFree pointers into the set's pool)
+    if (!C.pool) {  // the per-launch arrays take about 2.3 KB per position of a launch: a launch that does not fit is cut down
+        // (not for the streams of a block set: blocks_begin fitted their batch to the memory, and the free memory differs between the pass that
+        //  measures what a stream takes and the pass that takes it -- the pool itself is allocated in between)
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         const double room = 0.6 * (double)free_b - 4.0 * (double)(1ull << (g.wbits + 5 > 32 ? 32 : g.wbits + 5));
@@ -769,6 +772,8 @@ int refresh_stats(Ctx &C)
         fprintf(stderr, "table: blocks in which some position's front had more than 8 / 12 / 16 / 20 / 24 / the launch's capacity of entries at some step of the scan: %.2f / %.2f / %.2f / %.3f / %.3f / %.3f %%\n",
                 100.0 * P.prof[105] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[106] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[107] / (P.prof[6] ? P.prof[6] : 1),
                 100.0 * P.prof[108] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[109] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[7] / (P.prof[6] ? P.prof[6] : 1));
+        fprintf(stderr, "finder: RK256 entries cut short by the uint16 length parameter that became the growing top entry: %llu; that ended exactly where another entry ends: %llu (%llu of them the nearer one)\n",
+                P.prof[115], P.prof[116], P.prof[117]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "finder: blocks that had to wait for a worker result: %llu (%.0f cycles each); late results of hot bins' waves %llu, late results at lane 0 (the position the block before was cut at) %llu\n",
                 P.prof[112], (double)P.prof[25] / (double)(P.prof[112] ? P.prof[112] : 1), P.prof[110], P.prof[111]);
@@ -990,7 +995,7 @@ int nlzm_hip_get_counter(const char *key, uint64_t *value)
         { "finder_blocks", 0 }, { "table_blocks", 6 }, { "parser_blocks", 8 }, { "parser_passes", 13 },
         { "finder_wait_cycles", 16 }, { "finder_total_cycles", 17 }, { "table_wait_cycles", 18 }, { "table_total_cycles", 19 },
         { "parser_wait_cycles", 20 }, { "parser_total_cycles", 21 }, { "parser_emit_cycles", 22 }, { "parser_setup_cycles", 23 }, { "parser_pass_cycles", 24 },
-        { "finder_bt_wait_cycles", 25 }, { "table_slow_blocks", 7 }, { "table_shape_changes", 113 }, { "table_wide_launches", 114 },
+        { "finder_bt_wait_cycles", 25 }, { "table_slow_blocks", 7 }, { "rk_cut_short_grown", 115 }, { "rk_cut_short_ties", 116 }, { "rk_cut_short_ties_won", 117 }, { "table_shape_changes", 113 }, { "table_wide_launches", 114 },
         { "helper_jobs", 96 }, { "helper_taken", 97 }, { "helper_taken_nodes", 98 }, { "helper_wait_cycles", 99 }, { "helper_jobs_done", 101 }, { "helper_blocks", 102 }, { "helper_passes", 103 },
     };
     for (const auto &e : kProf) if (!strcmp(key, e.name)) { *value = C.prof_last[e.idx]; return 0; }

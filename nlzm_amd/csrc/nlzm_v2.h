@@ -118,7 +118,7 @@ struct GlobalsV2 {
 // stage state that survives between launches (HBM)
 struct StateV2 {
     // finder
-    uint32_t reach;                             // largest end (absolute) of any closed table entry so far
+    uint32_t reach, reach_d;                    // largest end (absolute) of any closed table entry so far, and the smallest distance of an entry that ends there
     uint32_t s_active, s_d, s_end, s_seen;      // growing top entry: distance, first mismatch (kNone: not found yet), verified up to
     uint32_t prev_nice, seg_s;
     // table: the front after the last position of the launch
@@ -209,6 +209,7 @@ struct Finder {
     // wave-uniform state
     uint32_t base;              // absolute offset of rebased 0 (:888-891)
     uint32_t reach;             // largest absolute end of a closed table entry
+    uint32_t reach_d = kNone;   // ... and the smallest distance among the entries that end there (what a cut-short RK256 entry of the same end is up against)
     uint32_t s_active, s_d, s_end, s_seen;
     uint32_t rk_from, rk_to, rk_len, rk_end;
     uint32_t rk_cut = 0;        // the carried RK256 match is shorter than the bytes agree: the uint16 length parameter ended its compare (:760, :1096)
@@ -219,6 +220,7 @@ struct Finder {
     unsigned long long n_pos, n_nice, n_unc, n_ht, n_rkp, n_rki, n_cmp, n_blocks, n_cut0, n_cut1, n_cut2, n_cut3, n_cut4, n_cut5;
     unsigned long long n_cmp_lane = 0;          // bytes compared, per lane
     unsigned long long t_wait, t_wait_bt = 0, t_total;
+    uint32_t n_so_top = 0, n_so_tie = 0, n_so_won = 0;  // cut-short RK256 entries that became the growing top entry; that ended exactly where another entry ends; and won that
     uint32_t n_late_unc = 0, n_late_other = 0, n_late_hot = 0, n_late_first = 0, n_late_blocks = 0;
     unsigned long long t_f[8] = {};             // profile build: cycles per section of block()
 #ifdef NLZM_PROFILE
@@ -497,11 +499,14 @@ struct Finder {
         const unsigned long long f4 = ptick();
         // ---- the record of this position: pairs of HT2 and HT3 (:917-933)
         uint32_t *st = L->stage + i * kFtStride;
-        uint32_t np = 0, ec = 0, od = kNone, cmpb = 0;      // pairs, largest closed end, smallest open distance, bytes compared
+        uint32_t np = 0, ec = 0, ec_d = kNone, od = kNone, cmpb = 0;   // pairs, largest closed end and the smallest distance that ends there, smallest open distance, bytes compared
+        auto closed_end = [&](uint32_t e, uint32_t d) __attribute__((always_inline)) {
+            if (e > ec || (e == ec && d < ec_d)) { ec = e; ec_d = d; }
+        };
         auto add_pair = [&](uint32_t d, uint32_t l) __attribute__((always_inline)) {
             if (l >= cap) { od = umin(od, d); return; }     // as long as the lookahead allows: may grow at the next position
             st[2 + 2 * np] = d; st[3 + 2 * np] = l; np++;
-            ec = umax(ec, a + l);
+            closed_end(a + l, d);
         };
         if (ht_call) {
             if (cd[0] && 1 < cap) {
@@ -609,7 +614,7 @@ struct Finder {
                         bt_n = w0 & 0x1FFu;
                         if (bt_n) {
                             const uint32_t d = q0.y, l = q0.z;
-                            if (l >= cap) od = umin(od, d); else ec = umax(ec, a + l);
+                            if (l >= cap) od = umin(od, d); else closed_end(a + l, d);
                         }
                     }
                     break;
@@ -642,10 +647,23 @@ struct Finder {
         const bool nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
         // a cut-short RK256 entry that is longer than everything else in this lane's table grows from the next position on (the lanes in front of
         // the first such lane hold theirs as closed entries: `before` is right for it).  As long as another entry: which of the two the table's
-        // end holds hangs on their distances (:835-852 keeps the smaller), and the other one's is not known here -- not met so far; refused.
+        // end holds hangs on their distances (:835-852 keeps the smaller): looked up then.
         const bool so_free = in_blk && so_end != 0 && od == kNone && !s_sliding;
-        const bool so_top = so_free && so_end > umax(before, ec);
         const bool so_tie = so_free && so_end == umax(before, ec);
+        bool so_win = false;
+        if (xw::any(so_tie)) {      // (rare: the smallest distance among the other entries that end exactly there -- own, of the lanes in front, older ones)
+            uint32_t d2 = kNone;
+            if (ec == so_end) d2 = ec_d;
+            if (reach == so_end) d2 = umin(d2, reach_d);
+            if (i >= jc && s_active && s_end == so_end) d2 = umin(d2, s_d);
+            for (uint32_t j = 0; j + 1 < n; j++) {
+                const uint32_t ej = xw::readlane(ec, j), dj = xw::readlane(ec_d, j), sj = xw::readlane(so_end, j), sdj = xw::readlane(so_d, j);
+                if (j < i && ej == so_end) d2 = umin(d2, dj);
+                if (j < i && sj == so_end) d2 = umin(d2, sdj);
+            }
+            so_win = so_tie && so_d < d2;
+        }
+        const bool so_top = so_free && (so_end > umax(before, ec) || so_win);
         const unsigned long long stm = xw::ballot(so_top);
         const uint32_t js = stm ? (uint32_t)__builtin_ctzll(stm) : 64u;
         const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
@@ -658,7 +676,6 @@ struct Finder {
         uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
         m = umin(m, js + 1 > 64 ? 64u : js + 1);
         if (m == 0) { fail(kErrInternal, a0, 7); return 1; }
-        if (xw::any(i < m && so_tie)) { fail(kErrInternal, a0, 9); return 1; }
         n_blocks++;
         if (m < n) {        // (why the block was cut; diagnostics)
             // (adds, not a chain of branches: the compiler turns the chain into ONE indexed access and the stage's state goes to scratch)
@@ -666,6 +683,10 @@ struct Finder {
             n_cut0 += w == 0; n_cut1 += w == 1; n_cut2 += w == 2; n_cut3 += w == 3; n_cut4 += w == 4; n_cut5 += w == 5;
         }
         const bool fin = i < m;
+        if (stm || xw::any(so_tie)) {       // (accounting)
+            n_so_top += (uint32_t)__builtin_popcountll(xw::ballot(fin && so_top)); n_so_tie += (uint32_t)__builtin_popcountll(xw::ballot(fin && so_tie));
+            n_so_won += (uint32_t)__builtin_popcountll(xw::ballot(fin && so_win));
+        }
 
         // a position that the pre-filter promised to be a BT4 position must not be nice
         if (xw::any(fin && nice_real && !unc && avail >= 4 && G.workers)) { fail(kErrV2Promise, a0, 8); return 1; }
@@ -699,8 +720,16 @@ struct Finder {
         {
             const uint32_t last = m - 1;
             const uint32_t pm_last = xw::readlane(pm, last);
-            reach = umax(reach, pm_last);
-            if (s_active && jc <= last) { reach = umax(reach, s_end); s_active = 0; }
+            if (pm_last >= reach && pm_last) {     // (whose entry ends there: nearly always one lane's)
+                uint32_t dm = pm_last == reach ? reach_d : kNone;
+                const uint32_t le = umax(ec, so_end), ld = umin(ec == le ? ec_d : kNone, so_end == le ? so_d : kNone);
+                for (unsigned long long mm = xw::ballot(fin && le == pm_last); mm; mm &= mm - 1) dm = umin(dm, xw::readlane(ld, (uint32_t)__builtin_ctzll(mm)));
+                reach = pm_last; reach_d = dm;
+            }
+            if (s_active && jc <= last) {
+                if (s_end > reach) { reach = s_end; reach_d = s_d; } else if (s_end == reach) reach_d = umin(reach_d, s_d);
+                s_active = 0;
+            }
             if (jo == last) { s_active = 1; s_d = xw::readlane(od, last); s_end = kNone; s_seen = a0 + last + xw::readlane(cap, last); }
             else if (js == last) { s_active = 1; s_d = xw::readlane(so_d, last); s_end = kNone; s_seen = xw::readlane(so_end, last); }
             prev_nice = xw::readlane(nice_real ? 1u : 0u, last);
@@ -751,7 +780,7 @@ struct Finder {
         for (uint32_t k = i; k < 4096; k += 64) L->ht2[k] = G.ht2[k];
         for (uint32_t k = i; k < ht3_rows; k += 64) L->ht3[k] = G.ht3[k];
         base = xw::readfirst((uint32_t)P->reb_base);
-        reach = xw::readfirst(S->reach); s_active = xw::readfirst(S->s_active); s_d = xw::readfirst(S->s_d);
+        reach = xw::readfirst(S->reach); reach_d = xw::readfirst(S->reach_d); s_active = xw::readfirst(S->s_active); s_d = xw::readfirst(S->s_d);
         s_end = xw::readfirst(S->s_end); s_seen = xw::readfirst(S->s_seen);
         prev_nice = xw::readfirst(S->prev_nice); seg_s = xw::readfirst(S->seg_s);
         rk_from = xw::readfirst(P->rk_from); rk_to = xw::readfirst(P->rk_to); rk_len = xw::readfirst(P->rk_len); rk_end = xw::readfirst(P->rk_end);
@@ -803,7 +832,7 @@ struct Finder {
         if (i == 0) {
             P->reb_base = base;
             P->rk_from = rk_from; P->rk_to = rk_to; P->rk_len = rk_len | (rk_cut << 31); P->rk_end = rk_end;
-            S->reach = reach; S->s_active = s_active; S->s_d = s_d; S->s_end = s_end; S->s_seen = s_seen;
+            S->reach = reach; S->reach_d = reach_d; S->s_active = s_active; S->s_d = s_d; S->s_end = s_end; S->s_seen = s_seen;
             S->prev_nice = prev_nice; S->seg_s = seg_s;
             // (every stage adds the counters it owns, with agent-scope atomics: the stages run on different CUs, in
             //  block mode on different XCDs, and finish within microseconds of each other)
@@ -818,6 +847,7 @@ struct Finder {
             xw::atomic_add64_agent(&pr[12], n_cut5);
             xw::atomic_add64_agent(&pr[16], t_wait); xw::atomic_add64_agent(&pr[17], xw::tick() - t_start); xw::atomic_add64_agent(&pr[25], t_wait_bt);
             xw::atomic_add64_agent(&pr[28], n_late_unc); xw::atomic_add64_agent(&pr[29], n_late_other);
+            xw::atomic_add64_agent(&pr[115], n_so_top); xw::atomic_add64_agent(&pr[116], n_so_tie); xw::atomic_add64_agent(&pr[117], n_so_won);
             xw::atomic_add64_agent(&pr[110], n_late_hot); xw::atomic_add64_agent(&pr[111], n_late_first); xw::atomic_add64_agent(&pr[112], n_late_blocks);
 #ifdef NLZM_PROFILE
             for (int z = 0; z < 8; z++) xw::atomic_add64_agent(&pr[88 + z], t_f[z]);

@@ -383,6 +383,7 @@ int main(int argc, char **argv)
     const double np = (double)(n ? n : 1);
     printf("finder: %llu blocks (%.1f positions each); cut by: nice %llu, new top entry %llu, RK candidate %llu, RK catch-up %llu, same worker bin %llu, other %llu\n",
            P.prof[0], np / (double)(P.prof[0] ? P.prof[0] : 1), P.prof[1], P.prof[2], P.prof[3], P.prof[4], P.prof[12], P.prof[5]);
+    printf("cut-short RK256 entries: %llu became the growing top entry, %llu ended where another entry ends (%llu of them the nearer one)\n", P.prof[115], P.prof[116], P.prof[117]);
     printf("table shape: %llu launches wide, changed %llu times\n", P.prof[114], P.prof[113]);
     printf("table: %llu blocks, %llu on the slow path; parser: %llu blocks (%.1f nodes each), %.2f passes per block, mask fills %llu, probe rounds %llu, re-sampled %llu (put back %llu)\n",
            P.prof[6], P.prof[7], P.prof[8], np / (double)(P.prof[8] ? P.prof[8] : 1), (double)P.prof[13] / (double)(P.prof[8] ? P.prof[8] : 1), P.prof[9], P.prof[10], P.prof[11], P.prof[14]);

@@ -44,14 +44,16 @@ def test_stages_match_oracle_rebased_duplicates(sim, name, tmp_path):
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_rk_entry_cut_short_by_uint16_grows_again(sim, tmp_path):
+@pytest.mark.parametrize("name", ["u16cut_734k_w24", "u16tie_979k_w24"])
+def test_rk_entry_cut_short_by_uint16_grows_again(sim, name, tmp_path):
     """An RK256 match found where `la_end - p` is just above 65,536 is compared over (uint16)(la_end - p) bytes only (NLZM.cpp:760, :1096);
     when that entry is the table's longest, the next position extends it again (:1503-1512).  The finder stage held such an entry for a
-    closed one until round 5 (real text meets it once in ~100 MB).  The case must contain the situation: the oracle
-    counts it."""
+    closed one until round 5 (real text meets it once in ~100 MB).  The cases must contain the situation: the oracle
+    counts it, and the stage says what it did -- in the second case the entry ends exactly where another entry ends, and grows only where
+    it is the nearer of the two (:835-852)."""
     import ctypes
     from tests import oracle_py
-    case = next(c for c in cases.CASES if c[0] == "u16cut_734k_w24")
+    case = next(c for c in cases.CASES if c[0] == name)
     data = cases.make_case(case)
     L = oracle_py.lib()
     L.nlzm_oracle_debug_rk_u16_cuts.restype = ctypes.c_uint64
@@ -62,6 +64,9 @@ def test_rk_entry_cut_short_by_uint16_grows_again(sim, tmp_path):
     data.tofile(p)
     r = subprocess.run([sim, str(p), str(case[4]), "2", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    import re
+    grown, ties, won = map(int, re.findall(r"\d+", next(l for l in r.stdout.splitlines() if l.startswith("cut-short RK256 entries:")).split(":", 1)[1]))
+    assert (grown >= 1 and ties >= 4 and 1 <= won < ties) if "tie" in name else grown >= 2, r.stdout[-600:]
 
 
 def test_table_stage_changes_shape_on_real_text(sim, tmp_path):
