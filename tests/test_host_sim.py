@@ -118,7 +118,9 @@ def test_helper_parser_takes_segments_over(sim, name, env, launches, tmp_path):
     line = next(l for l in r.stdout.splitlines() if l.startswith("helper parser:"))
     posted, taken = int(line.split()[2]), int(line.split()[5])
     assert posted >= 5 and taken >= 3, line
-    # ... and without the helper the same streams
+    # ... and without the helper the same streams (once per input: the plain variant)
+    if env:
+        return
     r0 = subprocess.run([sim, str(p), str(case[4]), "2", str(launches)], capture_output=True, text=True, timeout=1500,
                         env=dict(os.environ, NLZM_SIM_HELPER="0", **env))
     assert r0.returncode == 0 and ": OK" in r0.stdout, r0.stdout[-2000:] + r0.stderr[-2000:]
