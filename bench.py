@@ -66,7 +66,6 @@ CHUNK = 122_368
 STEPS_PER_STREAM = 25      # a step is 1/25 of the stream's launches: --steps 20 --warmup 5 is the whole stream
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E
 BLOCKS_BATCH = 8           # block-mode leg: chunks of every block per shared persistent launch
-BLOCKS_SETTLE_S = 4.0      # idle time between the single-stream leg and the block-mode leg (the driver clears the memory the first one freed)
 
 
 def algorithmic_bytes(st: dict) -> int:
@@ -233,7 +232,7 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
     nb_launch = -(-(-(-per // CHUNK)) // B)
     per_step = max(1, -(-nb_launch // STEPS_PER_STREAM)) * B
     geo = nlzm_amd.geometry(per, WINDOW)
-    out = {"streams": k, "settle_s": BLOCKS_SETTLE_S,
+    out = {"streams": k,
            "workload": f"{n} B split into {k} independent blocks of {per} B (-window:{WINDOW} auto-shrinks to {geo['hist_bits']}), "
                        f"all in flight on one GPU; step = {per_step} chunks of every block"}
     t_b0 = time.perf_counter()
@@ -440,10 +439,6 @@ def main():
     if args.block_streams > 0:
         del d_out
         torch.cuda.empty_cache()
-        # The single stream's ~40 GB have just been freed, and the driver zero-fills freed device memory in the background: a 113 GB hipMalloc issued
-        # at once waits for that (0.5 - 5.5 s), one issued a few seconds later does not.  The leg measures block mode, not the driver's
-        # page clearing behind another workload: the process idles BLOCKS_SETTLE_S first, outside every timed region, and says so in `blocks.settle_s`.
-        time.sleep(BLOCKS_SETTLE_S)
         blocks = blocks_leg(lib, torch, dev, d_in, n, args.block_streams, B, args.steps, args.warmup,
                             check=(world == 1 and data_kind == "synthetic"))
         if world > 1:
