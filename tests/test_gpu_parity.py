@@ -352,6 +352,26 @@ def test_block_mode_options_are_invisible(gpu):
     gpu.set_option("prefilter_bits_per_position", 4)
 
 
+def test_blocks_of_source_code(gpu):
+    """Source code (corpus.real_text: one BT4 head with 17 % of the positions, nice regions everywhere) as 32 independent blocks in flight on the one GPU --
+    what INTEGRATION.md recommends for it; eight of the streams against the oracle run on the block (whatever files the box has: the oracle sees the same bytes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from nlzm_amd import shard
+    try:
+        data = corpus.real_text(48_000_000)
+    except RuntimeError as e:
+        pytest.skip(f"REAL-TEXT FIXTURE NOT AVAILABLE ON THIS BOX: {e}")
+    k, hb = 32, 28
+    got = gpu.compress_blocks(data, k, hb)
+
+    def ref(i):
+        lo, hi = shard.block_range(data.size, k, i)
+        return i, oracle_py.compress(data[lo:hi], hb)
+    with ThreadPoolExecutor(8) as ex:
+        bad = [i for i, want in ex.map(ref, range(0, k, 4)) if want != got[i]]
+    assert not bad, bad
+
+
 def test_blocks_ragged_and_empty(gpu):
     """Fewer bytes than blocks: trailing blocks are empty streams (header + terminator), as the reference writes for an
     empty file; a last block shorter than the others; one block = the plain stream."""
