@@ -423,7 +423,43 @@ def u16_tie(size: int, seed: int = SEED) -> np.ndarray:
     return _u16_cut(size, seed, tie=True)
 
 
-_GENS = {"u16_cut": u16_cut, "u16_tie": u16_tie, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def splice(size: int, seed: int = SEED) -> np.ndarray:
+    """Fuzz input for the parity harness: pieces of every kind the finders treat differently, spliced at random -- incompressible bytes, text over 4 - 16
+    symbols, copies of earlier spans (distance and length log-uniform: 4 bytes to 3,000, one byte back to the start), near-copies (a copy with a few bytes
+    changed: matches that end and resume), runs, and copies forced across the chunk offsets where RK256's uint16 length parameter wraps (56,800 - 57,100 of every
+    122,368-byte chunk: section 12 of DESIGN.md).  No structure is intended; every seed is another arrangement."""
+    rng = np.random.default_rng(seed ^ 0x5B11CE)
+    out = np.empty(size + 4096, dtype=np.uint8)
+    n = 0
+    C = 122_368
+    while n < size:
+        kind = rng.random()
+        if n < 64 or kind < 0.15:
+            l = int(rng.integers(1, 200)); out[n:n + l] = rng.integers(0, 256, size=l, dtype=np.uint8)
+        elif kind < 0.35:
+            l = int(rng.integers(8, 400)); k = int(rng.integers(2, 17)); base = int(rng.integers(32, 200))
+            out[n:n + l] = (base + rng.integers(0, k, size=l)).astype(np.uint8)
+        elif kind < 0.45:
+            l = int(rng.integers(2, 600)); out[n:n + l] = int(rng.integers(0, 256))
+        else:
+            l = int(np.exp(rng.uniform(np.log(4), np.log(3000))))
+            d = int(np.exp(rng.uniform(0, np.log(n))))
+            d = max(1, min(d, n))
+            if kind > 0.9:      # put the copy across the zone of the nearest chunk, if there is room behind us for its source
+                zone = (n // C) * C + int(rng.integers(56_700, 57_100))
+                if zone > n and zone - n < 3000:
+                    pad = zone - n - int(rng.integers(0, 300))
+                    if pad > 0: out[n:n + pad] = rng.integers(0, 256, size=pad, dtype=np.uint8); n += pad
+                    l = int(rng.integers(300, 2500))
+            for i in range(0, l, max(d, 1)):        # (overlapping copies repeat, as LZ copies do)
+                m = min(d, l - i); out[n + i:n + i + m] = out[n + i - d:n + i - d + m]
+            if 0.75 < kind <= 0.9 and l > 16:
+                for _ in range(int(rng.integers(1, 4))): out[n + int(rng.integers(0, l))] ^= int(rng.integers(1, 256))
+        n += l
+    return out[:size].copy()
+
+
+_GENS = {"splice": splice, "u16_cut": u16_cut, "u16_tie": u16_tie, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:
