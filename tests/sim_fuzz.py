@@ -1,5 +1,6 @@
 """Fuzz of the pipeline stages in the fiber simulator against the oracle (not collected by pytest: a batch job for idle CPU time).
-python tests/sim_fuzz.py <first seed> <count> [jobs=6]      every seed: corpus.splice of 250 - 500 KB, a window of 15 - 22 bits, 1 - 4 launches, either worker emulation"""
+python tests/sim_fuzz.py <first seed> <count> [jobs=6] [kind=splice]     every seed: corpus.splice of 250 - 500 KB (kind real_text: a slice of that size out of the first 120 MB of
+corpus.real_text, at a random offset), a window of 15 - 22 bits, 1 - 4 launches, either worker emulation"""
 import os, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, '.')
@@ -9,6 +10,8 @@ from nlzm_amd import corpus
 SIM = os.path.join("tests", "host_sim", "sim2")
 first, count = int(sys.argv[1]), int(sys.argv[2])
 jobs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+kind = sys.argv[4] if len(sys.argv) > 4 else "splice"
+REAL = corpus.make("real_text", 120_000_000) if kind == "real_text" else None
 subprocess.run(["make", "-C", os.path.join("tests", "host_sim")], check=True, capture_output=True)
 
 def one(seed):
@@ -20,7 +23,10 @@ def one(seed):
     if rng.random() < 0.3: env["NLZM_SIM_PSTRIDE"] = str(int(rng.integers(4, 40)))
     if rng.random() < 0.3: env["NLZM_SIM_TABLE_SHAPE"] = str(int(rng.integers(0, 3)))
     with tempfile.NamedTemporaryFile(suffix=".bin", dir="/tmp") as f:
-        corpus.make("splice", size, seed).tofile(f.name)
+        if REAL is not None:
+            off = int(rng.integers(0, REAL.size - size)); REAL[off:off + size].tofile(f.name)
+        else:
+            corpus.make("splice", size, seed).tofile(f.name)
         r = subprocess.run([SIM, f.name, str(hb), str(workers), str(launches)], capture_output=True, text=True, env=env)
     ok = r.returncode == 0 and ": OK" in r.stdout
     line = next((l for l in r.stdout.splitlines() if "cut-short" in l), "")
