@@ -16,7 +16,8 @@ subprocess.run(["make", "-C", os.path.join("tests", "host_sim")], check=True, ca
 
 def one(seed):
     rng = np.random.default_rng(seed)
-    size, hb = int(rng.integers(250_000, 500_000)), int(rng.integers(15, 23))
+    lo, hi = (int(x) for x in os.environ.get("NLZM_FUZZ_SIZE", "250000,500000").split(","))      # (NLZM_FUZZ_SIZE=lo,hi: other sizes)
+    size, hb = int(rng.integers(lo, hi)), int(rng.integers(15, 25 if hi > 600_000 else 23))
     workers, launches = int(rng.integers(1, 3)), int(rng.integers(1, 5))
     env = dict(os.environ)
     if rng.random() < 0.3: env["NLZM_SIM_RANDOM_BLOCKS"] = str(int(rng.integers(1, 100)))
