@@ -352,6 +352,18 @@ def test_block_mode_options_are_invisible(gpu):
     gpu.set_option("prefilter_bits_per_position", 4)
 
 
+def test_spliced_fuzz_inputs(gpu):
+    """A handful of seeds of the fuzz that tests/gpu_fuzz.py runs in batches (corpus.splice), as one stream and as three blocks, against the oracle."""
+    from nlzm_amd import shard
+    for seed, size, hb in ((9001, 700_000, 17), (9002, 2_300_000, 21), (9003, 1_100_000, 24)):
+        data = corpus.make("splice", size, seed)
+        assert gpu.compress(data, hb) == oracle_py.compress(data, hb), seed
+        got = gpu.compress_blocks(data, 3, hb)
+        for i, s in enumerate(got):
+            lo, hi = shard.block_range(data.size, 3, i)
+            assert s == oracle_py.compress(data[lo:hi], hb), (seed, i)
+
+
 def test_blocks_of_source_code(gpu):
     """Source code (corpus.real_text: one BT4 head with 17 % of the positions, nice regions everywhere) as 32 independent blocks in flight on the one GPU --
     what INTEGRATION.md recommends for it; eight of the streams against the oracle run on the block (whatever files the box has: the oracle sees the same bytes)."""

@@ -69,6 +69,15 @@ def test_rk_entry_cut_short_by_uint16_grows_again(sim, name, tmp_path):
     assert (grown >= 1 and ties >= 3 and 1 <= won < ties) if "tie" in name else grown >= 2, r.stdout[-600:]
 
 
+def test_spliced_fuzz_input(sim, tmp_path):
+    """One seed of the fuzz that tests/sim_fuzz.py runs in batches (corpus.splice: pieces of every kind the finders treat differently, spliced at random), so that the
+    generator and the harness stay alive in the suite."""
+    p = tmp_path / "in.bin"
+    corpus.make("splice", 130_000, 4242).tofile(p)
+    r = subprocess.run([sim, str(p), "19", "2", "3"], capture_output=True, text=True, timeout=900, env=dict(os.environ, NLZM_SIM_PSTRIDE="9"))
+    assert r.returncode == 0 and ": OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_table_stage_changes_shape_on_real_text(sim, tmp_path):
     """The table stage runs a launch with 16-entry fronts on seven waves or with 24-entry fronts on five, as the launch before it asked (nlzm_v2.h, TLds): source code
     has positions with more BT4 record-setters than 16 in one block out of ten, the stand-ins in none.  400 KB of the image's own headers (corpus.real_text) in four
