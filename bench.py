@@ -297,6 +297,56 @@ def blocks_leg(lib, torch, dev, d_in, n: int, k: int, B: int, steps: int, warmup
     return out
 
 
+def workloads_leg(lib, torch, dev) -> dict:
+    """The headline's stand-in is prose-like and flatters the pipeline: source code (one BT4 head -- runs of spaces -- holds 17 % of the positions) and wiki-shaped
+    markup run several times slower.  Each workload below is a whole stream, input resident in HBM, timed from stream_begin to the
+    finished stream, compared with the REFERENCE's stream for the same bytes (tests/golden/workloads.json, made by `oracle/make_golden_real.py bench`);
+    `cpu_reference` is the reference's own wall time recorded there (one core of the build container).  real_text is the image's own source files: a box
+    whose files differ gets a loud null instead of a number."""
+    gold_path = os.path.join(ROOT, "tests", "golden", "workloads.json")
+    if not os.path.exists(gold_path):
+        return {"error": "tests/golden/workloads.json is missing"}
+    out = {}
+    for gold in json.load(open(gold_path))["cases"]:
+        name, rec = gold["name"], {"kind": gold["kind"], "bytes": gold["size"], "window_bits": gold["window"], "unit": "MB/s"}
+        out[name] = rec
+        try:
+            host = corpus.make(gold["kind"], gold["size"])
+        except RuntimeError as e:                       # (real_text: the source trees are not there)
+            rec.update(value=None, bit_exact=None, note=f"input not available on this box: {e}")
+            continue
+        if hashlib.sha256(host.tobytes()).hexdigest() != gold["input_sha256"]:
+            rec.update(value=None, bit_exact=None, note="this box's files give other input bytes than the golden record was made from: not run")
+            continue
+        n = int(host.size)
+        d_in = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
+        d_in[:n].copy_(torch.from_numpy(host))
+        cap = int(lib.nlzm_hip_compress_bound(n))
+        d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        dst_len = C.c_uint64(0)
+        t0 = time.perf_counter()
+        rc = lib.nlzm_hip_compress_dev(d_in.data_ptr(), n, gold["window"], d_out.data_ptr(), cap, C.byref(dst_len))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rc:
+            rec.update(value=None, bit_exact=None, error=lib.nlzm_hip_last_error().decode())
+            continue
+        sha = hashlib.sha256(d_out[:dst_len.value].cpu().numpy().tobytes()).hexdigest()
+        lb = latency_bound({k: 0 for k in STAGE_COUNTERS}, stage_counters())       # (the counters are the finished stream's own)
+        rec.update(value=round(n / 1e6 / dt, 4), seconds=round(dt, 2), stream_bytes=int(dst_len.value),
+                   bit_exact=bool(dst_len.value == gold["stream_size"] and sha == gold["stream_sha256"]),
+                   bit_exact_against="tests/golden/workloads.json (the reference's own stream for these bytes)",
+                   cycles_per_position={"achieved": lb["achieved"], "finder_busy": lb["stages"]["finder"]["busy"], "finder_waiting_for_bt4_results": lb["stages"]["finder"]["waiting_for_bt4_results"],
+                                        "table_busy": lb["stages"]["table"]["busy"], "parser_busy": lb["stages"]["parser"]["busy"]},
+                   cpu_reference={"value": gold["reference_mb_per_s"], "seconds": gold["reference_seconds"], "cores": 1,
+                                  "where": "the reference on one core of the build container, recorded with the golden stream"},
+                   vs_cpu_reference=round(n / 1e6 / dt / gold["reference_mb_per_s"], 2))
+        del d_in, d_out
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +356,7 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=25.0, help="size of the CPU leg's small sample (a prefix of the stream as a file of its own)")
     ap.add_argument("--cpu-deep-mb", type=float, default=280.0, help="size of the CPU leg's sample at the headline's depth (> 2^28 bytes keeps -window:28)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the real-text and markup workloads that follow the headline (about 3 minutes)")
     ap.add_argument("--block-streams", type=int, default=32,
                     help="also time the independent-block mode with this many streams in flight on each GPU (0: skip)")
     args = ap.parse_args()
@@ -399,14 +450,6 @@ def main():
 
     st1, tm1 = nlzm_amd.stats(), nlzm_amd.timing()
     sc1 = stage_counters()
-    mine = torch.tensor([in_done.value - in0, dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        total_in = sum(float(v[0]) for v in allv)
-        tmax = max(float(v[1]) for v in allv)
-    else:
-        total_in, tmax = float(mine[0]), dt
 
     # ---- the stream is complete: the reference's bytes? ------------------------------------------------------------
     bit_exact, stream_len, stream_sha = None, None, None
@@ -418,21 +461,10 @@ def main():
         stream_sha = hashlib.sha256(d_out[:stream_len].cpu().numpy().tobytes()).hexdigest()
         # N = 1: the 1e9-byte stand-in (tests/golden/full.json); N > 1: every rank's block has the reference's own stream in
         # tests/golden/gpus.json (oracle/make_golden_gpus.py: one reference run per block, NLZM.cpp:1711 with the auto-shrink of :1716-1718)
-        if world == 1:
-            gold = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))["cases"]}.get("text_1g_w28")
-        else:
-            gp = os.path.join(ROOT, "tests", "golden", "gpus.json")
-            gold = {(r["world"], r["rank"]): r for r in json.load(open(gp))["ranks"]}.get((world, rank)) if os.path.exists(gp) else None
-        if data_kind == "synthetic" and gold and gold["size"] == n:
-            bit_exact = bool(gold["stream_size"] == stream_len and gold["stream_sha256"] == stream_sha)
-    if world > 1:
-        flags = [None] * world
-        dist.all_gather_object(flags, bit_exact)
-        checked = [f for f in flags if f is not None]
-        ranks_checked = len(checked)
-        bit_exact = all(checked) if checked else None
-    else:
-        ranks_checked = 1 if bit_exact is not None else 0
+        if data_kind == "synthetic":
+            bit_exact = shard.stream_matches(shard.golden_for_rank(os.path.join(ROOT, "tests", "golden"), world, rank, n), stream_len, stream_sha)
+    # (the ranks' bytes and times, and their verdicts: nlzm_amd/shard.py -- tests/test_shard.py drives the same calls at world size 2 over gloo)
+    total_in, tmax, bit_exact, ranks_checked = shard.aggregate_ranks(rank, world, in_done.value - in0, dt, bit_exact, dev)
 
     # ---- block mode inside each GPU ----------------------------------------------------------------------------------
     blocks = None
@@ -441,20 +473,18 @@ def main():
         torch.cuda.empty_cache()
         blocks = blocks_leg(lib, torch, dev, d_in, n, args.block_streams, B, args.steps, args.warmup,
                             check=(world == 1 and data_kind == "synthetic"))
-        if world > 1:
-            allb = [None] * world
-            dist.all_gather_object(allb, blocks)
-            if rank == 0:
-                errs = [b["error"] for b in allb if "error" in b]
-                agg = dict(allb[0])
-                if not errs:
-                    agg["value"] = round(sum(b["bytes_timed"] for b in allb) / 1e6 / max(b["seconds"] for b in allb), 4)
-                    agg["per_gpu"] = [b["value"] for b in allb]
-                    agg["bytes_timed"] = sum(b["bytes_timed"] for b in allb)
-                    agg["workload"] = f"every one of the {world} GPUs: " + agg["workload"]
-                else:
-                    agg["error"] = "; ".join(errs)
-                blocks = agg
+        blocks = shard.aggregate_blocks(rank, world, blocks)
+
+    # ---- the inputs the stand-in flatters the pipeline on: real text (source code) and wiki-shaped markup, whole streams ------------------------------
+    workloads = None
+    if world == 1 and not args.no_workloads:
+        try:
+            del d_out
+        except NameError:
+            pass
+        del d_in
+        torch.cuda.empty_cache()
+        workloads = workloads_leg(lib, torch, dev)
 
     if rank == 0:
         d = {k: st1[k] - st0[k] for k in ("bt_calls", "bt_tests", "cmp_bytes", "ht_rows", "rk_probes", "rk_inserts",
@@ -524,6 +554,15 @@ def main():
             res["blocks"] = blocks
             if "error" in blocks:
                 errors.append("blocks: " + blocks["error"])
+        if workloads is not None:
+            res["workloads"] = workloads
+            for name, w in workloads.items():
+                if isinstance(w, dict) and (w.get("error") or w.get("bit_exact") is False):
+                    errors.append(f"workload {name}: " + (w.get("error") or "the stream differs from the reference's"))
+        try:
+            res["gpu_max_hw_queues_effective"] = nlzm_amd.counter("gpu_max_hw_queues_effective")     # (4: the HIP runtime had started before the variable was set -- block mode then runs ~30 % slower)
+        except nlzm_amd.NlzmError:
+            pass
         if errors:
             res["error"] = "; ".join(errors)
         print(json.dumps(res))

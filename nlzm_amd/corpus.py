@@ -429,7 +429,7 @@ def splice(size: int, seed: int = SEED) -> np.ndarray:
     changed: matches that end and resume), runs, and copies forced across the chunk offsets where RK256's uint16 length parameter wraps (56,800 - 57,100 of every
     122,368-byte chunk: section 12 of DESIGN.md).  No structure is intended; every seed is another arrangement."""
     rng = np.random.default_rng(seed ^ 0x5B11CE)
-    out = np.empty(size + 4096, dtype=np.uint8)
+    out = np.empty(size + 8192, dtype=np.uint8)       # (a piece may start just below `size`: 3,000 bytes of padding and a copy of 2,500 at most)
     n = 0
     C = 122_368
     while n < size:
@@ -459,7 +459,30 @@ def splice(size: int, seed: int = SEED) -> np.ndarray:
     return out[:size].copy()
 
 
-_GENS = {"splice": splice, "u16_cut": u16_cut, "u16_tie": u16_tie, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
+def spines(size: int, seed: int = SEED) -> np.ndarray:
+    """Positions with MANY BT4 record-setters of their own (NLZM.cpp:996-998): groups of K = 36 .. 120 strings that share ever longer prefixes with a
+    query that follows them -- the farthest shares the most -- so that the query's descent meets them by increasing distance and every one of them is
+    a longer match than the one before (none lies between the query and a later one in the tree's order: all are on the path).  A block set reserves
+    32 pairs per position and takes the rest from an arena per launch (nlzm_core.h, bt_pair_ptr): these are the positions that use it, and with a
+    small arena (option block_ext_blocks) the ones that use it up.  Between the groups: text over sixteen symbols."""
+    rng = np.random.default_rng(seed ^ 0x5917E5)
+    out = np.empty(size + 32768, dtype=np.uint8)
+    n = 0
+    while n < size:
+        l = int(rng.integers(200, 3000))
+        out[n:n + l] = (97 + rng.integers(0, 16, size=l)).astype(np.uint8); n += l
+        K = int(rng.integers(36, 121))
+        q = (97 + rng.integers(0, 26, size=K + 40)).astype(np.uint8)
+        for k in range(K, 0, -1):                   # the farthest first: it shares 3 + K bytes with the query
+            m = 3 + k
+            out[n:n + m] = q[:m]; out[n + m] = 65 + (int(q[m]) - 97 + 1 + int(rng.integers(0, 24))) % 26; n += m + 1    # (an upper-case byte: never the query's)
+            f = int(rng.integers(8, 40))
+            out[n:n + f] = (48 + rng.integers(0, 10, size=f)).astype(np.uint8); n += f
+        out[n:n + q.size] = q; n += q.size
+    return out[:size].copy()
+
+
+_GENS = {"spines": spines, "splice": splice, "u16_cut": u16_cut, "u16_tie": u16_tie, "xml_like": xml_like, "real_text": real_text, "dense_breaks": dense_breaks, "dense_text": dense_text, "syn_text": syn_text, "cutnice": cutnice, "block_set": block_set, "random": random_bytes, "runs": runs, "mixed": mixed, "dups": dups, "chains": chains}
 
 
 def make(kind: str, size: int, seed: int = SEED) -> np.ndarray:

@@ -122,7 +122,7 @@ NLZM_HD uint32_t *bt_pair_ptr(uint32_t *pairs, uint32_t pstride, uint32_t *ext, 
 {
     if (k < pstride) return pairs + 2 * k;
     if (!ext_idx) ext_idx = IO::atomic_inc(ext_cur) + 1;
-    if (ext_idx > ext_cap) return nullptr;              // the arena is used up: the caller fails the launch (never silently)
+    if (ext_idx > ext_cap) return nullptr;              // the arena is used up: the caller drops the pair, the host sees the cursor (Hx::ext_cur) beyond the arena
     return ext + (unsigned long long)(ext_idx - 1) * (2 * (kBtMaxPairs - pstride)) + 2 * (k - pstride);
 }
 constexpr uint32_t kBtReady = 0x80000000u;
@@ -140,6 +140,12 @@ struct WorkerCounters {
     unsigned long long hot_bins, hot_calls;         // hot bins over all launches; calls made by their waves
     unsigned long long spec_calls, spec_good;       // decisions "skip" that took calls back; calls behind the skipped position that were made again
     unsigned long long hot_steps, hot_blocked_dry, hot_blocked_risky;   // hot bins' waves: steps; steps in which the next call could not start (a call without stores on its way / a risky assumption open)
+    // hot bins' waves by the size of the bin (class k: 8,192 << k positions of the launch and more; the last class is open), what their steps were spent on:
+    //   0 waves, 1 calls, 2 tests, 3 steps, 4 steps in which some lane made a test, 5 tests made (summed over the lanes), 6 lane-steps repeated for a slot
+    //   another call holds, 7 idle steps while a wrong assumption is taken back, 8 idle: every lane holds a call that waits for a decision, 9 idle: the next
+    //   call may not start (dry / risky), 10 idle: no entry (the chunk's end, or its calls are held), 11 cycles, 12 entries skipped (decided "skip" when they came up),
+    //   13 idle steps with an undecided position open (any cause)
+    unsigned long long hot_class[8][14];
 };
 
 // Everything the master needs from HBM.
@@ -180,6 +186,7 @@ struct Globals {
     WorkerCounters *wcnt;
     uint32_t table_shape;       // the table stage's shape (nlzm_v2.h): 0 by the data, 1 narrow fronts, 2 wide fronts
     uint32_t launch_par;        // the stream's launch number & 1: a launch reads the shape from slot launch_par and leaves the next one's in the other
+    uint32_t test_fail;         // test only: nonzero -> the finder stage raises an error at the launch's start (the fault path of a block set's queued rounds)
     void *hook_user;            // host simulation only
 };
 
@@ -361,8 +368,7 @@ NLZM_HD void ResultSink<IO>::operator()(uint32_t d, uint32_t l)
     d2 = s2 ? d : d2; l2 = s2 ? l : l2; d3 = s3 ? d : d3; l3 = s3 ? l : l3;
     if (count >= 4) {
         uint32_t *q = bt_pair_ptr<IO>(pairs, view->pstride, view->ext, view->ext_cur, view->ext_cap, ext_idx, count);
-        if (q) { IO::st_agent(q, d); IO::st_agent(q + 1, l); }
-        else if (view->fail_word) IO::st_agent(view->fail_word, 3u);
+        if (q) { IO::st_agent(q, d); IO::st_agent(q + 1, l); }       // (else: dropped -- the host sees the arena's cursor beyond its end and makes the stream again)
     }
     count++;
 }

@@ -6,6 +6,8 @@
 // rANS-coded in parallel and gathered into the output stream.
 // There is no CPU implementation of any stage in this library.
 #include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <unistd.h>
 
 #include <stdarg.h>
 #include <stdint.h>
@@ -76,6 +78,7 @@ int set_err(int code, const char *fmt, ...)
                            "%s failed: %s", #expr, hipGetErrorString(e_));                        \
     } while (0)
 
+int g_hwq_effective = 0;                           // what the HIP runtime reads as GPU_MAX_HW_QUEUES (dev_init)
 void blocks_close(bool drop_pool = false);         // defined with the block-set entry points
 bool idle_block_pool_dropped();                    // no block set open and its kept allocation still there: frees it, true (defined there too)
 
@@ -125,6 +128,10 @@ struct Ctx {
                                             // threads, device states and gather loop run with two parts on a box with one GPU
     int64_t opt_table_shape = 0;            // the table stage's shape ("table_shape"): 0 every launch in the shape the launch before it asked for (nlzm_v2.h, TLds), 1 always 16-entry
                                             // fronts on seven waves, 2 always 24 entries on five
+    int64_t opt_test_fail_launch = -1;      // test only ("test_fail_launch", with "test_fail_stream" = index of the stream of a block set): the finder stage of that launch raises
+    int64_t opt_test_fail_stream = 0;       // an error at once -- the fault path of a round that is queued behind a failing one
+    int64_t opt_block_ext_blocks = -1;      // test only ("block_ext_blocks"): extension blocks of a block-set stream's pair-list arena per launch (default: positions / 64 + 1024)
+    bool arena_out = false;                 // the last step_post_check failed because the launch used its pair-list arena up (block mode makes the stream again by itself)
     int64_t opt_report = 0;                 // 1: the stages' cycle accounting of every finished stream on stderr (nlzm_hip_set_option "stage_report")
     int cu_count = 0;
     // what the open stream runs with: the options as they were at stream_begin (its buffers are sized for them)
@@ -247,6 +254,7 @@ struct BlockJob {
     uint64_t lo = 0, n = 0, len = 0, bound = 0;
     uint8_t *d_out = nullptr;
     int rc = 0;
+    bool redo = false;                              // a launch of this stream used its pair-list arena up: the stream is made again, by itself, when the set is finished
     Pool pool;                                      // this stream's slice of the block set's one allocation
 };
 
@@ -267,6 +275,7 @@ struct DevState {
     uint32_t blocks_hist = 0;
     int64_t blocks_wb = 0;
     uint64_t blocks_per = 0;                        // bytes per block when the caller fixes the partition (0: ceil(n / nblocks))
+    uint64_t redo_streams = 0;                      // streams of the last block set that were made again as single streams (their pair-list arena had run out)
     // the rounds of the block set (blocks_step_impl): two are open at a time, and one may stay queued when a step returns
     struct Rounds {
         bool have = false;                          // round `q` is queued (pre-passes and launch) and not collected yet
@@ -401,7 +410,11 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         //  measures what a stream takes and the pass that takes it -- the pool itself is allocated in between)
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const double room = 0.6 * (double)free_b - 4.0 * (double)(1ull << (g.wbits + 5 > 32 ? 32 : g.wbits + 5));
+        // (the pre-filter table as it will be sized below: up to 2^33 entries)
+        uint32_t tb = g.wbits + 5 > 33 ? 33 : (g.wbits + 5 < 16 ? 16 : g.wbits + 5);
+        { uint32_t lgn = 1; while ((1ull << lgn) < g.n) lgn++; const uint32_t want = lgn + (uint32_t)C.opt_tbits_per; if (want < tb) tb = want < 16 ? 16 : want; }
+        if ((int64_t)tb > C.opt_tbits_max) tb = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);
+        const double room = 0.6 * (double)free_b - 4.0 * (double)(1ull << tb);
         const double per_chunk = 2300.0 * g.chunk_size + 8.0 * g.chunk_size * 4;
         if (room > per_chunk && (double)C.batch * per_chunk > room) C.batch = (uint32_t)(room / per_chunk);
     }
@@ -451,7 +464,17 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         }
         if ((int64_t)C.t_bits > C.opt_tbits_max) C.t_bits = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);   // (smaller: only more `unc` marks)
         C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
-        DEVALLOC(C.pf_T, (size_t)4 << C.t_bits);
+        if (C.pool) DEVALLOC(C.pf_T, (size_t)4 << C.t_bits);
+        else {
+            // (a device with less free memory than the table wants: a smaller table only marks more positions as undecided)
+            for (;;) {
+                const int rc_t = dev_alloc(C, &C.pf_T, (size_t)4 << C.t_bits);
+                if (!rc_t) break;
+                if (rc_t != NLZM_HIP_E_NOMEM || C.t_bits <= 28) return rc_t;
+                (void)hipGetLastError();
+                C.t_bits--;
+            }
+        }
         DEVALLOC(C.pf_M, (size_t)4 << C.m_bits);
         DEVFILL(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
         DEVFILL(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
@@ -466,6 +489,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         // (nlzm_core.h, bt_pair_ptr; a launch that uses the arena up fails with an error, it never drops a pair)
         C.pstride = C.pool ? 32u : kBtMaxPairs;
         C.ext_cap = C.pstride < kBtMaxPairs ? (uint32_t)(bpos / 64 + 1024) : 0u;
+        if (C.ext_cap && C.opt_block_ext_blocks >= 0) C.ext_cap = (uint32_t)(C.opt_block_ext_blocks < 1 ? 1 : C.opt_block_ext_blocks);
         DEVALLOC(C.bt_pairs, bpos * (2ull * C.pstride * 4));
         if (C.ext_cap) DEVALLOC(C.bt_ext, (size_t)C.ext_cap * (2ull * (kBtMaxPairs - C.pstride) * 4));
         DEVALLOC(C.bt_flag, bpos * 4);
@@ -599,6 +623,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
         if (!ahead) HIPCHK(hipMemcpyAsync(C.v2_hx, &h, sizeof h, hipMemcpyHostToDevice, C.st));
         P.V.ft = C.v2_ft; P.V.tp = C.v2_tp; P.V.tf = C.v2_tf; P.V.hx = C.v2_hx; P.V.state = C.v2_state; P.V.hb = C.v2_hb;
         G.progress = &C.v2_hx->f_pos;
+        G.test_fail = C.opt_test_fail_launch >= 0 && (int64_t)C.v2_launch_no == C.opt_test_fail_launch ? 1u : 0u;
         G.table_shape = (uint32_t)C.opt_table_shape; G.launch_par = (uint32_t)(C.v2_launch_no++ & 1u);
     }
     HIPCHK(hipEventRecord(P.ev[6], C.st));
@@ -645,6 +670,7 @@ int step_post_check(Ctx &C, const StepPlan &P)
     HIPCHK(hipEventElapsedTime(&rk_ms, P.ev[7], P.ev[5]));
     HIPCHK(hipEventElapsedTime(&pre_ms, P.ev[5], P.ev[6]));
     C.tm.prep_ms += rk_ms + pre_ms; C.tm.prep_launches += C.workers ? 5 : 1; C.tm.total_ms += rk_ms + pre_ms;
+    C.arena_out = false;
     if (Pst.error || C.hx_host.err) {
         // the first error any stage raised, and where every stage was when it left (nlzm_v2.h: raise(), Hx::dbg)
         const v2::Hx &h = C.hx_host;
@@ -664,7 +690,9 @@ int step_post_check(Ctx &C, const StepPlan &P)
                        h.dbg[2][0], h.dbg[2][1], h.dbg[2][2], h.dbg[2][3], h.dbg[2][4], h.dbg[2][5], h.dbg[2][6],
                        wc.stuck_lanes, wc.stuck_lanes ? (uint32_t)~(uint32_t)wc.stuck_pos_inv : 0u);
     }
-    if (aborted == 3) return set_err(NLZM_HIP_E_KERNEL, "the extension arena of the BT4 pair lists (%u blocks per launch) was used up in chunks [%u,%u): more positions with over %u "
+    // (the worker lanes drop a pair that finds no extension block and go on: the cursor says how many blocks were asked for)
+    C.arena_out = C.ext_cap && C.hx_host.ext_cur > C.ext_cap;
+    if (C.arena_out) return set_err(NLZM_HIP_E_KERNEL, "the extension arena of the BT4 pair lists (%u blocks per launch) was used up in chunks [%u,%u): more positions with over %u "
                                      "record-setters than a block set reserves for", C.ext_cap, c0, c1, C.pstride);
     if (aborted) return set_err(NLZM_HIP_E_KERNEL, "worker lanes aborted (code %u) in chunks [%u,%u)", aborted, c0, c1);
     if (Pst.next_chunk != c1) return set_err(NLZM_HIP_E_KERNEL, "master stopped at chunk %u, expected %u", Pst.next_chunk, c1);
@@ -822,6 +850,17 @@ int refresh_stats(Ctx &C)
         if (C.opt_report && C.hot_max && wc.hot_steps)
             fprintf(stderr, "hot bins' waves: %llu steps (%.1f per call); the next call could not start in %.1f %% of them (a call without its stores on its way) + %.1f %% (an assumed \"skip\" behind a \"call\" still open); lanes: %llu turns spent waiting for a decision\n",
                     wc.hot_steps, (double)wc.hot_steps / (wc.hot_calls ? wc.hot_calls : 1), 100.0 * wc.hot_blocked_dry / wc.hot_steps, 100.0 * wc.hot_blocked_risky / wc.hot_steps, wc.flag_waits);
+        if (C.opt_report && C.hot_max && wc.hot_steps) {
+            fprintf(stderr, "hot bins' waves by the bin's positions in the launch (class: waves | calls, tests/call, entries skipped | steps, cycles/step | %% of the steps: some lane tests (tests per such step; lane-steps repeated for a held slot per step), "
+                            "taking back, every lane holds a call, next call may not start, no entry | idle steps with an undecided position open)\n");
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long *h = wc.hot_class[k];
+                if (!h[0]) continue;
+                const double st = (double)(h[3] ? h[3] : 1);
+                fprintf(stderr, "  >= %7u: %5llu | %10llu calls, %5.1f, %10llu | %12llu steps, %5.0f | %4.1f (%.2f; %.2f), %4.1f, %4.1f, %4.1f, %4.1f | %4.1f\n", 8192u << k, h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1), h[12],
+                        h[3], (double)h[11] / st, 100.0 * h[4] / st, (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / st, 100.0 * h[7] / st, 100.0 * h[8] / st, 100.0 * h[9] / st, 100.0 * h[10] / st, 100.0 * h[13] / st);
+            }
+        }
         if (C.opt_report && wc.call_tests)
             fprintf(stderr, "worker lanes: %.0f cycles per BT4 test, %.1f tests per timed call (lane clocks, divergence included)\n",
                     (double)wc.call_cycles / wc.call_tests, (double)wc.call_tests / (wc.bt_calls ? wc.bt_calls : 1));
@@ -856,7 +895,27 @@ static int dev_init(DevState &D, int device)
     // starts, i.e. at this process's first HIP call -- ours, unless the host program has made one already (then it has to export
     // GPU_MAX_HW_QUEUES=16 itself: include/nlzm_hip.h).  A value the caller has set is left alone.  Set, never read: the library has no
     // environment knobs of its own.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (once per process, and only here -- the per-device threads of nlzm_hip_compress_blocks_multi come in with the runtime long started.  What the
+    //  runtime will have read is kept for nlzm_hip_get_counter("gpu_max_hw_queues_effective"): the caller's value; 16 if this call set it in time;
+    //  the runtime's default of 4 if the process had the GPU open already -- /dev/kfd among its files -- when this library was first called.)
+    static std::once_flag hwq_once;
+    std::call_once(hwq_once, [] {
+        const char *have = getenv("GPU_MAX_HW_QUEUES");
+        if (have && *have) { g_hwq_effective = atoi(have); return; }
+        bool kfd = false;
+        if (DIR *d = opendir("/proc/self/fd")) {
+            while (struct dirent *e = readdir(d)) {
+                char path[64], to[64];
+                snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+                const ssize_t k = readlink(path, to, sizeof to - 1);
+                if (k > 0) { to[k] = 0; if (!strcmp(to, "/dev/kfd")) kfd = true; }
+            }
+            closedir(d);
+        }
+        if (kfd) { g_hwq_effective = 4; return; }       // (too late to matter: left alone)
+        (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        g_hwq_effective = 16;
+    });
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return set_err(NLZM_HIP_E_NODEVICE, "no HIP device (%s)", hipGetErrorString(e));
@@ -1005,6 +1064,8 @@ int nlzm_hip_get_counter(const char *key, uint64_t *value)
     if (!strcmp(key, "hot_bin_calls")) { *value = C.wc_last.hot_calls; return 0; }
     if (!strcmp(key, "positions")) { *value = C.stats.positions; return 0; }
     if (!strcmp(key, "block_pool_bytes")) { *value = cur().blocks_pool_size; return 0; }
+    if (!strcmp(key, "block_redo_streams")) { *value = cur().redo_streams; return 0; }
+    if (!strcmp(key, "gpu_max_hw_queues_effective")) { *value = (uint64_t)g_hwq_effective; return 0; }
     return set_err(NLZM_HIP_E_ARG, "unknown counter %s", key);
 }
 
@@ -1043,6 +1104,9 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     if (!strcmp(key, "parser_helper")) { C.opt_helper = value != 0; return 0; }
     if (!strcmp(key, "table_shape")) { if (value < 0 || value > 2) return set_err(NLZM_HIP_E_ARG, "table_shape out of range"); C.opt_table_shape = value; return 0; }
     if (!strcmp(key, "multi_allow_same_device")) { C.opt_multi_same = value != 0; return 0; }
+    if (!strcmp(key, "test_fail_launch")) { C.opt_test_fail_launch = value; return 0; }
+    if (!strcmp(key, "test_fail_stream")) { if (value < 0 || value > 63) return set_err(NLZM_HIP_E_ARG, "test_fail_stream out of range"); C.opt_test_fail_stream = value; return 0; }
+    if (!strcmp(key, "block_ext_blocks")) { C.opt_block_ext_blocks = value; return 0; }
     if (!strcmp(key, "block_parser_helper")) { C.opt_block_helper = value != 0; return 0; }
     if (!strcmp(key, "keep_block_pool")) { C.opt_keep_pool = value != 0; if (!value && g_jobs.empty()) blocks_close(true); return 0; }
     if (!strcmp(key, "block_batch_chunks")) { if (value < 1 || value > 4096) return set_err(NLZM_HIP_E_ARG, "block_batch_chunks out of range"); C.opt_block_batch = value; return 0; }
@@ -1297,6 +1361,7 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
             m.inited = true; m.device = device; m.st = C.st;
             m.opt_workers = 1; m.opt_worker_blocks = wb; m.opt_batch = batch; m.opt_worker_threads = C.opt_block_threads; m.opt_tbits_max = tbits_max; m.cu_count = C.cu_count;
             m.opt_hot_waves = C.opt_block_hot_waves; m.opt_hot_min = C.opt_hot_min; m.opt_tbits_per = C.opt_tbits_per; m.opt_helper = C.opt_block_helper;
+            m.opt_block_ext_blocks = C.opt_block_ext_blocks;
             Pool mp; mp.measuring = true;
             m.pool = &mp; m.double_sets = true;
             uint8_t *fake_out = nullptr;
@@ -1323,7 +1388,8 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         j.rc = block_ctx_init(j.c, device, wb, batch);
         j.c.opt_tbits_max = tbits_max; j.c.cu_count = C.cu_count;
         j.c.opt_hot_waves = C.opt_block_hot_waves; j.c.opt_hot_min = C.opt_hot_min; j.c.opt_tbits_per = C.opt_tbits_per; j.c.opt_helper = C.opt_block_helper;
-        j.c.opt_table_shape = C.opt_table_shape;
+        j.c.opt_table_shape = C.opt_table_shape; j.c.opt_block_ext_blocks = C.opt_block_ext_blocks;
+        j.c.opt_test_fail_launch = (int64_t)i == C.opt_test_fail_stream ? C.opt_test_fail_launch : -1;
         j.c.pool = &j.pool;
         if (!j.rc) j.rc = dev_alloc(j.c, &j.d_out, j.bound);
         if (!j.rc) j.rc = stream_begin(j.c, g_blocks_src + j.lo, j.n, hist_bits_req, j.d_out, j.bound);
@@ -1443,12 +1509,20 @@ static int blocks_step_impl(uint32_t max_chunks_per_block, uint64_t *in_done_tot
                     snprintf(first_msg, sizeof first_msg, "block %u: %.*s", i, (int)sizeof first_msg - 32, g_err);
                 }
             };
+            // (a stream marked `redo` -- a launch of it used its pair-list arena up -- is out of the set's rounds: what is still queued of it runs on
+            //  a state that is valid but not the reference's, and nothing of it is looked at; nlzm_hip_blocks_finish makes the stream again)
             for (uint32_t i : R.act[q]) {
+                if (g_jobs[i].redo) continue;
                 const hipError_t e = hipStreamWaitEvent(g_jobs[i].c.st, g_group_ev[q][2], 0);
                 note(i, e == hipSuccess ? step_post_issue(g_jobs[i].c, R.plan[q][i]) : set_err(NLZM_HIP_E_NODEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(e)));
             }
-            for (uint32_t i : R.act[q]) if (!rcs[i]) note(i, step_post_check(g_jobs[i].c, R.plan[q][i]));
-            for (uint32_t i : R.act[q]) if (!rcs[i]) note(i, step_post_done(g_jobs[i].c, R.plan[q][i], 0.0f));
+            for (uint32_t i : R.act[q]) if (!rcs[i] && !g_jobs[i].redo) {
+                Ctx &c = g_jobs[i].c;
+                const int rc = step_post_check(c, R.plan[q][i]);
+                if (rc && c.arena_out) { g_jobs[i].redo = true; c.next_chunk = c.pre_chunk = c.g.nchunks; continue; }
+                note(i, rc);
+            }
+            for (uint32_t i : R.act[q]) if (!rcs[i] && !g_jobs[i].redo) note(i, step_post_done(g_jobs[i].c, R.plan[q][i], 0.0f));
             if (first_rc) { std::lock_guard<std::mutex> lk(g_err_mu); memcpy(g_err, first_msg, sizeof g_err); return first_rc; }
         }
         {
@@ -1483,6 +1557,26 @@ int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, u
     if (g_jobs.empty()) return set_err(NLZM_HIP_E_ARG, "no open block set");
     if (!d_dst || !dst_len) return set_err(NLZM_HIP_E_ARG, "null argument");
     for_blocks((uint32_t)g_jobs.size(), [&](uint32_t, BlockJob &j) { j.rc = stream_finish(j.c, &j.len); });
+    // A stream whose launch ran out of extension blocks for its BT4 pair lists (a block set reserves 32 pairs per position and an arena for the
+    // positions that have more: an input with such positions all over it compresses as a single stream, which reserves all 256, but not here)
+    // is made again now, from its first byte, as a single stream with buffers of its own, into its place in the set: the bytes are the same
+    // either way (the reference run on the block), only the time differs.
+    cur().redo_streams = 0;
+    for (auto &j : g_jobs) {
+        if (!j.redo) continue;
+        cur().redo_streams++;
+        Ctx &c = j.c;
+        (void)hipStreamSynchronize(c.st);
+        for (auto &st : g_group_st) (void)hipStreamSynchronize(st);
+        c.pool = nullptr; c.double_sets = false;
+        c.opt_worker_blocks = C.opt_worker_blocks; c.opt_worker_threads = C.opt_worker_threads; c.opt_hot_waves = C.opt_hot_waves; c.opt_batch = C.opt_batch;
+        c.opt_helper = C.opt_helper; c.opt_tbits_max = C.opt_tbits_max; c.opt_test_fail_launch = -1;
+        j.rc = stream_begin(c, g_blocks_src + j.lo, j.n, g_blocks_hist, j.d_out, j.bound);
+        if (!j.rc) j.rc = stream_step(c, 0, nullptr, nullptr, nullptr);
+        if (!j.rc) j.rc = stream_finish(c, &j.len);
+        if (C.opt_report) fprintf(stderr, "block set: the stream of block %zu was made again as a single stream (its pair-list arena of %u blocks per launch had run out)%s\n",
+                                  (size_t)(&j - &g_jobs[0]), c.ext_cap, j.rc ? ": FAILED" : "");
+    }
     if (C.opt_report) {
         // which stage limits a stream under load: smallest / median / largest over the streams, cycles per position
         static const char *const what[8] = { "finder total", "finder waiting", "  of it for BT4 results", "table stage total", "table stage waiting",

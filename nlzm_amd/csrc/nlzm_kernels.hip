@@ -366,8 +366,9 @@ struct LaneSink {
         if (count < 4) { slot[(2 * count) * 512] = d; slot[(2 * count + 1) * 512] = l; }
         else {
             uint32_t *q = bt_pair_ptr<LaneIO>(pairs, B.pstride, B.ext, B.ext_cur, B.ext_cap, ext_idx, count);
+            // (no block left in the arena: the pair is dropped and the launch goes on to its end -- the host sees the cursor beyond the arena
+            //  (Hx::ext_cur) and makes the stream again with every pair reserved, nlzm_hip.cpp; nothing of this launch is used)
             if (q) { LaneIO::st_agent(q, d); LaneIO::st_agent(q + 1, l); }
-            else LaneIO::st_agent(B.fail_word, 3u);                 // (the launch fails: nlzm_hip.cpp reports the arena)
         }
         count++;
     }
@@ -518,6 +519,11 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     uint32_t idle = 0, prog_seen = 0, steps = 0;
     uint32_t behind_risky = 0;      // (wave-uniform) calls started while a risky assumption is open
     bool fail = false;
+    // (accounting by the bin's size: WorkerCounters::hot_class)
+    unsigned long long k_work = 0, k_tests = 0, k_rep = 0, k_rec = 0, k_full = 0, k_blk = 0, k_noent = 0, k_skip = 0, k_und = 0;
+    const unsigned long long k_t0 = __builtin_readcyclecounter();
+    uint32_t k_total = 0;
+    for (uint32_t cc = c0; cc < c1; cc++) { const uint32_t *off = G.bin_off + (unsigned long long)(cc - c0) * (G.nheads + 1); k_total += off[bin + 1] - off[bin]; }
 
     for (;;) {
         // ---- the oldest undecided position in flight; a wrong assumption
@@ -544,43 +550,49 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 }
             }
             uint32_t resume = 0;
+            bool resumes = false;
             if (st == kHeld && seq == rseq) {
-                for (uint32_t j = nu; j-- > 0;) {                   // (made with its stores: the values they replaced; without: the values they write)
+                for (uint32_t j = nu; j-- > 0;) {                   // (the position was assumed to be called and is skipped: the values its stores replaced)
                     const unsigned long long w = undo[j];
                     const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
                     if (t >> 31) heads[t & 0x7FFFFFFFu] = v; else tree[t] = v;
                 }
-                if (dry) { n_calls++; n_tests += tests; n_cmp += cb; }
                 st = kIdle; und = false; wrong = false; n_back++;
-                resume = binidx + 1;
+                // (assumed to be skipped and called: nothing was made of it -- the bin goes on AT it, and finds its decision)
+                resume = dry ? binidx : binidx + 1; resumes = true;
             }
-            for (unsigned long long m = __ballot(resume != 0); m; m &= m - 1) i0 = (uint32_t)__builtin_amdgcn_readlane((int)resume, (int)__builtin_ctzll(m));
+            for (unsigned long long m = __ballot(resumes); m; m &= m - 1) i0 = (uint32_t)__builtin_amdgcn_readlane((int)resume, (int)__builtin_ctzll(m));
             have_pe = false; more = true;
             rec = false;
             continue;
         }
         // ---- one call starts per step, on the first free lane (not while a wrong assumption is being undone)
         uint32_t start_lane = 64;
+        bool made_test = false, rep_step = false, skipped_now = false, started_now = false;
+        const bool have_pe_before = have_pe;
         const unsigned long long free_m = __ballot(st == kIdle);
         // (A call made without its stores does not hold later calls back -- they could overtake it and change what it has yet
         //  to read: nothing starts until it has ended.)
         // (An undecided position assumed to be skipped although the bin's last decision was "call" is wrong one time in eight,
         //  and a wrong assumption costs every call behind it: nothing starts behind such a position until it is decided.)
-        // (Round 5: ... but ONE call may -- the finder stage nearly always needs the bin's next position right behind such a decision, and
-        //  with nothing started it stood there for a whole call, 138,000 cycles a time: two thirds of its waits for worker results at
-        //  300 MB were a hot bin's.  Seven times in eight the call stands; the eighth it is the one call that is taken back.)
+        // (A build option, NLZM_RISKY_AHEAD = k, lets k calls start behind such a position all the same.  Measured in round 5 on the stand-in, 300 MB:
+        //  k = 1 / 2 / 8 gave 493 / 498 / 520 cycles per position against 488 with k = 0 -- NOT adopted: the default is 0, nothing starts, and the
+        //  counter hot_blocked_risky counts the steps spent under this rule.)
         const bool risky_open = __any(und && risky);
         if (!risky_open) behind_risky = 0;
-        const bool dry_on_its_way = __any((st == kStart || st == kRun) && dry) || (risky_open && behind_risky >= NLZM_RISKY_AHEAD);
+        const bool dry_on_its_way = risky_open && behind_risky >= NLZM_RISKY_AHEAD;
         if (!rec && !dry_on_its_way && have_pe && free_m) { start_lane = (uint32_t)__builtin_ctzll(free_m); have_pe = false; }
         n_steps++;
-        if (!rec && have_pe && free_m && dry_on_its_way) {             // (diagnostics: steps in which the next call could not start for one of the two reasons)
-            if (__any((st == kStart || st == kRun) && dry)) n_blk_dry++; else n_blk_risky++;
-        }
+        if (!rec && have_pe && free_m && dry_on_its_way) n_blk_risky++;          // (diagnostics: steps in which the next call could not start)
         if (lane == start_lane) {
             a = (uint32_t)pe; hidx = (uint32_t)(pe >> 32) & 0x1FFFFFFFu;
             max_len = umin(la_end - a, kMatchMax);
-            marked = (pe >> 63) != 0; dry = (pe >> 61) == 7u;           // (without stores: if it turns out to be undecided.  Assumed to be skipped: marked like both its neighbours -- see worker_role)
+#ifdef NLZM_EXP_SKIP_ANY
+            marked = (pe >> 63) != 0; dry = marked && ((pe >> 61) & 3u) != 0u;
+#else
+            marked = (pe >> 63) != 0; dry = (pe >> 61) == 7u;
+#endif
+                      // (without stores: if it turns out to be undecided.  Assumed to be skipped: marked like both its neighbours -- see worker_role)
             seq = seq_next; binidx = i0 - 1;
             st = kStart;
         }
@@ -628,21 +640,29 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         if (st == kStart) {
             bool go = true;
             if (marked) {
-                if (v_flag == kFlagSkip) { st = kIdle; go = false; }        // decided already: it does not happen
+                if (v_flag == kFlagSkip) { st = kIdle; go = false; skipped_now = true; }        // decided already: it does not happen
                 else if (v_flag == kFlagCall) dry = false;                  // decided already: it happens
-                else { und = true; risky = dry && !last_skip; n_open++; t_wait0 = 0; idle = 0; }       // its fate is open: assumed (dry as set at the start)
+                else { und = true; risky = dry && !last_skip; n_open += dry ? 0u : 1u; t_wait0 = 0; idle = 0; }       // its fate is open: assumed (dry as set at the start)
             } else dry = false;
-            if (go) {
+            if (go && dry) {
+                // Undecided and assumed to be skipped: NOTHING is made of it (round 6; until then a descent without its stores, whose result went
+                // out in case the decision was "call" -- a third of all BT4 work on source code, thrown away 99.7 % of the time, and nothing else
+                // of the bin could start while it ran).  It holds its lane as a call that has ended and published, so that what is behind it is held
+                // until the decision; "call" is a wrong assumption like any other, and the bin then goes on AT this position.  The finder stage says
+                // "call" as soon as the positions in front are settled, without waiting for a result (nlzm_v2.h, the block's wait loop).
+                started_now = true;
+                tests = 0; cb = 0; nu = 0; sink.count = 0; published = true;
+                st = kHeld;
+            } else if (go) {
+                started_now = true;
                 sp = v_word;                                        // :983
                 pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0;
                 sink.count = 0; sink.best = 1; sink.best_d = 0; sink.ext_idx = 0; sink.pairs = pairs + (unsigned long long)(a - batch_a0) * (2 * Bx.pstride);
                 published = false;
-                undo[0] = (0x80000000u | hidx) | ((unsigned long long)(dry ? a : sp) << 32);
+                undo[0] = (0x80000000u | hidx) | ((unsigned long long)sp << 32);
                 nu = 1;
-                if (!dry) {
-                    *(unsigned long long *)(tree + pend_l) = ((unsigned long long)kPending << 32) | kPending;   // the new node's two slots: taken
-                    heads[hidx] = a;                                // :984
-                }
+                *(unsigned long long *)(tree + pend_l) = ((unsigned long long)kPending << 32) | kPending;   // the new node's two slots: taken
+                heads[hidx] = a;                                    // :984
                 st = kRun;
             }
         } else if (st == kRun && !fin_now) {
@@ -671,7 +691,9 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             const bool right = sign != 0;
             // the slot(s) this step reads on: still held by an earlier call -> the step is repeated
             const bool held = full ? (pl == kPending || pr == kPending) : ((right ? pr : pl) == kPending);
+            rep_step = held;
             if (!held) {
+                made_test = true;
                 tests++;
                 cb += (l - init) + (full ? 0u : 1u);
                 const uint32_t d = a - sp;
@@ -680,18 +702,16 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 else {
                     // :1006-1017.  The slot taken is marked before the store that makes its node reachable for later calls.
                     const uint32_t slot = right ? pend_l : pend_r;
-                    if (!dry) {
-                        // (order matters to the later calls of this wave: the mark, then the link that makes the node reachable, both
-                        //  before the next step's loads.  The hardware issues one wave's memory operations in program order and
-                        //  returns loads behind earlier stores to the same address; the barriers keep the compiler from re-ordering
-                        //  or sinking the two plain stores)
-                        tree[right ? pair + 1 : pair] = kPending;
-                        asm volatile("" ::: "memory");
-                        tree[slot] = sp;
-                        asm volatile("" ::: "memory");
-                    }
-                    // noted -- with stores: the slot taken now and what it held; without: the store itself
-                    undo[nu] = dry ? (slot | ((unsigned long long)sp << 32)) : ((right ? pair + 1 : pair) | ((unsigned long long)(right ? pr : pl) << 32));
+                    // (order matters to the later calls of this wave: the mark, then the link that makes the node reachable, both
+                    //  before the next step's loads.  The hardware issues one wave's memory operations in program order and
+                    //  returns loads behind earlier stores to the same address; the barriers keep the compiler from re-ordering
+                    //  or sinking the two plain stores)
+                    tree[right ? pair + 1 : pair] = kPending;
+                    asm volatile("" ::: "memory");
+                    tree[slot] = sp;
+                    asm volatile("" ::: "memory");
+                    // noted: the slot taken now and what it held
+                    undo[nu] = (right ? pair + 1 : pair) | ((unsigned long long)(right ? pr : pl) << 32);
                     nu++;
                     pend_l = right ? pair + 1 : pend_l; pend_r = right ? pend_r : pair;
                     len_r = right ? l : len_r; len_l = right ? len_l : l;
@@ -700,8 +720,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             }
         }
         if (fin_now) {
-            if (!dry) { tree[pend_l] = fin_l; tree[pend_r] = fin_r; }
-            else { undo[nu] = pend_l | ((unsigned long long)fin_l << 32); undo[nu + 1] = pend_r | ((unsigned long long)fin_r << 32); nu += 2; }
+            tree[pend_l] = fin_l; tree[pend_r] = fin_r;
             st = kHeld;
         }
         // ---- a call that has ended: its result goes out when no undecided position stands before it
@@ -710,6 +729,18 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             if (published && !und && seq <= oseq) {
                 if (!dry) { n_calls++; n_tests += tests; n_cmp += cb; }
                 st = kIdle;
+            }
+        }
+        {   // (accounting)
+            const uint32_t nt = (uint32_t)__builtin_popcountll(__ballot(made_test)), nr = (uint32_t)__builtin_popcountll(__ballot(rep_step));
+            k_tests += nt; k_rep += nr; k_skip += (uint32_t)__builtin_popcountll(__ballot(skipped_now));
+            if (nt || __any(started_now)) k_work++;
+            else {
+                if (rec) k_rec++;
+                else if (!free_m) k_full++;
+                else if (have_pe_before && dry_on_its_way) k_blk++;
+                else k_noent++;
+                if (__any(und)) k_und++;
             }
         }
         // ---- watchdogs (a position whose decision does not come; a launch that failed elsewhere)
@@ -736,6 +767,12 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
         atomicAdd(&G.wcnt->hot_calls, n_calls);
         atomicAdd(&G.wcnt->hot_steps, n_steps); atomicAdd(&G.wcnt->hot_blocked_dry, n_blk_dry); atomicAdd(&G.wcnt->hot_blocked_risky, n_blk_risky);
+        uint32_t kc = 0;
+        while (kc < 7 && (k_total >> (14 + kc))) kc++;
+        unsigned long long *hc = G.wcnt->hot_class[kc];
+        atomicAdd(&hc[0], 1ull); atomicAdd(&hc[1], n_calls); atomicAdd(&hc[2], n_tests); atomicAdd(&hc[3], n_steps); atomicAdd(&hc[4], k_work);
+        atomicAdd(&hc[5], k_tests); atomicAdd(&hc[6], k_rep); atomicAdd(&hc[7], k_rec); atomicAdd(&hc[8], k_full); atomicAdd(&hc[9], k_blk);
+        atomicAdd(&hc[10], k_noent); atomicAdd(&hc[11], (unsigned long long)(__builtin_readcyclecounter() - k_t0)); atomicAdd(&hc[12], k_skip); atomicAdd(&hc[13], k_und);
     }
 }
 
@@ -819,8 +856,10 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                         if (!nq) break;
                         e = my + (first * kEntryWords) * 512;
                         const uint32_t ea = e[kWa * 512], einfo = e[kWinfo * 512];
-                        LaneSink sk{ e, B.pairs + (unsigned long long)(ea - B.batch_a0) * (2 * B.pstride), e[kWcount * 512] & 0x1FFu, e[kWbest * 512], e[kWbestd * 512], e[kWcount * 512] >> 9 };
-                        sk.publish(B.ready + (unsigned long long)(ea - B.batch_a0) * kBtRec, e[kWtests * 512]);
+                        if (!((einfo >> 28) & 1u)) {             // (a position assumed to be skipped has no result)
+                            LaneSink sk{ e, B.pairs + (unsigned long long)(ea - B.batch_a0) * (2 * B.pstride), e[kWcount * 512] & 0x1FFu, e[kWbest * 512], e[kWbestd * 512], e[kWcount * 512] >> 9 };
+                            sk.publish(B.ready + (unsigned long long)(ea - B.batch_a0) * kBtRec, e[kWtests * 512]);
+                        }
                         if (einfo & 1u) {                           // a marked position: the new oldest, unless its decision is in too, and as assumed
                             head_a = ea;
                             const uint32_t f2 = LaneIO::ld_agent(G.bt_flag + (ea - G.batch_a0));
@@ -843,8 +882,8 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                                 if (t >> 31) B.heads[t & 0x7FFFFFFFu] = v; else B.tree[t] = v;
                             }
                         }
-                        if (k == 0 && hdry) { n_calls++; n_tests += e[kWtests * 512]; n_cmp += e[kWcmp * 512]; }
                         if (k == 1) resume = (e[kWinfo * 512] & 0xFFFFFFu) >> 1;     // (the entry behind it: made again)
+                        if (k == 0 && hdry) resume = (e[kWinfo * 512] & 0xFFFFFFu) >> 1;    // (assumed to be skipped and called: nothing was made of it -- the lane goes on AT it)
                         if (k) n_redo++;
                     }
                     n_back++;
@@ -877,7 +916,12 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
                             // regions, :1529): act on it; otherwise the call is made with its fate open
                             const uint32_t f = LaneIO::ld_agent(G.bt_flag + (ja - G.batch_a0));
                             job = f == kFlagSkip ? 0u : ((f == kFlagCall && !nq) ? 1u : 2u);
-                            if (f != kFlagCall && ((pe >> 61) & 3u) == 3u) jinfo |= 1u << 28;   // (the positions before AND behind are marked too: assumed to be skipped)
+#ifdef NLZM_EXP_SKIP_ANY
+                            if (f != kFlagCall && ((pe >> 61) & 3u) != 0u) jinfo |= 1u << 28;
+#else
+                            if (f != kFlagCall && ((pe >> 61) & 3u) == 3u) jinfo |= 1u << 28;
+#endif
+                              // (the positions before AND behind are marked too: assumed to be skipped)
                         } else job = nq ? 2u : 1u;
                     }
                 }
@@ -904,16 +948,21 @@ __device__ __forceinline__ void worker_role(const Geom &g, const Globals &G, uin
             uint32_t *e = my + (slot * kEntryWords) * 512;
             LaneSink sink{ e, B.pairs + bi * (2 * B.pstride) };
             uint32_t tests = 0, cmpb = 0, nu = 0;
-            bt_descent(B, ja, jh, jlen, job == 2, (jinfo >> 28) & 1u, undo_base + slot * (kUndoCap * 2), nu, sink, tests, cmpb);
+            // An undecided position that is assumed to be skipped: NOTHING is made of it (round 6; until then a descent without its stores, whose
+            // result went out in case the decision was "call").  It is an open call without a result and without notes: what is behind it is
+            // held until its decision; "call" is a wrong assumption like any other, and the lane then goes on AT this position.  The finder stage
+            // says "call" as soon as the positions in front are settled, without waiting for a result (nlzm_v2.h, the block's wait loop).
+            const bool park = job == 2 && ((jinfo >> 28) & 1u);
+            if (!park) bt_descent(B, ja, jh, jlen, job == 2, false, undo_base + slot * (kUndoCap * 2), nu, sink, tests, cmpb);
             if (job == 1) {
                 sink.publish(B.ready + bi * kBtRec, tests);
                 n_calls++; n_tests += tests; n_cmp += cmpb;
                 n_cyc += __builtin_readcyclecounter() - t0; n_cyc_tests += tests;
             } else {
-                if (!nq) { sink.publish(B.ready + bi * kBtRec, tests); head_a = ja; t_wait0 = 0; idle = 0; }    // (the oldest: its result stands whatever is decided)
+                if (!nq) { if (!park) sink.publish(B.ready + bi * kBtRec, tests); head_a = ja; t_wait0 = 0; idle = 0; }    // (the oldest: its result stands whatever is decided)
                 e[kWa * 512] = ja; e[kWtests * 512] = tests; e[kWcmp * 512] = cmpb; e[kWcount * 512] = sink.count | (sink.ext_idx << 9);
                 e[kWbest * 512] = sink.best; e[kWbestd * 512] = sink.best_d; e[kWundo * 512] = nu; e[kWinfo * 512] = jinfo;
-                nq++; n_open++;
+                nq++; if (!park) n_open++;
             }
         }
         if (!__any(active && !waiting)) __builtin_amdgcn_s_sleep(8);
@@ -995,12 +1044,18 @@ __global__ __launch_bounds__(256) void round_open_kernel(const Stream2Args *__re
     auto *w = NLZM_G(uint32_t, a.V.hx);
     const uint32_t a0 = a.G.batch_a0;
     constexpr uint32_t kWords = sizeof(v2::Hx) / 4;
+    // A stream whose launch before this one failed (the sticky Persist::error: this launch was queued before the host had looked): its stages and worker
+    // lanes must leave at once -- the error word is what every wait of every stage looks at, the abort word what the worker lanes look at.  Cleared, the
+    // table stage stood at the finder's progress word until the 30 s bound of its wait.
+    const uint32_t sticky = NLZM_G(const uint32_t, a.G.persist)[offsetof(Persist, error) / 4];
     for (uint32_t i = threadIdx.x; i < kWords; i += 256) {
         uint32_t v = 0;
         if (i == offsetof(v2::Hx, f_pos) / 4 || i == offsetof(v2::Hx, t_pos) / 4 || i == offsetof(v2::Hx, t_out) / 4 || i == offsetof(v2::Hx, p_pos) / 4 ||
             i == offsetof(v2::Hx, p_seg) / 4 || i == offsetof(v2::Hx, p_seg) / 4 + 1) v = a0;         // (p_seg = a0 << 32 | a0)
+        if (i == offsetof(v2::Hx, err) / 4) v = sticky;
         w[i] = v;
     }
+    if (threadIdx.x == 0 && sticky && a.G.abort_word) *NLZM_G(uint32_t, a.G.abort_word) = 1u;
 }
 __global__ __launch_bounds__(256) void round_close_kernel(const Stream2Args *__restrict__ pack)
 {

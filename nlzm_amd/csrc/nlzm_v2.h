@@ -587,46 +587,102 @@ struct Finder {
         const bool bt_wait = bt_call && i < cut_bin;
         uint32_t bt_n = 0;
         flush_fpos();                                               // (the block before: its records have landed by now)
-        if (xw::any(bt_wait)) {
+        // ---- the worker lanes' results, and the verification: what the table's reach really is in front of every lane (:1514 sees it after carry
+        // + extend), where the block is cut.  Round 6: ONE loop.  The stage used to wait for the result of every lane it had predicted a call for,
+        // and verified then -- but a block is cut at the first lane whose prediction was wrong, and at the start of every long repeat that is the
+        // lane right behind the position that found the match (the lanes behind it are in a nice region, :1514: their calls never happen, and their
+        // results -- dry runs of lanes and waves that have better things to do -- were waited for all the same: one block in six on source code).
+        // A lane's reach, and so its decision, hangs on the lanes in front of it only: as soon as every lane in front of the first missing result
+        // is there, everything up to and including that lane's decision is exact, and a cut at or in front of it ends the wait.
+        const uint32_t ec0 = ec, ec_d0 = ec_d, od0 = od;            // (without the worker lanes' results)
+        uint32_t pm = 0, before = 0, js = 64, jo = 64, cut_nice = 64, m = 0;
+        bool nice_real = false, so_top = false, so_tie = false, so_win = false;
+        unsigned long long stm = 0, om = 0;
+        {
             const unsigned long long tw = xw::tick();
             const unsigned long long t0 = xw::clock100();
             uint32_t spins = 0;
-            if (bt_wait) xw::need_bt(G.hook_user, a);
+            const bool waits = xw::any(bt_wait);
+            bool have = !bt_wait;                                   // this lane's result is in (or none is awaited)
+            uint32_t r_d = 0, r_l = 0;
+            unsigned long long seen = ~0ull;                        // the lanes whose results were in when the block was last verified
             for (;;) {
                 // (quad 0 of the record in one load: the ready word and the longest pair behind it -- they were two dependent round trips)
-                xw::u32x4 q0 = { kBtReady, 0u, 0u, 0u };
-                if (bt_wait) q0 = xw::ld_agent128(G.bt_ready + bi * kBtRec);
-                const uint32_t w0 = q0.x;
-                if (spins == 0) {       // (accounting: whose results are not there when the block asks first)
-                    const unsigned long long late = xw::ballot(!(w0 & kBtReady));
-                    n_late_unc += (uint32_t)__builtin_popcountll(late & xw::ballot(unc));
-                    n_late_other += (uint32_t)__builtin_popcountll(late & ~xw::ballot(unc));
-                    if (late) {         // ... of a hot bin's wave or of a lane; lane 0 of the block (the position a block was cut at) or a later one
-                        const bool hot = G.hot_of_bin && bt_wait && !(w0 & kBtReady) && G.hot_of_bin[(hash4(v4) >> g.bt_shift) % G.nheads] != 0;
+                {   // (host simulation: the worker emulation is asked for the FIRST missing result only, so that results come in one by one and the
+                    //  ones behind a cut never do -- the device's worker lanes need no asking)
+                    const unsigned long long ask = xw::ballot(!have);
+                    if (ask && i == (uint32_t)__builtin_ctzll(ask)) xw::need_bt(G.hook_user, a);
+                }
+                if (!have) {
+                    const xw::u32x4 q0 = xw::ld_agent128(G.bt_ready + bi * kBtRec);
+                    if (q0.x & kBtReady) { have = true; bt_n = q0.x & 0x1FFu; r_d = q0.y; r_l = q0.z; }
+                }
+                const unsigned long long missing = xw::ballot(!have);
+                if (waits && spins == 0) {       // (accounting: whose results are not there when the block asks first)
+                    n_late_unc += (uint32_t)__builtin_popcountll(missing & xw::ballot(unc));
+                    n_late_other += (uint32_t)__builtin_popcountll(missing & ~xw::ballot(unc));
+                    if (missing) {      // ... of a hot bin's wave or of a lane; lane 0 of the block (the position a block was cut at) or a later one
+                        const bool hot = G.hot_of_bin && !have && G.hot_of_bin[(hash4(v4) >> g.bt_shift) % G.nheads] != 0;
                         n_late_hot += (uint32_t)__builtin_popcountll(xw::ballot(hot));
-                        n_late_first += (uint32_t)(late & 1ull);
+                        n_late_first += (uint32_t)(missing & 1ull);
                         n_late_blocks++;
                     }
                 }
-                if (!xw::any(!(w0 & kBtReady))) {
+                if (missing != seen) {
+                    seen = missing;
                     xw::after_poll();
-                    if (bt_wait) {
-                        bt_n = w0 & 0x1FFu;
-                        if (bt_n) {
-                            const uint32_t d = q0.y, l = q0.z;
-                            if (l >= cap) od = umin(od, d); else closed_end(a + l, d);
+                    const uint32_t F = missing ? (uint32_t)__builtin_ctzll(missing) : 64u;      // the first lane whose result is missing
+                    ec = ec0; ec_d = ec_d0; od = od0;
+                    if (bt_wait && have && bt_n) { if (r_l >= cap) od = umin(od, r_d); else closed_end(a + r_l, r_d); }
+                    pm = xw::scan_max(in_blk ? umax(ec, so_end) : 0u);          // inclusive prefix max of the closed ends
+                    before = umax(xw::lane_below(pm, 0u), reach);
+                    if (i >= jc && s_active) before = umax(before, s_end);      // the former top entry, closed
+                    nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
+                    // a cut-short RK256 entry that is longer than everything else in this lane's table grows from the next position on (the lanes in front of
+                    // the first such lane hold theirs as closed entries: `before` is right for it).  As long as another entry: which of the two the table's
+                    // end holds hangs on their distances (:835-852 keeps the smaller): looked up then.
+                    const bool so_free = in_blk && so_end != 0 && od == kNone && !s_sliding;
+                    so_tie = so_free && so_end == umax(before, ec);
+                    so_win = false;
+                    if (xw::any(so_tie)) {      // (rare: the smallest distance among the other entries that end exactly there -- own, of the lanes in front, older ones)
+                        uint32_t d2 = kNone;
+                        if (ec == so_end) d2 = ec_d;
+                        if (reach == so_end) d2 = umin(d2, reach_d);
+                        if (i >= jc && s_active && s_end == so_end) d2 = umin(d2, s_d);
+                        for (uint32_t j = 0; j + 1 < n; j++) {
+                            const uint32_t ej = xw::readlane(ec, j), dj = xw::readlane(ec_d, j), sj = xw::readlane(so_end, j), sdj = xw::readlane(so_d, j);
+                            if (j < i && ej == so_end) d2 = umin(d2, dj);
+                            if (j < i && sj == so_end) d2 = umin(d2, sdj);
                         }
+                        so_win = so_tie && so_d < d2;
                     }
-                    break;
+                    so_top = so_free && (so_end > umax(before, ec) || so_win);
+                    stm = xw::ballot(so_top);
+                    js = stm ? (uint32_t)__builtin_ctzll(stm) : 64u;
+                    const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
+                    cut_nice = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
+                    // a match as long as the lookahead allows becomes the growing top entry, unless one with a smaller
+                    // distance is growing already (:835-852 keeps the smaller distance at the table's end)
+                    om = xw::ballot(in_blk && od != kNone && (!s_sliding || od < s_d));
+                    jo = om ? (uint32_t)__builtin_ctzll(om) : 64u;
+                    m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
+                    m = umin(m, js + 1 > 64 ? 64u : js + 1);
+                    // (lanes behind the first missing one contribute what they have: a cut they ask for lies behind F and is not taken; a cut at or in
+                    //  front of F hangs on lanes in front of F only -- F's own decision included, which is why `<=`)
+                    if (m <= F) break;
+                    // Lane F's decision is exact now, and it is "call" (a nice lane F would be a wrong prediction: a cut at F, and the loop were left): said
+                    // at once, not at the block's commit.  The worker of an undecided position that it ASSUMES to be skipped does not make the call
+                    // (round 6: no dry run -- a third of all BT4 work on source code was descents thrown away): without this word it would not
+                    // make it before the commit, and the commit waits for its result.
+                    if (i == F && unc) xw::st_agent(G.bt_flag + bi, kFlagCall);
                 }
                 if ((++spins & 63u) == 0) {
                     if (xw::readfirst(xw::ld_agent(&V.hx->err))) { err = kErrInternal + 100; return 1; }
 #ifndef NLZM_SIM
                     if (xw::clock100() - t0 > 3000000000ull) {
                         // (which positions are missing, and whether the first of them is one whose call this stage decides)
-                        const unsigned long long late = xw::ballot(!(w0 & kBtReady));
-                        const uint32_t fl = (uint32_t)__builtin_ctzll(late | (1ull << 63));
-                        fail(kErrTimeout, a0 + fl, 6, (uint32_t)__builtin_popcountll(late) | (xw::readlane(unc ? 1u : 0u, fl) << 8) | (n << 16),
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(missing | (1ull << 63));
+                        fail(kErrTimeout, a0 + fl, 6, (uint32_t)__builtin_popcountll(missing) | (xw::readlane(unc ? 1u : 0u, fl) << 8) | (n << 16),
                              xw::readlane((hash4(v4) >> g.bt_shift) % G.nheads, fl));
                         return 1;
                     }
@@ -636,45 +692,10 @@ struct Finder {
                 }
                 xw::pause();
             }
-            t_wait += xw::tick() - tw; t_wait_bt += xw::tick() - tw;
+            if (waits) { t_wait += xw::tick() - tw; t_wait_bt += xw::tick() - tw; }
         }
 
         const unsigned long long f6 = ptick();
-        // ---- verification: what the table's reach really is in front of every lane (:1514 sees it after carry + extend)
-        const uint32_t pm = xw::scan_max(in_blk ? umax(ec, so_end) : 0u);       // inclusive prefix max of the closed ends
-        uint32_t before = umax(xw::lane_below(pm, 0u), reach);
-        if (i >= jc && s_active) before = umax(before, s_end);                  // the former top entry, closed
-        const bool nice_real = in_blk && umax(before, s_sliding ? s_e : 0u) >= a + kNice;
-        // a cut-short RK256 entry that is longer than everything else in this lane's table grows from the next position on (the lanes in front of
-        // the first such lane hold theirs as closed entries: `before` is right for it).  As long as another entry: which of the two the table's
-        // end holds hangs on their distances (:835-852 keeps the smaller): looked up then.
-        const bool so_free = in_blk && so_end != 0 && od == kNone && !s_sliding;
-        const bool so_tie = so_free && so_end == umax(before, ec);
-        bool so_win = false;
-        if (xw::any(so_tie)) {      // (rare: the smallest distance among the other entries that end exactly there -- own, of the lanes in front, older ones)
-            uint32_t d2 = kNone;
-            if (ec == so_end) d2 = ec_d;
-            if (reach == so_end) d2 = umin(d2, reach_d);
-            if (i >= jc && s_active && s_end == so_end) d2 = umin(d2, s_d);
-            for (uint32_t j = 0; j + 1 < n; j++) {
-                const uint32_t ej = xw::readlane(ec, j), dj = xw::readlane(ec_d, j), sj = xw::readlane(so_end, j), sdj = xw::readlane(so_d, j);
-                if (j < i && ej == so_end) d2 = umin(d2, dj);
-                if (j < i && sj == so_end) d2 = umin(d2, sdj);
-            }
-            so_win = so_tie && so_d < d2;
-        }
-        const bool so_top = so_free && (so_end > umax(before, ec) || so_win);
-        const unsigned long long stm = xw::ballot(so_top);
-        const uint32_t js = stm ? (uint32_t)__builtin_ctzll(stm) : 64u;
-        const unsigned long long bad = xw::ballot(in_blk && nice_real != nice_pred);
-        const uint32_t cut_nice = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;
-        // a match as long as the lookahead allows becomes the growing top entry, unless one with a smaller
-        // distance is growing already (:835-852 keeps the smaller distance at the table's end)
-        const bool s_here = s_sliding;                                          // the old one still grows at this lane
-        const unsigned long long om = xw::ballot(in_blk && od != kNone && (!s_here || od < s_d));
-        const uint32_t jo = om ? (uint32_t)__builtin_ctzll(om) : 64u;
-        uint32_t m = umin(n, umin(cut_nice, umin(jo + 1 > 64 ? 64u : jo + 1, umin(cut_ev, umin(cut_rk, umin(cut_slot, cut_bin))))));
-        m = umin(m, js + 1 > 64 ? 64u : js + 1);
         if (m == 0) { fail(kErrInternal, a0, 7); return 1; }
         n_blocks++;
         if (m < n) {        // (why the block was cut; diagnostics)
@@ -786,6 +807,7 @@ struct Finder {
         rk_from = xw::readfirst(P->rk_from); rk_to = xw::readfirst(P->rk_to); rk_len = xw::readfirst(P->rk_len); rk_end = xw::readfirst(P->rk_end);
         rk_cut = rk_len >> 31; rk_len &= 0x7FFFFFFFu;                       // (the length is at most 65,535)
         err = xw::readfirst(P->error);
+        if (!err && G.test_fail) fail(kErrInternal + 50, (uint32_t)((unsigned long long)c0 * g.chunk_size), 9);      // (test of the fault path: option "test_fail_stream")
         n_pos = n_nice = n_unc = n_ht = n_rkp = n_rki = n_cmp = n_blocks = 0;
         n_cut0 = n_cut1 = n_cut2 = n_cut3 = n_cut4 = n_cut5 = 0;
         t_wait = 0;
@@ -1002,8 +1024,12 @@ struct Table {
             }
             const uint32_t *pairs = G.bt_pairs + bi * (2 * G.bt_pstride);
             // (pairs beyond the position's reservation: in the extension block whose index + 1 is the record's word 14)
-            const uint32_t *extp = cnt > G.bt_pstride ? G.bt_ext + (unsigned long long)(bw[14] - 1) * (2 * (kBtMaxPairs - G.bt_pstride)) : pairs;
-            for (uint32_t k = 4; k < cnt; k++) {
+            // (a launch that used its arena up has positions whose block index lies beyond it: their pairs were never stored -- the launch is reported
+            //  as failed and the stream made again, nlzm_hip.cpp; nothing outside the arena is read meanwhile)
+            const bool ext_ok = cnt > G.bt_pstride && bw[14] - 1u < G.bt_ext_cap;
+            const uint32_t *extp = ext_ok ? G.bt_ext + (unsigned long long)(bw[14] - 1) * (2 * (kBtMaxPairs - G.bt_pstride)) : pairs;
+            const uint32_t cnt_there = (cnt > G.bt_pstride && !ext_ok) ? G.bt_pstride : cnt;
+            for (uint32_t k = 4; k < cnt_there; k++) {
                 const uint32_t *q = k < G.bt_pstride ? pairs + 2 * k : extp + 2 * (k - G.bt_pstride);
                 const uint32_t d = xw::ld_agent(q), l = xw::ld_agent(q + 1);
                 if (l >= cap_len) continue;

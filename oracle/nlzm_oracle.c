@@ -489,9 +489,14 @@ static void ht_find(enc_t *e, ht_t *h, mtab_t *mt, uint32_t hv, uint32_t p)
 
 /* ---- BT4 : MatchFinderBT, NLZM.cpp:959-1031 ----------------------------- */
 
+/* (debug, for oracle/skip_probe.c: the longest match the last bt_find call handed to the table, 0: none) */
+static uint32_t g_bt_last_best;
+uint32_t nlzm_oracle_debug_bt_last_best(void) { return g_bt_last_best; }
+
 static void bt_find(enc_t *e, mtab_t *mt, uint32_t h4, uint32_t p)
 {
     bt_t *b = &e->bt;
+    g_bt_last_best = 0;
     uint32_t *pend_l = b->tree + ((size_t)(p & e->wmask) << 1);
     uint32_t *pend_r = pend_l + 1;
     uint32_t len_l = 0, len_r = 0;
@@ -505,7 +510,7 @@ static void bt_find(enc_t *e, mtab_t *mt, uint32_t h4, uint32_t p)
         uint32_t *pair = b->tree + ((size_t)(sp & e->wmask) << 1);
         const uint32_t r = common_len_signed(e, sp, p, max_len, u32min(len_l, len_r));
         const uint32_t l = r & 0x7FFFFFFFu;
-        if (l >= nlzm_oracle_match_min(p - sp)) mt_update(mt, p - sp, l);
+        if (l >= nlzm_oracle_match_min(p - sp)) { mt_update(mt, p - sp, l); if (l > g_bt_last_best) g_bt_last_best = l; }
         if (l == max_len) {                             /* NLZM.cpp:1000-1004 */
             *pend_l = pair[0];
             *pend_r = pair[1];

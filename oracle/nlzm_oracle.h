@@ -92,6 +92,7 @@ uint32_t nlzm_oracle_crc32(const uint8_t *p, uint64_t n, uint32_t crc);
  * table's longest entry, summed over the process's compress calls so far (such an entry grows again at the next position,
  * NLZM.cpp:1503-1512). */
 uint64_t nlzm_oracle_debug_rk_u16_cuts(void);
+uint32_t nlzm_oracle_debug_bt_last_best(void);   /* the longest match of the last BT4 call (oracle/skip_probe.c) */
 
 /* Small pure functions exposed for known-answer tests. */
 const uint16_t *nlzm_oracle_log2_lut(void);                 /* 256 entries */

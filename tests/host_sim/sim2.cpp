@@ -123,13 +123,18 @@ struct SimWorkers {
         const uint32_t max_len = umin(la_end_of(a) - a, kMatchMax);
         unsigned long long dt = 0, dc = 0;
         if (G->unc[a - G->batch_a0]) {
-            if (!published[a - G->batch_a0]) {
+            // (as the device's worker lanes do: a marked position between two marked ones is assumed to be skipped and NOTHING is made of it until the
+            //  finder stage says "call" -- which it says without a result, as soon as the positions in front are settled; any other marked position
+            //  is assumed to be called: its result goes out at once, its stores wait for the decision)
+            const unsigned long long bi = a - G->batch_a0;
+            const bool park = bi > 0 && G->unc[bi - 1] && G->unc[bi + 1];
+            if (!park && !published[bi]) {
                 worker_bt_call<HostIO, false>(bt_view(g, *G), a, max_len, true, dt, dc);
-                published[a - G->batch_a0] = 1; dry++;
+                published[bi] = 1; dry++;
             }
-            const uint32_t f = G->bt_flag[a - G->batch_a0];
+            const uint32_t f = G->bt_flag[bi];
             if (f == 0) { if (final_flush) { printf("sim: flag of uncertain position %u never published\n", a); exit(1); } return; }
-            if (f == kFlagCall) { worker_bt_call<HostIO, true>(bt_view(g, *G), a, max_len, false, tests, cmp); calls++; }
+            if (f == kFlagCall) { worker_bt_call<HostIO, true>(bt_view(g, *G), a, max_len, park, tests, cmp); published[bi] = 1; calls++; }
         } else {
             worker_bt_call<HostIO, true>(bt_view(g, *G), a, max_len, true, tests, cmp);
             published[a - G->batch_a0] = 1; calls++;

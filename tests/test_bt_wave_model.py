@@ -6,9 +6,12 @@ The device code itself is checked on the GPU (tests/test_gpu_parity.py: bytes an
 threshold forced down so that nearly every bin is run by a wave).  This file pins the ARGUMENT, on the CPU, in plain Python:
   * a call assigns every slot at most once and reads a slot only on its way down, so a later call may read every slot the
     earlier calls have finished with; a call marks the slot it takes, a call that needs a marked slot repeats the step;
-  * one call starts per step; a call made without its stores lets nothing start until it has ended;
+  * one call starts per step; an undecided position that is assumed to be skipped is NOT made (round 6: no descent without
+    stores) -- it holds a lane as a call that has ended, with no result and no notes;
   * results behind an undecided position are held; a wrong assumption takes every call behind the position back, latest
-    first, from the (slot, value replaced) notes, takes back or makes the position's own stores, and goes on behind it.
+    first, from the (slot, value replaced) notes; a position that was assumed to be called has its own stores taken back and
+    the bin goes on behind it, one that was assumed to be skipped is made now: the bin goes on AT it;
+  * a decision may come before the position's result (the finder stage says "call" as soon as the positions in front are settled).
 A step of the model is a step of the wave: every lane loads from the memory as the step finds it, then the stores of the
 step are made (marks before links).  Lanes take steps in lockstep; which free lane a call starts on is random.
 """
@@ -69,8 +72,8 @@ def wave(buf, positions, marked, called, assume_skip, decide_at, rng, lanes_n=8)
     lanes = [Lane() for _ in range(lanes_n)]
     published, redone = {}, 0
     nxt, seq_next, step, recovering = 0, 1, 0, False
-    # (the finder decides "call" only after it has read the position's result: such a decision never precedes the result)
-    decided = lambda a: step >= decide_at[a] and (not called[a] or a in published)
+    # (a decision may precede the position's result: the finder stage does not wait for a result to say "call")
+    decided = lambda a: step >= decide_at[a]
 
     def replay(notes):
         for slot, v in reversed(notes):
@@ -94,15 +97,14 @@ def wave(buf, positions, marked, called, assume_skip, decide_at, rng, lanes_n=8)
                     replay(L.notes)
                 L.state = "idle"; redone += 1
             P = next(L for L in lanes if L.state == "held" and L.seq == rseq)
-            replay(P.notes)                  # made with its stores: the values they replaced; without: the values they write
+            replay(P.notes)                  # assumed to be called, and skipped: the values its stores replaced (assumed to be skipped: no notes)
             P.state = "idle"
-            nxt = P.index + 1
+            nxt = P.index if P.dry else P.index + 1     # (assumed to be skipped, and called: made now)
             recovering = False
             continue
         # ---- one call starts per step (not behind a call without its stores that is on its way, not while recovering)
         free = [L for L in lanes if L.state == "idle"]
-        dry_on_its_way = any(L.state in ("start", "run") and L.dry for L in lanes)
-        if not recovering and not dry_on_its_way and free and nxt < len(positions):
+        if not recovering and free and nxt < len(positions):
             L = rng.choice(free)
             a = positions[nxt]
             L.__dict__.update(state="start", a=a, index=nxt, seq=seq_next, und=False, wrong=False, dry=False, notes=[],
@@ -131,14 +133,14 @@ def wave(buf, positions, marked, called, assume_skip, decide_at, rng, lanes_n=8)
                     continue
                 if marked[a] and not decided(a):
                     L.und, L.dry = True, assume_skip[a]
+                if L.dry:                                           # nothing is made of it: a call that has ended, without a result
+                    L.state, L.out = "held", True
+                    continue
                 L.sp = loaded[id(L)]
                 L.pend_l, L.pend_r, L.len_l, L.len_r = 2 * a, 2 * a + 1, 0, 0
-                if L.dry:
-                    L.notes.append(("h", a))
-                else:
-                    L.notes.append(("h", L.sp))
-                    tree[2 * a] = PENDING; tree[2 * a + 1] = PENDING
-                    head[0] = a
+                L.notes.append(("h", L.sp))
+                tree[2 * a] = PENDING; tree[2 * a + 1] = PENDING
+                head[0] = a
                 L.state = "run"
             elif L.state == "run":
                 a, sp = L.a, L.sp
@@ -159,26 +161,20 @@ def wave(buf, positions, marked, called, assume_skip, decide_at, rng, lanes_n=8)
                         fin = (pl, pr)
                     else:
                         slot, taken, old = (L.pend_l, 2 * sp + 1, pr) if right else (L.pend_r, 2 * sp, pl)
-                        if L.dry:
-                            L.notes.append((slot, sp))
-                        else:
-                            L.notes.append((taken, old))
-                            tree[taken] = PENDING
-                            tree[slot] = sp
+                        L.notes.append((taken, old))
+                        tree[taken] = PENDING
+                        tree[slot] = sp
                         if right:
                             L.pend_l, L.len_r, L.sp = taken, l, pr
                         else:
                             L.pend_r, L.len_l, L.sp = taken, l, pl
                         continue
-                if L.dry:
-                    L.notes += [(L.pend_l, fin[0]), (L.pend_r, fin[1])]
-                else:
-                    tree[L.pend_l], tree[L.pend_r] = fin
+                tree[L.pend_l], tree[L.pend_r] = fin
                 L.state = "held"
         # ---- a call that has ended: its result goes out when no undecided position stands before it
         for L in lanes:
             if L.state == "held" and not L.wrong:
-                if not L.out and L.seq <= oseq:
+                if not L.out and L.seq <= oseq and not L.dry:
                     assert L.a not in published or published[L.a] == (tuple(L.res), L.tests), "a published result changed"
                     published[L.a] = (tuple(L.res), L.tests); L.out = True
                 if L.out and not L.und and L.seq <= oseq:

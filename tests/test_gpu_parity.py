@@ -66,21 +66,32 @@ def test_full_size_configs(gpu, name):
     assert st["shifts"] == {"text_100m_w24": 4, "text_100m_w26": 0, "block_125m_w28": 0, "text_1g_w28": 2}[name]
 
 
-@pytest.mark.parametrize("name", ["real_30m_w24", "real_300m_w28"])
-def test_real_text(gpu, name):
-    """REAL text -- the image's own source files (corpus.real_text: Python's standard library, C / C++ headers, the installed
-    packages' sources) -- against the reference's stream for exactly these bytes (tests/golden/real.json, oracle/make_golden_real.py).
-    Every other input is a seeded generator; this one has the skew of real source text: the hottest BT4 head (a run of spaces) holds
-    17 % of the positions, the 256 hottest 35 %.  The bytes depend on the image, so the input's SHA-256 is checked first and the test
-    SKIPS LOUDLY where the box's files differ from the build container's."""
-    g = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "real.json")))["cases"]}[name]
+def _pinned_input(g):
+    """the input of a golden record whose bytes depend on the image (corpus.real_text): SKIPS LOUDLY where this box's files differ from the build container's"""
     try:
-        data = corpus.real_text(g["size"])
+        data = corpus.make(g["kind"], g["size"])
     except RuntimeError as e:
         pytest.skip(f"REAL-TEXT FIXTURE NOT AVAILABLE ON THIS BOX: {e}")
     if hashlib.sha256(data.tobytes()).hexdigest() != g["input_sha256"]:
         pytest.skip("REAL-TEXT FIXTURE NOT AVAILABLE ON THIS BOX: the image's source files hash differently from the build container's "
-                    "(tests/golden/real.json pins the input) -- nothing was compared")
+                    "(the golden record pins the input) -- nothing was compared")
+    return data
+
+
+@pytest.mark.parametrize("name", ["real_30m_w24", "real_text_120m_w28", "xml_100m_w26"])
+def test_real_text(gpu, name):
+    """REAL text -- the image's own source files (corpus.real_text: Python's standard library, C / C++ headers, the installed
+    packages' sources) -- against the reference's stream for exactly these bytes (tests/golden/real.json, workloads.json: oracle/make_golden_real.py).
+    Every other input is a seeded generator; this one has the skew of real source text: the hottest BT4 head (a run of spaces) holds
+    17 % of the positions, the 256 hottest 35 %.  The bytes depend on the image, so the input's SHA-256 is checked first and the test
+    SKIPS LOUDLY where the box's files differ from the build container's.  The two larger cases are the workloads bench.py runs beside its
+    headline (120 MB of source code at -window:28; 100 MB of wiki-shaped markup at -window:26, a seeded generator).  real.json also holds
+    300 MB at -window:28 (the case that found round 5's RK256 bug): 6 minutes on the GPU, run by hand -- `python tests/gpu_opt.py 300e6 28 real_text`
+    must print 31822575 b7599d3a66d700cc."""
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    recs = json.load(open(os.path.join(gd, "real.json")))["cases"] + json.load(open(os.path.join(gd, "workloads.json")))["cases"]
+    g = {c["name"]: c for c in recs}[name]
+    data = _pinned_input(g)
     out = gpu.compress(data, g["window"])
     assert (out[0] << 8 | out[1]) == g["hist_bits"]
     assert (len(out), hashlib.sha256(out).hexdigest()) == (g["stream_size"], g["stream_sha256"])
@@ -162,7 +173,10 @@ def test_helper_parser_is_invisible_and_used(gpu):
 def test_table_stage_shape_is_invisible_and_follows_the_data(gpu):
     """The table stage's two shapes (16-entry fronts on seven waves, 24 on five: nlzm_v2.h TLds) must give the same bytes, forced or chosen launch by launch;
     left alone it must go wide on source code (positions with more BT4 record-setters than 16 in one block out of ten) and stay narrow on the stand-in."""
-    src = corpus.make("real_text", 12_000_000)[4_000_000:]
+    try:
+        src = corpus.make("real_text", 12_000_000)[4_000_000:]
+    except RuntimeError as e:
+        pytest.skip(f"REAL-TEXT FIXTURE NOT AVAILABLE ON THIS BOX: {e}")
     txt = corpus.make("syn_text", 4_000_000, corpus.SEED + 51)
     try:
         for data, hb, wide_expected in ((src, 23, True), (txt, 22, False)):
@@ -326,6 +340,51 @@ def test_blocks_stepwise_with_a_round_queued_ahead(gpu):
         lib.nlzm_hip_blocks_abandon()
         hip.hipFree(d_in); hip.hipFree(d_out)
     assert gpu.compress(data[:300_000], hb) == oracle_py.compress(data[:300_000], hb)      # (the single-stream path after it)
+
+
+def test_block_set_fault_in_a_queued_round_is_reported_at_once(gpu):
+    """The rounds of a block set overlap: when the host looks at a round, the next one is queued behind it.  A stream whose launch failed must
+    not keep that next launch on the device until the 30 s bound of a stage's wait: round_open_kernel hands the sticky error on (nlzm_kernels.hip).
+    Option test_fail_launch makes the finder stage of one stream raise an error in its second launch; the call must come back with it within
+    seconds, and the library must be usable afterwards (NLZM.cpp has no such path: its ASSERT exits, :25)."""
+    import time
+    data = corpus.mixed(5_000_000, corpus.SEED + 41)
+    want = gpu.compress_blocks(data, 5, 20)
+    gpu.set_option("block_batch_chunks", 2)
+    gpu.set_option("test_fail_stream", 2)
+    gpu.set_option("test_fail_launch", 1)
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(gpu.NlzmError, match="device error"):
+            gpu.compress_blocks(data, 5, 20)
+        dt = time.perf_counter() - t0
+        assert dt < 8.0, f"the failing block set took {dt:.1f} s to come back"
+    finally:
+        gpu.set_option("test_fail_launch", -1)
+        gpu.set_option("test_fail_stream", 0)
+    assert gpu.compress_blocks(data, 5, 20) == want
+    gpu.set_option("block_batch_chunks", 8)
+    assert gpu.compress(data[:300_000], 20) == oracle_py.compress(data[:300_000], 20)
+
+
+def test_pair_list_arena_exhausted_stream_is_made_again(gpu):
+    """A block set reserves 32 BT4 pairs per position and takes extension blocks from an arena per launch for the positions with more record-setters
+    (nlzm_core.h, bt_pair_ptr).  corpus.spines has thousands of such positions; with an arena of ONE block every launch that meets two of them
+    runs out.  The stream is then made again by itself when the set is finished (single-stream path: all 256 pairs reserved) -- same bytes as the
+    reference run on the block, and the counter says that this path was taken.  With the default arena nothing is made again."""
+    from nlzm_amd import shard
+    data = corpus.spines(3_000_000, corpus.SEED + 26)
+    k, hb = 4, 20
+    want = [oracle_py.compress(data[slice(*shard.block_range(data.size, k, i))], hb) for i in range(k)]
+    assert gpu.compress_blocks(data, k, hb) == want
+    assert gpu.counter("block_redo_streams") == 0
+    gpu.set_option("block_ext_blocks", 1)
+    try:
+        assert gpu.compress_blocks(data, k, hb) == want
+        assert gpu.counter("block_redo_streams") == k
+    finally:
+        gpu.set_option("block_ext_blocks", -1)
+    assert gpu.compress(data[:1_000_000], hb) == oracle_py.compress(data[:1_000_000], hb)       # (a single stream has no arena)
 
 
 def test_block_mode_options_are_invisible(gpu):
