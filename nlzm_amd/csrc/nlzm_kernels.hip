@@ -482,6 +482,19 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
 #define NLZM_RISKY_AHEAD 0
 #endif
 constexpr uint32_t kPending = 0xFFFFFFFEu;      // (no position: stream_begin refuses inputs of 0xFFFF0000 bytes and more)
+// Round 6: the bin's entries pass through a WINDOW of 64 (lane j of the wave holds entry wb + j of the chunk's list, loaded with one coalesced
+// load and one gather of the marked entries' decision words), and only CALLS take one of the wave's lanes:
+//   * an entry whose decision is "skip" already is dropped where it stands -- any number of them per step (they cost a step each before: half
+//     the steps of the hottest bin on source code);
+//   * an undecided entry that is assumed to be skipped (marked like both its neighbours) is PARKED in the window: nothing is made of it, it is
+//     passed at once, and it stands there as an undecided position -- what is behind it is held -- until its decision word says "skip" (dropped)
+//     or "call" (a wrong assumption: everything behind it is taken back and the bin goes on AT it);
+//   * every other entry is a call: unmarked, decided "call", or undecided and assumed to be called (its stores noted).  One call starts per
+//     step (a call starts by reading its head and storing itself there), on the first free lane; the entries between it and the next call are
+//     passed in the same step.
+// The window is loaded again behind its last entry once nothing undecided is parked in it; a wrong assumption loads it again where the bin
+// goes on.  Order: an entry's number in the chunk's list + 1 (`seq`), for calls and parked entries alike.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)xw::scan_max(v), 63); }
 __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G, uint32_t c0, uint32_t c1, uint32_t bin, uint32_t hot_index)
 {
     unsigned long long p0 = (unsigned long long)G.in, p1 = (unsigned long long)G.bt_heads, p2 = (unsigned long long)G.bt_tree,
@@ -502,22 +515,25 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     BtView Bx{ in, heads, tree, ready, pairs, batch_a0, 0u, wmask, tmask };         // (for LaneSink::put: where a position's later pairs go)
     Bx.pstride = G.bt_pstride; Bx.ext = G.bt_ext; Bx.ext_cur = G.bt_ext_cur; Bx.ext_cap = G.bt_ext_cap; Bx.fail_word = G.abort_word;
     enum : uint32_t { kIdle = 0, kStart = 1, kRun = 2, kHeld = 3 };
-    // the bin's entries, in order (wave-uniform)
-    uint32_t c = c0, i0 = 0, e0 = 0, la_end = 0, seq_next = 1;
+    enum : uint32_t { kwNone = 0, kwDone = 1, kwPark = 2, kwCall = 3 };             // a window entry: none / dropped or started / parked (undecided once passed) / a call to be started
+    // the bin's entries of the chunk, in order (wave-uniform): the window starts at entry wb, entries below `cur` are passed
+    uint32_t c = c0, wb = 0, cur = 0, e0 = 0, la_end = 0;
     const uint32_t *pos = G.bin_pos;
-    bool loaded = false, more = true, have_pe = false, rec = false;
-    unsigned long long pe = 0;
+    bool loaded = false, more = true, wvalid = false, rec = false;
+    // the lane's window entry
+    unsigned long long w_pe = 0;
+    uint32_t w_kind = kwNone;
+    bool w_risky = false, w_wrong = false;
     // the lane's call
     uint32_t st = kIdle, a = 0, hidx = 0, max_len = 0, sp = kNone, pend_l = 0, pend_r = 0, len_l = 0, len_r = 0, tests = 0, cb = 0;
-    uint32_t seq = 0, binidx = 0, nu = 0;
-    bool marked = false, und = false, dry = false, published = false, wrong = false, risky = false;
+    uint32_t seq = 0, nu = 0;
+    bool marked = false, und = false, published = false, wrong = false;
     bool last_skip = false;         // (wave-uniform) the bin's latest decision was "skip"
     LaneSink sink{ (uint32_t *)&g_v2_lds + threadIdx.x, nullptr };
     unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_open = 0, n_back = 0, n_redo = 0;
-    unsigned long long n_steps = 0, n_blk_dry = 0, n_blk_risky = 0;
+    unsigned long long n_steps = 0, n_blk_risky = 0;
     unsigned long long t_wait0 = 0;
     uint32_t idle = 0, prog_seen = 0, steps = 0;
-    uint32_t behind_risky = 0;      // (wave-uniform) calls started while a risky assumption is open
     bool fail = false;
     // (accounting by the bin's size: WorkerCounters::hot_class)
     unsigned long long k_work = 0, k_tests = 0, k_rep = 0, k_rec = 0, k_full = 0, k_blk = 0, k_noent = 0, k_skip = 0, k_und = 0;
@@ -526,22 +542,54 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     for (uint32_t cc = c0; cc < c1; cc++) { const uint32_t *off = G.bin_off + (unsigned long long)(cc - c0) * (G.nheads + 1); k_total += off[bin + 1] - off[bin]; }
 
     for (;;) {
-        // ---- the oldest undecided position in flight; a wrong assumption
-        uint32_t oseq = 0xFFFFFFFFu;
-        for (unsigned long long m = __ballot(und); m; m &= m - 1) oseq = umin(oseq, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
-        uint32_t rseq = 0xFFFFFFFFu;
-        for (unsigned long long m = __ballot(wrong); m; m &= m - 1) rseq = umin(rseq, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
+        // ---- the window: loaded where the bin goes on; the chunk is left when nothing of it is in flight
+        if (!wvalid && more && !rec) {
+            for (;;) {
+                if (!loaded) {
+                    if (c >= c1) { more = false; break; }
+                    const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
+                    cur = off[bin]; e0 = off[bin + 1];
+                    const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
+                    const unsigned long long remain = g.n - chunk_abs;
+                    la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
+                    pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size * 2;
+                    loaded = true;
+                }
+                if (cur < e0) break;
+                if (__any(st != kIdle)) break;                      // (a wrong assumption would bring the bin back into this chunk)
+                c++; loaded = false;
+            }
+            if (more && loaded && cur < e0) {
+                wb = cur;
+                const uint32_t idx = wb + lane;
+                w_pe = 0; w_kind = kwNone; w_risky = false; w_wrong = false;
+                if (idx < e0) {
+                    w_pe = *(const unsigned long long *)(pos + 2 * idx);
+                    const bool mk = (w_pe >> 63) != 0;
+                    uint32_t f = 0;
+                    if (mk) f = LaneIO::ld_agent(flags + ((uint32_t)w_pe - batch_a0));
+                    // (a decision that comes in after this look finds the entry as a parked one or as a call that polls its word)
+                    w_kind = !mk ? kwCall : (f == kFlagSkip ? kwDone : (f == kFlagCall ? kwCall : ((w_pe >> 61) == 7u ? kwPark : kwCall)));
+                    k_skip += mk && f == kFlagSkip;
+                }
+                wvalid = true;
+            }
+        }
+        const uint32_t wend = wvalid ? umin(64u, e0 - wb) : 0u;     // entries in the window
+        // ---- the oldest undecided position (a call's or a parked entry's); a wrong assumption
+        const bool w_und = wvalid && w_kind == kwPark && wb + lane < cur;
+        const uint32_t w_seq = wb + lane + 1;
+        const uint32_t oseq = ~wave_max_u32(umax(und ? ~seq : 0u, w_und ? ~w_seq : 0u));
+        const uint32_t rseq = ~wave_max_u32(umax(wrong ? ~seq : 0u, w_wrong ? ~w_seq : 0u));
         if (rseq != 0xFFFFFFFFu) rec = true;
         if (rec && !__any(st == kStart || st == kRun)) {
-            // every call in flight has ended: the stores of the calls behind the position are taken back, latest first, then
-            // the position's own are taken back ("skip") or made ("call"); the bin goes on behind it
+            // every call in flight has ended: the stores of the calls behind the position are taken back, latest first; then the position's
+            // own, if it was assumed to be called; the bin goes on behind it -- or AT it, if it was parked and is called
             for (;;) {
-                uint32_t smax = 0;
-                for (unsigned long long m = __ballot(st == kHeld && seq > rseq); m; m &= m - 1)
-                    smax = umax(smax, (uint32_t)__builtin_amdgcn_readlane((int)seq, (int)__builtin_ctzll(m)));
+                const uint32_t smax = wave_max_u32(st == kHeld && seq > rseq ? seq : 0u);
                 if (!smax) break;
                 if (st == kHeld && seq == smax) {
-                    if (!dry) for (uint32_t j = nu; j-- > 0;) {
+                    for (uint32_t j = nu; j-- > 0;) {
                         const unsigned long long w = undo[j];
                         const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
                         if (t >> 31) heads[t & 0x7FFFFFFFu] = v; else tree[t] = v;
@@ -549,80 +597,72 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                     st = kIdle; und = false; wrong = false; n_redo++;
                 }
             }
-            uint32_t resume = 0;
-            bool resumes = false;
             if (st == kHeld && seq == rseq) {
-                for (uint32_t j = nu; j-- > 0;) {                   // (the position was assumed to be called and is skipped: the values its stores replaced)
+                for (uint32_t j = nu; j-- > 0;) {                   // (assumed to be called, and skipped: the values its stores replaced)
                     const unsigned long long w = undo[j];
                     const uint32_t t = (uint32_t)w, v = (uint32_t)(w >> 32);
                     if (t >> 31) heads[t & 0x7FFFFFFFu] = v; else tree[t] = v;
                 }
                 st = kIdle; und = false; wrong = false; n_back++;
-                // (assumed to be skipped and called: nothing was made of it -- the bin goes on AT it, and finds its decision)
-                resume = dry ? binidx : binidx + 1; resumes = true;
             }
-            for (unsigned long long m = __ballot(resumes); m; m &= m - 1) i0 = (uint32_t)__builtin_amdgcn_readlane((int)resume, (int)__builtin_ctzll(m));
-            have_pe = false; more = true;
+            const bool parked = __any(w_wrong && w_seq == rseq);    // (assumed to be skipped, and called: made now)
+            if (parked && lane == 0) n_back++;
+            cur = parked ? rseq - 1 : rseq;
+            wvalid = false; w_wrong = false; w_kind = kwNone;
             rec = false;
             continue;
         }
-        // ---- one call starts per step, on the first free lane (not while a wrong assumption is being undone)
+        // ---- entries are passed: dropped ones and parked ones as many as there are, and ONE call -- on the first free lane, not while a wrong
+        // assumption is being undone, and not behind a parked entry that is assumed to be skipped although the bin's last decision was "call"
+        // (wrong one time in eight on prose, and a wrong assumption costs every call behind it)
         uint32_t start_lane = 64;
-        bool made_test = false, rep_step = false, skipped_now = false, started_now = false;
-        const bool have_pe_before = have_pe;
+        unsigned long long pe = 0;
+        uint32_t pe_seq = 0;
+        bool made_test = false, rep_step = false, started_now = false;
         const unsigned long long free_m = __ballot(st == kIdle);
-        // (A call made without its stores does not hold later calls back -- they could overtake it and change what it has yet
-        //  to read: nothing starts until it has ended.)
-        // (An undecided position assumed to be skipped although the bin's last decision was "call" is wrong one time in eight,
-        //  and a wrong assumption costs every call behind it: nothing starts behind such a position until it is decided.)
-        // (A build option, NLZM_RISKY_AHEAD = k, lets k calls start behind such a position all the same.  Measured in round 5 on the stand-in, 300 MB:
-        //  k = 1 / 2 / 8 gave 493 / 498 / 520 cycles per position against 488 with k = 0 -- NOT adopted: the default is 0, nothing starts, and the
-        //  counter hot_blocked_risky counts the steps spent under this rule.)
-        const bool risky_open = __any(und && risky);
-        if (!risky_open) behind_risky = 0;
-        const bool dry_on_its_way = risky_open && behind_risky >= NLZM_RISKY_AHEAD;
-        if (!rec && !dry_on_its_way && have_pe && free_m) { start_lane = (uint32_t)__builtin_ctzll(free_m); have_pe = false; }
+        const bool risky_open = __any(w_und && w_risky);
+        bool call_blocked = false;
         n_steps++;
-        if (!rec && have_pe && free_m && dry_on_its_way) n_blk_risky++;          // (diagnostics: steps in which the next call could not start)
+        if (wvalid && !rec && cur < wb + wend) {
+            const uint32_t cl = cur - wb;
+            const unsigned long long range = (~0ull << cl) & (wend < 64 ? (1ull << wend) - 1ull : ~0ull);
+            const unsigned long long mC = __ballot(w_kind == kwCall) & range, mP = __ballot(w_kind == kwPark) & range;
+            const uint32_t c1i = mC ? (uint32_t)__builtin_ctzll(mC) : 64u;
+            const bool park_before = c1i < 64 ? (mP & ((1ull << c1i) - 1ull)) != 0 : mP != 0;
+            const bool call_ok = c1i < 64 && free_m && !risky_open && !(park_before && !last_skip);
+            call_blocked = c1i < 64 && free_m && !call_ok;
+            uint32_t end = c1i;
+            if (call_ok) {
+                const unsigned long long restC = mC & ~(1ull << c1i);
+                end = restC ? (uint32_t)__builtin_ctzll(restC) : 64u;
+                start_lane = (uint32_t)__builtin_ctzll(free_m);
+                pe = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_pe >> 32), (int)c1i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_pe, (int)c1i);
+                pe_seq = wb + c1i + 1;
+            }
+            end = umin(end, wend);
+            if (w_kind == kwPark && lane >= cl && lane < end) w_risky = !last_skip;
+            if (call_ok && lane == c1i) w_kind = kwDone;            // (started: its lane has it)
+            cur = wb + end;
+        }
+        if (call_blocked) n_blk_risky++;
         if (lane == start_lane) {
             a = (uint32_t)pe; hidx = (uint32_t)(pe >> 32) & 0x1FFFFFFFu;
             max_len = umin(la_end - a, kMatchMax);
-#ifdef NLZM_EXP_SKIP_ANY
-            marked = (pe >> 63) != 0; dry = marked && ((pe >> 61) & 3u) != 0u;
-#else
-            marked = (pe >> 63) != 0; dry = (pe >> 61) == 7u;
-#endif
-                      // (without stores: if it turns out to be undecided.  Assumed to be skipped: marked like both its neighbours -- see worker_role)
-            seq = seq_next; binidx = i0 - 1;
+            marked = (pe >> 63) != 0;
+            seq = pe_seq;
             st = kStart;
         }
-        if (start_lane < 64) { seq_next++; if (risky_open) behind_risky++; }
-        // ---- the next entry of the bin (requested a step ahead of its use); the chunk is left when no call is in flight
-        if (!have_pe && more && !rec) {
-            for (;;) {
-                if (!loaded) {
-                    if (c >= c1) { more = false; break; }
-                    const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
-                    i0 = off[bin]; e0 = off[bin + 1];
-                    const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
-                    const unsigned long long remain = g.n - chunk_abs;
-                    la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
-                    pos = G.bin_pos + (unsigned long long)(c - c0) * g.chunk_size * 2;
-                    loaded = true;
-                }
-                if (i0 < e0) { pe = *(const unsigned long long *)(pos + 2 * i0); i0++; have_pe = true; break; }
-                if (__any(st != kIdle)) break;                      // (a wrong assumption would bring the bin back into this chunk)
-                c++; loaded = false;
-            }
-        }
+        // (the window is done with when every entry is passed and nothing undecided is parked in it)
+        if (wvalid && cur >= wb + wend && !__any(w_kind == kwPark)) wvalid = false;
         // ---- loads of this step
-        uint32_t v_word = 0, v_flag = 0;
+        uint32_t v_word = 0, v_flag = 0, w_flag = 0;
         unsigned long long pp = 0, x0 = 0, y0 = 0;
         bool fin_now = false;
         uint32_t fin_l = kNone, fin_r = kNone;
         if (st == kRun && !(sp != kNone && a > sp && a - sp <= wmask && tests < 256)) fin_now = true;   // :989, :1020-1021
         const uint32_t pair = (sp & tmask) << 1, init = umin(len_l, len_r);
         if ((st == kStart && marked) || und) v_flag = LaneIO::ld_agent(flags + (a - batch_a0));
+        if (w_und && !w_wrong) w_flag = LaneIO::ld_agent(flags + ((uint32_t)w_pe - batch_a0));
         if (st == kStart) v_word = heads[hidx];
         else if (st == kRun && !fin_now) {
             pp = *(const unsigned long long *)(tree + pair);
@@ -632,28 +672,23 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         {
             const bool decided = und && !wrong && (v_flag == kFlagCall || v_flag == kFlagSkip);
             if (decided) {
-                if ((v_flag == kFlagSkip) == dry) und = false;      // as assumed
+                if (v_flag == kFlagCall) und = false;               // as assumed
                 else wrong = true;                                  // (und stays: nothing behind it is released)
             }
-            if (__any(decided)) last_skip = __any(decided && v_flag == kFlagSkip);
+            const bool w_decided = w_und && !w_wrong && (w_flag == kFlagCall || w_flag == kFlagSkip);
+            if (w_decided) {
+                if (w_flag == kFlagSkip) w_kind = kwDone;           // as assumed: dropped
+                else w_wrong = true;                                // (stays parked: nothing behind it is released)
+            }
+            if (__any(decided || w_decided)) last_skip = __any((decided && v_flag == kFlagSkip) || (w_decided && w_flag == kFlagSkip));
         }
         if (st == kStart) {
             bool go = true;
             if (marked) {
-                if (v_flag == kFlagSkip) { st = kIdle; go = false; skipped_now = true; }        // decided already: it does not happen
-                else if (v_flag == kFlagCall) dry = false;                  // decided already: it happens
-                else { und = true; risky = dry && !last_skip; n_open += dry ? 0u : 1u; t_wait0 = 0; idle = 0; }       // its fate is open: assumed (dry as set at the start)
-            } else dry = false;
-            if (go && dry) {
-                // Undecided and assumed to be skipped: NOTHING is made of it (round 6; until then a descent without its stores, whose result went
-                // out in case the decision was "call" -- a third of all BT4 work on source code, thrown away 99.7 % of the time, and nothing else
-                // of the bin could start while it ran).  It holds its lane as a call that has ended and published, so that what is behind it is held
-                // until the decision; "call" is a wrong assumption like any other, and the bin then goes on AT this position.  The finder stage says
-                // "call" as soon as the positions in front are settled, without waiting for a result (nlzm_v2.h, the block's wait loop).
-                started_now = true;
-                tests = 0; cb = 0; nu = 0; sink.count = 0; published = true;
-                st = kHeld;
-            } else if (go) {
+                if (v_flag == kFlagSkip) { st = kIdle; go = false; }                                    // decided by now: it does not happen
+                else if (v_flag != kFlagCall) { und = true; n_open++; t_wait0 = 0; idle = 0; }          // its fate is open: assumed to be called, every store noted
+            }
+            if (go) {
                 started_now = true;
                 sp = v_word;                                        // :983
                 pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0;
@@ -727,24 +762,24 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         if (st == kHeld && !wrong) {
             if (!published && seq <= oseq) { sink.publish(ready + (unsigned long long)(a - batch_a0) * kBtRec, tests); published = true; }
             if (published && !und && seq <= oseq) {
-                if (!dry) { n_calls++; n_tests += tests; n_cmp += cb; }
+                n_calls++; n_tests += tests; n_cmp += cb;
                 st = kIdle;
             }
         }
         {   // (accounting)
             const uint32_t nt = (uint32_t)__builtin_popcountll(__ballot(made_test)), nr = (uint32_t)__builtin_popcountll(__ballot(rep_step));
-            k_tests += nt; k_rep += nr; k_skip += (uint32_t)__builtin_popcountll(__ballot(skipped_now));
+            k_tests += nt; k_rep += nr;
             if (nt || __any(started_now)) k_work++;
             else {
                 if (rec) k_rec++;
                 else if (!free_m) k_full++;
-                else if (have_pe_before && dry_on_its_way) k_blk++;
+                else if (call_blocked) k_blk++;
                 else k_noent++;
-                if (__any(und)) k_und++;
+                if (__any(und || w_und)) k_und++;
             }
         }
         // ---- watchdogs (a position whose decision does not come; a launch that failed elsewhere)
-        if (und && (++idle & 4095u) == 0) {
+        if ((und || w_und) && (++idle & 4095u) == 0) {
             const unsigned long long now = wall_clock64();
             const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
             if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
@@ -752,7 +787,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         }
         if (__any(fail)) { if (lane == 0) LaneIO::st_agent(G.abort_word, 2u); break; }
         if ((++steps & 0x3FFFu) == 0 && __any(LaneIO::ld_agent(G.abort_word) != 0)) break;
-        if (!more && !have_pe && !rec && !__any(st != kIdle)) break;
+        if (!more && !wvalid && !rec && !__any(st != kIdle)) break;
     }
     if (st != kIdle) {
         atomicAdd(&G.wcnt->stuck_lanes, 1ull);
@@ -761,12 +796,13 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     for (int m = 32; m >= 1; m >>= 1) {
         n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
         n_open += __shfl_xor(n_open, m, 64); n_back += __shfl_xor(n_back, m, 64); n_redo += __shfl_xor(n_redo, m, 64);
+        k_skip += __shfl_xor(k_skip, m, 64);
     }
     if (lane == 0) {
         atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
         atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
         atomicAdd(&G.wcnt->hot_calls, n_calls);
-        atomicAdd(&G.wcnt->hot_steps, n_steps); atomicAdd(&G.wcnt->hot_blocked_dry, n_blk_dry); atomicAdd(&G.wcnt->hot_blocked_risky, n_blk_risky);
+        atomicAdd(&G.wcnt->hot_steps, n_steps); atomicAdd(&G.wcnt->hot_blocked_risky, n_blk_risky);
         uint32_t kc = 0;
         while (kc < 7 && (k_total >> (14 + kc))) kc++;
         unsigned long long *hc = G.wcnt->hot_class[kc];

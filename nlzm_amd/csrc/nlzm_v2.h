@@ -605,7 +605,7 @@ struct Finder {
             const bool waits = xw::any(bt_wait);
             bool have = !bt_wait;                                   // this lane's result is in (or none is awaited)
             uint32_t r_d = 0, r_l = 0;
-            unsigned long long seen = ~0ull;                        // the lanes whose results were in when the block was last verified
+            uint32_t f_seen = 65;                                   // the first lane whose result was missing when the block was last verified (65: not yet)
             for (;;) {
                 // (quad 0 of the record in one load: the ready word and the longest pair behind it -- they were two dependent round trips)
                 {   // (host simulation: the worker emulation is asked for the FIRST missing result only, so that results come in one by one and the
@@ -628,10 +628,10 @@ struct Finder {
                         n_late_blocks++;
                     }
                 }
-                if (missing != seen) {
-                    seen = missing;
+                const uint32_t F = missing ? (uint32_t)__builtin_ctzll(missing) : 64u;          // the first lane whose result is missing
+                if (F != f_seen) {      // (results behind the first missing one change nothing that can be used yet: verified again when THAT one has come)
+                    f_seen = F;
                     xw::after_poll();
-                    const uint32_t F = missing ? (uint32_t)__builtin_ctzll(missing) : 64u;      // the first lane whose result is missing
                     ec = ec0; ec_d = ec_d0; od = od0;
                     if (bt_wait && have && bt_n) { if (r_l >= cap) od = umin(od, r_d); else closed_end(a + r_l, r_d); }
                     pm = xw::scan_max(in_blk ? umax(ec, so_end) : 0u);          // inclusive prefix max of the closed ends
