@@ -60,9 +60,11 @@ typedef struct nlzm_hip_timing {
 
 /* Select the device and create the library's stream.  Fails (NLZM_HIP_E_NODEVICE)
  * when there is no GPU: there is no CPU fallback behind this ABI. */
-/* nlzm_hip_init sets GPU_MAX_HW_QUEUES=16 in the process environment unless the caller has set it (block mode runs the small kernels of 32
- * streams beside one persistent launch; with the HIP runtime's default of 4 hardware queues they serialise: ~70 instead of ~100 MB/s).  The
- * runtime reads the variable at the process's FIRST HIP call: a host program that uses HIP before nlzm_hip_init must export it itself. */
+/* The process's FIRST nlzm_hip_init sets GPU_MAX_HW_QUEUES=16 in the process environment -- once, and only if the caller has not set it and the
+ * process does not have the GPU open yet (block mode runs the small kernels of 32 streams beside one persistent launch; with the HIP runtime's
+ * default of 4 hardware queues they serialise: ~70 instead of ~100 MB/s).  The runtime reads the variable at the process's FIRST HIP call: a host
+ * program that uses HIP before nlzm_hip_init must export it itself.  nlzm_hip_get_counter("gpu_max_hw_queues_effective") says what the runtime
+ * has read: the caller's value, 16, or 4 when it was too late. */
 int nlzm_hip_init(int device);
 void nlzm_hip_shutdown(void);
 const char *nlzm_hip_last_error(void);
@@ -101,7 +103,8 @@ int nlzm_hip_stream_finish(uint64_t *dst_len);
 
 int nlzm_hip_get_stats(nlzm_hip_stats *out);
 int nlzm_hip_get_timing(nlzm_hip_timing *out);
-/* Diagnostic counters of the pipeline stages for the last stream (what "stage_report" prints, by name): cycles are summed over the
+/* Diagnostic counters of the pipeline stages for the last stream (what "stage_report" prints, by name; also "block_pool_bytes", "block_redo_streams",
+ * "gpu_max_hw_queues_effective"): cycles are summed over the
  * stream's launches, e.g. "parser_total_cycles", "parser_wait_cycles", "parser_pass_cycles", "parser_passes", "parser_blocks",
  * "finder_total_cycles", "finder_wait_cycles", "finder_bt_wait_cycles", "table_total_cycles", "table_wait_cycles", "helper_jobs",
  * "helper_taken", "helper_taken_nodes", "helper_wait_cycles", "worker_call_cycles", "worker_call_tests", "worker_calls",
@@ -157,7 +160,13 @@ int nlzm_hip_parse_emit(const uint8_t *src, uint64_t n, uint32_t hist_bits_req,
  * device buffers are therefore read and written between the calls too: the input must not change until finish or abandon.
  * A begin or step that fails has closed
  * the set (every stream's buffers freed, nothing left queued that reads d_src): there is nothing to abandon then;
- * nlzm_hip_blocks_abandon() drops a set the caller does not want to finish. */
+ * nlzm_hip_blocks_abandon() drops a set the caller does not want to finish.  A stream whose launch fails hands its error on to the launch
+ * that is already queued behind it, whose stages leave at once: the failing step returns within the time of a launch, not after a wait's bound.
+ * Memory: the streams of a set reserve 32 BT4 (distance, length) pairs per position of a launch and take the rest from a per-launch arena of
+ * positions / 64 + 1024 extension blocks (a single stream reserves all 256 pairs a position can have, NLZM.cpp:777).  An input with more such
+ * positions than the arena serves (contrived: nlzm_amd/corpus.py `spines`) does not fail: the stream concerned is made again from its first
+ * byte as a single stream, with buffers of its own, when the set is finished -- the same bytes, later; nlzm_hip_get_counter("block_redo_streams")
+ * counts them. */
 int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint32_t hist_bits_req);
 int nlzm_hip_blocks_step(uint32_t max_chunks_per_block, uint64_t *in_done_total, int *finished, double *device_ms);
 int nlzm_hip_blocks_finish(void *d_dst, uint64_t dst_cap, uint64_t *block_len, uint64_t *dst_len);
@@ -216,6 +225,8 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
  * "table_shape" (default 0: the table stage runs every launch with 16-entry fronts on seven waves or with 24-entry fronts on five, whichever the
  * launch before it asked for -- the share of its blocks in which some position had more entries than the fronts hold decides; 1 / 2 fix the
  * shape: source code runs ~20 % faster in the wide one, prose ~8 % faster in the narrow one);
+ * test only: "test_fail_launch" (default -1) / "test_fail_stream": the finder stage of that launch of that stream of a block set (of the single stream)
+ * raises an error at once; "block_ext_blocks" (default -1: by the launch's size): extension blocks of a block-set stream's pair-list arena;
  * "stage_report" (1: the stages' cycle accounting of
  * every finished stream, and of a block set per stream, on stderr).  There are no environment knobs.
  * None of them changes a byte of the output.  The options are read when a stream or a block set is opened

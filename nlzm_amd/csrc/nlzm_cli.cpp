@@ -16,6 +16,7 @@
 #include <time.h>
 
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../../include/nlzm_hip.h"
@@ -336,6 +337,24 @@ int main(int argc, char **argv)
         if (rc) { printf("Error: %s\n", nlzm_hip_last_error()); fclose(fout); remove(argv[3]); return -1; }
         fwrite(out.data(), 1, (size_t)out_n, fout);
         fclose(fout);
+        if (nstreams > 1) {
+            // the block index, a sidecar: where every block's stream starts, how long it is and how many input bytes it holds.  The
+            // streams stay self-delimiting -- the index only saves d/t the hop over every frame header of every block before the parallel decode can
+            // start, and keeps the later blocks' boundaries when the container is damaged inside an earlier one.
+            const std::string ip = std::string(argv[3]) + ".idx";
+            if (FILE *fi = fopen(ip.c_str(), "wb")) {
+                fprintf(fi, "NLZMIDX 1 %u %" PRIu64 " %" PRIu64 "\n", nstreams, (uint64_t)in.size(), out_n);
+                const uint64_t per = (in.size() + nstreams - 1) / nstreams;
+                uint64_t off = 0;
+                for (uint32_t i = 0; i < nstreams; i++) {
+                    const uint64_t lo = (uint64_t)i * per < in.size() ? (uint64_t)i * per : in.size(), hi = lo + per < in.size() ? lo + per : in.size();
+                    fprintf(fi, "%" PRIu64 " %" PRIu64 " %" PRIu64 "\n", off, blen[i], hi - lo);
+                    off += blen[i];
+                }
+                fclose(fi);
+                printf("Block index: %s\n", ip.c_str());
+            }
+        }
         printf("Working... %" PRIu64 " -> %" PRIu64 "\n", (uint64_t)in.size(), out_n);
         printf("Done (input CRC32 %X, %.2f sec)\n", crc_calc(in.data(), in.size(), 0),
                (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec));
@@ -357,7 +376,32 @@ int main(int argc, char **argv)
         // decoded on a host thread each, written in order
         std::vector<Span> parts;
         size_t cut_tail = 0;
-        for (size_t pos = 0; pos < in.size();) {
+        bool by_index = false;
+        {   // the sidecar index of a block container, if it is there and fits the file: the blocks' boundaries without hopping over their frames
+            const std::string ip = std::string(argv[2]) + ".idx";
+            if (FILE *fi = fopen(ip.c_str(), "rb")) {
+                unsigned ver = 0, k = 0;
+                unsigned long long n_in = 0, n_out = 0;
+                std::vector<Span> idx;
+                bool ok = fscanf(fi, "NLZMIDX %u %u %llu %llu", &ver, &k, &n_in, &n_out) == 4 && ver == 1 && k >= 1 && k <= 4096 && n_out >= in.size();
+                unsigned long long expect = 0;
+                bool cut = false;
+                for (unsigned i = 0; ok && i < k && !cut; i++) {
+                    unsigned long long off = 0, len = 0, raw = 0;
+                    ok = fscanf(fi, "%llu %llu %llu", &off, &len, &raw) == 3 && off == expect && len >= 8;
+                    if (ok && off + len > in.size()) { cut = true; break; }      // (the file ends inside this block: the ones in front of it are whole)
+                    // (a block's stream starts with its header and ends with its terminator, :1915-1921, :646-648)
+                    if (ok) ok = in[off] == 0 && in[off + 1] >= 10 && in[off + 1] <= 28 && be32(&in[off + len - 4]) == 0;
+                    if (ok) { idx.push_back(Span{ in.data() + off, (size_t)len }); expect = off + len; }
+                }
+                fclose(fi);
+                if (ok && !idx.empty() && (cut || (expect == in.size() && n_out == in.size()))) {
+                    parts = idx; by_index = true;
+                    if (cut) cut_tail = in.size() - (size_t)expect;
+                } else printf("Note: %s does not fit this file; the blocks are found by their frame headers\n", ip.c_str());
+            }
+        }
+        for (size_t pos = 0; !by_index && pos < in.size();) {
             const Span rest{ in.data() + pos, in.size() - pos };
             const size_t len = stream_length(rest);
             if (!len) {

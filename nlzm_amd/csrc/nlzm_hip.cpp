@@ -37,7 +37,7 @@ void fill_stream2_args(void *host_pack, uint32_t i, const Geom &g, const Globals
 void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t worker_blocks, hipStream_t st);
 void launch_round_open(const void *dev_pack, uint32_t nstreams, hipStream_t st);
 void launch_round_close(const void *dev_pack, uint32_t nstreams, hipStream_t st);
-void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits, uint32_t t_bitmap,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint32_t *hbuf2, uint8_t *c1, uint8_t *unc, hipStream_t st);
 unsigned long long worker_undo_bytes_per_lane();
 unsigned long long worker_hot_undo_bytes_per_wave();
@@ -164,6 +164,7 @@ struct Ctx {
     bool workers = false;
     uint32_t *pf_T = nullptr, *pf_M = nullptr, *pf_h = nullptr, *pf_h2 = nullptr; uint8_t *pf_c1 = nullptr, *unc = nullptr;
     uint32_t t_bits = 0, m_bits = 0, nheads = 0;
+    uint32_t t_bitmap = 0;                  // the pre-filter table holds one bit per slot (a stream no longer than its window: every earlier position is inside it)
     uint32_t v2_launch_no = 0;              // persistent launches of the open stream so far (its parity picks the table stage's shape slot)
     uint32_t *bt_ready = nullptr, *bt_pairs = nullptr, *bt_flag = nullptr, *abort_word = nullptr;
     uint32_t *bt_ext = nullptr; uint32_t pstride = kBtMaxPairs, ext_cap = 0;       // pairs reserved per position; extension blocks for the rest
@@ -464,11 +465,15 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
         }
         if ((int64_t)C.t_bits > C.opt_tbits_max) C.t_bits = (uint32_t)(C.opt_tbits_max < 16 ? 16 : C.opt_tbits_max);   // (smaller: only more `unc` marks)
         C.m_bits = lg + 6 > 28 ? 28 : lg + 6;
-        if (C.pool) DEVALLOC(C.pf_T, (size_t)4 << C.t_bits);
+        // (a stream that is no longer than its window -- every stream of a block set, whose window the reference shrinks to the block, :1716-1718 --
+        //  never meets an earlier position outside the window: one bit per slot says all a 32-bit position would; 2 GB -> 64 MB per stream of the bench's set)
+        C.t_bitmap = g.n <= (unsigned long long)g.wmask + 1 ? 1u : 0u;
+        const auto t_bytes = [&]() { return C.t_bitmap ? (((size_t)1 << C.t_bits) / 8 < 4 ? (size_t)4 : ((size_t)1 << C.t_bits) / 8) : (size_t)4 << C.t_bits; };
+        if (C.pool) DEVALLOC(C.pf_T, t_bytes());
         else {
             // (a device with less free memory than the table wants: a smaller table only marks more positions as undecided)
             for (;;) {
-                const int rc_t = dev_alloc(C, &C.pf_T, (size_t)4 << C.t_bits);
+                const int rc_t = dev_alloc(C, &C.pf_T, t_bytes());
                 if (!rc_t) break;
                 if (rc_t != NLZM_HIP_E_NOMEM || C.t_bits <= 28) return rc_t;
                 (void)hipGetLastError();
@@ -476,7 +481,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
             }
         }
         DEVALLOC(C.pf_M, (size_t)4 << C.m_bits);
-        DEVFILL(hipMemsetAsync(C.pf_T, 0, (size_t)4 << C.t_bits, C.st));
+        DEVFILL(hipMemsetAsync(C.pf_T, 0, t_bytes(), C.st));
         DEVFILL(hipMemsetAsync(C.pf_M, 0xFF, (size_t)4 << C.m_bits, C.st));
         DEVALLOC(C.pf_h, bpos * 4);
         DEVALLOC(C.pf_h2, bpos * 4);
@@ -607,7 +612,7 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
         HIPCHK(hipMemsetAsync(C.bt_flag, 0, cnt * 4, C.st));
         HIPCHK(hipMemsetAsync(C.abort_word, 0, 4, C.st));
         HIPCHK(hipMemsetAsync(C.bin_off, 0, (size_t)nb * (C.nheads + 1) * 4, C.st));
-        launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.m_bits, C.pf_T, C.pf_M, C.pf_h, C.pf_h2,
+        launch_prefilter(C.d_in, g.n, (uint32_t)a0, (uint32_t)a1, g.wmask, C.t_bits, C.t_bitmap, C.m_bits, C.pf_T, C.pf_M, C.pf_h, C.pf_h2,
                          C.pf_c1, C.unc, C.st);
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
         if (C.hot_max) {
@@ -1338,8 +1343,9 @@ int nlzm_hip_blocks_begin(const void *d_src, uint64_t n, uint32_t nblocks, uint3
         double left = per_stream - fixed;
         if (left < 2e8) return set_err(NLZM_HIP_E_NOMEM, "%u streams of %llu bytes at -window:%u do not fit %.1f GB of free memory", nblocks,
                                        (unsigned long long)g0.n, g0.wbits, free_b / 1e9);
-        while (tbits_max > 16 && 4.0 * (double)(1ull << tbits_max) > 0.4 * left) tbits_max--;
-        left -= 4.0 * (double)(1ull << (tbits_max < (int64_t)g0.wbits + 5 ? tbits_max : (int64_t)g0.wbits + 5));
+        const double slot_bytes = g0.n <= (unsigned long long)g0.wmask + 1 ? 0.125 : 4.0;        // (one bit per slot where the block is no longer than its window: stream_begin)
+        while (tbits_max > 16 && slot_bytes * (double)(1ull << tbits_max) > 0.4 * left) tbits_max--;
+        left -= slot_bytes * (double)(1ull << (tbits_max < (int64_t)g0.wbits + 5 ? tbits_max : (int64_t)g0.wbits + 5));
         const int64_t fit = (int64_t)(left / (2300.0 * g0.chunk_size + 8.0 * g0.chunk_size * 4));
         if (fit < 1) return set_err(NLZM_HIP_E_NOMEM, "%u streams do not fit the device memory", nblocks);
         if (batch > fit) batch = fit;

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void rk_hash_kernel(const uint8_t *__restrict_
 // without running anything serial; the others are marked `unc` and wait for the
 // master.  The filter is conservative: slot collisions only add `unc` marks.
 //   T[slot]  = 1 + latest position (from earlier launches) whose 65-gram hashes there
+//              (t_bitmap: ONE BIT per slot, "some earlier position hashes there" -- a stream that is no longer than its window, as every
+//               stream of a block set is, has every earlier position inside the window: the same marks from 1/32 of the memory, round 6)
 //   M[slot2] = earliest position of THIS launch hashing there
 // ---------------------------------------------------------------------------
 constexpr uint32_t kPfLen = 65;
@@ -94,7 +96,7 @@ __device__ __forceinline__ unsigned long long pf_slot(uint32_t h, uint32_t h2, u
 }
 
 __global__ __launch_bounds__(256) void prefilter_hash_kernel(const uint8_t *__restrict__ in, unsigned long long n,
-                                                             uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+                                                             uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits, uint32_t t_bitmap,
                                                              uint32_t m_bits, const uint32_t *__restrict__ T,
                                                              uint32_t *__restrict__ M, uint32_t *__restrict__ hbuf,
                                                              uint32_t *__restrict__ hbuf2, uint8_t *__restrict__ c1)
@@ -120,8 +122,9 @@ __global__ __launch_bounds__(256) void prefilter_hash_kernel(const uint8_t *__re
         hbuf[a - a0] = h; hbuf2[a - a0] = h2;
         uint8_t f = 0;
         if (ok) {
-            const uint32_t t = T[pf_slot(h, h2, t_bits)];
-            f = t != 0 && (uint32_t)a - (t - 1) <= wmask;
+            const unsigned long long sl = pf_slot(h, h2, t_bits);
+            if (t_bitmap) f = (T[sl >> 5] >> (sl & 31u)) & 1u;
+            else { const uint32_t t = T[sl]; f = t != 0 && (uint32_t)a - (t - 1) <= wmask; }
             atomicMin(&M[(h * kPfMul2) >> (32 - m_bits)], (uint32_t)a);
         }
         c1[a - a0] = f;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void prefilter_mark_kernel(unsigned long long 
     if (a + 1 < a1) unc[a + 1 - a0] = f;
 }
 
-__global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long long n, uint32_t a0, uint32_t a1, uint32_t t_bits,
+__global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long long n, uint32_t a0, uint32_t a1, uint32_t t_bits, uint32_t t_bitmap,
                                                                uint32_t m_bits, uint32_t *__restrict__ T,
                                                                uint32_t *__restrict__ M, const uint32_t *__restrict__ hbuf,
                                                                const uint32_t *__restrict__ hbuf2)
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(256) void prefilter_insert_kernel(unsigned long lon
     const unsigned long long a = (unsigned long long)a0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (a >= a1 || a + kPfLen > n) return;
     const uint32_t h = hbuf[a - a0];
-    atomicMax(&T[pf_slot(h, hbuf2[a - a0], t_bits)], (uint32_t)a + 1);
+    const unsigned long long sl = pf_slot(h, hbuf2[a - a0], t_bits);
+    if (t_bitmap) atomicOr(&T[sl >> 5], 1u << (sl & 31u));
+    else atomicMax(&T[sl], (uint32_t)a + 1);
     M[(h * kPfMul2) >> (32 - m_bits)] = kNone;
 }
 
@@ -1242,15 +1247,15 @@ void launch_pipeline2_multi(const void *dev_pack, uint32_t nstreams, uint32_t wo
                        kV2Roles + worker_blocks);
 }
 
-void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits,
+void launch_prefilter(const uint8_t *in, unsigned long long n, uint32_t a0, uint32_t a1, uint32_t wmask, uint32_t t_bits, uint32_t t_bitmap,
                       uint32_t m_bits, uint32_t *T, uint32_t *M, uint32_t *hbuf, uint32_t *hbuf2, uint8_t *c1, uint8_t *unc, hipStream_t st)
 {
     if (a1 <= a0) return;
     const uint32_t cnt = a1 - a0;
-    hipLaunchKernelGGL(prefilter_hash_kernel, dim3((cnt + 1023) / 1024), dim3(256), 0, st, in, n, a0, a1, wmask, t_bits, m_bits,
+    hipLaunchKernelGGL(prefilter_hash_kernel, dim3((cnt + 1023) / 1024), dim3(256), 0, st, in, n, a0, a1, wmask, t_bits, t_bitmap, m_bits,
                        T, M, hbuf, hbuf2, c1);
     hipLaunchKernelGGL(prefilter_mark_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, m_bits, M, hbuf, c1, unc);
-    hipLaunchKernelGGL(prefilter_insert_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, t_bits, m_bits, T, M, hbuf, hbuf2);
+    hipLaunchKernelGGL(prefilter_insert_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, n, a0, a1, t_bits, t_bitmap, m_bits, T, M, hbuf, hbuf2);
 }
 
 void launch_bin(const uint8_t *in, const Geom &g, uint32_t c0, uint32_t nchunks, uint32_t nheads, uint32_t *off, uint32_t *cur,

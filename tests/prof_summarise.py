@@ -15,7 +15,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-out = {"round": R, "command": "python3 bench.py --no-cpu --block-streams 0", "kernel": "pipeline2_kernel", "csrc_sha16": csrc_sha()}
+out = {"round": R, "command": "python3 bench.py --no-cpu --block-streams 0 --no-workloads", "kernel": "pipeline2_kernel", "csrc_sha16": csrc_sha()}
 for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
     f = newest(f"{src}/{name}/**/*_counter_collection.csv")
     agg, n = {}, {}

@@ -150,3 +150,41 @@ def test_cli_decodes_streams_back_to_back(tmp_path, lib):
     r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(f)], capture_output=True, text=True)
     assert r.returncode != 0 and "malformed" in r.stdout
 
+
+
+def test_cli_block_index_sidecar(tmp_path, lib):
+    """The block container's index: `c -blocks:k` writes <output>.idx -- every block's offset, stream length and input length --
+    and `d` / `t` take the boundaries from it when it fits the file: no hop over every frame header before the parallel decode starts, and a
+    container that is DAMAGED INSIDE an early block still gives up the later ones' boundaries... here: cut off inside block 3 of 5, blocks 1 and 2
+    come out and the exit status says so; an index that does not fit the file is ignored with a note."""
+    from nlzm_amd import corpus, shard
+    from tests import oracle_py
+    data = corpus.mixed(600_000, corpus.SEED + 10)
+    k = 5
+    ranges = [shard.block_range(data.size, k, i) for i in range(k)]
+    streams = [oracle_py.compress(data[lo:hi], 18) for lo, hi in ranges]
+    blob = b"".join(streams)
+    f, idx, out = tmp_path / "c.nlzm", tmp_path / "c.nlzm.idx", tmp_path / "o.bin"
+
+    def write_index(total):
+        off, lines = 0, [f"NLZMIDX 1 {k} {data.size} {total}"]
+        for s_, (lo, hi) in zip(streams, ranges):
+            lines.append(f"{off} {len(s_)} {hi - lo}")
+            off += len(s_)
+        idx.write_text("\n".join(lines) + "\n")
+
+    f.write_bytes(blob); write_index(len(blob))
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(f), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and f"Blocks: {k}" in r.stdout and "does not fit" not in r.stdout, r.stdout
+    assert out.read_bytes() == data.tobytes()
+    # cut inside block 3: the index still says where blocks 1 and 2 are
+    cut = len(streams[0]) + len(streams[1]) + len(streams[2]) // 2
+    f.write_bytes(blob[:cut])
+    out2 = tmp_path / "o2.bin"
+    r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(f), str(out2)], capture_output=True, text=True)
+    assert r.returncode not in (0, 255) and "cut off inside block 3" in r.stdout and "Blocks: 2" in r.stdout, r.stdout
+    assert out2.read_bytes() == data.tobytes()[:ranges[2][0]]
+    # an index of another file: ignored, the frame headers are hopped over as before
+    f.write_bytes(blob); write_index(len(blob) - 7)
+    r = subprocess.run([nlzm_amd.CLI_PATH, "t", str(f)], capture_output=True, text=True)
+    assert r.returncode == 0 and "does not fit" in r.stdout and f"Blocks: {k}" in r.stdout, r.stdout

@@ -466,8 +466,11 @@ def test_cli_block_mode_round_trip(gpu, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     want = b"".join(oracle_py.compress(data[slice(*shard.block_range(data.size, 6, i))], 19) for i in range(6))
     assert dst.read_bytes() == want
+    # the sidecar index: offsets and lengths of the six streams, used by `d`
+    idx = (tmp_path / "out.nlzm.idx").read_text().split("\n")
+    assert idx[0] == f"NLZMIDX 1 6 {data.size} {len(want)}" and len([l for l in idx[1:] if l]) == 6
     r = subprocess.run([nlzm_amd.CLI_PATH, "d", str(dst), str(back)], capture_output=True, text=True)
-    assert r.returncode == 0 and back.read_bytes() == data.tobytes()
+    assert r.returncode == 0 and back.read_bytes() == data.tobytes() and "does not fit" not in r.stdout
 
 
 def test_streaming_feed(gpu):
