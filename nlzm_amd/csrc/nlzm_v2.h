@@ -572,18 +572,11 @@ struct Finder {
         // ---- BT4: the worker lanes' result (longest record-setter in the record's words 9, 10).
         // A worker lane walks its bin in position order.  At an `unc` position it does not wait for this stage's decision: it
         // assumes it and goes on, but the RESULTS of the calls behind such a position are held back until the decision is
-        // stored (a decision the other way takes those calls back).  So the result of a later position of the same bin cannot
-        // arrive before this block is committed: such a position becomes lane 0 of the next block.
-        uint32_t cut_bin = 64;
-        if (G.workers) {
-            const uint32_t bin = (hash4(v4) >> g.bt_shift) % G.nheads;
-            for (unsigned long long um = xw::ballot(unc && avail >= 4); um; um &= um - 1) {
-                const uint32_t x = (uint32_t)__builtin_ctzll(um);
-                const uint32_t bx = xw::readlane(bin, x);
-                const unsigned long long later = xw::ballot(bt_call && i > x && bin == bx);
-                if (later) cut_bin = umin(cut_bin, (uint32_t)__builtin_ctzll(later));
-            }
-        }
+        // stored (a decision the other way takes those calls back).  Until round 6 a decision was stored at the block's commit, so a later
+        // position of the same bin could not be in the block (it became lane 0 of the next one: 9 - 18 % of all blocks were cut for that).
+        // Now every decision is stored as soon as it is exact -- in the wait loop below, when the lanes in front are settled -- and the worker
+        // lets the held results go: nothing is cut for the bins any more.
+        constexpr uint32_t cut_bin = 64;
         const bool bt_wait = bt_call && i < cut_bin;
         uint32_t bt_n = 0;
         flush_fpos();                                               // (the block before: its records have landed by now)
@@ -605,6 +598,7 @@ struct Finder {
             const bool waits = xw::any(bt_wait);
             bool have = !bt_wait;                                   // this lane's result is in (or none is awaited)
             uint32_t r_d = 0, r_l = 0;
+            bool told = false;                                      // this lane's decision is stored
             uint32_t f_seen = 65;                                   // the first lane whose result was missing when the block was last verified (65: not yet)
             for (;;) {
                 // (quad 0 of the record in one load: the ready word and the longest pair behind it -- they were two dependent round trips)
@@ -669,6 +663,9 @@ struct Finder {
                     m = umin(m, js + 1 > 64 ? 64u : js + 1);
                     // (lanes behind the first missing one contribute what they have: a cut they ask for lies behind F and is not taken; a cut at or in
                     //  front of F hangs on lanes in front of F only -- F's own decision included, which is why `<=`)
+                    // every lane in front of F, and in front of the cut, is exact and will be committed as it stands: its decision is said now (the
+                    // worker lanes hold the results of the same bin's later positions until they have it)
+                    if (unc && avail >= 4 && !told && i < umin(F, m)) { xw::st_agent(G.bt_flag + bi, nice_real ? kFlagSkip : kFlagCall); told = true; }
                     if (m <= F) break;
                     // Lane F's decision is exact now, and it is "call" (a nice lane F would be a wrong prediction: a cut at F, and the loop were left): said
                     // at once, not at the block's commit.  The worker of an undecided position that it ASSUMES to be skipped does not make the call
