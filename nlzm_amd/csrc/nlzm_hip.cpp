@@ -807,6 +807,7 @@ int refresh_stats(Ctx &C)
                 100.0 * P.prof[108] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[109] / (P.prof[6] ? P.prof[6] : 1), 100.0 * P.prof[7] / (P.prof[6] ? P.prof[6] : 1));
         fprintf(stderr, "finder: RK256 entries cut short by the uint16 length parameter that became the growing top entry: %llu; that ended exactly where another entry ends: %llu (%llu of them the nearer one)\n",
                 P.prof[115], P.prof[116], P.prof[117]);
+        fprintf(stderr, "finder: starts of nice regions whose segment the stage knew itself, ahead of the parser's word: %llu; that it had to wait for: %llu\n", P.prof[118], P.prof[119]);
         fprintf(stderr, "finder: worker results not there at the first look: %llu of positions whose call is the finder's decision (unc), %llu of others\n", P.prof[28], P.prof[29]);
         fprintf(stderr, "finder: blocks that had to wait for a worker result: %llu (%.0f cycles each); late results of hot bins' waves %llu, late results at lane 0 (the position the block before was cut at) %llu\n",
                 P.prof[112], (double)P.prof[25] / (double)(P.prof[112] ? P.prof[112] : 1), P.prof[110], P.prof[111]);
@@ -1060,7 +1061,7 @@ int nlzm_hip_get_counter(const char *key, uint64_t *value)
         { "finder_wait_cycles", 16 }, { "finder_total_cycles", 17 }, { "table_wait_cycles", 18 }, { "table_total_cycles", 19 },
         { "parser_wait_cycles", 20 }, { "parser_total_cycles", 21 }, { "parser_emit_cycles", 22 }, { "parser_setup_cycles", 23 }, { "parser_pass_cycles", 24 },
         { "finder_bt_wait_cycles", 25 }, { "table_slow_blocks", 7 }, { "rk_cut_short_grown", 115 }, { "rk_cut_short_ties", 116 }, { "rk_cut_short_ties_won", 117 }, { "table_shape_changes", 113 }, { "table_wide_launches", 114 },
-        { "helper_jobs", 96 }, { "helper_taken", 97 }, { "helper_taken_nodes", 98 }, { "helper_wait_cycles", 99 }, { "helper_jobs_done", 101 }, { "helper_blocks", 102 }, { "helper_passes", 103 },
+        { "finder_seg_own", 118 }, { "finder_seg_waited", 119 }, { "helper_jobs", 96 }, { "helper_taken", 97 }, { "helper_taken_nodes", 98 }, { "helper_wait_cycles", 99 }, { "helper_jobs_done", 101 }, { "helper_blocks", 102 }, { "helper_passes", 103 },
     };
     for (const auto &e : kProf) if (!strcmp(key, e.name)) { *value = C.prof_last[e.idx]; return 0; }
     if (!strcmp(key, "worker_call_cycles")) { *value = C.wc_last.call_cycles; return 0; }

@@ -529,6 +529,12 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     unsigned long long w_pe = 0;
     uint32_t w_kind = kwNone;
     bool w_risky = false, w_wrong = false;
+    // ... and its entry of the window BEFORE (entries ob + j, all passed): only what is parked there and not decided yet still matters.  With it the
+    // bin is looked at up to 128 entries ahead of its oldest undecided entry; with one window the bin stood with nothing in hand whenever the finder
+    // stage had decided a window's last parked entry -- and the finder met it there.
+    unsigned long long o_pe = 0;
+    bool o_park = false, o_risky = false, o_wrong = false, ovalid = false;
+    uint32_t ob = 0;
     // the lane's call
     uint32_t st = kIdle, a = 0, hidx = 0, max_len = 0, sp = kNone, pend_l = 0, pend_r = 0, len_l = 0, len_r = 0, tests = 0, cb = 0;
     uint32_t seq = 0, nu = 0;
@@ -547,6 +553,12 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     for (uint32_t cc = c0; cc < c1; cc++) { const uint32_t *off = G.bin_off + (unsigned long long)(cc - c0) * (G.nheads + 1); k_total += off[bin + 1] - off[bin]; }
 
     for (;;) {
+        // ---- the window before is done with when nothing parked is left in it; a window that is passed but still holds parked entries takes its place
+        if (ovalid && !__any(o_park)) ovalid = false;
+        if (wvalid && !ovalid && !rec && cur >= wb + umin(64u, e0 - wb) && cur < e0) {
+            o_pe = w_pe; o_park = w_kind == kwPark; o_risky = w_risky; o_wrong = w_wrong; ob = wb; ovalid = true;
+            wvalid = false; w_kind = kwNone; w_wrong = false; w_risky = false;
+        }
         // ---- the window: loaded where the bin goes on; the chunk is left when nothing of it is in flight
         if (!wvalid && more && !rec) {
             for (;;) {
@@ -561,7 +573,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                     loaded = true;
                 }
                 if (cur < e0) break;
-                if (__any(st != kIdle)) break;                      // (a wrong assumption would bring the bin back into this chunk)
+                if (__any(st != kIdle) || ovalid) break;            // (a wrong assumption would bring the bin back into this chunk)
                 c++; loaded = false;
             }
             if (more && loaded && cur < e0) {
@@ -583,9 +595,10 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         const uint32_t wend = wvalid ? umin(64u, e0 - wb) : 0u;     // entries in the window
         // ---- the oldest undecided position (a call's or a parked entry's); a wrong assumption
         const bool w_und = wvalid && w_kind == kwPark && wb + lane < cur;
-        const uint32_t w_seq = wb + lane + 1;
-        const uint32_t oseq = ~wave_max_u32(umax(und ? ~seq : 0u, w_und ? ~w_seq : 0u));
-        const uint32_t rseq = ~wave_max_u32(umax(wrong ? ~seq : 0u, w_wrong ? ~w_seq : 0u));
+        const bool o_und = ovalid && o_park;
+        const uint32_t w_seq = wb + lane + 1, o_seq = ob + lane + 1;
+        const uint32_t oseq = ~wave_max_u32(umax(und ? ~seq : 0u, umax(w_und ? ~w_seq : 0u, o_und ? ~o_seq : 0u)));
+        const uint32_t rseq = ~wave_max_u32(umax(wrong ? ~seq : 0u, umax(w_wrong ? ~w_seq : 0u, (ovalid && o_wrong) ? ~o_seq : 0u)));
         if (rseq != 0xFFFFFFFFu) rec = true;
         if (rec && !__any(st == kStart || st == kRun)) {
             // every call in flight has ended: the stores of the calls behind the position are taken back, latest first; then the position's
@@ -610,10 +623,31 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 }
                 st = kIdle; und = false; wrong = false; n_back++;
             }
-            const bool parked = __any(w_wrong && w_seq == rseq);    // (assumed to be skipped, and called: made now)
+            const bool parked = __any((w_wrong && w_seq == rseq) || (ovalid && o_wrong && o_seq == rseq));    // (assumed to be skipped, and called: made now)
             if (parked && lane == 0) n_back++;
             cur = parked ? rseq - 1 : rseq;
-            wvalid = false; w_wrong = false; w_kind = kwNone;
+            // Where the bin goes on, the entries are looked at again (their calls are taken back, decisions may have come in).  What is parked IN
+            // FRONT of that place stays as it is: it is older than the wrong assumption and may be undecided still (decisions are stored in position
+            // order, but two stores of one instruction need not become visible in that order).
+            if (ovalid && cur < ob + 64) {
+                if (cur >= ob) {                                    // inside the window before: it is the window again
+                    w_pe = o_pe; w_kind = o_park ? kwPark : kwDone; w_risky = o_risky; w_wrong = o_wrong; wb = ob; wvalid = true;
+                } else wvalid = false;                              // (in front of both: nothing undecided can be parked in front of it)
+                ovalid = false; o_park = false; o_wrong = false;
+            } else if (wvalid && cur < wb) wvalid = false;
+            if (wvalid) {
+                const uint32_t idx = wb + lane;
+                if (idx >= cur) {
+                    w_kind = kwNone; w_risky = false; w_wrong = false;
+                    if (idx < e0) {
+                        w_pe = *(const unsigned long long *)(pos + 2 * idx);
+                        const bool mk = (w_pe >> 63) != 0;
+                        uint32_t f = 0;
+                        if (mk) f = LaneIO::ld_agent(flags + ((uint32_t)w_pe - batch_a0));
+                        w_kind = !mk ? kwCall : (f == kFlagSkip ? kwDone : (f == kFlagCall ? kwCall : ((w_pe >> 61) == 7u ? kwPark : kwCall)));
+                    }
+                }
+            } else { w_wrong = false; w_kind = kwNone; }
             rec = false;
             continue;
         }
@@ -625,21 +659,28 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         uint32_t pe_seq = 0;
         bool made_test = false, rep_step = false, started_now = false;
         const unsigned long long free_m = __ballot(st == kIdle);
-        const bool risky_open = __any(w_und && w_risky);
+        const bool risky_open = __any((w_und && w_risky) || (o_und && o_risky));
         bool call_blocked = false;
         n_steps++;
         if (wvalid && !rec && cur < wb + wend) {
             const uint32_t cl = cur - wb;
             const unsigned long long range = (~0ull << cl) & (wend < 64 ? (1ull << wend) - 1ull : ~0ull);
             const unsigned long long mC = __ballot(w_kind == kwCall) & range, mP = __ballot(w_kind == kwPark) & range;
-            const uint32_t c1i = mC ? (uint32_t)__builtin_ctzll(mC) : 64u;
-            const bool park_before = c1i < 64 ? (mP & ((1ull << c1i) - 1ull)) != 0 : mP != 0;
-            const bool call_ok = c1i < 64 && free_m && !risky_open && !(park_before && !last_skip);
+            const uint32_t c1i = mC ? (uint32_t)__builtin_ctzll(mC) : 64u, p1 = mP ? (uint32_t)__builtin_ctzll(mP) : 64u;
+            // (a parked entry is RISKY when the bin's last decision was not "skip": nothing is passed behind it until it is decided -- the entries
+            //  behind it are then no longer risky, the decision being "skip" -- and it is passed with nothing but what stands in front of it)
+            bool call_ok = c1i < 64 && free_m && !risky_open && !(!last_skip && p1 < c1i);
             call_blocked = c1i < 64 && free_m && !call_ok;
-            uint32_t end = c1i;
+            uint32_t end = cl;
+            if (!risky_open) {
+                end = c1i;
+                if (call_ok) {
+                    const unsigned long long restC = mC & ~(1ull << c1i);
+                    end = restC ? (uint32_t)__builtin_ctzll(restC) : 64u;
+                }
+                if (!last_skip && p1 < end) end = p1 + 1;
+            }
             if (call_ok) {
-                const unsigned long long restC = mC & ~(1ull << c1i);
-                end = restC ? (uint32_t)__builtin_ctzll(restC) : 64u;
                 start_lane = (uint32_t)__builtin_ctzll(free_m);
                 pe = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_pe >> 32), (int)c1i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_pe, (int)c1i);
                 pe_seq = wb + c1i + 1;
@@ -667,7 +708,17 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         if (st == kRun && !(sp != kNone && a > sp && a - sp <= wmask && tests < 256)) fin_now = true;   // :989, :1020-1021
         const uint32_t pair = (sp & tmask) << 1, init = umin(len_l, len_r);
         if ((st == kStart && marked) || und) v_flag = LaneIO::ld_agent(flags + (a - batch_a0));
-        if (w_und && !w_wrong) w_flag = LaneIO::ld_agent(flags + ((uint32_t)w_pe - batch_a0));
+        // (decisions are made in position order: only the OLDEST undecided entries' words can have changed -- eight of them are looked at, the window
+        //  before first.  Every parked entry looking at its word in every step was a gather of up to 128 uncached loads per step: steps of 5,600
+        //  cycles where 4,000 were the rule.)
+        uint32_t o_flag = 0;
+        {
+            const unsigned long long om = __ballot(o_und && !o_wrong), wm = __ballot(w_und && !w_wrong);
+            const uint32_t o_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+            const uint32_t w_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u)) + (uint32_t)__builtin_popcountll(om);
+            if (o_und && !o_wrong && o_rank < 8u) o_flag = LaneIO::ld_agent(flags + ((uint32_t)o_pe - batch_a0));
+            if (w_und && !w_wrong && w_rank < 8u) w_flag = LaneIO::ld_agent(flags + ((uint32_t)w_pe - batch_a0));
+        }
         if (st == kStart) v_word = heads[hidx];
         else if (st == kRun && !fin_now) {
             pp = *(const unsigned long long *)(tree + pair);
@@ -685,7 +736,13 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 if (w_flag == kFlagSkip) w_kind = kwDone;           // as assumed: dropped
                 else w_wrong = true;                                // (stays parked: nothing behind it is released)
             }
-            if (__any(decided || w_decided)) last_skip = __any((decided && v_flag == kFlagSkip) || (w_decided && w_flag == kFlagSkip));
+            const bool o_decided = o_und && !o_wrong && (o_flag == kFlagCall || o_flag == kFlagSkip);
+            if (o_decided) {
+                if (o_flag == kFlagSkip) o_park = false;
+                else o_wrong = true;
+            }
+            if (__any(decided || w_decided || o_decided))
+                last_skip = __any((decided && v_flag == kFlagSkip) || (w_decided && w_flag == kFlagSkip) || (o_decided && o_flag == kFlagSkip));
         }
         if (st == kStart) {
             bool go = true;
@@ -780,11 +837,11 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 else if (!free_m) k_full++;
                 else if (call_blocked) k_blk++;
                 else k_noent++;
-                if (__any(und || w_und)) k_und++;
+                if (__any(und || w_und || o_und)) k_und++;
             }
         }
         // ---- watchdogs (a position whose decision does not come; a launch that failed elsewhere)
-        if ((und || w_und) && (++idle & 4095u) == 0) {
+        if ((und || w_und || o_und) && (++idle & 4095u) == 0) {
             const unsigned long long now = wall_clock64();
             const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
             if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
@@ -792,7 +849,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         }
         if (__any(fail)) { if (lane == 0) LaneIO::st_agent(G.abort_word, 2u); break; }
         if ((++steps & 0x3FFFu) == 0 && __any(LaneIO::ld_agent(G.abort_word) != 0)) break;
-        if (!more && !wvalid && !rec && !__any(st != kIdle)) break;
+        if (!more && !wvalid && !ovalid && !rec && !__any(st != kIdle)) break;
     }
     if (st != kIdle) {
         atomicAdd(&G.wcnt->stuck_lanes, 1ull);
