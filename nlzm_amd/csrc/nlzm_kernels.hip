@@ -411,13 +411,16 @@ __device__ __forceinline__ void bt_descent(const BtView &B, uint32_t a, uint32_t
         // the node's pair and the first eight bytes of both sides: requested together, one round trip
         const unsigned long long pp = *(const unsigned long long *)(B.tree + pair);     // left, right
         const unsigned long long x0 = load64u(ps + init), y0 = load64u(pa + init), d0 = x0 ^ y0;
+        const unsigned long long x1 = load64u(ps + init + 8), y1 = load64u(pa + init + 8), d1 = x1 ^ y1;
         // RingDictionary::MatchLengthSigned (:854-877): common prefix from `init`, at most max_len; sign = which side is smaller.
-        // Nearly always decided inside these eight bytes; the rest goes round by round.
-        const uint32_t nb0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u;
+        // Nearly always decided inside these sixteen bytes (all requested together: a second round is a dependent round trip for all 64 lanes of
+        // the wave, which take their tests in lockstep); the rest goes round by round.
+        const uint32_t nb0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : (d1 ? 8u + ((uint32_t)__builtin_ctzll(d1) >> 3) : 16u);
         uint32_t l = init + nb0;
         bool full = l >= max_len;
-        uint32_t sign = (uint32_t)(((x0 >> (8 * (nb0 & 7u))) & 0xFF) < ((y0 >> (8 * (nb0 & 7u))) & 0xFF));
-        if (!d0 && !full) {
+        const unsigned long long xs = nb0 < 8 ? x0 : x1, ys = nb0 < 8 ? y0 : y1;
+        uint32_t sign = (uint32_t)(((xs >> (8 * (nb0 & 7u))) & 0xFF) < ((ys >> (8 * (nb0 & 7u))) & 0xFF));
+        if (nb0 == 16 && !full) {
             for (;;) {
                 const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
                 if (d) {
@@ -538,6 +541,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     // the lane's call
     uint32_t st = kIdle, a = 0, hidx = 0, max_len = 0, sp = kNone, pend_l = 0, pend_r = 0, len_l = 0, len_r = 0, tests = 0, cb = 0;
     uint32_t seq = 0, nu = 0;
+    uint32_t cmp_off = 0;           // bytes of the test in hand that are known to agree beyond `init` (a compare longer than a step's sixteen bytes goes on in the next step)
     bool marked = false, und = false, published = false, wrong = false;
     bool last_skip = false;         // (wave-uniform) the bin's latest decision was "skip"
     LaneSink sink{ (uint32_t *)&g_v2_lds + threadIdx.x, nullptr };
@@ -702,7 +706,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         if (wvalid && cur >= wb + wend && !__any(w_kind == kwPark)) wvalid = false;
         // ---- loads of this step
         uint32_t v_word = 0, v_flag = 0, w_flag = 0;
-        unsigned long long pp = 0, x0 = 0, y0 = 0;
+        unsigned long long pp = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         bool fin_now = false;
         uint32_t fin_l = kNone, fin_r = kNone;
         if (st == kRun && !(sp != kNone && a > sp && a - sp <= wmask && tests < 256)) fin_now = true;   // :989, :1020-1021
@@ -722,7 +726,11 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         if (st == kStart) v_word = heads[hidx];
         else if (st == kRun && !fin_now) {
             pp = *(const unsigned long long *)(tree + pair);
-            x0 = load64u(in + sp + init); y0 = load64u(in + a + init);
+            // (sixteen bytes of both sides from where the test stands: ONE round trip per step whatever the lanes' compares do -- a compare that ran on
+            //  inside the step, round by round, was a second and third dependent round trip for the whole wave, and the runs of spaces of source code,
+            //  the hottest bin there is, agree over more than eight bytes in most of their tests: steps of 6,000 cycles)
+            const uint8_t *ps = in + sp + init + cmp_off, *pa = in + a + init + cmp_off;
+            x0 = load64u(ps); y0 = load64u(pa); x1 = load64u(ps + 8); y1 = load64u(pa + 8);
         }
         // ---- what they say
         {
@@ -753,7 +761,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             if (go) {
                 started_now = true;
                 sp = v_word;                                        // :983
-                pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0;
+                pend_l = (a & tmask) << 1; pend_r = pend_l + 1; len_l = 0; len_r = 0; tests = 0; cb = 0; cmp_off = 0;
                 sink.count = 0; sink.best = 1; sink.best_d = 0; sink.ext_idx = 0; sink.pairs = pairs + (unsigned long long)(a - batch_a0) * (2 * Bx.pstride);
                 published = false;
                 undo[0] = (0x80000000u | hidx) | ((unsigned long long)sp << 32);
@@ -763,34 +771,25 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 st = kRun;
             }
         } else if (st == kRun && !fin_now) {
-            const unsigned long long d0 = x0 ^ y0;
-            const uint32_t nb0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u;
-            uint32_t l = init + nb0;
+            // RingDictionary::MatchLengthSigned (:854-877) over this step's sixteen bytes
+            const unsigned long long d0 = x0 ^ y0, d1 = x1 ^ y1;
+            const uint32_t from = init + cmp_off;
+            uint32_t nb = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : (d1 ? 8u + ((uint32_t)__builtin_ctzll(d1) >> 3) : 16u);
+            uint32_t l = from + nb;
             bool full = l >= max_len;
-            uint32_t sign = (uint32_t)(((x0 >> (8 * (nb0 & 7u))) & 0xFF) < ((y0 >> (8 * (nb0 & 7u))) & 0xFF));
+            const unsigned long long xs = nb < 8 ? x0 : x1, ys = nb < 8 ? y0 : y1;
+            const uint32_t sign = (uint32_t)(((xs >> (8 * (nb & 7u))) & 0xFF) < ((ys >> (8 * (nb & 7u))) & 0xFF));
             const uint32_t pl = (uint32_t)pp, pr = (uint32_t)(pp >> 32);
-            if (!d0 && !full) {
-                const uint8_t *ps = in + sp, *pa = in + a;
-                for (;;) {
-                    const unsigned long long x = load64u(ps + l), y = load64u(pa + l), d = x ^ y;
-                    if (d) {
-                        const uint32_t nb = (uint32_t)__builtin_ctzll(d) >> 3;
-                        l += nb;
-                        sign = (uint32_t)(((x >> (8 * nb)) & 0xFF) < ((y >> (8 * nb)) & 0xFF));
-                        break;
-                    }
-                    l += 8;
-                    if (l >= max_len) break;
-                }
-                full = l >= max_len;
-            }
+            const bool more_cmp = nb == 16 && !full;                // all sixteen agree and the cap is not reached: the compare goes on in the next step
+            if (more_cmp) cmp_off += 16;
             if (full) l = max_len;
             const bool right = sign != 0;
             // the slot(s) this step reads on: still held by an earlier call -> the step is repeated
-            const bool held = full ? (pl == kPending || pr == kPending) : ((right ? pr : pl) == kPending);
+            const bool held = more_cmp || (full ? (pl == kPending || pr == kPending) : ((right ? pr : pl) == kPending));
             rep_step = held;
             if (!held) {
                 made_test = true;
+                cmp_off = 0;
                 tests++;
                 cb += (l - init) + (full ? 0u : 1u);
                 const uint32_t d = a - sp;
