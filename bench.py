@@ -34,6 +34,9 @@ The JSON line also carries:
                 --block-streams independent blocks, all in flight at once.  A second measurement next to `value`,
                 never part of it (k streams instead of one).  At N = 1 every block's stream is compared with the
                 reference run on that block (tests/golden/blocks_1g.json).
+  workloads     the same path on the inputs the stand-in flatters it on: 120 MB of real text (source code) at -window:28 and 100 MB of wiki-shaped
+                markup at -window:26, each a whole stream timed from stream_begin to the finished stream and compared with the REFERENCE's own stream
+                (tests/golden/workloads.json, which also holds the reference's wall time: cpu_reference).  --no-workloads skips them.
 Any leg that fails puts an "error" key at the top level of the line and the exit code is 1.
 """
 from __future__ import annotations
