@@ -112,7 +112,9 @@ struct Ctx {
     int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (with two of a CU's eight waves walking trees a test takes less
                                             // time than with all eight -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
-    int64_t opt_hot_min = 8192;             // positions per launch from which a bin may count as hot
+    int64_t opt_hot_min = 0;                // positions per launch from which a bin may count as hot; 0: the launch's positions / 480 (8,160 at the default launch
+                                            // of 32 chunks, the value rounds 3 - 5 fixed -- and four times too high for the bench's launches of 8 chunks, where only 8 of
+                                            // 480 wave slots were used: 401 -> 371 cycles per position at 300 MB with the threshold scaled, profiles/r06_ab_runs.txt)
     int64_t opt_tbits_max = 34;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
     int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
     int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
@@ -616,7 +618,9 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
                          C.pf_c1, C.unc, C.st);
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
         if (C.hot_max) {
-            launch_hot_select(C.bin_off, nb, C.nheads, C.hot_max, (uint32_t)C.opt_hot_min, C.hot_of_bin, C.hot_list, C.wcnt, C.st);
+            const unsigned long long lpos = (unsigned long long)C.batch * g.chunk_size;
+            const uint32_t hot_min = C.opt_hot_min > 0 ? (uint32_t)C.opt_hot_min : (uint32_t)(lpos / 480 < 512 ? 512 : lpos / 480);
+            launch_hot_select(C.bin_off, nb, C.nheads, C.hot_max, hot_min, C.hot_of_bin, C.hot_list, C.wcnt, C.st);
             G.hot_of_bin = C.hot_of_bin; G.hot_list = C.hot_list; G.hot_undo = C.hot_undo;
         }
     }
@@ -1101,7 +1105,7 @@ int nlzm_hip_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "worker_blocks")) { if (value < 1 || value > 255) return set_err(NLZM_HIP_E_ARG, "worker_blocks out of range"); C.opt_worker_blocks = value; return 0; }
     if (!strcmp(key, "hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "hot_waves out of range"); C.opt_hot_waves = value; return 0; }
-    if (!strcmp(key, "hot_min")) { if (value < 1 || value > (1 << 30)) return set_err(NLZM_HIP_E_ARG, "hot_min out of range"); C.opt_hot_min = value; return 0; }
+    if (!strcmp(key, "hot_min")) { if (value < 0 || value > (1 << 30)) return set_err(NLZM_HIP_E_ARG, "hot_min out of range"); C.opt_hot_min = value; return 0; }
     if (!strcmp(key, "worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "worker_threads out of range"); C.opt_worker_threads = value; return 0; }
     if (!strcmp(key, "block_worker_threads")) { if (value < 64 || value > 512 || value % 64) return set_err(NLZM_HIP_E_ARG, "block_worker_threads out of range"); C.opt_block_threads = value; return 0; }
     if (!strcmp(key, "block_hot_waves")) { if (value < 0 || value > 6) return set_err(NLZM_HIP_E_ARG, "block_hot_waves out of range"); C.opt_block_hot_waves = value; return 0; }

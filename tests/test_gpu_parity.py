@@ -212,7 +212,7 @@ def test_worker_lanes_and_hot_bin_waves_are_invisible(gpu):
                 assert st[k] == want[1][k], (k, hot_waves, hot_min, lanes)
             assert gpu.compress(dups, 16) == want_dups, (hot_waves, hot_min, lanes)
     finally:
-        gpu.set_option("hot_waves", 2); gpu.set_option("hot_min", 8192); gpu.set_option("worker_threads", 128)
+        gpu.set_option("hot_waves", 2); gpu.set_option("hot_min", 0); gpu.set_option("worker_threads", 128)
 
 
 def test_rans_frames_stage(gpu):
