@@ -212,7 +212,7 @@ void nlzm_hip_block_placement(uint32_t nstreams, uint32_t blocks_per_stream, uin
 /* ---- tuning knobs (defaults are what bench.py measures) -------------------- */
 /* key: "workers" (only 1: BT4 runs on per-head worker lanes), "batch_chunks" (chunks per persistent launch), "worker_blocks" (worker CUs of a stream, default 240: the stage CUs and these fill the device),
  * "worker_threads" (bin-taking lanes per worker CU, 64..512, default 128), "hot_waves" (waves per worker CU that take a hot
- * BT4 bin each, 0..6, default 2), "hot_min" (positions per launch from which a bin counts as hot, default 0: the launch's positions / 480);
+ * BT4 bin each, 0..6, default 2), "hot_min" (positions per launch from which a bin counts as hot, default 0: by the stream's pace -- 24 positions per millisecond of the launch before);
  * block mode: "block_worker_threads" (default 320) and "block_hot_waves" (default 3), the same two for the streams of a block set
  * (their worker CUs are few: the count follows from the number of streams), "block_batch_chunks" (chunks of every stream per
  * shared launch, default 8); "prefilter_bits_per_position" (log2 of the pre-filter table's entries per input position, default 4);

@@ -112,9 +112,13 @@ struct Ctx {
     int64_t opt_worker_threads = 128;       // lanes of a worker block that take bins (with two of a CU's eight waves walking trees a test takes less
                                             // time than with all eight -- measured at 60 MB: 512 lanes per CU 2.48 MB/s, 256 2.58, 128 2.62, 64 2.62)
     int64_t opt_hot_waves = 2;              // waves of a worker block behind its bin-taking lanes that take a hot bin each (0: none)
-    int64_t opt_hot_min = 0;                // positions per launch from which a bin may count as hot; 0: the launch's positions / 480 (8,160 at the default launch
-                                            // of 32 chunks, the value rounds 3 - 5 fixed -- and four times too high for the bench's launches of 8 chunks, where only 8 of
-                                            // 480 wave slots were used: 401 -> 371 cycles per position at 300 MB with the threshold scaled, profiles/r06_ab_runs.txt)
+    int64_t opt_hot_min = 0;                // positions per launch from which a bin may count as hot; 0 (default): by the stream's pace.  A bin needs a wave when its calls
+                                            // come faster than a lane serves them -- a lane's call costs ~42 us with its lockstep partners' --, and how fast they come hangs on
+                                            // how fast the FINDER moves: bins of 24 positions per millisecond of the launch before and more (the first launch: positions / 240).
+                                            // Measured at launches of 8 chunks (profiles/r06_ab_runs.txt): the stand-in (166 ms a launch) 401 / 390 / 382 / 371 cycles per position
+                                            // at 8,192 / 6,144 / 4,096 / 2,048; markup (362 ms) 872 / 906 / 1,005 / 1,007 -- a wave's call takes twice a lane's (its steps are
+                                            // heavier), which is lost where a lane would have kept up.  Rounds 3 - 5 had 8,192 fixed.
+    double last_launch_ms = 0;              // duration of the stream's last persistent launch (0: none yet)
     int64_t opt_tbits_max = 34;             // log2 of the pre-filter table's entries at most (block mode shrinks it to fit)
     int64_t opt_block_threads = 320;        // block mode: lanes of a worker block that take bins, and the waves behind them that take a hot bin each.  Measured
     int64_t opt_block_hot_waves = 3;        // with 32 streams of 17 MB (4 worker CUs each): 512 lanes and no such waves 9.6 s, 256 + 4 waves 8.2 s, 128 + 6 waves 8.6 s
@@ -364,7 +368,7 @@ int stream_begin(Ctx &C, const void *d_src, uint64_t n, uint32_t hist_bits_req, 
     make_geom(n, hist_bits_req, C.g);
     const Geom &g = C.g;
     C.d_in = (const uint8_t *)d_src; C.d_dst = (uint8_t *)d_dst; C.dst_cap = dst_cap;
-    C.out_pos = 0; C.next_chunk = 0; C.pre_chunk = 0;
+    C.out_pos = 0; C.next_chunk = 0; C.pre_chunk = 0; C.last_launch_ms = 0;
     memset(&C.stats, 0, sizeof C.stats);
     memset(&C.tm, 0, sizeof C.tm);
     C.stats.in_bytes = n;
@@ -619,7 +623,9 @@ int step_pre(Ctx &C, uint32_t todo, StepPlan &P, bool ahead = false)
         launch_bin(C.d_in, g, c0, nb, C.nheads, C.bin_off, C.bin_cur, C.bin_pos, C.unc, (uint32_t)a0, C.st);
         if (C.hot_max) {
             const unsigned long long lpos = (unsigned long long)C.batch * g.chunk_size;
-            const uint32_t hot_min = C.opt_hot_min > 0 ? (uint32_t)C.opt_hot_min : (uint32_t)(lpos / 480 < 512 ? 512 : lpos / 480);
+            // (the streams of a block set have a hundred heads to a lane: there a wave pays from positions / 480 on -- 112.6 -> 115.6 MB/s against 8,192)
+            const double by_pace = C.pool ? (double)lpos / 480.0 : (C.last_launch_ms > 0 ? 24.0 * C.last_launch_ms : (double)lpos / 240.0);
+            const uint32_t hot_min = C.opt_hot_min > 0 ? (uint32_t)C.opt_hot_min : (uint32_t)(by_pace < 512 ? 512 : (by_pace > 1e9 ? 1e9 : by_pace));
             launch_hot_select(C.bin_off, nb, C.nheads, C.hot_max, hot_min, C.hot_of_bin, C.hot_list, C.wcnt, C.st);
             G.hot_of_bin = C.hot_of_bin; G.hot_list = C.hot_list; G.hot_undo = C.hot_undo;
         }
@@ -739,6 +745,7 @@ int step_post_done(Ctx &C, const StepPlan &P, float pipe_ms)
     HIPCHK(hipEventElapsedTime(&b, P.ev[1], P.ev[2]));
     HIPCHK(hipEventElapsedTime(&c, P.ev[3], P.ev[4]));
     C.tm.match_parse_ms += a; C.tm.match_parse_launches++;
+    if (a > 0) C.last_launch_ms = a;
     C.tm.rans_ms += b + c; C.tm.rans_launches++;
     C.tm.total_ms += a + b + c;
     C.out_pos = pos;
