@@ -58,7 +58,7 @@ struct Hx {                                     // progress words, one 128-byte 
         alignas(128) uint32_t verdict;          //   whoever drops the helper's job (the parser stage, or the helper in front of it): job << 2 | 2
         alignas(128) unsigned long long prog;   //   helper: job << 32 | nodes it knows to be inside the segment << 16 | nodes final (HelpBox arrays valid below)
         alignas(128) uint32_t state;            //   helper: job << 2 | 1 done (seg_len, end_rep valid), 2 given up
-    } hw[2];
+    } hw[3];
     alignas(128) uint32_t ext_cur;              // worker lanes: extension blocks of pair lists taken in this launch (Globals::bt_ext_cur)
     alignas(128) uint32_t err;                  // any stage: nonzero -> every stage leaves (the FIRST code stays: raise())
     uint32_t err_info[7];                       // of the stage that raised it: stage (11 finder, 12 table, 13 parser), wait site, position, what it saw
@@ -83,11 +83,12 @@ struct RoundSnap { uint32_t error, next_chunk, aborted, pad; Hx hx; };
 #ifndef NLZM_HELPERS
 #define NLZM_HELPERS 2
 #endif
-constexpr uint32_t kHelpers = NLZM_HELPERS;     // (1 or 2)
-static_assert(kHelpers >= 1 && kHelpers <= 2, "Hx::hw holds two helpers' words");
+constexpr uint32_t kHelpers = NLZM_HELPERS;     // (1, 2 or 3.  Three, measured in round 6: the parser stage's busy cycles 305 -> 266 per position, the headline 6.35 -> 6.40 MB/s -- the finder stage
+                                                //  bounds the stream there; not the default, one CU more for 0.7 %: DESIGN.md section 13)
+static_assert(kHelpers >= 1 && kHelpers <= 3, "Hx::hw holds three helpers' words");
 // helper k's first node (a segment that is cut at 4,096: one helper -- the front 2,400 nodes stay with the parser stage, the helper has
 // 1,792 .. 4,096; two -- 1,900 / 1,280 .. 3,100 / 2,496 .. 4,096; the helpers further back wait for their records longer)
-NLZM_HD uint32_t help_start(uint32_t k) { return kHelpers == 1 ? 1792u : (k == 0 ? 1280u : 2496u); }
+NLZM_HD uint32_t help_start(uint32_t k) { return kHelpers == 1 ? 1792u : (kHelpers == 2 ? (k == 0 ? 1280u : 2496u) : 880u * (k + 1)); }
 constexpr uint32_t kHelpWarm = 576;             // nodes a helper has behind it where the frontiers are compared
 constexpr uint32_t kHelpExit = 0xFFFFFFFFu;
 struct HelpBox {

@@ -333,7 +333,8 @@ int main(int argc, char **argv)
     uint32_t abort_word = 0; WorkerCounters wc = {};
     unsigned long long unc_total = 0;
     pf.init(g.wbits, (unsigned long long)(g.nchunks / nlaunch + 2) * g.chunk_size); wk.g = g; wk.G = &G; g_workers = &wk;
-    unsigned long long lds_bytes[5] = { sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds), sizeof(v2::PLds), sizeof(v2::PLds) };
+    unsigned long long lds_bytes[3 + v2::kHelpers] = { sizeof(v2::FLds), sizeof(v2::TLds) };
+    for (uint32_t b = 2; b < 3 + v2::kHelpers; b++) lds_bytes[b] = sizeof(v2::PLds);
     printf("LDS: finder %zu, table %zu, parser %zu bytes\n", sizeof(v2::FLds), sizeof(v2::TLds), sizeof(v2::PLds));
     for (uint32_t r = 0; r < nlaunch; r++) {
         const uint32_t c0 = (uint32_t)((unsigned long long)g.nchunks * r / nlaunch), c1 = (uint32_t)((unsigned long long)g.nchunks * (r + 1) / nlaunch);
