@@ -527,7 +527,13 @@ def main():
                          "algorithmic_bytes_per_input_byte": round(algorithmic_bytes(d) / max(1, d["in_bytes_step"]), 2),
                          "algorithmic_bytes_line_granular": int(algorithmic_bytes_lines(d) / launches),
                          "frac_line_granular": round(algorithmic_bytes_lines(d) / launches / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 8) if k_ms > 0 else 0.0,
-                         "latency_bound": latency_bound(sc0, sc1)},
+                         "latency_bound": latency_bound(sc0, sc1),
+                         # (SURVEY 8d defines cmp_bytes as the iterations of the reference's compare loop, NLZM.cpp:863; the device counts the oracle's
+                         #  cmp_bytes_needed -- an explicit rep probe measured up to the 264 bytes that can matter, the reference compares up to 4,096 and then
+                         #  caps the length, :1605-1606.  The oracle counts both: 1,039,103,767 against 1,087,452,480 on the first 16 MB of this workload at
+                         #  -window:28, identical on markup; 2 x cmp_bytes is 28 % of the algorithmic bytes)
+                         "cmp_bytes_definition": {"counted": "oracle cmp_bytes_needed (rep probes up to 264 bytes)", "ratio_to_reference_loop_iterations": 0.9555,
+                                                  "measured_on": "corpus.syn_text(16e6) at -window:28, tests/oracle_py.compress(want_stats=True)"}},
             "kernel_ms": {"prep": round(tm1["prep_ms"] - tm0["prep_ms"], 3),
                           "match_parse": round(tm1["match_parse_ms"] - tm0["match_parse_ms"], 3),
                           "rans_gather": round(tm1["rans_ms"] - tm0["rans_ms"], 3)},
