@@ -874,7 +874,7 @@ int refresh_stats(Ctx &C)
                 const unsigned long long *h = wc.hot_class[k];
                 if (!h[0]) continue;
                 const double st = (double)(h[3] ? h[3] : 1);
-                fprintf(stderr, "  >= %7u: %5llu | %10llu calls, %5.1f, %10llu | %12llu steps, %5.0f | %4.1f (%.2f; %.2f), %4.1f, %4.1f, %4.1f, %4.1f | %4.1f\n", 8192u << k, h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1), h[12],
+                fprintf(stderr, "  %s %7u: %5llu | %10llu calls, %5.1f, %10llu | %12llu steps, %5.0f | %4.1f (%.2f; %.2f), %4.1f, %4.1f, %4.1f, %4.1f | %4.1f\n", k ? ">=" : "< ", k ? 8192u << k : 16384u, h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1), h[12],
                         h[3], (double)h[11] / st, 100.0 * h[4] / st, (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / st, 100.0 * h[7] / st, 100.0 * h[8] / st, 100.0 * h[9] / st, 100.0 * h[10] / st, 100.0 * h[13] / st);
             }
         }
