@@ -145,7 +145,11 @@ struct WorkerCounters {
     //   another call holds, 7 idle steps while a wrong assumption is taken back, 8 idle: every lane holds a call that waits for a decision, 9 idle: the next
     //   call may not start (dry / risky), 10 idle: no entry (the chunk's end, or its calls are held), 11 cycles, 12 entries skipped (decided "skip" when they came up),
     //   13 idle steps with an undecided position open (any cause)
-    unsigned long long hot_class[8][14];
+    //   (4 .. 10 and 13 are counted by the profile build only, NLZM_PROFILE: counting them was a tenth of a step)
+    //   14 .. 20 (profile build): cycles of a step by section -- the oldest undecided position and recovery, passing entries and the start, the step's loads
+    //   until they are back (the round trip), a call's start and its test, the call's end and its result, accounting and watchdogs; 20: the end of the step before
+    //   and the windows' upkeep (in front of 14)
+    unsigned long long hot_class[8][21];
 };
 
 // Everything the master needs from HBM.

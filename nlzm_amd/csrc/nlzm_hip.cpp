@@ -868,14 +868,20 @@ int refresh_stats(Ctx &C)
             fprintf(stderr, "hot bins' waves: %llu steps (%.1f per call); the next call could not start in %.1f %% of them (a call without its stores on its way) + %.1f %% (an assumed \"skip\" behind a \"call\" still open); lanes: %llu turns spent waiting for a decision\n",
                     wc.hot_steps, (double)wc.hot_steps / (wc.hot_calls ? wc.hot_calls : 1), 100.0 * wc.hot_blocked_dry / wc.hot_steps, 100.0 * wc.hot_blocked_risky / wc.hot_steps, wc.flag_waits);
         if (C.opt_report && C.hot_max && wc.hot_steps) {
-            fprintf(stderr, "hot bins' waves by the bin's positions in the launch (class: waves | calls, tests/call, entries skipped | steps, cycles/step | %% of the steps: some lane tests (tests per such step; lane-steps repeated for a held slot per step), "
-                            "taking back, every lane holds a call, next call may not start, no entry | idle steps with an undecided position open)\n");
+            // (what a step was spent on is counted by the profile build only: the counting was a tenth of the step)
+            fprintf(stderr, "hot bins' waves by the bin's positions in the launch (class: waves | calls, tests/call, entries skipped | steps, cycles/step; the profile build adds | %% of the steps: some lane tests "
+                            "(tests per such step; lane-steps repeated for a held slot per step), taking back, every lane holds a call, next call may not start, no entry | idle steps with an undecided position open)\n");
             for (int k = 0; k < 8; k++) {
                 const unsigned long long *h = wc.hot_class[k];
                 if (!h[0]) continue;
                 const double st = (double)(h[3] ? h[3] : 1);
-                fprintf(stderr, "  %s %7u: %5llu | %10llu calls, %5.1f, %10llu | %12llu steps, %5.0f | %4.1f (%.2f; %.2f), %4.1f, %4.1f, %4.1f, %4.1f | %4.1f\n", k ? ">=" : "< ", k ? 8192u << k : 16384u, h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1), h[12],
-                        h[3], (double)h[11] / st, 100.0 * h[4] / st, (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / st, 100.0 * h[7] / st, 100.0 * h[8] / st, 100.0 * h[9] / st, 100.0 * h[10] / st, 100.0 * h[13] / st);
+                fprintf(stderr, "  %s %7u: %5llu | %10llu calls, %5.1f, %10llu | %12llu steps, %5.0f", k ? ">=" : "< ", k ? 8192u << k : 16384u, h[0], h[1], (double)h[2] / (h[1] ? h[1] : 1), h[12], h[3], (double)h[11] / st);
+                if (h[14] + h[16]) {
+                    fprintf(stderr, " | %4.1f (%.2f; %.2f), %4.1f, %4.1f, %4.1f, %4.1f | %4.1f\n", 100.0 * h[4] / st, (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / st, 100.0 * h[7] / st, 100.0 * h[8] / st, 100.0 * h[9] / st,
+                            100.0 * h[10] / st, 100.0 * h[13] / st);
+                    fprintf(stderr, "              cycles of a step by section: end of the step before + windows %.0f, oldest undecided + recovery %.0f, entries passed + start %.0f, loads until they are back %.0f, "
+                                    "call start / test %.0f, call end + result %.0f, accounting + watchdogs %.0f\n", h[20] / st, h[14] / st, h[15] / st, h[16] / st, h[17] / st, h[18] / st, h[19] / st);
+                } else fprintf(stderr, "\n");
             }
         }
         if (C.opt_report && wc.call_tests)

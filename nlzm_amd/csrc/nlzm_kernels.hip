@@ -545,16 +545,23 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
     bool marked = false, und = false, published = false, wrong = false;
     bool last_skip = false;         // (wave-uniform) the bin's latest decision was "skip"
     LaneSink sink{ (uint32_t *)&g_v2_lds + threadIdx.x, nullptr };
-    unsigned long long n_calls = 0, n_tests = 0, n_cmp = 0, n_open = 0, n_back = 0, n_redo = 0;
-    unsigned long long n_steps = 0, n_blk_risky = 0;
+    // (counters of a launch: 32 bits each inside the loop -- a launch is a few hundred thousand steps -- but the two that add up whole calls)
+    unsigned long long n_tests = 0, n_cmp = 0;
+    uint32_t n_calls = 0, n_open = 0, n_back = 0, n_redo = 0;
+    uint32_t n_steps = 0, n_blk_risky = 0;
     unsigned long long t_wait0 = 0;
-    uint32_t idle = 0, prog_seen = 0, steps = 0;
-    bool fail = false;
+    uint32_t prog_seen = 0, steps = 0;
     // (accounting by the bin's size: WorkerCounters::hot_class)
-    unsigned long long k_work = 0, k_tests = 0, k_rep = 0, k_rec = 0, k_full = 0, k_blk = 0, k_noent = 0, k_skip = 0, k_und = 0;
+    uint32_t k_work = 0, k_tests = 0, k_rep = 0, k_rec = 0, k_full = 0, k_blk = 0, k_noent = 0, k_skip = 0, k_und = 0;
     const unsigned long long k_t0 = __builtin_readcyclecounter();
     uint32_t k_total = 0;
     for (uint32_t cc = c0; cc < c1; cc++) { const uint32_t *off = G.bin_off + (unsigned long long)(cc - c0) * (G.nheads + 1); k_total += off[bin + 1] - off[bin]; }
+#ifdef NLZM_PROFILE
+    unsigned long long t_sec[7] = {}, t_last = __builtin_readcyclecounter();
+#define NLZM_HOT_STAMP(k) do { const unsigned long long t_now = __builtin_readcyclecounter(); t_sec[k] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define NLZM_HOT_STAMP(k) do { } while (0)
+#endif
 
     for (;;) {
         // ---- the window before is done with when nothing parked is left in it; a window that is passed but still holds parked entries takes its place
@@ -569,7 +576,8 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 if (!loaded) {
                     if (c >= c1) { more = false; break; }
                     const uint32_t *off = G.bin_off + (unsigned long long)(c - c0) * (G.nheads + 1);
-                    cur = off[bin]; e0 = off[bin + 1];
+                    // (every lane reads the same two words: said so, or the whole loop's control flow is compiled as if the lanes could part)
+                    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[bin]); e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[bin + 1]);
                     const unsigned long long chunk_abs = (unsigned long long)c * g.chunk_size;
                     const unsigned long long remain = g.n - chunk_abs;
                     la_end = (uint32_t)(chunk_abs + (remain < g.feed ? remain : g.feed));
@@ -596,14 +604,23 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 wvalid = true;
             }
         }
+        NLZM_HOT_STAMP(6);
         const uint32_t wend = wvalid ? umin(64u, e0 - wb) : 0u;     // entries in the window
         // ---- the oldest undecided position (a call's or a parked entry's); a wrong assumption
         const bool w_und = wvalid && w_kind == kwPark && wb + lane < cur;
         const bool o_und = ovalid && o_park;
         const uint32_t w_seq = wb + lane + 1, o_seq = ob + lane + 1;
-        const uint32_t oseq = ~wave_max_u32(umax(und ? ~seq : 0u, umax(w_und ? ~w_seq : 0u, o_und ? ~o_seq : 0u)));
-        const uint32_t rseq = ~wave_max_u32(umax(wrong ? ~seq : 0u, umax(w_wrong ? ~w_seq : 0u, (ovalid && o_wrong) ? ~o_seq : 0u)));
-        if (rseq != 0xFFFFFFFFu) rec = true;
+        // (a window's entries stand in lane order: its oldest is its first; the calls stand on whatever lane was free.  One instruction of a
+        //  lone wave is four cycles whatever it does, and a reduction over the wave is fifteen of them: made only where something can be found)
+        const unsigned long long w_um = __ballot(w_und), o_um = __ballot(o_und);
+        uint32_t oseq = 0xFFFFFFFFu, rseq = 0xFFFFFFFFu;
+        if (__any(und)) oseq = ~wave_max_u32(und ? ~seq : 0u);
+        if (w_um) oseq = umin(oseq, wb + (uint32_t)__builtin_ctzll(w_um) + 1u);
+        if (o_um) oseq = umin(oseq, ob + (uint32_t)__builtin_ctzll(o_um) + 1u);
+        if (__any(wrong || w_wrong || (ovalid && o_wrong))) {
+            rseq = ~wave_max_u32(umax(wrong ? ~seq : 0u, umax(w_wrong ? ~w_seq : 0u, (ovalid && o_wrong) ? ~o_seq : 0u)));
+            rec = true;
+        }
         if (rec && !__any(st == kStart || st == kRun)) {
             // every call in flight has ended: the stores of the calls behind the position are taken back, latest first; then the position's
             // own, if it was assumed to be called; the bin goes on behind it -- or AT it, if it was parked and is called
@@ -655,6 +672,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             rec = false;
             continue;
         }
+        NLZM_HOT_STAMP(0);
         // ---- entries are passed: dropped ones and parked ones as many as there are, and ONE call -- on the first free lane, not while a wrong
         // assumption is being undone, and not behind a parked entry that is assumed to be skipped although the bin's last decision was "call"
         // (wrong one time in eight on prose, and a wrong assumption costs every call behind it)
@@ -704,6 +722,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
         }
         // (the window is done with when every entry is passed and nothing undecided is parked in it)
         if (wvalid && cur >= wb + wend && !__any(w_kind == kwPark)) wvalid = false;
+        NLZM_HOT_STAMP(1);
         // ---- loads of this step
         uint32_t v_word = 0, v_flag = 0, w_flag = 0;
         unsigned long long pp = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -752,11 +771,15 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
             if (__any(decided || w_decided || o_decided))
                 last_skip = __any((decided && v_flag == kFlagSkip) || (w_decided && w_flag == kFlagSkip) || (o_decided && o_flag == kFlagSkip));
         }
+#ifdef NLZM_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (profile build: the round trip ends here, not at the first use of what was loaded)
+#endif
+        NLZM_HOT_STAMP(2);
         if (st == kStart) {
             bool go = true;
             if (marked) {
                 if (v_flag == kFlagSkip) { st = kIdle; go = false; }                                    // decided by now: it does not happen
-                else if (v_flag != kFlagCall) { und = true; n_open++; t_wait0 = 0; idle = 0; }          // its fate is open: assumed to be called, every store noted
+                else if (v_flag != kFlagCall) { und = true; n_open++; }          // its fate is open: assumed to be called, every store noted
             }
             if (go) {
                 started_now = true;
@@ -815,6 +838,7 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 }
             }
         }
+        NLZM_HOT_STAMP(3);
         if (fin_now) {
             tree[pend_l] = fin_l; tree[pend_r] = fin_r;
             st = kHeld;
@@ -827,6 +851,8 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 st = kIdle;
             }
         }
+        NLZM_HOT_STAMP(4);
+#ifdef NLZM_PROFILE
         {   // (accounting)
             const uint32_t nt = (uint32_t)__builtin_popcountll(__ballot(made_test)), nr = (uint32_t)__builtin_popcountll(__ballot(rep_step));
             k_tests += nt; k_rep += nr;
@@ -839,38 +865,48 @@ __device__ __forceinline__ void worker_role_hot(const Geom &g, const Globals &G,
                 if (__any(und || w_und || o_und)) k_und++;
             }
         }
-        // ---- watchdogs (a position whose decision does not come; a launch that failed elsewhere)
-        if ((und || w_und || o_und) && (++idle & 4095u) == 0) {
-            const unsigned long long now = wall_clock64();
-            const uint32_t prog = G.progress ? LaneIO::ld_agent(G.progress) : 0u;
-            if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
-            else if (now - t_wait0 > 3000000000ull) fail = true;
+#else
+        (void)made_test; (void)rep_step; (void)started_now;
+#endif
+        // ---- watchdogs, every 4,096 steps (a launch that failed elsewhere; a position whose decision does not come while the finder stage stands)
+        if ((++steps & 4095u) == 0) {
+            if (__any(LaneIO::ld_agent(G.abort_word) != 0)) break;
+            if (__any(und || w_und || o_und)) {
+                const unsigned long long now = wall_clock64();
+                const uint32_t prog = G.progress ? (uint32_t)__builtin_amdgcn_readfirstlane((int)LaneIO::ld_agent(G.progress)) : 0u;
+                if (!t_wait0 || prog != prog_seen) { t_wait0 = now; prog_seen = prog; }
+                else if (now - t_wait0 > 3000000000ull) { if (lane == 0) LaneIO::st_agent(G.abort_word, 2u); break; }
+            } else t_wait0 = 0;
         }
-        if (__any(fail)) { if (lane == 0) LaneIO::st_agent(G.abort_word, 2u); break; }
-        if ((++steps & 0x3FFFu) == 0 && __any(LaneIO::ld_agent(G.abort_word) != 0)) break;
+        NLZM_HOT_STAMP(5);
         if (!more && !wvalid && !ovalid && !rec && !__any(st != kIdle)) break;
     }
     if (st != kIdle) {
         atomicAdd(&G.wcnt->stuck_lanes, 1ull);
         atomicMax(&G.wcnt->stuck_pos_inv, (unsigned long long)(uint32_t)~a);
     }
+    unsigned long long t_calls = n_calls, t_open = n_open, t_back = n_back, t_redo = n_redo, t_skip = k_skip;
     for (int m = 32; m >= 1; m >>= 1) {
-        n_calls += __shfl_xor(n_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
-        n_open += __shfl_xor(n_open, m, 64); n_back += __shfl_xor(n_back, m, 64); n_redo += __shfl_xor(n_redo, m, 64);
-        k_skip += __shfl_xor(k_skip, m, 64);
+        t_calls += __shfl_xor(t_calls, m, 64); n_tests += __shfl_xor(n_tests, m, 64); n_cmp += __shfl_xor(n_cmp, m, 64);
+        t_open += __shfl_xor(t_open, m, 64); t_back += __shfl_xor(t_back, m, 64); t_redo += __shfl_xor(t_redo, m, 64);
+        t_skip += __shfl_xor(t_skip, m, 64);
     }
     if (lane == 0) {
-        atomicAdd(&G.wcnt->bt_calls, n_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
-        atomicAdd(&G.wcnt->dry_runs, n_open); atomicAdd(&G.wcnt->spec_calls, n_back); atomicAdd(&G.wcnt->spec_good, n_redo);
-        atomicAdd(&G.wcnt->hot_calls, n_calls);
-        atomicAdd(&G.wcnt->hot_steps, n_steps); atomicAdd(&G.wcnt->hot_blocked_risky, n_blk_risky);
+        atomicAdd(&G.wcnt->bt_calls, t_calls); atomicAdd(&G.wcnt->bt_tests, n_tests); atomicAdd(&G.wcnt->cmp_bytes, n_cmp);
+        atomicAdd(&G.wcnt->dry_runs, t_open); atomicAdd(&G.wcnt->spec_calls, t_back); atomicAdd(&G.wcnt->spec_good, t_redo);
+        atomicAdd(&G.wcnt->hot_calls, t_calls);
+        atomicAdd(&G.wcnt->hot_steps, (unsigned long long)n_steps); atomicAdd(&G.wcnt->hot_blocked_risky, (unsigned long long)n_blk_risky);
         uint32_t kc = 0;
         while (kc < 7 && (k_total >> (14 + kc))) kc++;
         unsigned long long *hc = G.wcnt->hot_class[kc];
-        atomicAdd(&hc[0], 1ull); atomicAdd(&hc[1], n_calls); atomicAdd(&hc[2], n_tests); atomicAdd(&hc[3], n_steps); atomicAdd(&hc[4], k_work);
-        atomicAdd(&hc[5], k_tests); atomicAdd(&hc[6], k_rep); atomicAdd(&hc[7], k_rec); atomicAdd(&hc[8], k_full); atomicAdd(&hc[9], k_blk);
-        atomicAdd(&hc[10], k_noent); atomicAdd(&hc[11], (unsigned long long)(__builtin_readcyclecounter() - k_t0)); atomicAdd(&hc[12], k_skip); atomicAdd(&hc[13], k_und);
+        atomicAdd(&hc[0], 1ull); atomicAdd(&hc[1], t_calls); atomicAdd(&hc[2], n_tests); atomicAdd(&hc[3], (unsigned long long)n_steps); atomicAdd(&hc[4], (unsigned long long)k_work);
+        atomicAdd(&hc[5], (unsigned long long)k_tests); atomicAdd(&hc[6], (unsigned long long)k_rep); atomicAdd(&hc[7], (unsigned long long)k_rec); atomicAdd(&hc[8], (unsigned long long)k_full); atomicAdd(&hc[9], (unsigned long long)k_blk);
+        atomicAdd(&hc[10], (unsigned long long)k_noent); atomicAdd(&hc[11], (unsigned long long)(__builtin_readcyclecounter() - k_t0)); atomicAdd(&hc[12], t_skip); atomicAdd(&hc[13], (unsigned long long)k_und);
+#ifdef NLZM_PROFILE
+        for (int z = 0; z < 7; z++) atomicAdd(&hc[14 + z], t_sec[z]);
+#endif
     }
+#undef NLZM_HOT_STAMP
 }
 
 // A worker lane.  Bin b holds, in ascending order, the positions of every BT4 head h with h % bins == b; lane b walks it.
