@@ -74,7 +74,9 @@ for _n, _w, _l in sorted(STAGES, key=lambda t: -case_of(t[0])[2]):
 CUTS = [{"NLZM_SIM_RANDOM_BLOCKS": "7", "NLZM_SIM_POISON": "3"}, {"NLZM_SIM_PSTRIDE": "5", "NLZM_SIM_POISON": "4"}]
 for _env in CUTS:
     job(("cuts", tuple(sorted(_env.items()))), case_input("chains_150k_w17"), [case_of("chains_150k_w17")[4], 1, 2], _env)
-job("splice", lambda: corpus.make("splice", 130_000, 4242), [19, 2, 3], {"NLZM_SIM_PSTRIDE": "9"})
+SPLICE = [(4242, 2, 3, {"NLZM_SIM_PSTRIDE": "9"}), (777, 2, 2, {"NLZM_SIM_RANDOM_BLOCKS": "5", "NLZM_SIM_POISON": "2"}), (31337, 1, 2, {})]
+for _seed, _w, _l, _env in SPLICE:
+    job(("splice", _seed), (lambda sd: lambda: corpus.make("splice", 130_000, sd))(_seed), [19, _w, _l], _env)
 
 
 @pytest.fixture(scope="module")
@@ -134,10 +136,12 @@ def test_rk_entry_cut_short_by_uint16_grows_again(runs, name):
     assert (grown >= 1 and ties >= 3 and 1 <= won < ties) if "tie" in name else grown >= 2, r.stdout[-600:]
 
 
-def test_spliced_fuzz_input(runs):
-    """One seed of the fuzz that tests/sim_fuzz.py runs in batches (corpus.splice: pieces of every kind the finders treat differently, spliced at random), so that the
-    generator and the harness stay alive in the suite."""
-    ok(runs, "splice")
+@pytest.mark.parametrize("seed", [t[0] for t in SPLICE])
+def test_spliced_fuzz_input(runs, seed):
+    """Three seeds of the fuzz that tests/sim_fuzz.py runs in batches (corpus.splice: pieces of every kind the finders treat differently, spliced at random), so that the
+    generator and the harness stay alive in the suite: one with nine pairs reserved per position and the rest in the launch's arena, one with the parser's blocks cut at
+    random over poisoned buffers, one with the slowest worker lanes."""
+    ok(runs, ("splice", seed))
 
 
 def test_table_stage_changes_shape_on_real_text(runs):
