@@ -1,5 +1,7 @@
 #!/bin/bash
 # builds nlzm_amd/libnlzm_hip_prof.so (-DNLZM_PROFILE: per-section cycle accounting) next to the product library
+# (the file is listed in .gpurunignore: build it on the GPU box inside the gpurun command, or under another name -- round 6 used
+#  nlzm_amd/libnlzm_exp_prof.so -- and load it through NLZM_LIB; the profile build also counts what a hot bin's wave spends its steps on, by section)
 set -e
 cd "$(dirname "$0")/../nlzm_amd/csrc"
 mkdir -p /tmp/nlzm_prof_build
